@@ -56,6 +56,63 @@ int diagan_ldr_scores_f32(const float* rec, int T, int64_t N, int64_t row_stride
 int diagan_logit_scatter(const float* logit, const int64_t* idx, int64_t n, void* rec_row,
                          int64_t N, int out_is_f64, int* oob_counter, void* stream);
 
+/* ---- convolution (implicit GEMM on the fp32 matrix cores) --------------------------------- */
+
+/* Gather geometry shared by the three conv entry points (DESIGN.md "Gather formula"):
+ *   iy_num = oy*sy + r*dr + off; the tap is valid iff iy_num >= 0, iy_num % up == 0 and
+ *   iy_num/up < Hi (same in x).  conv(stride s,pad p): (s,+1,-p,1); transposed conv and every
+ *   data-gradient: (1,-1,+p,s).
+ * Prologue modes (applied to gathered values): 0 none, 1 ReLU, 2 scale[c]*x+shift[c] then ReLU
+ * (BatchNorm apply), 3 LeakyReLU(0.2), 4 affine only. */
+
+/* Forward conv / transposed conv / data-gradient:
+ *   y[b,oy,ox,n] = epi(out_scale * sum_{r,s,c} pro(x[b,iy,ix,c]) * w[n][(r*S+s)*Ci+c])
+ *   epi: + bias[n], + residual, then (mask_src > 0 ? v : mask_slope*v).
+ * Replaces F.conv2d / nn.ConvTranspose2d forward and their input gradient
+ * (SNGAN blocks: SURVEY §8 a2-a7; DCGAN: diagan-pkg/diagan/models/mnist.py:55-71,163-190).
+ * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto. */
+int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
+                     const float* residual, const float* mask_src, float mask_slope,
+                     const float* pro_scale, const float* pro_shift, int pro_mode, float out_scale,
+                     int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                     int dr, int off, int up, int Kp, int tile_cfg, void* stream);
+
+/* Weight gradient, split over pixels: slab[s][n][k] = sum_{m in split s} dy[m][n]*pro(x gathered).
+ * Replaces the weight half of conv2d / conv_transpose2d backward (errD.backward()/errG.backward()
+ * in the train steps, diagan-pkg/diagan/models/topk_models.py:90, mnist.py:126).
+ * dy NHWC [B,Ho,Wo,Co] (Co % 4 == 0), slab [splits][Co][Kp]. */
+int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, const float* pro_scale,
+                      const float* pro_shift, int pro_mode, int B, int Hi, int Wi, int Ci, int Ho,
+                      int Wo, int Co, int R, int S, int sy, int dr, int off, int up, int Kp,
+                      void* stream);
+int diagan_conv_wgrad_splits(int M, int Co, int Kp); /* host heuristic: number of splits */
+
+/* out (+)= sum_s slab[s]; if w: dot_partials[block] = partial <sum, w> (fp64, for the SN backward);
+ * ceil(n_elem/1024) partials. */
+int diagan_wgrad_reduce(const float* slab, int splits, int64_t n_elem, float* out, int accumulate,
+                        const float* w, double* dot_partials, void* stream);
+
+/* ---- spectral norm (torch_mimicry SpectralNorm) ------------------------------- */
+
+/* One power iteration + sigma on packed master weight W[Co][Kp]:
+ *   v = normalize(u W), u' = normalize(W v), sigma = u' W v  (eps 1e-12).
+ * u_out/v_out: [Co]/[Kp] copies kept for the backward; state[0]=sigma, state[1]=1/sigma;
+ * u_buffer/sigma_buffer are the module buffers, overwritten iff update_buffers (training mode).
+ * work: Kp + Co floats. */
+int diagan_sn_power_iter(const float* W, float* u_buffer, float* sigma_buffer, float* u_out,
+                         float* v_out, float* state, float* work, int Co, int Kp, float eps,
+                         int update_buffers, void* stream);
+
+/* GEMM operand packing: Wf = W*inv (same [Co][Kp] layout), Wd[ci][(rs)*Co+co] = W[co][(rs)*Ci+ci]*inv
+ * (data-gradient operand, row length Kd).  inv_sigma: device float* or NULL (= 1). */
+int diagan_pack_weights(const float* W, const float* inv_sigma, float* Wf, float* Wd, int Co, int Ci,
+                        int RS, int Kp, int Kd, void* stream);
+
+/* Backward through W/sigma: grad (+)= (G - <G,W>/sigma * u^T v) / sigma. */
+int diagan_sn_grad_fix(const float* G, const double* dot_partials, int nparts, const float* u,
+                       const float* v, const float* state, float* grad, int Co, int Kp,
+                       int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,62 @@
+// Shared definitions of the implicit-GEMM convolution kernels (fwd/dgrad in conv_gemm.hip,
+// wgrad in conv_wgrad.hip).
+//
+// Tensor layout: activations NHWC fp32 (C % 4 == 0), packed weights Wp[Co][Kp] with
+// k = (r*S + s)*Ci + c, Kp = roundup(R*S*Ci, 32), zero padded.
+//
+// Gather geometry (one formula for conv, strided conv, transposed conv and every dgrad):
+//   iy_num = oy*sy + r*dr + off ;  valid iff iy_num >= 0, iy_num % up == 0, iy_num/up < Hi
+//     forward conv (stride s, pad p)         : sy = s, dr = +1, off = -p, up = 1
+//     transposed conv / dgrad (stride s, p)  : sy = 1, dr = -1, off = +p, up = s
+#pragma once
+#include "common.h"
+
+namespace diagan {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum ProMode : int {
+  PRO_NONE = 0,
+  PRO_RELU = 1,          // a = max(x, 0)
+  PRO_AFFINE_RELU = 2,   // a = max(x*scale[c] + shift[c], 0)   (BatchNorm apply + ReLU)
+  PRO_LRELU = 3,         // a = x > 0 ? x : 0.2 x
+  PRO_AFFINE = 4,        // a = x*scale[c] + shift[c]
+};
+
+struct ConvGeom {
+  int B, Hi, Wi, Ci;   // gathered tensor (conv input for fwd / wgrad, dy for dgrad)
+  int Ho, Wo, Co;      // pixel-indexed tensor (conv output for fwd, dx for dgrad, dy for wgrad)
+  int R, S;
+  int sy, dr, off, up; // gather formula above (same for x and y directions)
+  int K;               // R*S*Ci
+  int Kp;              // padded K (multiple of 32): row length of packed weights
+};
+
+__device__ __forceinline__ f32x4 apply_pro(f32x4 v, int mode, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, int c) {
+  if (mode == PRO_NONE) return v;
+  if (mode == PRO_AFFINE_RELU || mode == PRO_AFFINE) {
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+    v = v * sc + sh;
+    if (mode == PRO_AFFINE) return v;
+  }
+  if (mode == PRO_LRELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+    return v;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id (cdna guide T1): consecutive logical tiles
+// land on the same XCD (= same L2), so neighbouring tiles share halo rows and weight panels.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+}  // namespace diagan

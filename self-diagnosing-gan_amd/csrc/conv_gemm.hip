@@ -1,0 +1,250 @@
+// Implicit-GEMM convolution, forward and data-gradient, on the fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s dense peak on MI355X).
+//
+// Replaces the ATen/cuDNN calls under F.conv2d / nn.ConvTranspose2d and their input-gradient
+// in the SNGAN / DCGAN stacks (e.g. torch_mimicry GBlock/DBlock convs
+// invoked from diagan-pkg/diagan/models/predefined_models.py:19-21,38-40,57-59,76-78, and
+// diagan-pkg/diagan/models/mnist.py:55-71,163-190).
+//
+//   Y[m][n] = epi( sum_k A(m,k) * Wp[n][k] ),   m = (b,oy,ox) pixel, n = out channel,
+//   k = (r,s,c);  A(m,k) = pro(X[b, iy(oy,r), ix(ox,s), c]) or 0 outside the image.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN x 32; each wave owns a (TM*32) x (TN*32)
+// sub-tile as TM x TN MFMA 32x32 accumulators.  A and B tiles are register-staged
+// (global_load_dwordx4 -> prologue in VGPRs -> ds_write_b128) into double-buffered LDS with a
+// 16-byte-chunk XOR swizzle so that the ds_read_b128 fragment reads are bank-conflict free; one
+// s_barrier per K-step.  The im2col gather happens in the loader: no column matrix exists in HBM.
+// Prologue (ReLU / BatchNorm-apply+ReLU / LeakyReLU) is applied to the gathered values on their way
+// to LDS; epilogue adds bias, a residual tensor and/or a ReLU-backward mask before the store.
+//
+// Roofline: MFMA fp32 (algorithmic FLOP = 2*M*Co*K).
+#include "conv_common.h"
+
+namespace diagan {
+
+struct ConvGemmArgs {
+  const float* x;         // gathered tensor, NHWC [B,Hi,Wi,Ci]
+  const float* w;         // packed weights [Co][Kp]
+  float* y;               // output NHWC [B,Ho,Wo,Co]
+  const float* bias;      // [Co] or null
+  const float* residual;  // same shape as y or null: y += residual
+  const float* mask_src;  // same shape as y or null: y = mask_src > 0 ? y : lrelu_slope*y
+  const float* pro_scale; // [Ci] for PRO_AFFINE*
+  const float* pro_shift;
+  float mask_slope;       // 0 for ReLU backward, 0.2 for LeakyReLU backward
+  float out_scale;        // multiplies the accumulator before bias/residual (1.0 normally)
+  int pro_mode;
+  int M;                  // B*Ho*Wo
+  ConvGeom g;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
+  constexpr int AJ = BM / 32, BJ = BN / 32;            // 16-byte chunks per thread per tile
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                  // [2][BM*32]
+  float* Bs = smem + 2 * BM * BK;    // [2][BN*32]
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (g.Co + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+  // ---- loader state -------------------------------------------------------------------------
+  const int lrow = tid >> 3, lq = tid & 7;  // row within a 32-row group, 16-byte chunk in the K-step
+  int pix_base[AJ], iy0[AJ], ix0[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + lrow + 32 * j;
+    if (m < a.M) {
+      const int ox = m % g.Wo, t = m / g.Wo;
+      const int oy = t % g.Ho, b = t / g.Ho;
+      pix_base[j] = b * g.Hi * g.Wi;
+      iy0[j] = oy * g.sy + g.off;
+      ix0[j] = ox * g.sy + g.off;
+    } else {
+      pix_base[j] = 0;
+      iy0[j] = -(1 << 28);  // never valid
+      ix0[j] = -(1 << 28);
+    }
+  }
+  // (tap, c) of this thread's chunk, advanced incrementally by 32 channels per K-step
+  int kc = lq * 4, kr = 0, ks = 0;
+  while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
+  const int upm = g.up - 1, ush = g.up >> 1;  // up in {1,2}
+
+  f32x4 ra[AJ], rb[BJ];
+  const int nk = g.Kp / BK;
+
+  auto load_tiles = [&](int kk) {
+    const bool tap_ok = kr < g.R;
+    const int dy = kr * g.dr, dx = ks * g.dr;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int yn = iy0[j] + dy, xn = ix0[j] + dx;
+      const int iy = yn >> ush, ix = xn >> ush;
+      const bool ok = tap_ok && yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v = *reinterpret_cast<const f32x4*>(a.x + ((long)(pix_base[j] + iy * g.Wi + ix) * g.Ci + kc));
+        v = apply_pro(v, a.pro_mode, a.pro_scale, a.pro_shift, kc);
+      }
+      ra[j] = v;
+    }
+    const int kcol = kk * BK + lq * 4;
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int n = n0 + lrow + 32 * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < g.Co) v = *reinterpret_cast<const f32x4*>(a.w + (long)n * g.Kp + kcol);
+      rb[j] = v;
+    }
+    // advance (tap, c) to the next K-step
+    kc += BK;
+    while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
+  };
+  auto store_tiles = [&](int buf) {
+    float* Ad = As + buf * BM * BK;
+    float* Bd = Bs + buf * BN * BK;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int row = lrow + 32 * j;
+      *reinterpret_cast<f32x4*>(Ad + row * BK + ((lq ^ ((row >> 1) & 7)) << 2)) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int row = lrow + 32 * j;
+      *reinterpret_cast<f32x4*>(Bd + row * BK + ((lq ^ ((row >> 1) & 7)) << 2)) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fi = lane & 31, fh = lane >> 5;
+
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kk = 0; kk < nk; ++kk) {
+    const int cur = kk & 1;
+    if (kk + 1 < nk) load_tiles(kk + 1);  // global loads in flight under the MFMAs below
+    const float* Ac = As + cur * BM * BK;
+    const float* Bc = Bs + cur * BN * BK;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = 2 * u + fh;
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + fi;
+        fa[i] = *reinterpret_cast<const f32x4*>(Ac + row * BK + ((q ^ ((row >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + fi;
+        fb[j] = *reinterpret_cast<const f32x4*>(Bc + row * BK + ((q ^ ((row >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (kk + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (TN * 32) + j * 32 + fi;
+      if (n >= g.Co) continue;
+      const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (m >= a.M) continue;
+        const long o = (long)m * g.Co + n;
+        float v = acc[i][j][e] * a.out_scale + bv;
+        if (a.residual) v += a.residual[o];
+        if (a.mask_src) v = a.mask_src[o] > 0.f ? v : v * a.mask_slope;
+        a.y[o] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
+  const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, a);
+  return check_launch("conv_gemm");
+}
+
+}  // namespace diagan
+
+using namespace diagan;
+
+// see include/diagan_hip.h
+DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
+                                const float* residual, const float* mask_src, float mask_slope,
+                                const float* pro_scale, const float* pro_shift, int pro_mode,
+                                float out_scale, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                                int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
+                                void* stream) {
+  DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
+  DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
+  DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
+  DG_REQUIRE(up == 1 || up == 2, "conv_gemm: up=%d unsupported (1 or 2)", up);
+  DG_REQUIRE(dr == 1 || dr == -1, "conv_gemm: dr must be +-1");
+  DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_gemm: Kp=%d must be a multiple of 32 and >= R*S*Ci=%d", Kp, R * S * Ci);
+  DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "conv_gemm: bad pro_mode %d", pro_mode);
+  DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift),
+             "conv_gemm: affine prologue needs scale/shift");
+  DG_REQUIRE((long)B * Ho * Wo < (1L << 31) && (long)B * Hi * Wi < (1L << 31), "conv_gemm: too many pixels");
+  ConvGemmArgs a;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_src = mask_src;
+  a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.mask_slope = mask_slope; a.out_scale = out_scale;
+  a.pro_mode = pro_mode; a.M = B * Ho * Wo;
+  a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
+  hipStream_t st = (hipStream_t)stream;
+  // tile selection: 0 = auto
+  int cfg = tile_cfg;
+  if (cfg == 0) {
+    if (Co <= 64) cfg = 2;                    // 256 x 64
+    else cfg = 1;                             // 128 x 128
+    const long tiles = (long)cdiv(a.M, cfg == 2 ? 256 : 128) * cdiv(Co, cfg == 2 ? 64 : 128);
+    if (tiles < 256) cfg = 3;                 // small problems: 64 x 64 tiles to fill the CUs
+  }
+  switch (cfg) {
+    case 1: return launch_cfg<128, 128, 2, 2>(a, st);
+    case 2: return launch_cfg<256, 64, 4, 1>(a, st);
+    case 3: return launch_cfg<64, 64, 2, 2>(a, st);
+    case 4: return launch_cfg<128, 64, 2, 2>(a, st);
+    default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
+  }
+}

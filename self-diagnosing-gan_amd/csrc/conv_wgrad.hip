@@ -1,0 +1,257 @@
+// Implicit-GEMM weight gradient on the fp32 matrix cores, split-K over pixels.
+//
+// Replaces the weight-gradient half of autograd's conv2d / conv_transpose2d backward in the
+// SNGAN / DCGAN stacks (the errD.backward() / errG.backward() calls of the train steps,
+// diagan-pkg/diagan/models/topk_models.py:90, mnist.py:126 and torch_mimicry's base train_step).
+//
+//   dWp[n][k] = sum_m dY[m][n] * A(m,k),  k = (r,s,c),  A = pro(gathered X) exactly as in forward
+//
+// GEMM view: rows n (Co), cols k (packed weight index), reduction over pixels m (65k..262k long),
+// so the output is small and the reduction is split over gridDim.y workgroups that each write one
+// fp32 slab; a second kernel sums the slabs in a fixed order (deterministic, no float atomics).
+// LDS holds both operands pixel-major ([32 pixels][128]) straight from their NHWC rows, so the
+// MFMA fragments are conflict-free ds_read_b32 (lanes = consecutive channels).
+//
+// Roofline: MFMA fp32 (algorithmic FLOP = 2*M*Co*K).
+#include "conv_common.h"
+
+namespace diagan {
+
+struct FastDiv {  // unsigned division by a runtime constant: q = (n * mul) >> 32 >> shift  (n < 2^31)
+  unsigned mul, shift, d;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  unsigned l = 0;
+  while ((1u << l) < d) ++l;                                   // ceil(log2 d)
+  const unsigned long long m = ((1ull << (32 + l)) + d - 1) / d;  // needs 33 bits in general
+  f.mul = (unsigned)(m - (1ull << 32));
+  f.shift = l;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const unsigned t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
+struct WgradArgs {
+  const float* dy;        // pixel tensor [M][Co]
+  const float* x;         // gathered tensor NHWC [B,Hi,Wi,Ci]
+  float* slab;            // [splits][Co][Kp]
+  const float* pro_scale;
+  const float* pro_shift;
+  int pro_mode;
+  int M;
+  int steps_per_split;    // K-steps (of 32 pixels) per split
+  ConvGeom g;
+  FastDiv dWo, dHo;
+};
+
+template <int BNn, int BNk>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  constexpr int BK = 32;                       // pixels per K-step
+  constexpr int TM = BNn / 64, TN = BNk / 64;  // 2x2 waves
+  constexpr int AC = BNn / 4, BC = BNk / 4;    // 16-byte chunks per pixel row
+  constexpr int AJ = BK * AC / 256, BJ = BK * BC / 256;
+  constexpr int APR = 256 / AC, BPR = 256 / BC;  // pixel rows covered per pass
+  __shared__ __attribute__((aligned(16))) float As[2][BK * BNn];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * BNk];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_k = (g.Kp + BNk - 1) / BNk;
+  const int nwg = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
+  const int split = blockIdx.y;
+  const int step0 = split * a.steps_per_split;
+  const int total_steps = (a.M + BK - 1) / BK;
+  const int step1 = min(step0 + a.steps_per_split, total_steps);
+
+  // A' loader (dy rows): fixed channel chunk, pixel rows ap + APR*j
+  const int ac = tid % AC, ap = tid / AC;
+  const int an = n0 + ac * 4;
+  const bool a_ok = an < g.Co;
+  // B' loader (gathered x): fixed (tap, c) per thread
+  const int bc = tid % BC, bp = tid / BC;
+  const int kf = k0 + bc * 4;
+  const int tap = kf / g.Ci, kc = kf - tap * g.Ci;
+  const int kr = tap / g.S, ks = tap - kr * g.S;
+  const bool b_ok = kf < g.K;
+  const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
+  const int upm = g.up - 1, ush = g.up >> 1;
+
+  f32x4 ra[AJ], rb[BJ];
+  auto load_tiles = [&](int step) {
+    const int mb = step * BK;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const int m = mb + ap + APR * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok && m < a.M) v = *reinterpret_cast<const f32x4*>(a.dy + (long)m * g.Co + an);
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+      const int m = mb + bp + BPR * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok && m < a.M) {
+        const unsigned t = fdiv((unsigned)m, a.dWo);
+        const int ox = m - (int)t * g.Wo;
+        const unsigned b = fdiv(t, a.dHo);
+        const int oy = (int)t - (int)b * g.Ho;
+        const int yn = oy * g.sy + dyo, xn = ox * g.sy + dxo;
+        const int iy = yn >> ush, ix = xn >> ush;
+        if (yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi) {
+          v = *reinterpret_cast<const f32x4*>(a.x + ((long)((int)b * g.Hi * g.Wi + iy * g.Wi + ix) * g.Ci + kc));
+          v = apply_pro(v, a.pro_mode, a.pro_scale, a.pro_shift, kc);
+        }
+      }
+      rb[j] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      *reinterpret_cast<f32x4*>(&As[buf][(ap + APR * j) * BNn + ac * 4]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(bp + BPR * j) * BNk + bc * 4]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fi = lane & 31, fh = lane >> 5;
+  if (step0 < step1) {
+    load_tiles(step0);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int step = step0; step < step1; ++step) {
+    const int cur = (step - step0) & 1;
+    if (step + 1 < step1) load_tiles(step + 1);
+    const float* Ac = As[cur];
+    const float* Bc = Bs[cur];
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const int p = 2 * s + fh;
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = Ac[p * BNn + wm * (TM * 32) + i * 32 + fi];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = Bc[p * BNk + wn * (TN * 32) + j * 32 + fi];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (step + 1 < step1) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = a.slab + (long)split * g.Co * g.Kp;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int k = k0 + wn * (TN * 32) + j * 32 + fi;
+      if (k >= g.Kp) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = n0 + wm * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (n < g.Co) out[(long)n * g.Kp + k] = acc[i][j][e];
+      }
+    }
+}
+
+// out[i] (+)= sum_s slab[s][i]; optionally per-block partial of <G, W> for the SN backward
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
+                                                           long n4, float* __restrict__ out, int accumulate,
+                                                           const float* __restrict__ w,
+                                                           double* __restrict__ dot_partials) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  double dot = 0.0;
+  if (i < n4) {
+    f32x4 s = reinterpret_cast<const f32x4*>(slab)[i];
+    for (int k = 1; k < splits; ++k) s += reinterpret_cast<const f32x4*>(slab)[(long)k * n4 + i];
+    if (w) {
+      const f32x4 wv = reinterpret_cast<const f32x4*>(w)[i];
+      dot = (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
+    }
+    if (accumulate) s += reinterpret_cast<f32x4*>(out)[i];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+  if (dot_partials) {
+    __shared__ double red[4];
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) dot_partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+}  // namespace diagan
+
+using namespace diagan;
+
+DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits,
+                                 const float* pro_scale, const float* pro_shift, int pro_mode, int B,
+                                 int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                 int dr, int off, int up, int Kp, void* stream) {
+  DG_REQUIRE(dy && x && slab, "conv_wgrad: null tensor");
+  DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && R > 0 && S > 0, "conv_wgrad: bad dims");
+  DG_REQUIRE(Ci > 0 && (Ci & 3) == 0 && Co > 0 && (Co & 3) == 0, "conv_wgrad: Ci=%d, Co=%d must be multiples of 4", Ci, Co);
+  DG_REQUIRE(up == 1 || up == 2, "conv_wgrad: up=%d unsupported", up);
+  DG_REQUIRE(dr == 1 || dr == -1, "conv_wgrad: dr must be +-1");
+  DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_wgrad: bad Kp=%d", Kp);
+  DG_REQUIRE(splits >= 1, "conv_wgrad: splits=%d", splits);
+  DG_REQUIRE((long)B * Ho * Wo < (1L << 31) && (long)B * Hi * Wi < (1L << 31), "conv_wgrad: too many pixels");
+  WgradArgs a;
+  a.dy = dy; a.x = x; a.slab = slab; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_mode = pro_mode;
+  a.M = B * Ho * Wo;
+  a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
+  a.dWo = make_fastdiv((unsigned)Wo);
+  a.dHo = make_fastdiv((unsigned)Ho);
+  const int total_steps = cdiv(a.M, 32);
+  a.steps_per_split = cdiv(total_steps, splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (Co <= 64 || Kp <= 64) {
+    const int tiles = cdiv(Co, 64) * cdiv(Kp, 64);
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3(tiles, splits), dim3(256), 0, st, a);
+  } else {
+    const int tiles = cdiv(Co, 128) * cdiv(Kp, 128);
+    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3(tiles, splits), dim3(256), 0, st, a);
+  }
+  return check_launch("conv_wgrad");
+}
+
+// how many splits conv_wgrad should use for this problem (host-side heuristic, no device work)
+DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
+  const int tiles = (Co <= 64 || Kp <= 64) ? cdiv(Co, 64) * cdiv(Kp, 64) : cdiv(Co, 128) * cdiv(Kp, 128);
+  const int total_steps = cdiv(M, 32);
+  int splits = cdiv(512, tiles);                 // ~2 workgroups per CU
+  if (splits > total_steps / 4) splits = total_steps / 4;  // at least 4 K-steps per split
+  if (splits < 1) splits = 1;
+  if (splits > 256) splits = 256;
+  return splits;
+}
+
+DIAGAN_API int diagan_wgrad_reduce(const float* slab, int splits, int64_t n_elem, float* out, int accumulate,
+                                   const float* w, double* dot_partials, void* stream) {
+  DG_REQUIRE(slab && out && splits >= 1 && n_elem > 0 && (n_elem & 3) == 0, "wgrad_reduce: bad args");
+  const long n4 = n_elem / 4;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, slab,
+                     splits, n4, out, accumulate, w, dot_partials);
+  return check_launch("wgrad_reduce");
+}

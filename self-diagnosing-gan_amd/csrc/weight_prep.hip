@@ -1,0 +1,176 @@
+// Spectral normalisation (power iteration, sigma, scaled weight packing) and its backward.
+//
+// Replaces torch_mimicry's SpectralNorm.sn_weights() as used by SNConv2d / SNLinear in the SNGAN
+// discriminators (reached from diagan-pkg/diagan/models/predefined_models.py:38-40,
+// 76-78), i.e. per forward:
+//     W = weight.view(Co, -1);  v = normalize(u W);  u' = normalize(v W^T)   (no grad, eps 1e-12)
+//     sigma = u' W v^T;  conv uses W / sigma;  buffers u, sigma updated in training mode
+// and the autograd backward through W / sigma (u', v constants):
+//     dL/dW = (G - <G, W/sigma> u'^T v) / sigma,   G = dL/d(W/sigma)
+//
+// W is the master weight in packed layout [Co][Kp] (zero padded columns: they stay zero).
+// Outputs of the forward: Wf = W/sigma in the same packed layout (forward GEMM operand) and
+// Wd[ci][(r,s,co)] = W[co][(r,s,ci)]/sigma (data-gradient GEMM operand).  W/sigma is only ever
+// materialised in these two GEMM-ready forms.
+//
+// Roofline: HBM (W is read 3x, written 2x per forward; <= 19 MB per layer).
+#include "conv_common.h"
+
+namespace diagan {
+
+// v_raw[k] = sum_n u[n] W[n][k]     (grid over 256-column strips)
+__global__ __launch_bounds__(256) void sn_gemv_cols_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                           float* __restrict__ v_raw, int Co, int Kp) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= Kp) return;
+  float s = 0.f;
+  for (int n = 0; n < Co; ++n) s = fmaf(u[n], W[(long)n * Kp + k], s);
+  v_raw[k] = s;
+}
+
+// t_raw[n] = sum_k W[n][k] v_raw[k]  (one wave per row)
+__global__ __launch_bounds__(256) void sn_gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ v_raw,
+                                                           float* __restrict__ t_raw, int Co, int Kp) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= Co) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int k = lane * 4; k < Kp; k += 256) {
+    const f32x4 w = *reinterpret_cast<const f32x4*>(W + (long)n * Kp + k);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(v_raw + k);
+    s += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+  }
+  s = wave_sum(s);
+  if (lane == 0) t_raw[n] = s;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// single block: norms, v, u', sigma.   state[0] = sigma, state[1] = 1/sigma
+__global__ __launch_bounds__(256) void sn_finalize_kernel(const float* __restrict__ v_raw, const float* __restrict__ t_raw,
+                                                          float* __restrict__ v_out, float* __restrict__ u_out,
+                                                          float* __restrict__ u_buffer, float* __restrict__ sigma_buffer,
+                                                          float* __restrict__ state, int Co, int Kp, float eps,
+                                                          int update_buffers) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < Kp; k += 256) s += v_raw[k] * v_raw[k];
+  const float nv = fmaxf(sqrtf(block_sum_256(s, red)), eps);
+  for (int k = threadIdx.x; k < Kp; k += 256) v_out[k] = v_raw[k] / nv;
+  s = 0.f;
+  for (int n = threadIdx.x; n < Co; n += 256) { const float t = t_raw[n] / nv; s += t * t; }
+  const float nt = fmaxf(sqrtf(block_sum_256(s, red)), eps);
+  s = 0.f;
+  for (int n = threadIdx.x; n < Co; n += 256) {
+    const float t = t_raw[n] / nv;
+    const float un = t / nt;
+    u_out[n] = un;
+    if (update_buffers) u_buffer[n] = un;
+    s += un * t;
+  }
+  const float sigma = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    state[0] = sigma;
+    state[1] = 1.f / sigma;
+    if (update_buffers) sigma_buffer[0] = sigma;
+  }
+}
+
+// Wf = W * inv (same layout) and/or Wd[ci][(rs, co)] = W[co][(rs, ci)] * inv ; inv read from device
+// tile: 32 (co) x 32 (ci) per tap through LDS so both sides are coalesced
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, const float* __restrict__ inv_ptr,
+                                                           float* __restrict__ Wf, float* __restrict__ Wd,
+                                                           int Co, int Ci, int RS, int Kp, int Kd) {
+  __shared__ float tile[32][33];
+  const float inv = inv_ptr ? inv_ptr[0] : 1.f;
+  const int tap = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < Co && ci < Ci) {
+      v = W[(long)co * Kp + tap * Ci + ci] * inv;
+      if (Wf) Wf[(long)co * Kp + tap * Ci + ci] = v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (Wd) {
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      if (ci < Ci && co < Co) Wd[(long)ci * Kd + tap * Co + co] = tile[tx][r];
+    }
+  }
+}
+
+// grad[n][k] += (G[n][k] - (dot/sigma) * u[n] * v[k]) / sigma ; dot = sum(partials) = <G, W>
+__global__ __launch_bounds__(256) void sn_grad_fix_kernel(const float* __restrict__ G, const double* __restrict__ partials,
+                                                          int nparts, const float* __restrict__ u,
+                                                          const float* __restrict__ v, const float* __restrict__ state,
+                                                          float* __restrict__ grad, int Co, int Kp, int accumulate) {
+  __shared__ double sdot;
+  if (threadIdx.x == 0) {
+    double d = 0.0;
+    for (int i = 0; i < nparts; ++i) d += partials[i];  // fixed order: deterministic
+    sdot = d;
+  }
+  __syncthreads();
+  const float inv = state[1];
+  const float coef = (float)(sdot * (double)inv);  // <G, W/sigma>
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (long)Co * Kp) return;
+  const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(G + i);
+  const f32x4 vv = *reinterpret_cast<const f32x4*>(v + k);
+  const float un = u[n] * coef;
+  f32x4 o = (g - un * vv) * inv;
+  if (accumulate) o += *reinterpret_cast<const f32x4*>(grad + i);
+  *reinterpret_cast<f32x4*>(grad + i) = o;
+}
+
+}  // namespace diagan
+
+using namespace diagan;
+
+// One SN forward for one layer.  work: >= (Kp + Co) floats of scratch.
+DIAGAN_API int diagan_sn_power_iter(const float* W, float* u_buffer, float* sigma_buffer, float* u_out,
+                                    float* v_out, float* state, float* work, int Co, int Kp, float eps,
+                                    int update_buffers, void* stream) {
+  DG_REQUIRE(W && u_buffer && sigma_buffer && u_out && v_out && state && work, "sn_power_iter: null pointer");
+  DG_REQUIRE(Co > 0 && Kp > 0 && (Kp & 3) == 0, "sn_power_iter: bad dims Co=%d Kp=%d", Co, Kp);
+  hipStream_t st = (hipStream_t)stream;
+  float* v_raw = work;
+  float* t_raw = work + Kp;
+  hipLaunchKernelGGL(sn_gemv_cols_kernel, dim3(cdiv(Kp, 256)), dim3(256), 0, st, W, u_buffer, v_raw, Co, Kp);
+  hipLaunchKernelGGL(sn_gemv_rows_kernel, dim3(cdiv(Co, 4)), dim3(256), 0, st, W, v_raw, t_raw, Co, Kp);
+  hipLaunchKernelGGL(sn_finalize_kernel, dim3(1), dim3(256), 0, st, v_raw, t_raw, v_out, u_out, u_buffer,
+                     sigma_buffer, state, Co, Kp, eps, update_buffers);
+  return check_launch("sn_power_iter");
+}
+
+// Wf (optional) = W*inv_sigma, Wd (optional) = transposed pack * inv_sigma.  inv_sigma: device ptr or NULL (=1)
+DIAGAN_API int diagan_pack_weights(const float* W, const float* inv_sigma, float* Wf, float* Wd, int Co, int Ci,
+                                   int RS, int Kp, int Kd, void* stream) {
+  DG_REQUIRE(W && (Wf || Wd), "pack_weights: null pointer");
+  DG_REQUIRE(Co > 0 && Ci > 0 && RS > 0 && Kp >= RS * Ci && (!Wd || Kd >= RS * Co), "pack_weights: bad dims");
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(cdiv(Ci, 32), cdiv(Co, 32), RS), dim3(256), 0, (hipStream_t)stream, W,
+                     inv_sigma, Wf, Wd, Co, Ci, RS, Kp, Kd);
+  return check_launch("pack_weights");
+}
+
+DIAGAN_API int diagan_sn_grad_fix(const float* G, const double* dot_partials, int nparts, const float* u,
+                                  const float* v, const float* state, float* grad, int Co, int Kp, int accumulate,
+                                  void* stream) {
+  DG_REQUIRE(G && dot_partials && u && v && state && grad, "sn_grad_fix: null pointer");
+  DG_REQUIRE(Co > 0 && Kp > 0 && (Kp & 3) == 0 && nparts > 0, "sn_grad_fix: bad dims");
+  hipLaunchKernelGGL(sn_grad_fix_kernel, dim3(cdiv((long)Co * Kp / 4, 256)), dim3(256), 0, (hipStream_t)stream, G,
+                     dot_partials, nparts, u, v, state, grad, Co, Kp, accumulate);
+  return check_launch("sn_grad_fix");
+}

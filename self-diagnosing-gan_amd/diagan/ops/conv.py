@@ -1,0 +1,195 @@
+"""Convolution ops over the C ABI: implicit-GEMM forward / data-gradient / weight-gradient,
+spectral-norm power iteration and GEMM operand packing.
+
+All tensors are torch CUDA fp32.  Activations are NHWC ([B,H,W,C], C % 4 == 0); weights live in
+the packed layout Wp[Co][Kp], k = (r*S+s)*Ci + c, Kp = roundup(R*S*Ci, 32)."""
+import ctypes
+
+import torch
+
+from diagan import _native as nat
+
+P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
+nat.register("diagan_conv_gemm", [P, P, P, P, P, P, F, P, P, I, F] + [I] * 15 + [P])
+nat.register("diagan_conv_wgrad", [P, P, P, I, P, P, I] + [I] * 14 + [P])
+nat.register("diagan_conv_wgrad_splits", [I, I, I])
+nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
+nat.register("diagan_sn_power_iter", [P, P, P, P, P, P, P, I, I, F, I, P])
+nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
+nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
+
+PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Geom:
+    """Gather geometry of one convolution (see include/diagan_hip.h).
+
+    kind 'conv'  : y = conv2d(x, stride, pad)            fwd params (s,+1,-p,1)
+    kind 'convT' : y = conv_transpose2d(x, stride, pad)  fwd params (1,-1,+p,s)
+    The data-gradient of either kind is the other kind's gather with Ci/Co swapped."""
+
+    def __init__(self, kind, Ci, Co, R, S, stride=1, pad=0):
+        assert kind in ('conv', 'convT')
+        self.kind, self.Ci, self.Co, self.R, self.S, self.stride, self.pad = kind, Ci, Co, R, S, stride, pad
+        self.Kp = round_up(R * S * Ci, 32)      # packed forward/wgrad operand row
+        self.Kd = round_up(R * S * Co, 32)      # packed data-gradient operand row
+
+    def out_hw(self, Hi, Wi):
+        if self.kind == 'conv':
+            return ((Hi + 2 * self.pad - self.R) // self.stride + 1,
+                    (Wi + 2 * self.pad - self.S) // self.stride + 1)
+        return ((Hi - 1) * self.stride - 2 * self.pad + self.R, (Wi - 1) * self.stride - 2 * self.pad + self.S)
+
+    def fwd_params(self):
+        return (self.stride, 1, -self.pad, 1) if self.kind == 'conv' else (1, -1, self.pad, self.stride)
+
+    def dgrad_params(self):
+        return (1, -1, self.pad, self.stride) if self.kind == 'conv' else (self.stride, 1, -self.pad, 1)
+
+
+def _chk(t, name):
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise RuntimeError(f"{name}: expected a contiguous CUDA float32 tensor, got "
+                           f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg):
+    B, Hi, Wi, Ci = x.shape
+    _, Ho, Wo, Co = out.shape
+    mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
+    for t, n in ((x, 'x'), (w, 'w'), (out, 'out'), (bias, 'bias'), (residual, 'residual'),
+                 (mask_src, 'mask_src'), (scale, 'pro_scale'), (shift, 'pro_shift')):
+        _chk(t, n)
+    if w.shape != (Co, Kp):
+        raise RuntimeError(f"conv_gemm: packed weight shape {tuple(w.shape)} != ({Co}, {Kp})")
+    for t, n in ((residual, 'residual'), (mask_src, 'mask_src')):
+        if t is not None and t.shape != out.shape:
+            raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
+    sy, dr, off, up = geo_params
+    nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
+             nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
+             B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.current_stream())
+    return out
+
+
+def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0):
+    """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
+    B, Hi, Wi, Ci = x.shape
+    if Ci != geom.Ci:
+        raise RuntimeError(f"conv_fwd: input has {Ci} channels, layer expects {geom.Ci}")
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
+    return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, 1.0,
+                 tile_cfg)
+
+
+def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0):
+    """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci]."""
+    B, Ho, Wo, Co = dy.shape
+    if Co != geom.Co:
+        raise RuntimeError(f"conv_dgrad: dy has {Co} channels, layer has {geom.Co}")
+    Hi, Wi = in_hw
+    if out is None:
+        out = torch.empty((B, Hi, Wi, geom.Ci), dtype=torch.float32, device=dy.device)
+    return _gemm(dy, wd, out, geom.dgrad_params(), geom.R, geom.S, geom.Kd, None, residual, mask_src, mask_slope,
+                 None, 1.0, tile_cfg)
+
+
+_slabs = {}
+
+
+def _slab(dev, nfloat):
+    key = (dev.index, )
+    s = _slabs.get(key)
+    if s is None or s.numel() < nfloat:
+        s = torch.empty(max(nfloat, 1 << 22), dtype=torch.float32, device=dev)
+        _slabs[key] = s
+    return s
+
+
+def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
+    """grad[Co][Kp] (+)= d(loss)/d(Wp) given dy and the layer input x (prologue recomputed).
+
+    sn = (W_master, u, v, state): backward through W/sigma (diagan_sn_grad_fix)."""
+    B, Ho, Wo, Co = dy.shape
+    _, Hi, Wi, Ci = x.shape
+    mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
+    for t, n in ((dy, 'dy'), (x, 'x'), (grad, 'grad'), (scale, 'pro_scale'), (shift, 'pro_shift')):
+        _chk(t, n)
+    M = B * Ho * Wo
+    splits = nat.fn("diagan_conv_wgrad_splits")(M, Co, geom.Kp)
+    n_elem = Co * geom.Kp
+    extra = n_elem if sn is not None else 0
+    slab = _slab(dy.device, splits * n_elem + extra)
+    sy, dr, off, up = geom.fwd_params()
+    st = nat.current_stream()
+    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, nat.ptr(scale), nat.ptr(shift),
+             mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
+    if sn is None:
+        nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
+                 None, None, st)
+    else:
+        W, u, v, state = sn
+        G = slab[splits * n_elem: splits * n_elem + n_elem]
+        nparts = (n_elem // 4 + 255) // 256
+        parts = torch.empty(nparts, dtype=torch.float64, device=dy.device)
+        nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, G.data_ptr(), 0, nat.ptr(W),
+                 nat.ptr(parts), st)
+        nat.call("diagan_sn_grad_fix", G.data_ptr(), nat.ptr(parts), nparts, nat.ptr(u), nat.ptr(v),
+                 nat.ptr(state), nat.ptr(grad), Co, geom.Kp, 1 if accumulate else 0, st)
+    return grad
+
+
+def sn_power_iter(W, u_buffer, sigma_buffer, training=True, eps=1e-12):
+    """One torch_mimicry SpectralNorm step on packed W[Co][Kp]; returns (u, v, state[sigma, 1/sigma])."""
+    Co, Kp = W.shape
+    dev = W.device
+    u = torch.empty(Co, dtype=torch.float32, device=dev)
+    v = torch.empty(Kp, dtype=torch.float32, device=dev)
+    state = torch.empty(2, dtype=torch.float32, device=dev)
+    work = torch.empty(Kp + Co, dtype=torch.float32, device=dev)
+    nat.call("diagan_sn_power_iter", nat.ptr(W), nat.ptr(u_buffer), nat.ptr(sigma_buffer), nat.ptr(u), nat.ptr(v),
+             nat.ptr(state), nat.ptr(work), Co, Kp, eps, 1 if training else 0, nat.current_stream())
+    return u, v, state
+
+
+def pack_weights(W, Co, Ci, RS, Kp, Kd, inv_sigma=None, Wf=None, Wd=None):
+    nat.call("diagan_pack_weights", nat.ptr(W), nat.ptr(inv_sigma), nat.ptr(Wf), nat.ptr(Wd), Co, Ci, RS, Kp, Kd,
+             nat.current_stream())
+
+
+# ---- layout helpers (host/torch side, run at init / checkpoint time only) --------------------
+
+def pack_oihw(w_oihw, Kp, ci_pad=None):
+    """torch Conv2d weight [Co,Ci,R,S] -> packed [Co][Kp] (k = (r*S+s)*Ci' + c), zero padded."""
+    Co, Ci, R, S = w_oihw.shape
+    Cp = ci_pad or Ci
+    w = w_oihw.permute(0, 2, 3, 1)                      # [Co,R,S,Ci]
+    if Cp != Ci:
+        w = torch.nn.functional.pad(w, (0, Cp - Ci))
+    w = w.reshape(Co, R * S * Cp)
+    out = torch.zeros((Co, Kp), dtype=w.dtype, device=w.device)
+    out[:, : R * S * Cp] = w
+    return out
+
+
+def unpack_oihw(wp, Co, Ci, R, S, ci_pad=None):
+    Cp = ci_pad or Ci
+    w = wp[:, : R * S * Cp].reshape(Co, R, S, Cp)[..., :Ci]
+    return w.permute(0, 3, 1, 2).contiguous()
+
+
+def pack_iohw(w_iohw, Kp):
+    """torch ConvTranspose2d weight [Ci,Co,R,S] -> packed forward operand [Co][(r,s,ci)]."""
+    return pack_oihw(w_iohw.permute(1, 0, 2, 3), Kp)
+
+
+def unpack_iohw(wp, Ci, Co, R, S):
+    return unpack_oihw(wp, Co, Ci, R, S).permute(1, 0, 2, 3).contiguous()

@@ -1,0 +1,181 @@
+"""GPU: implicit-GEMM conv kernels (fwd / dgrad / wgrad, all gather modes, prologues, epilogues)
+against plain PyTorch CPU fp32 references of the same op (tolerance: fp32 accumulation order,
+rtol 1e-4 of the output scale)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=2e-4):
+    a, b = a.double().cpu(), b.double().cpu()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def ref_pro(x, mode, scale, shift):
+    if mode in (2, 4):
+        x = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if mode in (1, 2):
+        x = F.relu(x)
+    if mode == 3:
+        x = F.leaky_relu(x, 0.2)
+    return x
+
+
+CASES = [
+    # kind, B, H, W, Ci, Co, R, stride, pad
+    ("conv", 4, 16, 16, 32, 64, 3, 1, 1),
+    ("conv", 2, 8, 8, 128, 128, 3, 1, 1),
+    ("conv", 3, 5, 7, 4, 64, 3, 1, 1),          # ragged M, padded-RGB input
+    ("conv", 2, 16, 16, 64, 48, 3, 1, 1),        # Co not a tile multiple
+    ("conv", 2, 8, 8, 64, 128, 1, 1, 0),         # 1x1 shortcut conv
+    ("conv", 2, 16, 16, 16, 32, 3, 2, 1),        # DCGAN D strided conv
+    ("conv", 2, 16, 16, 48, 20, 3, 1, 1),        # K not a multiple of 32
+    ("convT", 2, 8, 8, 96, 48, 4, 2, 1),         # DCGAN G
+    ("convT", 4, 1, 1, 384, 192, 4, 1, 0),       # DCGAN G first layer
+    ("conv", 64, 4, 4, 256, 256, 3, 1, 1),
+]
+
+
+def make(kind, B, H, W, Ci, Co, R, stride, pad, seed=0):
+    from diagan.ops import conv as C
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    if kind == "conv":
+        w = torch.randn(Co, Ci, R, R, generator=g) / (Ci * R * R) ** 0.5
+    else:
+        w = torch.randn(Ci, Co, R, R, generator=g) / (Ci * R * R) ** 0.5
+    geom = C.Geom(kind, Ci, Co, R, R, stride, pad)
+    wp = (C.pack_oihw(w, geom.Kp) if kind == "conv" else C.pack_iohw(w, geom.Kp)).cuda()
+    return geom, x, w, wp
+
+
+def ref_fwd(kind, x, w, bias, stride, pad):
+    if kind == "conv":
+        return F.conv2d(x, w, bias, stride=stride, padding=pad)
+    return F.conv_transpose2d(x, w, bias, stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("pro", [0, 1, 2, 3])
+def test_fwd(case, pro):
+    from diagan.ops import conv as C
+    kind, B, H, W, Ci, Co, R, stride, pad = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(1)
+    bias = torch.randn(Co, generator=g)
+    scale = torch.rand(Ci, generator=g) + 0.5
+    shift = torch.randn(Ci, generator=g) * 0.3
+    ref = ref_fwd(kind, ref_pro(x, pro, scale, shift), w, bias, stride, pad)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(),
+                   pro=(pro, scale.cuda(), shift.cuda()))
+    close(nchw(y), ref + res)
+
+
+@pytest.mark.parametrize("tile_cfg", [1, 2, 3, 4])
+def test_fwd_all_tile_configs(tile_cfg):
+    from diagan.ops import conv as C
+    case = ("conv", 3, 9, 11, 64, 96, 3, 1, 1)
+    geom, x, w, wp = make(*case)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=tile_cfg)
+    close(nchw(y), ref_fwd("conv", x, w, None, 1, 1))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_dgrad_and_wgrad(case):
+    from diagan.ops import conv as C
+    kind, B, H, W, Ci, Co, R, stride, pad = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(2)
+    scale = torch.rand(Ci, generator=g) + 0.5
+    shift = torch.randn(Ci, generator=g) * 0.3
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    a = ref_pro(xr, 2, scale, shift)
+    a.retain_grad()
+    y = ref_fwd(kind, a, wr, None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    # dgrad: gradient w.r.t. the conv input a (after prologue)
+    wd = torch.zeros((Ci, geom.Kd), device="cuda")
+    C.pack_weights(wp, Co, Ci, R * R, geom.Kp, geom.Kd, Wd=wd)
+    dyd = nhwc(dy).cuda()
+    da = C.conv_dgrad(geom, dyd, wd, (H, W))
+    close(nchw(da), a.grad)
+    # with the ReLU-backward mask + residual epilogue
+    msrc = torch.randn(B, Ci, H, W, generator=g)
+    res = torch.randn(B, Ci, H, W, generator=g)
+    da2 = C.conv_dgrad(geom, dyd, wd, (H, W), residual=nhwc(res).cuda(), mask_src=nhwc(msrc).cuda())
+    close(nchw(da2), (a.grad + res) * (msrc > 0))
+    # wgrad (prologue recomputed from raw x), accumulate on top of an existing gradient
+    grad = torch.full((Co, geom.Kp), 0.5, device="cuda")
+    C.conv_wgrad(geom, dyd, nhwc(x).cuda(), grad, accumulate=True, pro=(2, scale.cuda(), shift.cuda()))
+    gw = (C.unpack_oihw(grad, Co, Ci, R, R) if kind == "conv" else C.unpack_iohw(grad, Ci, Co, R, R)) - 0.5
+    close(gw, wr.grad, tol=5e-4)
+    if geom.Kp > R * R * Ci:   # padded columns receive exactly zero gradient
+        assert torch.all(grad[:, R * R * Ci:] == 0.5)
+
+
+def test_full_size_sngan32_g_block4():
+    """BASELINE configs[1] dominant GEMM: M=65536, N=256, K=2304 (SNGAN G-32 block4.c1)."""
+    from diagan.ops import conv as C
+    case = ("conv", 64, 32, 32, 256, 256, 3, 1, 1)
+    geom, x, w, wp = make(*case)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp)
+    close(nchw(y), ref_fwd("conv", x, w, None, 1, 1))
+
+
+def test_spectral_norm_forward_backward():
+    """torch_mimicry SpectralNorm semantics: one power iteration, sigma = u W v^T, W/sigma used by
+    the conv, gradient through sigma with u, v constant."""
+    from diagan.ops import conv as C
+    Co, Ci, R = 64, 32, 3
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(Co, Ci, R, R, generator=g) * 0.1
+    u0 = torch.randn(1, Co, generator=g)
+    geom = C.Geom("conv", Ci, Co, R, R, 1, 1)
+    wp = C.pack_oihw(w, geom.Kp).cuda()
+    # reference (written from SURVEY §8 a8)
+    wr = w.clone().requires_grad_(True)
+    Wm = wr.view(Co, -1)
+    with torch.no_grad():
+        v = F.normalize(torch.matmul(u0, Wm), eps=1e-12)
+        u1 = F.normalize(torch.matmul(v, Wm.t()), eps=1e-12)
+    sigma = torch.mm(u1, torch.mm(Wm, v.t()))
+    w_sn = wr / sigma
+    x = torch.randn(2, Ci, 8, 8, generator=g)
+    y = F.conv2d(x, w_sn, None, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    # device
+    u_buf = u0.view(-1).clone().cuda()
+    s_buf = torch.ones(1, device="cuda")
+    u, vv, state = C.sn_power_iter(wp, u_buf, s_buf, training=True)
+    close(u.view(1, -1), u1, 1e-5)
+    close(u_buf.view(1, -1), u1, 1e-5)
+    assert abs(state[0].item() - sigma.item()) < 1e-5 * abs(sigma.item())
+    assert abs(s_buf.item() - sigma.item()) < 1e-5 * abs(sigma.item())
+    wf = torch.zeros_like(wp)
+    wd = torch.zeros((Ci, geom.Kd), device="cuda")
+    C.pack_weights(wp, Co, Ci, R * R, geom.Kp, geom.Kd, inv_sigma=state[1:], Wf=wf, Wd=wd)
+    yd = C.conv_fwd(geom, nhwc(x).cuda(), wf)
+    close(nchw(yd), y.detach(), 1e-4)
+    grad = torch.zeros_like(wp)
+    C.conv_wgrad(geom, nhwc(dy).cuda(), nhwc(x).cuda(), grad, accumulate=False, sn=(wp, u, vv, state))
+    close(C.unpack_oihw(grad, Co, Ci, R, R), wr.grad, 5e-4)
+    # eval mode must not touch the buffers
+    before = u_buf.clone()
+    C.sn_power_iter(wp, u_buf, s_buf, training=False)
+    assert torch.equal(before, u_buf)
