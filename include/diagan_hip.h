@@ -67,12 +67,12 @@ int diagan_logit_scatter(const float* logit, const int64_t* idx, int64_t n, void
 
 /* Forward conv / transposed conv / data-gradient:
  *   y[b,oy,ox,n] = epi(out_scale * sum_{r,s,c} pro(x[b,iy,ix,c]) * w[n][(r*S+s)*Ci+c])
- *   epi: + bias[n], + residual, then (mask_src > 0 ? v : mask_slope*v).
+ *   epi: + bias[n], + residual (or max(residual,0) if res_relu), then (mask_src > 0 ? v : mask_slope*v).
  * Replaces F.conv2d / nn.ConvTranspose2d forward and their input gradient
  * (SNGAN blocks: SURVEY §8 a2-a7; DCGAN: diagan-pkg/diagan/models/mnist.py:55-71,163-190).
  * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto. */
 int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
-                     const float* residual, const float* mask_src, float mask_slope,
+                     const float* residual, int res_relu, const float* mask_src, float mask_slope,
                      const float* pro_scale, const float* pro_shift, int pro_mode, float out_scale,
                      int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                      int dr, int off, int up, int Kp, int tile_cfg, void* stream);
@@ -112,6 +112,74 @@ int diagan_pack_weights(const float* W, const float* inv_sigma, float* Wf, float
 int diagan_sn_grad_fix(const float* G, const double* dot_partials, int nparts, const float* u,
                        const float* v, const float* state, float* grad, int Co, int Kp,
                        int accumulate, void* stream);
+
+/* ---- HBM-bound layers between the convolutions (NHWC fp32, C % 4 == 0) ------------------- */
+
+/* NCHW [B,C,H,W] <-> NHWC [B,H,W,Cp] (zero padded channels): the dataloader / generate_images
+ * boundary (reference tensors are NCHW: diagan-pkg/diagan/datasets/transform.py:9-10). */
+int diagan_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);
+int diagan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);
+
+/* torch.tanh at the generator output and its backward gx = g*(1-y^2). */
+int diagan_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int diagan_tanh_bwd(const float* y, const float* g, float* gx, int64_t n, void* stream);
+
+/* bytes of scratch for the column reductions below */
+int64_t diagan_colred_workspace(int64_t M, int C);
+
+/* nn.BatchNorm2d statistics over x[M][C] (training: batch stats + running-stat update with
+ * unbiased variance; eval: running stats).  Emits mean/invstd and the affine form
+ * scale = gamma*invstd, shift = beta - mean*scale consumed by the conv prologue. */
+int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, int training,
+                    float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                    void* workspace, void* stream);
+
+/* Backward of [BatchNorm -> optional ReLU]: dx (+ residual), dgamma/dbeta (+)=.  coef: 2*C floats. */
+int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, const float* scale, const float* shift,
+                  const float* mean, const float* invstd, int relu, float* dgamma, float* dbeta,
+                  int accumulate_param_grads, const float* residual, float* dx, float* coef,
+                  void* workspace, void* stream);
+
+/* out[c] (+)= sum_m x[m][c]  (bias gradients). */
+int diagan_colsum(const float* x, int64_t M, int C, float* out, int accumulate, void* workspace, void* stream);
+
+/* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) with the conv prologue
+ * modes applied to the source pixels, and its adjoint (+ residual). x [B,H,W,C] -> [B,2H,2W,C]. */
+int diagan_upsample2x(const float* x, float* out, int B, int H, int W, int C, int pro_mode,
+                      const float* scale, const float* shift, void* stream);
+int diagan_upsample2x_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
+                          void* stream);
+
+/* F.avg_pool2d(x, 2) (+ residual at the pooled resolution) and its adjoint (+ residual). H, W = input size. */
+int diagan_avgpool2(const float* x, float* out, int B, int H, int W, int C, const float* residual, void* stream);
+int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
+                        void* stream);
+
+/* SNGAN discriminator head: pooled = sum_hw relu(x); logit = inv_sigma * pooled.w + bias
+ * (torch.sum(activation(h), dim=(2,3)) -> SNLinear(C, 1)). */
+int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* bias, float* pooled,
+                    float* logit, int B, int HW, int C, void* stream);
+/* gx = dlogit*w*inv_sigma*(x>0) (if gx); G[c] = sum_b dlogit*pooled, dot = <G,w>, dbias (if G). */
+int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* x,
+                    const float* pooled, float* gx, float* G, double* dot, float* dbias, int accumulate_bias,
+                    int B, int HW, int C, void* stream);
+
+int diagan_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+/* ---- loss heads and optimiser ---------------------------------------------------------------- */
+
+/* loss types: 0 'gan', 1 'ns', 2 'hinge', 3 'wasserstein' (torch_mimicry.modules.losses).
+ * Discriminator: out3 = {errD, D(x), D(G(z))}; d_real/d_fake = dL/dlogit.  gold: GOLD re-weighting
+ * of the fake term (diagan-pkg/diagan/models/gold_reweight_models.py:10-61). */
+int diagan_loss_dis(const float* out_real, int n_real, const float* out_fake, int n_fake, int loss_type,
+                    int gold, float* d_real, float* d_fake, float* out3, void* stream);
+/* Generator loss over the k largest logits (TopKGenerator.get_topk, topk_models.py:31-38; k = n: all). */
+int diagan_loss_gen(const float* out_fake, int n, int k, int loss_type, float* d_fake, float* out1, void* stream);
+
+/* torch.optim.Adam.step on one flat buffer (predefined_models.py:32,51,70,89,114,123). */
+int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, void* stream);
 
 #ifdef __cplusplus
 }

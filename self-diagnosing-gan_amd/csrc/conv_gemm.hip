@@ -33,6 +33,7 @@ struct ConvGemmArgs {
   const float* pro_shift;
   float mask_slope;       // 0 for ReLU backward, 0.2 for LeakyReLU backward
   float out_scale;        // multiplies the accumulator before bias/residual (1.0 normally)
+  int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
   int pro_mode;
   int M;                  // B*Ho*Wo
   ConvGeom g;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         if (m >= a.M) continue;
         const long o = (long)m * g.Co + n;
         float v = acc[i][j][e] * a.out_scale + bv;
-        if (a.residual) v += a.residual[o];
+        if (a.residual) { const float r = a.residual[o]; v += a.res_relu ? fmaxf(r, 0.f) : r; }
         if (a.mask_src) v = a.mask_src[o] > 0.f ? v : v * a.mask_slope;
         a.y[o] = v;
       }
@@ -198,7 +199,7 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, a);
@@ -211,7 +212,7 @@ using namespace diagan;
 
 // see include/diagan_hip.h
 DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
-                                const float* residual, const float* mask_src, float mask_slope,
+                                const float* residual, int res_relu, const float* mask_src, float mask_slope,
                                 const float* pro_scale, const float* pro_shift, int pro_mode,
                                 float out_scale, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                 int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
@@ -229,7 +230,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_src = mask_src;
   a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.mask_slope = mask_slope; a.out_scale = out_scale;
-  a.pro_mode = pro_mode; a.M = B * Ho * Wo;
+  a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   hipStream_t st = (hipStream_t)stream;
   // tile selection: 0 = auto

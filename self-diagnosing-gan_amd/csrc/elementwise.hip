@@ -1,0 +1,576 @@
+// HBM-bound kernels of the SNGAN / DCGAN stacks: layout conversion at the NCHW boundary,
+// BatchNorm statistics / backward, bilinear 2x upsample (fwd + adjoint), 2x2 average pool
+// (fwd + adjoint), the discriminator head (ReLU + global sum pool + SN linear), bias gradients.
+//
+// They replace the ATen ops between the convolutions of torch_mimicry's GBlock / DBlock /
+// DBlockOptimized and the SNGAN heads: nn.BatchNorm2d (batch statistics),
+// F.interpolate(scale_factor=2, mode='bilinear', align_corners=False), F.avg_pool2d(x, 2),
+// torch.sum(h, dim=(2,3)), torch.tanh, nn.ReLU, and the matching autograd backward formulas.
+//
+// Everything is NHWC fp32 with C % 4 == 0, processed as float4 (16 B per lane, coalesced).
+// Reductions are two-stage with fp64 partials combined in a fixed order: deterministic, no atomics.
+// Roofline: HBM (each kernel reads its inputs once and writes its outputs once).
+#include "conv_common.h"
+
+namespace diagan {
+
+constexpr int EW_T = 256;
+static inline int ew_blocks(long n) {
+  long b = (n + EW_T - 1) / EW_T;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));  // grid-stride beyond 8192 blocks
+}
+
+// ---- layout conversion at the API boundary ---------------------------------------------------
+// dst[b,h,w,0..Cp) = src[b,0..C,h,w] (zero padded channels)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, long npix, int HW, int C,
+                                    int Cp) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / HW, hw = p - b * HW;
+    for (int c = 0; c < Cp; ++c) dst[p * Cp + c] = c < C ? src[(b * C + c) * HW + hw] : 0.f;
+  }
+}
+// dst[b,c,h,w] = src[b,h,w,c], c < C
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, long npix, int HW, int C,
+                                    int Cp) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+    const long b = p / HW, hw = p - b * HW;
+    for (int c = 0; c < C; ++c) dst[(b * C + c) * HW + hw] = src[p * Cp + c];
+  }
+}
+
+// mode 0: y = tanh(x) ; mode 1 (backward): y = g * (1 - t*t) with t = tanh output (in `x`)
+__global__ void tanh_kernel(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ y, long n4,
+                            int mode) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (mode == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = tanhf(v[e]);
+    } else {
+      const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+      v = gv * (1.f - v * v);
+    }
+    reinterpret_cast<f32x4*>(y)[i] = v;
+  }
+}
+
+// ---- column reductions over [M][C] ------------------------------------------------------------
+// Stage 1: thread = (row lane, float4 column); block (CW columns x RL row lanes) reduces a row range.
+// MODE 0: {sum x, sum x^2}            (BatchNorm statistics)
+// MODE 1: {sum g', sum g' * xhat}     (BatchNorm backward; g' = g masked by the ReLU after BN)
+// MODE 2: {sum x, -}                  (bias gradient)
+struct ColRedArgs {
+  const float* x;      // MODE 0/2: input ; MODE 1: pre-BN activation
+  const float* g;      // MODE 1: upstream gradient
+  const float* scale;  // MODE 1: gamma*invstd
+  const float* shift;  // MODE 1: beta - mean*scale
+  const float* mean;
+  const float* invstd;
+  double* partials;    // [splits][2][C]
+  long M;
+  int C;
+  int rows_per_split;
+  int relu;            // MODE 1: mask g by (scale*x+shift > 0)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
+  __shared__ double red[2][EW_T][4];
+  const int C4 = a.C >> 2;
+  const int CW = C4 < 64 ? C4 : 64;          // float4 columns per block
+  const int RL = EW_T / CW;                  // row lanes
+  const int cc = threadIdx.x % CW, rl = threadIdx.x / CW;
+  const int c4 = blockIdx.x * CW + cc;
+  const bool col_ok = c4 < C4 && rl < RL;
+  const long r0 = (long)blockIdx.y * a.rows_per_split;
+  const long r1 = r0 + a.rows_per_split < a.M ? r0 + a.rows_per_split : a.M;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (col_ok) {
+    f32x4 sc, sh, mu, is;
+    if (MODE == 1) {
+      sc = reinterpret_cast<const f32x4*>(a.scale)[c4];
+      sh = reinterpret_cast<const f32x4*>(a.shift)[c4];
+      mu = reinterpret_cast<const f32x4*>(a.mean)[c4];
+      is = reinterpret_cast<const f32x4*>(a.invstd)[c4];
+    }
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const f32x4 xv = reinterpret_cast<const f32x4*>(a.x)[r * C4 + c4];
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += xv[e]; s2[e] += (double)xv[e] * xv[e]; }
+      } else if (MODE == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[e] += xv[e];
+      } else {
+        f32x4 gv = reinterpret_cast<const f32x4*>(a.g)[r * C4 + c4];
+        const f32x4 xh = (xv - mu) * is;
+        if (a.relu) {
+          const f32x4 y = xv * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] += gv[e]; s2[e] += (double)gv[e] * xh[e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+  __syncthreads();
+  if (rl == 0 && c4 < C4) {
+    double t1[4] = {0, 0, 0, 0}, t2[4] = {0, 0, 0, 0};
+    for (int k = 0; k < RL; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t1[e] += red[0][k * CW + cc][e]; t2[e] += red[1][k * CW + cc][e]; }
+    double* p = a.partials + (long)blockIdx.y * 2 * a.C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[c4 * 4 + e] = t1[e]; p[a.C + c4 * 4 + e] = t2[e]; }
+  }
+}
+
+// BatchNorm forward finalize: batch statistics -> affine form + running stats (momentum 0.1, unbiased var)
+__global__ void bn_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < splits; ++k) { s1 += partials[(long)k * 2 * C + c]; s2 += partials[(long)k * 2 * C + C + c]; }
+    const double m = s1 / (double)M;
+    double v = s2 / (double)M - m * m;
+    v = v < 0 ? 0 : v;
+    mean = (float)m;
+    var = (float)v;
+    const float unbiased = M > 1 ? (float)(v * (double)M / (double)(M - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float invstd = 1.f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  mean_out[c] = mean;
+  invstd_out[c] = invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - mean * sc;
+}
+
+// BatchNorm backward finalize: dgamma += s2, dbeta += s1, coef = {s1/M, s2/M}
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int k = 0; k < splits; ++k) { s1 += partials[(long)k * 2 * C + c]; s2 += partials[(long)k * 2 * C + C + c]; }
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  coef[c] = (float)(s1 / (double)M);
+  coef[C + c] = (float)(s2 / (double)M);
+}
+
+__global__ void colsum_finalize_kernel(const double* __restrict__ partials, int splits, int C, float* __restrict__ out,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int k = 0; k < splits; ++k) s += partials[(long)k * 2 * C + c];
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+}
+
+// dx = scale * (g' - c1 - xhat*c2) (+ residual)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ coef, const float* __restrict__ residual,
+                                    float* __restrict__ out, long M, int C, int relu) {
+  const int C4 = C >> 2;
+  const long n4 = M * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4];
+    const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
+    const f32x4 k1 = reinterpret_cast<const f32x4*>(coef)[c4];
+    const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + C)[c4];
+    if (relu) {
+      const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
+      const f32x4 y = xv * sc + sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : 0.f;
+    }
+    f32x4 o = sc * (gv - k1 - (xv - mu) * is * k2);
+    if (residual) o += reinterpret_cast<const f32x4*>(residual)[i];
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// ---- bilinear 2x upsample (align_corners=False) and its adjoint ---------------------------------
+// out[2j]   = 0.25*x[max(j-1,0)] + 0.75*x[j] ; out[2j+1] = 0.75*x[j] + 0.25*x[min(j+1,H-1)]
+__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
+                                  int pro_mode, const float* __restrict__ scale, const float* __restrict__ shift) {
+  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
+  const long n4 = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const int jy = oy >> 1, jx = ox >> 1;
+    const int y0 = (oy & 1) ? jy : max(jy - 1, 0), y1 = (oy & 1) ? min(jy + 1, H - 1) : jy;
+    const int x0 = (ox & 1) ? jx : max(jx - 1, 0), x1 = (ox & 1) ? min(jx + 1, W - 1) : jx;
+    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+    const float wy1 = 1.f - wy0, wx1 = 1.f - wx0;
+    const float* base = x + (long)b * H * W * C + c4 * 4;
+    auto ld = [&](int yy, int xx) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(base + ((long)yy * W + xx) * C);
+      return apply_pro(v, pro_mode, scale, shift, c4 * 4);
+    };
+    // PyTorch evaluates (w0*a + w1*b) along x inside the y blend; same grouping here
+    const f32x4 top = wx0 * ld(y0, x0) + wx1 * ld(y0, x1);
+    const f32x4 bot = wx0 * ld(y1, x0) + wx1 * ld(y1, x1);
+    reinterpret_cast<f32x4*>(out)[i] = wy0 * top + wy1 * bot;
+  }
+}
+
+// adjoint: gx[j] = 0.25*g[clamp(2j-1)] + 0.75*g[2j] + 0.75*g[2j+1] + 0.25*g[clamp(2j+2)]
+__global__ void upsample2x_bwd_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int H, int W, int C,
+                                      const float* __restrict__ residual) {
+  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
+  const long n4 = (long)B * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int jx = (int)(p % W); p /= W;
+    const int jy = (int)(p % H);
+    const int b = (int)(p / H);
+    const float* base = g + (long)b * Ho * Wo * C + c4 * 4;
+    const float wt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      const int yy = min(max(2 * jy - 1 + dy, 0), Ho - 1);
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dx = 0; dx < 4; ++dx) {
+        const int xx = min(max(2 * jx - 1 + dx, 0), Wo - 1);
+        row += wt[dx] * *reinterpret_cast<const f32x4*>(base + ((long)yy * Wo + xx) * C);
+      }
+      acc += wt[dy] * row;
+    }
+    if (residual) acc += reinterpret_cast<const f32x4*>(residual)[i];
+    reinterpret_cast<f32x4*>(out)[i] = acc;
+  }
+}
+
+// ---- 2x2 average pool and its adjoint ----------------------------------------------------------
+__global__ void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
+                                const float* __restrict__ residual) {
+  const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long n4 = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const float* base = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + c4 * 4;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + C);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(base + (long)W * C);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(base + (long)W * C + C);
+    f32x4 o = ((a0 + a1) + (a2 + a3)) * 0.25f;
+    if (residual) o += reinterpret_cast<const f32x4*>(residual)[i];
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// out[b,y,x,c] = 0.25*g[b,y/2,x/2,c] (+ residual)
+__global__ void avgpool2_bwd_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int H, int W, int C,
+                                    const float* __restrict__ residual) {
+  const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const long n4 = (long)B * H * W * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    f32x4 o = reinterpret_cast<const f32x4*>(g)[(((long)b * Ho + (yy >> 1)) * Wo + (xx >> 1)) * C4 + c4] * 0.25f;
+    if (residual) o += reinterpret_cast<const f32x4*>(residual)[i];
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+// ---- discriminator head: ReLU -> sum over H,W -> (SN) linear to one logit ----------------------
+// pooled[b][c] = sum_hw relu(x[b,hw,c])           grid (C4/64, B)
+__global__ __launch_bounds__(EW_T) void relu_sumpool_kernel(const float* __restrict__ x, float* __restrict__ pooled,
+                                                            int HW, int C) {
+  __shared__ float red[EW_T][4];
+  const int C4 = C >> 2;
+  const int CW = C4 < 64 ? C4 : 64, RL = EW_T / CW;
+  const int cc = threadIdx.x % CW, rl = threadIdx.x / CW;
+  const int c4 = blockIdx.x * CW + cc, b = blockIdx.y;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < C4 && rl < RL)
+    for (int r = rl; r < HW; r += RL) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(x)[((long)b * HW + r) * C4 + c4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += fmaxf(v[e], 0.f);
+    }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[threadIdx.x][e] = s[e];
+  __syncthreads();
+  if (rl == 0 && c4 < C4) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < RL; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] += red[k * CW + cc][e];
+    reinterpret_cast<f32x4*>(pooled)[(long)b * C4 + c4] = t;
+  }
+}
+
+// logit[b] = inv_sigma * sum_c pooled[b][c]*w[c] + bias        (one wave per sample)
+__global__ void head_linear_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
+                                   const float* __restrict__ inv_sigma, const float* __restrict__ bias,
+                                   float* __restrict__ logit, int B, int C) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(pooled[(long)b * C + c], w[c], s);
+  s = wave_sum(s);
+  if (lane == 0) logit[b] = s * (inv_sigma ? inv_sigma[0] : 1.f) + (bias ? bias[0] : 0.f);
+}
+
+// gx[b,hw,c] = dlogit[b] * w[c] * inv_sigma * (x > 0)
+__global__ void head_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
+                                const float* __restrict__ inv_sigma, const float* __restrict__ x,
+                                float* __restrict__ gx, long n4, int HW, int C) {
+  const int C4 = C >> 2;
+  const float inv = inv_sigma ? inv_sigma[0] : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long b = i / ((long)C4 * HW);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 wv = reinterpret_cast<const f32x4*>(w)[c4];
+    const float d = dlogit[b] * inv;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = xv[e] > 0.f ? d * wv[e] : 0.f;
+    reinterpret_cast<f32x4*>(gx)[i] = o;
+  }
+}
+
+// single block: G[c] = sum_b dlogit[b]*pooled[b][c]; dot = <G, w>; dbias (+)= sum_b dlogit[b]
+__global__ __launch_bounds__(EW_T) void head_wgrad_kernel(const float* __restrict__ dlogit, const float* __restrict__ pooled,
+                                                          const float* __restrict__ w, float* __restrict__ G,
+                                                          double* __restrict__ dot, float* __restrict__ dbias, int B,
+                                                          int C, int accumulate_bias) {
+  __shared__ double red[4];
+  double d = 0.0;
+  for (int c = threadIdx.x; c < C; c += EW_T) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(dlogit[b], pooled[(long)b * C + c], s);
+    G[c] = s;
+    d += (double)s * w[c];
+  }
+  d = wave_sum(d);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dot[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (dbias) {
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += dlogit[b];
+      dbias[0] = (accumulate_bias ? dbias[0] : 0.f) + s;
+    }
+  }
+}
+
+// out = a + b (float4)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+}
+
+static int colred_geometry(long M, int C, int* splits, int* rows_per_split, dim3* grid) {
+  const int C4 = C / 4;
+  const int CW = C4 < 64 ? C4 : 64;
+  const int gx = cdiv(C4, CW);
+  int s = cdiv(1024, gx);                       // ~4 blocks per CU in total
+  const long max_s = (M + 63) / 64;             // at least 64 rows per split
+  if (s > max_s) s = (int)max_s;
+  if (s < 1) s = 1;
+  *rows_per_split = (int)((M + s - 1) / s);
+  *splits = (int)((M + *rows_per_split - 1) / *rows_per_split);
+  *grid = dim3(gx, *splits);
+  return 0;
+}
+
+}  // namespace diagan
+
+using namespace diagan;
+
+#define ST ((hipStream_t)stream)
+
+DIAGAN_API int diagan_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+  DG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_nhwc: bad args");
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_blocks(npix)), dim3(EW_T), 0, ST, src, dst, npix, H * W, C, Cp);
+  return check_launch("nchw_to_nhwc");
+}
+
+DIAGAN_API int diagan_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+  DG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nhwc_to_nchw: bad args");
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_blocks(npix)), dim3(EW_T), 0, ST, src, dst, npix, H * W, C, Cp);
+  return check_launch("nhwc_to_nchw");
+}
+
+DIAGAN_API int diagan_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+  DG_REQUIRE(x && y && n > 0 && (n & 3) == 0, "tanh_fwd: bad args");
+  hipLaunchKernelGGL(tanh_kernel, dim3(ew_blocks(n / 4)), dim3(EW_T), 0, ST, x, nullptr, y, (long)(n / 4), 0);
+  return check_launch("tanh_fwd");
+}
+
+DIAGAN_API int diagan_tanh_bwd(const float* y, const float* g, float* gx, int64_t n, void* stream) {
+  DG_REQUIRE(y && g && gx && n > 0 && (n & 3) == 0, "tanh_bwd: bad args");
+  hipLaunchKernelGGL(tanh_kernel, dim3(ew_blocks(n / 4)), dim3(EW_T), 0, ST, y, g, gx, (long)(n / 4), 1);
+  return check_launch("tanh_bwd");
+}
+
+// workspace: diagan_colred_workspace(M, C) bytes
+DIAGAN_API int64_t diagan_colred_workspace(int64_t M, int C) {
+  int splits, rps;
+  dim3 grid;
+  colred_geometry(M, C, &splits, &rps, &grid);
+  return (int64_t)splits * 2 * C * sizeof(double);
+}
+
+DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, int training,
+                               float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                               void* workspace, void* stream) {
+  DG_REQUIRE(x && gamma && beta && running_mean && running_var && mean_out && invstd_out && scale_out && shift_out,
+             "bn_stats: null pointer");
+  DG_REQUIRE(M > 0 && C > 0 && (C & 3) == 0, "bn_stats: bad dims M=%ld C=%d", (long)M, C);
+  int splits = 0, rps = 0;
+  dim3 grid;
+  if (training) {
+    DG_REQUIRE(workspace, "bn_stats: workspace required in training mode");
+    colred_geometry(M, C, &splits, &rps, &grid);
+    ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0};
+    hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(EW_T), 0, ST, a);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, (const double*)workspace, splits, C,
+                     (long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
+                     shift_out, training);
+  return check_launch("bn_stats");
+}
+
+// dx = BN_backward(relu_backward(g)); dgamma/dbeta (+)=.  coef: 2*C floats scratch.
+DIAGAN_API int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, int relu, float* dgamma, float* dbeta,
+                             int accumulate_param_grads, const float* residual, float* dx, float* coef,
+                             void* workspace, void* stream) {
+  DG_REQUIRE(g && x && scale && shift && mean && invstd && dgamma && dbeta && dx && coef && workspace,
+             "bn_bwd: null pointer");
+  DG_REQUIRE(M > 0 && C > 0 && (C & 3) == 0, "bn_bwd: bad dims");
+  int splits, rps;
+  dim3 grid;
+  colred_geometry(M, C, &splits, &rps, &grid);
+  ColRedArgs a{x, g, scale, shift, mean, invstd, (double*)workspace, (long)M, C, rps, relu};
+  hipLaunchKernelGGL(colred_kernel<1>, grid, dim3(EW_T), 0, ST, a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, (const double*)workspace, splits,
+                     C, (long)M, dgamma, dbeta, coef, accumulate_param_grads);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4))), dim3(EW_T), 0, ST, g, x, scale, shift, mean,
+                     invstd, coef, residual, dx, (long)M, C, relu);
+  return check_launch("bn_bwd");
+}
+
+DIAGAN_API int diagan_colsum(const float* x, int64_t M, int C, float* out, int accumulate, void* workspace,
+                             void* stream) {
+  DG_REQUIRE(x && out && workspace && M > 0 && C > 0 && (C & 3) == 0, "colsum: bad args");
+  int splits, rps;
+  dim3 grid;
+  colred_geometry(M, C, &splits, &rps, &grid);
+  ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0};
+  hipLaunchKernelGGL(colred_kernel<2>, grid, dim3(EW_T), 0, ST, a);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, (const double*)workspace, splits, C,
+                     out, accumulate);
+  return check_launch("colsum");
+}
+
+DIAGAN_API int diagan_upsample2x(const float* x, float* out, int B, int H, int W, int C, int pro_mode,
+                                 const float* scale, const float* shift, void* stream) {
+  DG_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "upsample2x: bad args");
+  DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "upsample2x: bad pro_mode");
+  DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (scale && shift), "upsample2x: affine needs scale/shift");
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(EW_T), 0, ST, x, out, B, H, W, C,
+                     pro_mode, scale, shift);
+  return check_launch("upsample2x");
+}
+
+DIAGAN_API int diagan_upsample2x_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
+                                     void* stream) {
+  DG_REQUIRE(g && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "upsample2x_bwd: bad args");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(EW_T), 0, ST, g, out, B, H,
+                     W, C, residual);
+  return check_launch("upsample2x_bwd");
+}
+
+DIAGAN_API int diagan_avgpool2(const float* x, float* out, int B, int H, int W, int C, const float* residual,
+                               void* stream) {
+  DG_REQUIRE(x && out && B > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0 && C > 0 && (C & 3) == 0,
+             "avgpool2: bad args (even H, W required)");
+  hipLaunchKernelGGL(avgpool2_kernel, dim3(ew_blocks((long)B * H * W * C / 16)), dim3(EW_T), 0, ST, x, out, B, H, W, C,
+                     residual);
+  return check_launch("avgpool2");
+}
+
+DIAGAN_API int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
+                                   void* stream) {
+  DG_REQUIRE(g && out && B > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0 && C > 0 && (C & 3) == 0,
+             "avgpool2_bwd: bad args");
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(EW_T), 0, ST, g, out, B, H, W,
+                     C, residual);
+  return check_launch("avgpool2_bwd");
+}
+
+DIAGAN_API int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* bias,
+                               float* pooled, float* logit, int B, int HW, int C, void* stream) {
+  DG_REQUIRE(x && w && pooled && logit && B > 0 && HW > 0 && C > 0 && (C & 3) == 0, "head_fwd: bad args");
+  const int C4 = C / 4, CW = C4 < 64 ? C4 : 64;
+  hipLaunchKernelGGL(relu_sumpool_kernel, dim3(cdiv(C4, CW), B), dim3(EW_T), 0, ST, x, pooled, HW, C);
+  hipLaunchKernelGGL(head_linear_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ST, pooled, w, inv_sigma, bias, logit, B, C);
+  return check_launch("head_fwd");
+}
+
+DIAGAN_API int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* x,
+                               const float* pooled, float* gx, float* G, double* dot, float* dbias,
+                               int accumulate_bias, int B, int HW, int C, void* stream) {
+  DG_REQUIRE(dlogit && w && x && B > 0 && HW > 0 && C > 0 && (C & 3) == 0, "head_bwd: bad args");
+  if (gx) {
+    const long n4 = (long)B * HW * C / 4;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, dlogit, w, inv_sigma, x, gx, n4, HW, C);
+  }
+  if (G) {
+    DG_REQUIRE(pooled && dot, "head_bwd: weight gradient needs pooled and dot");
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(1), dim3(EW_T), 0, ST, dlogit, pooled, w, G, dot, dbias, B, C,
+                       accumulate_bias);
+  }
+  return check_launch("head_bwd");
+}
+
+DIAGAN_API int diagan_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+  DG_REQUIRE(a && b && out && n > 0 && (n & 3) == 0, "add: bad args");
+  hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n / 4)), dim3(EW_T), 0, ST, a, b, out, (long)(n / 4));
+  return check_launch("add");
+}

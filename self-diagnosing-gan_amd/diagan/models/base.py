@@ -1,0 +1,159 @@
+"""Model protocol of the hot path: the methods LogTrainer calls on netG / netD
+(diagan-pkg/diagan/trainer/trainer.py:257-291; contract listed in SURVEY §8(b)).
+
+These mirror torch_mimicry's BaseGenerator / BaseDiscriminator / BaseModel (the reference imports
+them at diagan-pkg/diagan/models/mnist.py:4 and through torch_mimicry.nets.sngan): same method
+names, argument names and return values; the bodies run on the HIP engine with an explicit
+backward instead of autograd.
+"""
+import os
+
+import torch
+
+from diagan.models.layers import FlatNet
+from diagan.ops import eltwise as E
+
+
+class BaseModel(FlatNet):
+    """Checkpoint I/O with mimicry's file layout: {model_state_dict, optimizer_state_dict,
+    global_step} at <directory>/<basename(directory)>_<step>_steps.pth (consumers:
+    train_mimicry_phase1.py:97-98, train_mimicry_phase2.py:98-101)."""
+
+    def restore_checkpoint(self, ckpt_file, optimizer=None):
+        if not ckpt_file:
+            raise ValueError("No checkpoint file to be restored.")
+        try:
+            ckpt_dict = torch.load(ckpt_file, weights_only=False)
+        except RuntimeError:
+            ckpt_dict = torch.load(ckpt_file, map_location=lambda storage, loc: storage, weights_only=False)
+        self.load_state_dict(ckpt_dict['model_state_dict'])
+        self.param_version += 1
+        if optimizer:
+            optimizer.load_state_dict(ckpt_dict['optimizer_state_dict'])
+        return ckpt_dict['global_step']
+
+    def save_checkpoint(self, directory, global_step, optimizer=None, name=None):
+        if not os.path.exists(directory):
+            os.makedirs(directory)
+        ckpt_dict = {
+            'model_state_dict': self.state_dict(),
+            'optimizer_state_dict': optimizer.state_dict() if optimizer is not None else None,
+            'global_step': global_step,
+        }
+        if name is None:
+            name = "{}_{}_steps.pth".format(os.path.basename(directory), global_step)
+        torch.save(ckpt_dict, os.path.join(directory, name))
+
+    def count_params(self):
+        return FlatNet.count_params(self)
+
+    def sync_grads(self):
+        """Data-parallel gradient exchange: ONE all-reduce (mean) of the network's flat gradient
+        slab over RCCL/xGMI (pattern: DistributedDataParallel in stylegan2/train_ffhq.py:572-585)."""
+        from diagan.trainer import distributed as dist
+        dist.all_reduce_mean_(self.flat_grads)
+
+
+class BaseGenerator(BaseModel):
+    def __init__(self, nz, ngf, bottom_width, loss_type, **kwargs):
+        super().__init__()
+        self.nz, self.ngf, self.bottom_width, self.loss_type = nz, ngf, bottom_width, loss_type
+
+    # -- subclasses implement: forward_nhwc(z, training, save) -> (img NHWC4, ctx); backward_nhwc(ctx, g)
+    def forward(self, x):
+        """noise [n, nz] -> images NCHW [n, 3, H, W] (reference-visible tensor layout)."""
+        img, _ = self.forward_nhwc(x, self.training, save=False)
+        return E.nhwc_to_nchw(img, self.out_channels)
+
+    def generate_images(self, num_images, device=None, noise=None):
+        if device is None:
+            device = self.device
+        if noise is None:
+            noise = torch.randn((num_images, self.nz), device=device)
+        return self.forward(noise)
+
+    def generate_images_nhwc(self, num_images, device=None, noise=None, save=False):
+        if device is None:
+            device = self.device
+        if noise is None:
+            noise = torch.randn((num_images, self.nz), device=device)
+        return self.forward_nhwc(noise, self.training, save=save)
+
+    def compute_gan_loss(self, output):
+        k = None
+        if getattr(self, 'use_topk', False):
+            k = int(self.topk_rate * output.shape[0])
+        errG, _ = E.loss_gen(output.detach().contiguous(), self.loss_type, k=k, need_grad=False)
+        return errG[0]
+
+    def train_step(self, real_batch, netD, optG, log_data, device=None, global_step=None, scaler=None, noise=None,
+                   **kwargs):
+        """One G update (restated base step, topk_models.py:46-116 / mnist.py:82-152)."""
+        if scaler is not None:
+            raise NotImplementedError("amp/GradScaler is not part of the fp32 MI355X path")
+        self.zero_grad()
+        batch_size = real_batch[0].shape[0]
+        fake, gctx = self.generate_images_nhwc(batch_size, device=device, noise=noise, save=True)
+        output, dctx = netD.forward_nhwc(fake, netD.training, save=True, need_dgrad=True, need_in_dgrad=True)
+        k = None
+        if getattr(self, 'use_topk', False):          # get_topk, topk_models.py:31-38
+            k = int(self.topk_rate * batch_size)
+        errG, dlogit = E.loss_gen(output, self.loss_type, k=k)
+        # backward: through D to the images (D's own weight gradients are dead values in the
+        # reference -- zeroed at the next D step before use -- so they are not computed), then G
+        g_img = netD.backward_nhwc(dctx, dlogit, need_wgrad=False, need_gx=True)
+        self.backward_nhwc(gctx, g_img)
+        self.sync_grads()
+        optG.step()
+        log_data.add_metric('errG', errG[0], group='loss')
+        return log_data
+
+
+class BaseDiscriminator(BaseModel):
+    def __init__(self, ndf, loss_type, **kwargs):
+        super().__init__()
+        self.ndf, self.loss_type = ndf, loss_type
+        self.use_gold = False
+
+    # -- subclasses implement forward_nhwc(x NHWC4, training, save, need_dgrad) -> (logit [n,1], ctx)
+    #    and backward_nhwc(ctx, dlogit, need_wgrad, need_gx) -> g_x or None
+    def to_nhwc(self, x):
+        return E.nchw_to_nhwc(x.to(dtype=torch.float32), self.in_channels_padded)
+
+    def forward(self, x):
+        """images NCHW [n, C, H, W] -> logits [n, 1]."""
+        logit, _ = self.forward_nhwc(self.to_nhwc(x), self.training, save=False, need_dgrad=False)
+        return logit
+
+    def compute_gan_loss(self, output_real, output_fake):
+        out3, _, _ = E.loss_dis(output_real.detach().contiguous(), output_fake.detach().contiguous(),
+                                self.loss_type, gold=self.use_gold, need_grad=False)
+        return out3[0]
+
+    def compute_probs(self, output_real, output_fake):
+        out3, _, _ = E.loss_dis(output_real.detach().contiguous(), output_fake.detach().contiguous(),
+                                self.loss_type, gold=False, need_grad=False)
+        return out3[1].item(), out3[2].item()
+
+    def train_step(self, real_batch, netG, optD, log_data, device=None, global_step=None, scaler=None, noise=None,
+                   **kwargs):
+        """One D update (torch_mimicry BaseDiscriminator.train_step; call site trainer.py:257-264)."""
+        if scaler is not None:
+            raise NotImplementedError("amp/GradScaler is not part of the fp32 MI355X path")
+        self.zero_grad()
+        real_images = real_batch[0]
+        batch_size = real_images.shape[0]
+        out_real, ctx_r = self.forward_nhwc(self.to_nhwc(real_images), self.training, save=True, need_dgrad=True,
+                                            need_in_dgrad=False)
+        fake, _ = netG.generate_images_nhwc(batch_size, device=device, noise=noise, save=False)   # .detach()
+        out_fake, ctx_f = self.forward_nhwc(fake, self.training, save=True, need_dgrad=True, need_in_dgrad=False)
+        out3, d_real, d_fake = E.loss_dis(out_real, out_fake, self.loss_type, gold=self.use_gold)
+        self.backward_nhwc(ctx_r, d_real, need_wgrad=True, need_gx=False)
+        self.backward_nhwc(ctx_f, d_fake, need_wgrad=True, need_gx=False)
+        self.sync_grads()
+        optD.step()
+        # device scalars: no host sync here (the reference calls .item() three times per D step)
+        log_data.add_metric('errD', out3[0], group='loss')
+        log_data.add_metric('D(x)', out3[1], group='prob')
+        log_data.add_metric('D(G(z))', out3[2], group='prob')
+        return log_data

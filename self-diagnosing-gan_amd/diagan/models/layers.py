@@ -1,0 +1,388 @@
+"""Layer objects of the MI355X engine: explicit forward / backward over the HIP kernels.
+
+There is no autograd in the product path.  Every layer keeps its parameters in GEMM-ready HBM
+layouts (packed weights Wp[Co][Kp], NHWC activations) inside ONE flat fp32 buffer per network
+(`FlatNet`), so that zero_grad is one memset, Adam is one launch and the data-parallel gradient
+all-reduce is one RCCL call per network.  state_dict()/load_state_dict() present the reference's
+tensor shapes (OIHW conv weights, [out,in] linear weights, mimicry's sn_u / sn_sigma buffers).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from diagan.ops import conv as C
+from diagan.ops import eltwise as E
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class ConvLayer(nn.Module):
+    """Conv2d / ConvTranspose2d (+ optional spectral norm) stored as packed Wp[Co_p][Kp].
+
+    init: default PyTorch Conv init, then optional xavier_uniform_(gain) exactly like
+    torch_mimicry's blocks (RNG consumption order: weight, bias, [xavier], [sn_u])."""
+
+    def __init__(self, kind, in_ch, out_ch, ksize, stride=1, pad=0, bias=True, sn=False, xavier_gain=None):
+        super().__init__()
+        self.kind, self.in_ch, self.out_ch, self.ksize = kind, in_ch, out_ch, ksize
+        self.Cip, self.Cop = _r4(in_ch), _r4(out_ch)
+        self.geom = C.Geom(kind, self.Cip, self.Cop, ksize, ksize, stride, pad)
+        self.sn = sn
+        ref = (nn.Conv2d if kind == 'conv' else nn.ConvTranspose2d)(in_ch, out_ch, ksize, stride, pad, bias=bias)
+        self._oihw_shape = tuple(ref.weight.shape)
+        self.weight = nn.Parameter(self._pack(ref.weight.data))
+        if bias:
+            b = torch.zeros(self.Cop)
+            b[:out_ch] = ref.bias.data
+            self.bias = nn.Parameter(b)
+        else:
+            self.bias = None
+        if sn:
+            self.register_buffer('sn_u', torch.randn(1, out_ch))
+            self.register_buffer('sn_sigma', torch.ones(1))
+        self._wd = None
+        self._wd_version = -1
+        self._register_state_dict_hook(self._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
+        if xavier_gain is not None:
+            self.xavier_(xavier_gain)
+
+    def xavier_(self, gain):
+        """nn.init.xavier_uniform_(weight, gain) on the reference-shaped tensor, then re-pack.  Kept a
+        separate step so blocks can replay torch_mimicry's RNG order (convs created, then xavier)."""
+        w = torch.empty(self._oihw_shape)
+        nn.init.xavier_uniform_(w, gain)
+        self.weight.data.copy_(self._pack(w).to(self.weight.device))
+        return self
+
+    # ---- layout conversion (checkpoint boundary only) ----
+    def _pack(self, w):
+        if self.kind == 'convT':
+            w = w.permute(1, 0, 2, 3)
+        Co, Ci, R, S = w.shape
+        wp = w.permute(0, 2, 3, 1)
+        wp = torch.nn.functional.pad(wp, (0, self.Cip - Ci))
+        out = torch.zeros((self.Cop, self.geom.Kp), dtype=w.dtype, device=w.device)
+        out[:Co, : R * S * self.Cip] = wp.reshape(Co, -1)
+        return out
+
+    def _unpack(self, wp):
+        R = self.ksize
+        w = wp[: self.out_ch, : R * R * self.Cip].reshape(self.out_ch, R, R, self.Cip)[..., : self.in_ch]
+        w = w.permute(0, 3, 1, 2)
+        if self.kind == 'convT':
+            w = w.permute(1, 0, 2, 3)
+        return w.contiguous()
+
+    @staticmethod
+    def _sd_hook(module, sd, prefix, local_metadata):
+        sd[prefix + 'weight'] = module._unpack(sd[prefix + 'weight'])
+        if module.bias is not None:
+            sd[prefix + 'bias'] = sd[prefix + 'bias'][: module.out_ch].clone()
+        return sd
+
+    def _load_hook(self, sd, prefix, *args):
+        k = prefix + 'weight'
+        if k in sd and sd[k].dim() == 4:
+            sd[k] = self._pack(sd[k].to(torch.float32))
+        k = prefix + 'bias'
+        if k in sd and sd[k].numel() == self.out_ch and self.out_ch != self.Cop:
+            b = torch.zeros(self.Cop, dtype=torch.float32, device=sd[k].device)
+            b[: self.out_ch] = sd[k]
+            sd[k] = b
+        net = getattr(self, '_net', None)
+        if net is not None:
+            net.param_version += 1
+
+    # ---- compute ----
+    class Ctx:
+        __slots__ = ("wf", "wd", "u", "v", "state")
+
+    def prepare(self, training, need_dgrad=True):
+        """Per-forward operand preparation.  SN layers: one power iteration + scaled packing."""
+        ctx = ConvLayer.Ctx()
+        g = self.geom
+        dev = self.weight.device
+        if self.sn:
+            u_buf = self.sn_u.view(-1)
+            if self.Cop != self.out_ch:
+                raise RuntimeError("spectral norm with padded output channels is not supported")
+            ctx.u, ctx.v, ctx.state = C.sn_power_iter(self.weight.data, u_buf, self.sn_sigma, training=training)
+            alloc = torch.zeros if g.Kp != g.R * g.S * g.Ci else torch.empty
+            ctx.wf = alloc((g.Co, g.Kp), dtype=torch.float32, device=dev)
+            ctx.wd = None
+            if need_dgrad:
+                allocd = torch.zeros if g.Kd != g.R * g.S * g.Co else torch.empty
+                ctx.wd = allocd((g.Ci, g.Kd), dtype=torch.float32, device=dev)
+            C.pack_weights(self.weight.data, g.Co, g.Ci, g.R * g.S, g.Kp, g.Kd, inv_sigma=ctx.state[1:],
+                           Wf=ctx.wf, Wd=ctx.wd)
+        else:
+            ctx.u = ctx.v = ctx.state = None
+            ctx.wf = self.weight.data
+            ctx.wd = None
+            if need_dgrad:
+                ver = self._net.param_version if getattr(self, '_net', None) is not None else -2
+                if self._wd is None or self._wd_version != ver or ver == -2:
+                    if self._wd is None or self._wd.device != dev:
+                        self._wd = torch.zeros((g.Ci, g.Kd), dtype=torch.float32, device=dev)
+                    C.pack_weights(self.weight.data, g.Co, g.Ci, g.R * g.S, g.Kp, g.Kd, Wd=self._wd)
+                    self._wd_version = ver
+                ctx.wd = self._wd
+        return ctx
+
+    def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0):
+        return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
+                          residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu)
+
+    def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
+        return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
+                            mask_slope=mask_slope)
+
+    def wgrad(self, ctx, dy, x, pro=None):
+        """Accumulates into weight.grad / bias.grad (views of the net's flat gradient buffer)."""
+        sn = (self.weight.data, ctx.u, ctx.v, ctx.state) if self.sn else None
+        C.conv_wgrad(self.geom, dy, x, self.weight.grad, accumulate=True, pro=pro, sn=sn)
+        if self.bias is not None:
+            E.colsum(dy, self.bias.grad, accumulate=True)
+
+
+class BatchNorm(nn.Module):
+    """nn.BatchNorm2d parameters/buffers; statistics and backward run in elementwise.hip."""
+
+    def __init__(self, ch, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.ch, self.eps, self.momentum = ch, eps, momentum
+        self.weight = nn.Parameter(torch.ones(ch))
+        self.bias = nn.Parameter(torch.zeros(ch))
+        self.register_buffer('running_mean', torch.zeros(ch))
+        self.register_buffer('running_var', torch.ones(ch))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+    def stats(self, x, training):
+        if training:
+            self.num_batches_tracked += 1
+        return E.bn_stats(x, self.weight.data, self.bias.data, self.running_mean, self.running_var, training,
+                          self.eps, self.momentum)
+
+    def bwd(self, g, x, ctx, relu, residual=None):
+        return E.bn_bwd(g, x, ctx, relu, self.weight.grad, self.bias.grad, True, residual=residual)
+
+
+class LatentLinear(nn.Module):
+    """Generator input layer nn.Linear(nz, bw*bw*ch) whose output is viewed [B, ch, bw, bw]
+    (sngan l1; mnist.py:53 fc).  Stored as a 1x1 'conv' with its rows permuted to NHWC order so the
+    GEMM writes the [B, bw, bw, ch] activation directly."""
+
+    def __init__(self, nz, ch, bw, xavier_gain=None):
+        super().__init__()
+        self.nz, self.ch, self.bw = nz, ch, bw
+        ref = nn.Linear(nz, bw * bw * ch)
+        if xavier_gain is not None:
+            nn.init.xavier_uniform_(ref.weight.data, xavier_gain)
+        self.nzp = _r4(nz)
+        self.geom = C.Geom('conv', self.nzp, bw * bw * ch, 1, 1, 1, 0)
+        self.weight = nn.Parameter(self._pack(ref.weight.data))
+        self.bias = nn.Parameter(self._perm(ref.bias.data.view(-1, 1)).view(-1).contiguous())
+        self._register_state_dict_hook(self._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
+
+    def xavier_(self, gain):
+        w = torch.empty(self.bw * self.bw * self.ch, self.nz)
+        nn.init.xavier_uniform_(w, gain)
+        self.weight.data.copy_(self._pack(w).to(self.weight.device))
+        return self
+
+    def _perm(self, w):      # rows (c, h, w) -> (h, w, c)
+        return w.view(self.ch, self.bw * self.bw, -1).permute(1, 0, 2).reshape(self.ch * self.bw * self.bw, -1)
+
+    def _unperm(self, w):
+        return w.view(self.bw * self.bw, self.ch, -1).permute(1, 0, 2).reshape(self.ch * self.bw * self.bw, -1)
+
+    def _pack(self, w):
+        out = torch.zeros((w.shape[0], self.geom.Kp), dtype=w.dtype, device=w.device)
+        out[:, : self.nz] = self._perm(w)
+        return out
+
+    @staticmethod
+    def _sd_hook(module, sd, prefix, local_metadata):
+        sd[prefix + 'weight'] = module._unperm(sd[prefix + 'weight'][:, : module.nz]).contiguous()
+        sd[prefix + 'bias'] = module._unperm(sd[prefix + 'bias'].view(-1, 1)).view(-1).contiguous()
+        return sd
+
+    def _load_hook(self, sd, prefix, *args):
+        k = prefix + 'weight'     # checkpoints always hold the reference layout [bw*bw*ch (c,h,w), nz]
+        if k in sd:
+            sd[k] = self._pack(sd[k].to(torch.float32))
+        if prefix + 'bias' in sd:
+            sd[prefix + 'bias'] = self._perm(sd[prefix + 'bias'].to(torch.float32).view(-1, 1)).view(-1).contiguous()
+        net = getattr(self, '_net', None)
+        if net is not None:
+            net.param_version += 1
+
+    def fwd(self, z):
+        """z [B, nz] -> [B, bw, bw, ch]"""
+        B = z.shape[0]
+        if self.nzp != self.nz:
+            z = torch.nn.functional.pad(z, (0, self.nzp - self.nz))
+        x = z.contiguous().view(B, 1, 1, self.nzp)
+        y = C.conv_fwd(self.geom, x, self.weight.data, bias=self.bias.data)
+        return x, y.view(B, self.bw, self.bw, self.ch)
+
+    def wgrad(self, x, dy):
+        B = x.shape[0]
+        dy2 = dy.reshape(B, 1, 1, -1)
+        C.conv_wgrad(self.geom, dy2, x, self.weight.grad, accumulate=True)
+        E.colsum(dy2, self.bias.grad, accumulate=True)
+
+
+class HeadLinear(nn.Module):
+    """SNLinear(C, 1) (or nn.Linear) on the globally pooled feature: the discriminator logit."""
+
+    def __init__(self, in_ch, sn=True, xavier_gain=None):
+        super().__init__()
+        self.in_ch, self.sn = in_ch, sn
+        ref = nn.Linear(in_ch, 1)
+        if xavier_gain is not None:
+            nn.init.xavier_uniform_(ref.weight.data, xavier_gain)
+        self.weight = nn.Parameter(ref.weight.data.clone())      # [1, C] (already "packed")
+        self.bias = nn.Parameter(torch.cat([ref.bias.data, torch.zeros(3)]))   # padded to 4 floats
+        if sn:
+            self.register_buffer('sn_u', torch.randn(1, 1))
+            self.register_buffer('sn_sigma', torch.ones(1))
+        self._register_state_dict_hook(self._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
+
+    def xavier_(self, gain):
+        w = torch.empty(1, self.in_ch)
+        nn.init.xavier_uniform_(w, gain)
+        self.weight.data.copy_(w.to(self.weight.device))
+        return self
+
+    @staticmethod
+    def _sd_hook(module, sd, prefix, local_metadata):
+        sd[prefix + 'bias'] = sd[prefix + 'bias'][:1].clone()
+        return sd
+
+    def _load_hook(self, sd, prefix, *args):
+        k = prefix + 'bias'
+        if k in sd and sd[k].numel() == 1:
+            sd[k] = torch.cat([sd[k].to(torch.float32), torch.zeros(3, device=sd[k].device)])
+
+    class Ctx:
+        __slots__ = ("u", "v", "state", "x", "pooled")
+
+    def fwd(self, x, training):
+        ctx = HeadLinear.Ctx()
+        inv = None
+        if self.sn:
+            ctx.u, ctx.v, ctx.state = C.sn_power_iter(self.weight.data, self.sn_u.view(-1), self.sn_sigma,
+                                                      training=training)
+            inv = ctx.state[1:]
+        ctx.x = x
+        ctx.pooled, logit = E.head_fwd(x, self.weight.data, inv, self.bias.data)
+        return ctx, logit
+
+    def bwd(self, ctx, dlogit, need_wgrad=True):
+        inv = ctx.state[1:] if self.sn else None
+        gx, G, dot = E.head_bwd(dlogit, self.weight.data, inv, ctx.x, ctx.pooled, need_gx=True,
+                                need_wgrad=need_wgrad, dbias=self.bias.grad if need_wgrad else None)
+        if need_wgrad:
+            if self.sn:
+                from diagan import _native as nat
+                nat.call("diagan_sn_grad_fix", nat.ptr(G), nat.ptr(dot), 1, nat.ptr(ctx.u), nat.ptr(ctx.v),
+                         nat.ptr(ctx.state), nat.ptr(self.weight.grad), 1, self.in_ch, 1, nat.current_stream())
+            else:
+                self.weight.grad.view(-1).add_(G)
+        return gx
+
+
+class FlatNet(nn.Module):
+    """Base of the engine's networks: owns the flat parameter / gradient buffers."""
+
+    def __init__(self):
+        super().__init__()
+        self.param_version = 0        # bumped whenever parameters change (optimizer step, load)
+        self._flat = None
+        self._flat_grad = None
+
+    def _link_layers(self):
+        for m in self.modules():
+            if m is not self:
+                object.__setattr__(m, '_net', self)
+
+    def _build_flat(self):
+        """(Re)allocate one contiguous fp32 slab for all parameters and one for all gradients and
+        re-point every nn.Parameter (and its .grad) at 16-byte aligned views of them."""
+        params = list(self.parameters())
+        if not params:
+            return
+        dev = params[0].device
+        total = sum(_r4(p.numel()) for p in params)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off: off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off: off + n].view(p.shape)
+            p.grad = grad[off: off + n].view(p.shape)
+            off += _r4(n)
+        self._flat, self._flat_grad = flat, grad
+        self.param_version += 1
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn)
+        self._build_flat()
+        for m in self.modules():
+            if isinstance(m, ConvLayer):
+                m._wd = None
+        return out
+
+    def zero_grad(self, set_to_none=False):
+        if self._flat_grad is None:
+            self._build_flat()
+        self._flat_grad.zero_()
+
+    @property
+    def flat_params(self):
+        if self._flat is None:
+            self._build_flat()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        if self._flat_grad is None:
+            self._build_flat()
+        return self._flat_grad
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def export_grads(self):
+        """Gradients in the reference's tensor shapes, keyed like state_dict() (tests, debugging)."""
+        out = {}
+        for name, m in self.named_modules():
+            pre = name + '.' if name else ''
+            if isinstance(m, ConvLayer):
+                out[pre + 'weight'] = m._unpack(m.weight.grad)
+                if m.bias is not None:
+                    out[pre + 'bias'] = m.bias.grad[: m.out_ch].clone()
+            elif isinstance(m, LatentLinear):
+                out[pre + 'weight'] = m._unperm(m.weight.grad[:, : m.nz]).contiguous()
+                out[pre + 'bias'] = m._unperm(m.bias.grad.view(-1, 1)).view(-1).contiguous()
+            elif isinstance(m, HeadLinear):
+                out[pre + 'weight'] = m.weight.grad.clone()
+                out[pre + 'bias'] = m.bias.grad[:1].clone()
+            elif isinstance(m, BatchNorm):
+                out[pre + 'weight'] = m.weight.grad.clone()
+                out[pre + 'bias'] = m.bias.grad.clone()
+        return out
+
+    def count_params(self):
+        """Reference-visible parameter count (padding excluded)."""
+        return sum(v.numel() for k, v in self.state_dict().items()
+                   if not any(s in k for s in ('running_', 'num_batches', 'sn_u', 'sn_sigma')))

@@ -1,0 +1,318 @@
+"""SNGAN generators / discriminators (32x32 CIFAR-10, 64x64 CelebA) on the HIP engine.
+
+Architecture = torch_mimicry.nets.sngan.{SNGANGenerator32, SNGANDiscriminator32, SNGANGenerator64,
+SNGANDiscriminator64} with its GBlock / DBlock / DBlockOptimized residual blocks, as selected by
+the reference at diagan-pkg/diagan/models/predefined_models.py:17-92 (summarised in SURVEY §8
+a2-a8; torch_mimicry itself is not vendored in the reference tree).  Module / parameter / buffer
+names follow mimicry's so that state_dict keys line up (block2.c1.weight, block2.b1.running_mean,
+block1.c_sc.sn_u, l5.sn_sigma, ...).
+
+Each block has forward(x, training, save, ...) -> (out, ctx) and backward(ctx, g, ...) -> g_in with
+the kernel fusion described in DESIGN.md (ReLU / BN-apply+ReLU in the conv loader, bias + shortcut
+add in the conv epilogue, ReLU-backward mask in the dgrad epilogue).
+"""
+import math
+
+import torch.nn as nn
+
+from diagan.models.base import BaseDiscriminator, BaseGenerator
+from diagan.models.layers import BatchNorm, ConvLayer, HeadLinear, LatentLinear
+from diagan.ops import conv as C
+from diagan.ops import eltwise as E
+
+RELU = (C.PRO_RELU, None, None)
+
+
+def _bn_pro(bn):
+    return (C.PRO_AFFINE_RELU, bn.scale, bn.shift)
+
+
+class GBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, hidden_channels=None, upsample=False):
+        super().__init__()
+        hidden_channels = hidden_channels if hidden_channels is not None else out_channels
+        self.learnable_sc = in_channels != out_channels or upsample
+        self.upsample = upsample
+        self.c1 = ConvLayer('conv', in_channels, hidden_channels, 3, 1, 1)
+        self.c2 = ConvLayer('conv', hidden_channels, out_channels, 3, 1, 1)
+        self.b1 = BatchNorm(in_channels)
+        self.b2 = BatchNorm(hidden_channels)
+        self.c1.xavier_(math.sqrt(2.0))
+        self.c2.xavier_(math.sqrt(2.0))
+        if self.learnable_sc:
+            self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0)
+            self.c_sc.xavier_(1.0)
+
+    def forward(self, x, training, save=True, need_dgrad=True):
+        ctx = {}
+        bn1 = self.b1.stats(x, training)
+        if self.upsample:
+            c1_in, c1_pro = E.upsample2x(x, pro=_bn_pro(bn1)), None
+        else:
+            c1_in, c1_pro = x, _bn_pro(bn1)
+        k1 = self.c1.prepare(training, need_dgrad)
+        h1 = self.c1.fwd(k1, c1_in, pro=c1_pro)
+        bn2 = self.b2.stats(h1, training)
+        if self.learnable_sc:
+            sc_in = E.upsample2x(x) if self.upsample else x
+            ksc = self.c_sc.prepare(training, need_dgrad)
+            sc = self.c_sc.fwd(ksc, sc_in)
+        else:
+            sc_in, ksc, sc = None, None, x
+        k2 = self.c2.prepare(training, need_dgrad)
+        out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc)
+        if save:
+            ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, sc_in=sc_in, ksc=ksc, k2=k2)
+        return out, ctx
+
+    def backward(self, ctx, gout):
+        x, h1 = ctx['x'], ctx['h1']
+        hw1 = h1.shape[1:3]
+        self.c2.wgrad(ctx['k2'], gout, h1, pro=_bn_pro(ctx['bn2']))
+        g_a2 = self.c2.dgrad(ctx['k2'], gout, hw1)
+        g_h1 = self.b2.bwd(g_a2, h1, ctx['bn2'], relu=True)
+        self.c1.wgrad(ctx['k1'], g_h1, ctx['c1_in'], pro=ctx['c1_pro'])
+        g_c1in = self.c1.dgrad(ctx['k1'], g_h1, ctx['c1_in'].shape[1:3])
+        if self.learnable_sc:
+            self.c_sc.wgrad(ctx['ksc'], gout, ctx['sc_in'])
+            g_scin = self.c_sc.dgrad(ctx['ksc'], gout, ctx['sc_in'].shape[1:3])
+            g_x_sc = E.upsample2x_bwd(g_scin) if self.upsample else g_scin
+        else:
+            g_x_sc = gout
+        g_a1 = E.upsample2x_bwd(g_c1in) if self.upsample else g_c1in
+        return self.b1.bwd(g_a1, x, ctx['bn1'], relu=True, residual=g_x_sc)
+
+
+class DBlock(nn.Module):
+    """mimicry's DBlock applies nn.ReLU(True) to `h = x`, which mutates x in place, so the shortcut
+    branch consumes relu(x) as well (SURVEY §7 'In-place ReLU aliasing')."""
+
+    def __init__(self, in_channels, out_channels, hidden_channels=None, downsample=False):
+        super().__init__()
+        hidden_channels = hidden_channels if hidden_channels is not None else in_channels
+        self.downsample = downsample
+        self.learnable_sc = (in_channels != out_channels) or downsample
+        self.c1 = ConvLayer('conv', in_channels, hidden_channels, 3, 1, 1, sn=True)
+        self.c2 = ConvLayer('conv', hidden_channels, out_channels, 3, 1, 1, sn=True)
+        self.c1.xavier_(math.sqrt(2.0))
+        self.c2.xavier_(math.sqrt(2.0))
+        if self.learnable_sc:
+            self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0, sn=True)
+            self.c_sc.xavier_(1.0)
+
+    def forward(self, x, training, save=True, need_dgrad=True):
+        k1 = self.c1.prepare(training, need_dgrad)
+        k2 = self.c2.prepare(training, need_dgrad)
+        h1 = self.c1.fwd(k1, x, pro=RELU)
+        if self.learnable_sc:
+            ksc = self.c_sc.prepare(training, need_dgrad)
+            sc = self.c_sc.fwd(ksc, x, pro=RELU)
+            h2 = self.c2.fwd(k2, h1, pro=RELU, residual=sc)
+        else:
+            ksc = None
+            h2 = self.c2.fwd(k2, h1, pro=RELU, residual=x, res_relu=True)
+        out = E.avgpool2(h2) if self.downsample else h2
+        ctx = dict(x=x, h1=h1, k1=k1, k2=k2, ksc=ksc) if save else {}
+        return out, ctx
+
+    def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
+        x, h1 = ctx['x'], ctx['h1']
+        hw = x.shape[1:3]
+        g_full = E.avgpool2_bwd(gout) if self.downsample else gout
+        if need_wgrad:
+            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU)
+        g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
+        if need_wgrad:
+            self.c1.wgrad(ctx['k1'], g_h1, x, pro=RELU)
+            if self.learnable_sc:
+                self.c_sc.wgrad(ctx['ksc'], g_full, x, pro=RELU)
+        if not need_gx:
+            return None
+        if self.learnable_sc:
+            tmp = self.c_sc.dgrad(ctx['ksc'], g_full, hw)
+            return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=tmp, mask_src=x)
+        return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=g_full, mask_src=x)
+
+
+class DBlockOptimized(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.c1 = ConvLayer('conv', in_channels, out_channels, 3, 1, 1, sn=True)
+        self.c2 = ConvLayer('conv', out_channels, out_channels, 3, 1, 1, sn=True)
+        self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0, sn=True)
+        self.c1.xavier_(math.sqrt(2.0))
+        self.c2.xavier_(math.sqrt(2.0))
+        self.c_sc.xavier_(1.0)
+
+    def forward(self, x, training, save=True, need_dgrad=True, need_in_dgrad=False):
+        k1 = self.c1.prepare(training, need_dgrad and need_in_dgrad)
+        k2 = self.c2.prepare(training, need_dgrad)
+        ksc = self.c_sc.prepare(training, need_dgrad and need_in_dgrad)
+        h1 = self.c1.fwd(k1, x)
+        xp = E.avgpool2(x)
+        sc = self.c_sc.fwd(ksc, xp)
+        h2 = self.c2.fwd(k2, h1, pro=RELU)
+        out = E.avgpool2(h2, residual=sc)
+        ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc) if save else {}
+        return out, ctx
+
+    def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
+        x, xp, h1 = ctx['x'], ctx['xp'], ctx['h1']
+        hw = x.shape[1:3]
+        g_full = E.avgpool2_bwd(gout)
+        if need_wgrad:
+            self.c_sc.wgrad(ctx['ksc'], gout, xp)
+            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU)
+        g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
+        if need_wgrad:
+            self.c1.wgrad(ctx['k1'], g_h1, x)
+        if not need_gx:
+            return None
+        g_xp = self.c_sc.dgrad(ctx['ksc'], gout, xp.shape[1:3])
+        g_sc_full = E.avgpool2_bwd(g_xp)
+        return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=g_sc_full)
+
+
+class SNGANBaseGenerator(BaseGenerator):
+    out_channels = 3
+
+    def _blocks(self):
+        raise NotImplementedError
+
+    def forward_nhwc(self, z, training, save=True):
+        z = z.to(dtype=self.l1.weight.dtype)
+        x0, h = self.l1.fwd(z)
+        bctx = []
+        for blk in self._blocks():
+            h, c = blk.forward(h, training, save=save, need_dgrad=save)
+            bctx.append(c)
+        bn = self._last_bn.stats(h, training)
+        k = self._last_conv.prepare(training, need_dgrad=save)
+        y_pre = self._last_conv.fwd(k, h, pro=_bn_pro(bn))
+        y = E.tanh_fwd(y_pre)
+        ctx = dict(x0=x0, bctx=bctx, h=h, bn=bn, k=k, y=y) if save else None
+        return y, ctx
+
+    def backward_nhwc(self, ctx, g_img):
+        g_pre = E.tanh_bwd(ctx['y'], g_img)
+        h = ctx['h']
+        self._last_conv.wgrad(ctx['k'], g_pre, h, pro=_bn_pro(ctx['bn']))
+        g_a = self._last_conv.dgrad(ctx['k'], g_pre, h.shape[1:3])
+        g = self._last_bn.bwd(g_a, h, ctx['bn'], relu=True)
+        for blk, c in zip(reversed(self._blocks()), reversed(ctx['bctx'])):
+            g = blk.backward(c, g)
+        self.l1.wgrad(ctx['x0'], g)
+
+
+class SNGANGenerator32(SNGANBaseGenerator):
+    def __init__(self, nz=128, ngf=256, bottom_width=4, loss_type='hinge', **kwargs):
+        super().__init__(nz=nz, ngf=ngf, bottom_width=bottom_width, loss_type=loss_type, **kwargs)
+        self.l1 = LatentLinear(nz, ngf, bottom_width)
+        self.block2 = GBlock(ngf, ngf, upsample=True)
+        self.block3 = GBlock(ngf, ngf, upsample=True)
+        self.block4 = GBlock(ngf, ngf, upsample=True)
+        self.b5 = BatchNorm(ngf)
+        self.c5 = ConvLayer('conv', ngf, 3, 3, 1, 1)
+        self.l1.xavier_(1.0)
+        self.c5.xavier_(1.0)
+        self._link_layers()
+
+    def _blocks(self):
+        return [self.block2, self.block3, self.block4]
+
+    @property
+    def _last_bn(self):
+        return self.b5
+
+    @property
+    def _last_conv(self):
+        return self.c5
+
+
+class SNGANGenerator64(SNGANBaseGenerator):
+    def __init__(self, nz=128, ngf=1024, bottom_width=4, loss_type='hinge', **kwargs):
+        super().__init__(nz=nz, ngf=ngf, bottom_width=bottom_width, loss_type=loss_type, **kwargs)
+        self.l1 = LatentLinear(nz, ngf, bottom_width)
+        self.block2 = GBlock(ngf, ngf >> 1, upsample=True)
+        self.block3 = GBlock(ngf >> 1, ngf >> 2, upsample=True)
+        self.block4 = GBlock(ngf >> 2, ngf >> 3, upsample=True)
+        self.block5 = GBlock(ngf >> 3, ngf >> 4, upsample=True)
+        self.b6 = BatchNorm(ngf >> 4)
+        self.c6 = ConvLayer('conv', ngf >> 4, 3, 3, 1, 1)
+        self.l1.xavier_(1.0)
+        self.c6.xavier_(1.0)
+        self._link_layers()
+
+    def _blocks(self):
+        return [self.block2, self.block3, self.block4, self.block5]
+
+    @property
+    def _last_bn(self):
+        return self.b6
+
+    @property
+    def _last_conv(self):
+        return self.c6
+
+
+class SNGANBaseDiscriminator(BaseDiscriminator):
+    in_channels_padded = 4
+
+    def _blocks(self):
+        raise NotImplementedError
+
+    def forward_nhwc(self, x, training, save=True, need_dgrad=True, need_in_dgrad=True):
+        blocks = self._blocks()
+        h, c0 = blocks[0].forward(x, training, save=save, need_dgrad=need_dgrad, need_in_dgrad=need_in_dgrad)
+        bctx = [c0]
+        for blk in blocks[1:]:
+            h, c = blk.forward(h, training, save=save, need_dgrad=need_dgrad)
+            bctx.append(c)
+        hctx, logit = self._head.fwd(h, training)
+        return logit, (dict(bctx=bctx, hctx=hctx) if save else None)
+
+    def backward_nhwc(self, ctx, dlogit, need_wgrad=True, need_gx=False):
+        g = self._head.bwd(ctx['hctx'], dlogit, need_wgrad=need_wgrad)
+        blocks = self._blocks()
+        for i in range(len(blocks) - 1, -1, -1):
+            g = blocks[i].backward(ctx['bctx'][i], g, need_wgrad=need_wgrad, need_gx=(need_gx or i > 0))
+        return g
+
+
+class SNGANDiscriminator32(SNGANBaseDiscriminator):
+    def __init__(self, ndf=128, loss_type='hinge', **kwargs):
+        super().__init__(ndf=ndf, loss_type=loss_type, **kwargs)
+        self.block1 = DBlockOptimized(3, ndf)
+        self.block2 = DBlock(ndf, ndf, downsample=True)
+        self.block3 = DBlock(ndf, ndf, downsample=False)
+        self.block4 = DBlock(ndf, ndf, downsample=False)
+        self.l5 = HeadLinear(ndf, sn=True)
+        self.l5.xavier_(1.0)
+        self._link_layers()
+
+    def _blocks(self):
+        return [self.block1, self.block2, self.block3, self.block4]
+
+    @property
+    def _head(self):
+        return self.l5
+
+
+class SNGANDiscriminator64(SNGANBaseDiscriminator):
+    def __init__(self, ndf=1024, loss_type='hinge', **kwargs):
+        super().__init__(ndf=ndf, loss_type=loss_type, **kwargs)
+        self.block1 = DBlockOptimized(3, ndf >> 4)
+        self.block2 = DBlock(ndf >> 4, ndf >> 3, downsample=True)
+        self.block3 = DBlock(ndf >> 3, ndf >> 2, downsample=True)
+        self.block4 = DBlock(ndf >> 2, ndf >> 1, downsample=True)
+        self.block5 = DBlock(ndf >> 1, ndf, downsample=True)
+        self.l6 = HeadLinear(ndf, sn=True)
+        self.l6.xavier_(1.0)
+        self._link_layers()
+
+    def _blocks(self):
+        return [self.block1, self.block2, self.block3, self.block4, self.block5]
+
+    @property
+    def _head(self):
+        return self.l6

@@ -1,2 +1,2 @@
 """Python-side op wrappers over the C ABI (one module per kernel family)."""
-from diagan.ops import conv  # noqa: F401  (registers the entry-point signatures)
+from diagan.ops import conv, eltwise  # noqa: F401  (register the entry-point signatures)

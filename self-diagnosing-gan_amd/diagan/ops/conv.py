@@ -10,7 +10,7 @@ import torch
 from diagan import _native as nat
 
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
-nat.register("diagan_conv_gemm", [P, P, P, P, P, P, F, P, P, I, F] + [I] * 15 + [P])
+nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F] + [I] * 15 + [P])
 nat.register("diagan_conv_wgrad", [P, P, P, I, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_conv_wgrad_splits", [I, I, I])
 nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
@@ -59,7 +59,8 @@ def _chk(t, name):
                            f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
-def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg):
+def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
+          res_relu=False):
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
     mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
@@ -73,12 +74,12 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
             raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
     sy, dr, off, up = geo_params
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
-             nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
+             1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.current_stream())
     return out
 
 
-def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0):
+def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
@@ -87,7 +88,7 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, 1.0,
-                 tile_cfg)
+                 tile_cfg, res_relu=res_relu)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0):

@@ -1,0 +1,192 @@
+"""HBM-bound layer ops, loss heads and Adam over the C ABI (csrc/elementwise.hip, train_ops.hip)."""
+import ctypes
+
+import torch
+
+from diagan import _native as nat
+
+P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
+nat.register("diagan_nchw_to_nhwc", [P, P, I, I, I, I, I, P])
+nat.register("diagan_nhwc_to_nchw", [P, P, I, I, I, I, I, P])
+nat.register("diagan_tanh_fwd", [P, P, I64, P])
+nat.register("diagan_tanh_bwd", [P, P, P, I64, P])
+nat.register("diagan_colred_workspace", [I64, I])
+nat.register("diagan_bn_stats", [P, I64, I, P, P, F, F, P, P, I, P, P, P, P, P, P])
+nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, P, P, I, P, P, P, P, P])
+nat.register("diagan_colsum", [P, I64, I, P, I, P, P])
+nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, P])
+nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
+nat.register("diagan_avgpool2", [P, P, I, I, I, I, P, P])
+nat.register("diagan_avgpool2_bwd", [P, P, I, I, I, I, P, P])
+nat.register("diagan_head_fwd", [P, P, P, P, P, P, I, I, I, P])
+nat.register("diagan_head_bwd", [P, P, P, P, P, P, P, P, P, I, I, I, I, P])
+nat.register("diagan_add", [P, P, P, I64, P])
+nat.register("diagan_loss_dis", [P, I, P, I, I, I, P, P, P, P])
+nat.register("diagan_loss_gen", [P, I, I, I, P, P, P])
+nat.register("diagan_adam_step", [P, P, P, P, I64, F, F, F, F, F, F, P])
+
+LOSS_TYPES = {'gan': 0, 'ns': 1, 'hinge': 2, 'wasserstein': 3}
+ptr, st = nat.ptr, nat.current_stream
+
+
+def _f32(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+_ws = {}
+
+
+def _workspace(dev, nbytes):
+    w = _ws.get(dev.index)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+        _ws[dev.index] = w
+    return w
+
+
+def _colred_ws(dev, M, C):
+    fn = nat.lib().diagan_colred_workspace
+    fn.restype = ctypes.c_int64
+    fn.argtypes = [ctypes.c_int64, ctypes.c_int]
+    return _workspace(dev, fn(M, C))
+
+
+def nchw_to_nhwc(x, Cp):
+    B, C, H, W = x.shape
+    out = _f32((B, H, W, Cp), x.device)
+    nat.call("diagan_nchw_to_nhwc", ptr(x.contiguous()), ptr(out), B, C, H, W, Cp, st())
+    return out
+
+
+def nhwc_to_nchw(x, C):
+    B, H, W, Cp = x.shape
+    out = _f32((B, C, H, W), x.device)
+    nat.call("diagan_nhwc_to_nchw", ptr(x), ptr(out), B, C, H, W, Cp, st())
+    return out
+
+
+def tanh_fwd(x):
+    y = torch.empty_like(x)
+    nat.call("diagan_tanh_fwd", ptr(x), ptr(y), x.numel(), st())
+    return y
+
+
+def tanh_bwd(y, g):
+    gx = torch.empty_like(y)
+    nat.call("diagan_tanh_bwd", ptr(y), ptr(g), ptr(gx), y.numel(), st())
+    return gx
+
+
+class BNCtx:
+    __slots__ = ("mean", "invstd", "scale", "shift", "M", "C")
+
+
+def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1):
+    C = x.shape[-1]
+    M = x.numel() // C
+    buf = _f32((4, C), x.device)
+    ctx = BNCtx()
+    ctx.mean, ctx.invstd, ctx.scale, ctx.shift, ctx.M, ctx.C = buf[0], buf[1], buf[2], buf[3], M, C
+    ws = _colred_ws(x.device, M, C) if training else None
+    nat.call("diagan_bn_stats", ptr(x), M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+             ptr(running_var), 1 if training else 0, ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale),
+             ptr(ctx.shift), ptr(ws), st())
+    return ctx
+
+
+def bn_bwd(g, x, ctx, relu, dgamma, dbeta, accumulate, residual=None):
+    dx = torch.empty_like(x)
+    coef = _f32((2 * ctx.C,), x.device)
+    ws = _colred_ws(x.device, ctx.M, ctx.C)
+    nat.call("diagan_bn_bwd", ptr(g), ptr(x), ctx.M, ctx.C, ptr(ctx.scale), ptr(ctx.shift), ptr(ctx.mean),
+             ptr(ctx.invstd), 1 if relu else 0, ptr(dgamma), ptr(dbeta), 1 if accumulate else 0, ptr(residual),
+             ptr(dx), ptr(coef), ptr(ws), st())
+    return dx
+
+
+def colsum(x, out, accumulate):
+    C = x.shape[-1]
+    M = x.numel() // C
+    ws = _colred_ws(x.device, M, C)
+    nat.call("diagan_colsum", ptr(x), M, C, ptr(out), 1 if accumulate else 0, ptr(ws), st())
+    return out
+
+
+def upsample2x(x, pro=None):
+    B, H, W, C = x.shape
+    mode, scale, shift = pro if pro is not None else (0, None, None)
+    out = _f32((B, 2 * H, 2 * W, C), x.device)
+    nat.call("diagan_upsample2x", ptr(x), ptr(out), B, H, W, C, mode, ptr(scale), ptr(shift), st())
+    return out
+
+
+def upsample2x_bwd(g, residual=None):
+    B, H2, W2, C = g.shape
+    out = _f32((B, H2 // 2, W2 // 2, C), g.device)
+    nat.call("diagan_upsample2x_bwd", ptr(g), ptr(out), B, H2 // 2, W2 // 2, C, ptr(residual), st())
+    return out
+
+
+def avgpool2(x, residual=None):
+    B, H, W, C = x.shape
+    out = _f32((B, H // 2, W // 2, C), x.device)
+    nat.call("diagan_avgpool2", ptr(x), ptr(out), B, H, W, C, ptr(residual), st())
+    return out
+
+
+def avgpool2_bwd(g, residual=None):
+    B, Ho, Wo, C = g.shape
+    out = _f32((B, 2 * Ho, 2 * Wo, C), g.device)
+    nat.call("diagan_avgpool2_bwd", ptr(g), ptr(out), B, 2 * Ho, 2 * Wo, C, ptr(residual), st())
+    return out
+
+
+def head_fwd(x, w, inv_sigma, bias):
+    B, H, W, C = x.shape
+    pooled = _f32((B, C), x.device)
+    logit = _f32((B, 1), x.device)
+    nat.call("diagan_head_fwd", ptr(x), ptr(w), ptr(inv_sigma), ptr(bias), ptr(pooled), ptr(logit), B, H * W, C, st())
+    return pooled, logit
+
+
+def head_bwd(dlogit, w, inv_sigma, x, pooled, need_gx=True, need_wgrad=True, dbias=None, accumulate_bias=True):
+    B, H, W, C = x.shape
+    gx = torch.empty_like(x) if need_gx else None
+    G = _f32((C,), x.device) if need_wgrad else None
+    dot = torch.empty(1, dtype=torch.float64, device=x.device) if need_wgrad else None
+    nat.call("diagan_head_bwd", ptr(dlogit), ptr(w), ptr(inv_sigma), ptr(x), ptr(pooled), ptr(gx), ptr(G), ptr(dot),
+             ptr(dbias), 1 if accumulate_bias else 0, B, H * W, C, st())
+    return gx, G, dot
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    nat.call("diagan_add", ptr(a), ptr(b), ptr(out), a.numel(), st())
+    return out
+
+
+def loss_dis(out_real, out_fake, loss_type, gold=False, need_grad=True):
+    dev = out_real.device
+    nr, nf = out_real.numel(), out_fake.numel()
+    d_real = _f32((nr,), dev) if need_grad else None
+    d_fake = _f32((nf,), dev) if need_grad else None
+    out3 = _f32((3,), dev)
+    nat.call("diagan_loss_dis", ptr(out_real), nr, ptr(out_fake), nf, LOSS_TYPES[loss_type], 1 if gold else 0,
+             ptr(d_real), ptr(d_fake), ptr(out3), st())
+    return out3, d_real, d_fake
+
+
+def loss_gen(out_fake, loss_type, k=None, need_grad=True):
+    dev = out_fake.device
+    n = out_fake.numel()
+    k = n if k is None else k
+    d_fake = _f32((n,), dev) if need_grad else None
+    out1 = _f32((1,), dev)
+    nat.call("diagan_loss_gen", ptr(out_fake), n, k, LOSS_TYPES[loss_type], ptr(d_fake), ptr(out1), st())
+    return out1, d_fake
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    nat.call("diagan_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, st())

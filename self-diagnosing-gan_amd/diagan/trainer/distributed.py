@@ -1,0 +1,98 @@
+"""Process-group helpers: one process per GPU, torch.distributed over RCCL/xGMI ('nccl' backend on
+ROCm) or gloo on CPU.
+
+Same helper names as the reference (diagan-pkg/diagan/trainer/distributed.py:8-126 ==
+stylegan2/distributed.py) plus the two collectives the SNGAN data-parallel path needs:
+`all_reduce_mean_` (gradient slab, pattern of DDP at stylegan2/train_ffhq.py:572-585) and
+`all_gather_cat` (per-sample logits, pattern of concat_all_gather at train_ffhq.py:150-161).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def init_from_env(backend=None):
+    """env:// rendezvous (RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run), as the
+    reference does at stylegan2/train_ffhq.py:503-506.  Returns (rank, local_rank, world_size)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not is_dist():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+        synchronize()
+    return rank, local_rank, world
+
+
+def synchronize():
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_mean_(flat):
+    """In-place mean over ranks of one contiguous slab (no-op for a single process)."""
+    world = get_world_size()
+    if world == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / world)
+    return flat
+
+
+def reduce_sum(tensor):
+    if get_world_size() == 1:
+        return tensor
+    tensor = tensor.clone()
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return tensor
+
+
+def all_gather_cat(tensor):
+    """Rank-major concatenation of equally shaped per-rank tensors."""
+    world = get_world_size()
+    if world == 1:
+        return tensor
+    out = [torch.empty_like(tensor) for _ in range(world)]
+    dist.all_gather(out, tensor.contiguous())
+    return torch.cat(out, dim=0)
+
+
+def reduce_loss_dict(loss_dict):
+    """Mean of each scalar over ranks, valid on rank 0 (reference: distributed.py:104-126)."""
+    world = get_world_size()
+    if world < 2:
+        return loss_dict
+    with torch.no_grad():
+        keys = sorted(loss_dict.keys())
+        stacked = torch.stack([loss_dict[k].detach().float().reshape(()) for k in keys])
+        dist.reduce(stacked, dst=0)
+        if dist.get_rank() == 0:
+            stacked /= world
+        return {k: v for k, v in zip(keys, stacked)}
+
+
+def broadcast_module_(module, src=0):
+    """Make parameters and buffers identical on every rank (done once at start; afterwards the
+    replicas stay in lock-step because they apply identical averaged gradients)."""
+    if get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src)

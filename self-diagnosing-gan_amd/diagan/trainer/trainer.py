@@ -1,0 +1,267 @@
+"""LogTrainer: the phase-1 / phase-2 training loop with the per-index logit record.
+
+Host-side mirror of diagan-pkg/diagan/trainer/trainer.py (class LogTrainer, :15-361), which itself
+extends torch_mimicry.training.Trainer.  Constructor keywords, loop order, snapshot condition, file
+names and checkpoint cadence are the reference's; what differs is what runs underneath:
+
+  * netD/netG.train_step launch HIP kernels (no autograd, no per-step .item() syncs);
+  * the logit record lives in HBM (utils.plot.LogitRecord): D(x) rows are scattered on device
+    (diagan_logit_scatter) instead of `.cpu().numpy()` per batch (trainer.py:154);
+  * under torch.distributed (one process per GPU) gradients are averaged by one all-reduce per
+    network inside train_step, and the logit pass is sharded by contiguous index range with one
+    all-gather per snapshot (pattern: stylegan2/train_ffhq.py:128-143).
+"""
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from diagan.trainer import distributed as dist
+from diagan.trainer.logger import Logger, MetricLog
+from diagan.trainer.scheduler import DRS_LRScheduler
+from diagan.utils.plot import LogitRecord
+
+
+class LogTrainer:
+    def __init__(self, output_path, netD, netG, optD, optG, dataloader, num_steps, netD_drs=None, optD_drs=None,
+                 dataloader_drs=None, netD_drs_ckpt_file=None, log_dir='./log', n_dis=1, lr_decay=None, device=None,
+                 netG_ckpt_file=None, netD_ckpt_file=None, print_steps=1, vis_steps=500, log_steps=50,
+                 save_steps=5000, flush_secs=30, logit_save_steps=500, amp=False, save_logits=True, topk=False,
+                 gold=False, gold_step=None, save_logit_after=0, stop_save_logit_after=100000,
+                 save_eval_logits=True, compat_fetch_quirk=False):
+        self.output_path = output_path
+        self.logit_save_steps = logit_save_steps
+        self.netD, self.netG, self.optD, self.optG = netD, netG, optD, optG
+        self.n_dis, self.lr_decay = n_dis, lr_decay
+        self.dataloader, self.num_steps, self.device, self.log_dir = dataloader, num_steps, device, log_dir
+        self.netG_ckpt_file, self.netD_ckpt_file = netG_ckpt_file, netD_ckpt_file
+        self.print_steps, self.vis_steps, self.log_steps, self.save_steps = print_steps, vis_steps, log_steps, save_steps
+        self.amp, self.save_logits = amp, save_logits
+        self.save_logit_after, self.stop_save_logit_after = save_logit_after, stop_save_logit_after
+        self.save_eval_logits = save_eval_logits
+        self.netD_drs, self.dataloader_drs, self.optD_drs = netD_drs, dataloader_drs, optD_drs
+        self.netD_drs_ckpt_file = netD_drs_ckpt_file
+        self.topk, self.gold, self.gold_step = topk, gold, gold_step
+        self.compat_fetch_quirk = compat_fetch_quirk
+        if self.amp:
+            raise NotImplementedError("amp is not part of the fp32 MI355X path")
+        if self.gold:
+            assert self.gold_step is not None
+        if self.netD_drs is not None:
+            assert self.dataloader_drs is not None and self.optD_drs is not None
+            self.train_drs = True
+        else:
+            self.train_drs = False
+        for name, var in dict(num_steps=num_steps, n_dis=n_dis, print_steps=print_steps, vis_steps=vis_steps,
+                              log_steps=log_steps, save_steps=save_steps, flush_secs=flush_secs).items():
+            if var < 1:
+                raise ValueError('{} must be at least 1 but got {}.'.format(name, var))
+        os.makedirs(self.log_dir, exist_ok=True)
+        self.logger = Logger(log_dir=self.log_dir, num_steps=self.num_steps, dataset_size=len(self.dataloader),
+                             flush_secs=flush_secs, device=self.device)
+        # base learning rates are cached here, i.e. before any checkpoint restore (scheduler.py:38)
+        self.scheduler = DRS_LRScheduler(lr_decay=self.lr_decay,
+                                         optimizers=[o for o in [self.optD, self.optD_drs, self.optG] if o is not None],
+                                         num_steps=self.num_steps)
+        self.netG_ckpt_dir = os.path.join(self.log_dir, 'checkpoints', 'netG')
+        self.netD_ckpt_dir = os.path.join(self.log_dir, 'checkpoints', 'netD')
+        self.netD_drs_ckpt_dir = os.path.join(self.log_dir, 'checkpoints', 'netD_drs') if self.train_drs else None
+        if not self.device:
+            self.device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
+        self.device = torch.device(self.device)
+        if self.device.type == 'cuda' and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
+        for net in [self.netD, self.netG, self.netD_drs]:
+            if net is not None and net.device != self.device:
+                net.to(self.device)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.logit_records = {}
+        self.events = []          # (global_step, event) trace used by the control-flow tests
+
+    # ---- logit record -------------------------------------------------------------------------
+    @property
+    def logit_results(self):
+        """dict{name -> dict{step -> float64 ndarray[N]}}: what the reference pickles (trainer.py:138-140)."""
+        return {name: rec.to_dict() for name, rec in self.logit_records.items()}
+
+    def _save_logit(self, logits_dict=None):
+        if self.rank != 0:
+            return
+        logits_dict = self.logit_results if logits_dict is None else logits_dict
+        for name, logits in logits_dict.items():
+            with open(os.path.join(str(self.output_path), f'logits_{name}.pkl'), 'wb') as f:
+                pickle.dump(logits, f)
+
+    def _eval_loader(self):
+        """Loader for the logit pass.  Single process: the training loader itself (trainer.py:143).
+        Data parallel: this rank's contiguous index range [lo, hi) of the dataset."""
+        if self.world == 1:
+            return self.dataloader, None
+        ds = self.dataloader.dataset
+        n = len(ds)
+        per = (n + self.world - 1) // self.world
+        lo, hi = min(self.rank * per, n), min((self.rank + 1) * per, n)
+        sub = torch.utils.data.Subset(ds, range(lo, hi))
+        loader = torch.utils.data.DataLoader(sub, batch_size=self.dataloader.batch_size, shuffle=False,
+                                             num_workers=getattr(self.dataloader, 'num_workers', 0))
+        return loader, (lo, hi, per)
+
+    def _get_logit(self, netD, eval_mode=False, record=None, step=None):
+        """Full pass of D over the dataset; rec[row, idx] = D(x).  Returns the float64 row (device)."""
+        n_data = len(self.dataloader.dataset)
+        if record is None:
+            record = LogitRecord(n_data, capacity=1, device=self.device)
+        row = record.new_snapshot(step if step is not None else -1)
+        loader, shard = self._eval_loader()
+        if eval_mode:
+            netD.eval()
+        with torch.no_grad():
+            for data, targets, _, idx in loader:
+                logit = netD(data.to(self.device, non_blocking=True))
+                if type(logit) is tuple:
+                    logit = logit[0]
+                record.scatter(row, idx, logit.view(-1))
+        netD.train()
+        record.check_bounds()
+        if shard is not None:                     # one all-gather of the contiguous shards
+            lo, hi, per = shard
+            mine = torch.zeros(per, dtype=record.buf.dtype, device=self.device)
+            mine[: hi - lo] = record.buf[row, lo:hi]
+            full = dist.all_gather_cat(mine)[:n_data]
+            record.buf[row].copy_(full)
+        return record.buf[row]
+
+    # ---- checkpoints --------------------------------------------------------------------------
+    def _restore_models_and_step(self):
+        global_step_D = global_step_G = 0
+        if self.netD_ckpt_file:
+            assert os.path.exists(self.netD_ckpt_file)
+            print("INFO: Restoring checkpoint for D...")
+            global_step_D = self.netD.restore_checkpoint(ckpt_file=self.netD_ckpt_file, optimizer=self.optD)
+        if self.netG_ckpt_file:
+            assert os.path.exists(self.netG_ckpt_file)
+            print("INFO: Restoring checkpoint for G...")
+            global_step_G = self.netG.restore_checkpoint(ckpt_file=self.netG_ckpt_file, optimizer=self.optG)
+        if self.train_drs and self.netD_drs_ckpt_file:
+            assert os.path.exists(self.netD_drs_ckpt_file)
+            print("INFO: Restoring checkpoint for D_drs...")
+            global_step_D = self.netD_drs.restore_checkpoint(ckpt_file=self.netD_drs_ckpt_file,
+                                                             optimizer=self.optD_drs)
+        if global_step_D != global_step_G:
+            print(f'WARN: global_step_D {global_step_D} != global_step_G {global_step_G}, use global_step_G')
+        return global_step_G
+
+    def _save_model_checkpoints(self, global_step):
+        if self.rank != 0:
+            return
+        self.netG.save_checkpoint(directory=self.netG_ckpt_dir, global_step=global_step, optimizer=self.optG)
+        if self.netD is not None:
+            self.netD.save_checkpoint(directory=self.netD_ckpt_dir, global_step=global_step, optimizer=self.optD)
+        if self.train_drs:
+            self.netD_drs.save_checkpoint(directory=self.netD_drs_ckpt_dir, global_step=global_step,
+                                          optimizer=self.optD_drs)
+
+    # ---- data ---------------------------------------------------------------------------------
+    def _fetch_data(self, iter_dataloader, dataloader=None):
+        """next(batch) with re-iteration at the end of an epoch, moved to the device.
+
+        mimicry's Trainer._fetch_data always re-iterates `self.dataloader`; LogTrainer does not
+        override it, so in the reference an exhausted D_drs iterator silently restarts on the
+        *weighted* loader.  Default here is the intended behaviour (each iterator restarts on its
+        own loader); compat_fetch_quirk=True reproduces the reference's."""
+        if dataloader is None or self.compat_fetch_quirk:
+            dataloader = self.dataloader
+        try:
+            real_batch = next(iter_dataloader)
+        except StopIteration:
+            iter_dataloader = iter(dataloader)
+            real_batch = next(iter_dataloader)
+        real_batch = (real_batch[0].to(self.device, non_blocking=True), real_batch[1].to(self.device, non_blocking=True))
+        return iter_dataloader, real_batch
+
+    # ---- the loop -----------------------------------------------------------------------------
+    def train(self):
+        global_step = self._restore_models_and_step()
+        if self.gold and global_step >= self.gold_step:
+            self.netD.use_gold = True
+        print("INFO: Starting training from global step {}...".format(global_step))
+        try:
+            start_time = time.time()
+            scaler = None
+            iter_dataloader = iter(self.dataloader)
+            if self.train_drs:
+                iter_dataloader_drs = iter(self.dataloader_drs)
+            while global_step < self.num_steps:
+                log_data = MetricLog()
+                if self.topk:
+                    self.netG.decay_topk_rate(global_step, epoch_steps=len(self.dataloader))
+                if self.gold and global_step == self.gold_step:
+                    self.netD.use_gold = True
+                for i in range(self.n_dis):
+                    iter_dataloader, real_batch = self._fetch_data(iter_dataloader=iter_dataloader)
+                    log_data = self.netD.train_step(real_batch=real_batch, netG=self.netG, optD=self.optD,
+                                                    log_data=log_data, global_step=global_step, device=self.device,
+                                                    scaler=scaler)
+                    self.events.append((global_step, 'D'))
+                    if self.train_drs:
+                        iter_dataloader_drs, real_batch_drs = self._fetch_data(iter_dataloader=iter_dataloader_drs,
+                                                                               dataloader=self.dataloader_drs)
+                        log_data = self.netD_drs.train_step(real_batch=real_batch_drs, netG=self.netG,
+                                                            optD=self.optD_drs, log_data=log_data,
+                                                            global_step=global_step, device=self.device, scaler=scaler)
+                        self.events.append((global_step, 'D_drs'))
+                    if i == (self.n_dis - 1):       # G once per global step, on the last D batch
+                        log_data = self.netG.train_step(real_batch=real_batch, netD=self.netD, optG=self.optG,
+                                                        global_step=global_step, log_data=log_data,
+                                                        device=self.device, scaler=scaler)
+                        self.events.append((global_step, 'G'))
+                global_step += 1
+                log_data = self.scheduler.step(log_data=log_data, global_step=global_step)
+
+                if global_step % self.log_steps == 0 and self.rank == 0:
+                    self.logger.write_summaries(log_data=log_data, global_step=global_step)
+                if global_step % self.print_steps == 0:
+                    curr_time = time.time()
+                    topk_rate = self.netG.topk_rate if hasattr(self.netG, 'topk_rate') else 1
+                    log_data.add_metric('topk_rate', topk_rate, group='topk_rate', precision=6)
+                    if self.rank == 0:
+                        self.logger.print_log(global_step=global_step, log_data=log_data,
+                                              time_taken=(curr_time - start_time) / self.print_steps)
+                    start_time = curr_time
+                if global_step % self.vis_steps == 0 and self.rank == 0:
+                    self.logger.vis_images(netG=self.netG, global_step=global_step)
+
+                if (self.save_logits and global_step % self.logit_save_steps == 0
+                        and global_step >= self.save_logit_after and global_step <= self.stop_save_logit_after):
+                    netD, netD_name = (self.netD_drs, 'netD_drs') if self.train_drs else (self.netD, 'netD')
+                    mode = 'eval' if self.save_eval_logits else 'train'
+                    print(f"INFO: logit saving {mode} netD: {netD_name}...")
+                    key = f'{netD_name}_{mode}'
+                    if key not in self.logit_records:
+                        self.logit_records[key] = LogitRecord(len(self.dataloader.dataset), capacity=64,
+                                                              device=self.device)
+                    self._get_logit(netD=netD, eval_mode=(mode == 'eval'), record=self.logit_records[key],
+                                    step=global_step)
+                    self.events.append((global_step, 'logit'))
+
+                if global_step % self.save_steps == 0:
+                    print("INFO: Saving checkpoints...")
+                    self._save_model_checkpoints(global_step)
+                    self.events.append((global_step, 'ckpt'))
+                    if self.save_logits and global_step >= self.save_logit_after:
+                        self._save_logit()
+
+            print("INFO: Saving final checkpoints...")
+            self._save_model_checkpoints(global_step)
+            if self.save_logits and global_step >= self.save_logit_after:
+                self._save_logit()
+        except KeyboardInterrupt:
+            print("INFO: Saving checkpoints from keyboard interrupt...")
+            self._save_model_checkpoints(global_step)
+            if self.save_logits and global_step >= self.save_logit_after:
+                self._save_logit()
+        finally:
+            self.logger.close_writers()
+        print("INFO: Training Ended.")

@@ -1,0 +1,224 @@
+"""GPU: SNGAN-32 / SNGAN-64 forward, backward and train steps of the HIP engine against the
+plain-PyTorch CPU oracle (oracle/nets.py) on identical weights, images and noise.
+Tolerances: logits/losses 1e-3 absolute (BASELINE.json north_star), gradients 1e-3 relative to
+their max magnitude."""
+import copy
+
+import pytest
+import torch
+
+from oracle import nets as O
+
+pytestmark = pytest.mark.gpu
+
+
+class Log:
+    def __init__(self):
+        self.m = {}
+
+    def add_metric(self, name, value, group=None, precision=4):
+        self.m[name] = value
+
+
+def build(dataset, loss_type, seed=1):
+    from diagan.models.predefined_models import get_gan_model
+    oG, oD, ooptG, ooptD = O.make_pair(dataset, loss_type, seed=seed)
+    torch.manual_seed(seed)
+    netG, netD, optG, optD = get_gan_model(dataset, model='sngan', loss_type=loss_type)
+    netG.load_state_dict(oG.state_dict())
+    netD.load_state_dict(oD.state_dict())
+    netG.to('cuda')
+    netD.to('cuda')
+    return (oG, oD, ooptG, ooptD), (netG, netD, optG, optD)
+
+
+def relclose(a, b, tol, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = b.abs().max().item() + 1e-20
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e}, scale {scale:.3e}"
+
+
+def l2close(a, b, tol, what="", floor=0.0):
+    """Relative L2 error.  Used for gradients that pass through ReLU masks: a pre-activation that is
+    +1e-7 in one fp32 implementation and -1e-7 in the other flips one mask element (observed: 1 of
+    262144), which is an O(1) error in a single element and ~1e-3 in L2 -- not a kernel error."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).norm().item()
+    assert err <= tol * (b.norm().item() + floor), f"{what}: L2 err {err:.3e}, norm {b.norm().item():.3e}"
+
+
+def is_dead_bias(k):
+    """Conv biases that feed a BatchNorm have an exactly-zero true gradient (BN removes the mean)."""
+    return k.startswith('block') and k.endswith('.bias') and ('.c1.' in k or '.c2.' in k or '.c_sc.' in k)
+
+
+def test_same_seed_init_matches_oracle():
+    """RNG consumption order of the constructors replays torch_mimicry's (set_seed contract)."""
+    from diagan.models.predefined_models import get_gan_model
+    oG, oD, _, _ = O.make_pair('cifar10', 'ns', seed=7)
+    torch.manual_seed(7)
+    netG, netD, _, _ = get_gan_model('cifar10', model='sngan', loss_type='ns')
+    for o, n in ((oG, netG), (oD, netD)):
+        so, sn = o.state_dict(), n.state_dict()
+        assert list(so.keys()) == list(sn.keys())
+        for k in so:
+            assert so[k].shape == sn[k].shape, k
+            assert torch.equal(so[k], sn[k].cpu()), k
+    assert netG.count_params() == sum(p.numel() for p in oG.parameters())
+    assert netD.count_params() == sum(p.numel() for p in oD.parameters())
+
+
+@pytest.mark.parametrize("dataset,res", [("cifar10", 32), ("celeba", 64)])
+def test_forward_eval_and_train(dataset, res):
+    (oG, oD, _, _), (netG, netD, _, _) = build(dataset, 'ns')
+    B = 4
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(B, 128, generator=g)
+    x = torch.rand(B, 3, res, res, generator=g) * 2 - 1
+    for mode in ("eval", "train"):
+        for n in (oG, oD, netG, netD):
+            n.train(mode == "train")
+        with torch.no_grad():
+            ref_img, ref_logit = oG(z), oD(x)
+        img, logit = netG(z.cuda()), netD(x.cuda())
+        assert img.shape == ref_img.shape and logit.shape == ref_logit.shape
+        assert (img.cpu() - ref_img).abs().max() < 1e-3, mode
+        assert (logit.cpu() - ref_logit).abs().max() < 1e-3, mode
+    # training-mode forwards updated BN running stats and SN u / sigma identically
+    sG, sD = netG.state_dict(), netD.state_dict()
+    for k, v in oG.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            relclose(sG[k].float(), v.float(), 1e-4, k)
+    for k, v in oD.state_dict().items():
+        if 'sn_' in k:
+            relclose(sD[k], v, 1e-4, k)
+
+
+@pytest.mark.parametrize("dataset,res,loss", [("cifar10", 32, "ns"), ("cifar10", 32, "hinge"), ("celeba", 64, "ns")])
+def test_train_steps_match_oracle(dataset, res, loss):
+    (oG, oD, ooptG, ooptD), (netG, netD, optG, optD) = build(dataset, loss)
+    B = 8 if res == 32 else 4
+    g = torch.Generator().manual_seed(3)
+    for step in range(2):
+        # step 0 starts from identical parameters: 1e-3 absolute (observed ~1e-6).  Later steps start
+        # from parameters that already went through Adam with beta1 = 0 (update = lr * g/|g|), which
+        # turns rounding noise on near-zero gradients into +-lr parameter differences: the loss
+        # trajectories of ANY two fp32 implementations separate at that rate, so the bound is relative.
+        tol = (lambda ref: 1e-3) if step == 0 else (lambda ref: 5e-3 * max(1.0, abs(ref)))
+        x = torch.rand(B, 3, res, res, generator=g) * 2 - 1
+        zd = torch.randn(B, 128, generator=g)
+        zg = torch.randn(B, 128, generator=g)
+        # ---- D step
+        errD, D_x, D_Gz = oD.train_step((x, None), oG, ooptD, noise=zd)
+        log = netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda',
+                              noise=zd.cuda())
+        assert abs(log.m['errD'].item() - errD) < tol(errD), (step, log.m['errD'].item(), errD)
+        assert abs(log.m['D(x)'].item() - D_x) < 1e-3 and abs(log.m['D(G(z))'].item() - D_Gz) < 1e-3
+        if step == 0:
+            gr = netD.export_grads()
+            for k, p in oD.named_parameters():
+                l2close(gr[k], p.grad, 1e-2, f"D grad {k}")
+        # ---- G step
+        errG = oG.train_step((x, None), oD, ooptG, noise=zg)
+        log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda',
+                              noise=zg.cuda())
+        assert abs(log.m['errG'].item() - errG) < tol(errG), (step, log.m['errG'].item(), errG)
+        if step == 0:
+            gr = netG.export_grads()
+            wscale = max(p.grad.norm().item() for p in oG.parameters())
+            for k, p in oG.named_parameters():
+                if is_dead_bias(k):
+                    assert gr[k].abs().max().item() < 1e-4 * wscale, k
+                else:
+                    l2close(gr[k], p.grad, 5e-2, f"G grad {k}")
+    # after two Adam updates of each net the parameters still agree
+    sG, sD = netG.state_dict(), netD.state_dict()
+    for k, v in oG.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert (sG[k].cpu() - v).abs().max() < 2e-3, k
+    for k, v in oD.state_dict().items():
+        assert (sD[k].cpu() - v).abs().max() < 2e-3, k
+
+
+def test_generator_backward_isolated():
+    """Same upstream gradient into both generators: no ReLU-flip noise from D on the path."""
+    from diagan.ops import eltwise as E
+    (oG, _, _, _), (netG, _, _, _) = build("cifar10", "ns")
+    g = torch.Generator().manual_seed(11)
+    z = torch.randn(8, 128, generator=g)
+    gi = torch.randn(8, 3, 32, 32, generator=g)
+    oG(z).backward(gi)
+    netG.zero_grad()
+    y, ctx = netG.forward_nhwc(z.cuda(), True, save=True)
+    netG.backward_nhwc(ctx, E.nchw_to_nhwc(gi.cuda(), 4))
+    gr = netG.export_grads()
+    wscale = max(p.grad.abs().max().item() for p in oG.parameters())
+    for k, p in oG.named_parameters():
+        if is_dead_bias(k):
+            assert gr[k].abs().max().item() < 1e-4 * wscale, k
+        else:
+            l2close(gr[k], p.grad, 1e-2, f"G grad {k}")   # ReLU-flip noise bound, see l2close
+
+
+def test_discriminator_backward_isolated():
+    from diagan.ops import eltwise as E
+    (_, oD, _, _), (_, netD, _, _) = build("cifar10", "hinge")
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1
+    dl = torch.randn(8, generator=g)
+    xr = x.clone().requires_grad_(True)
+    oD(xr).view(-1).mul(dl).sum().backward()
+    netD.zero_grad()
+    logit, ctx = netD.forward_nhwc(E.nchw_to_nhwc(x.cuda(), 4), True, save=True, need_dgrad=True, need_in_dgrad=True)
+    gx = netD.backward_nhwc(ctx, dl.cuda(), need_wgrad=True, need_gx=True)
+    l2close(E.nhwc_to_nchw(gx, 3), xr.grad, 2e-2, "image gradient")
+    gr = netD.export_grads()
+    for k, p in oD.named_parameters():
+        l2close(gr[k], p.grad, 1e-2, f"D grad {k}")
+    # the deepest blocks see no flips at all: tight check that the kernels are exact there
+    for k, p in oD.named_parameters():
+        if k.startswith('block4') or k.startswith('l5'):
+            relclose(gr[k], p.grad, 1e-4, f"D grad {k}")
+
+
+def test_topk_and_gold_losses_vs_oracle():
+    from diagan.ops import eltwise as E
+    g = torch.Generator().manual_seed(5)
+    r = torch.randn(64, 1, generator=g) * 2
+    f = torch.randn(64, 1, generator=g) * 2
+    for loss in ('ns', 'hinge', 'gan', 'wasserstein'):
+        for gold in ((False, True) if loss in ('ns', 'hinge') else (False,)):
+            rr, ff = r.clone().requires_grad_(True), f.clone().requires_grad_(True)
+            ref = O.dis_loss(loss, rr, ff, gold=gold)
+            ref.backward()
+            out3, dr, df = E.loss_dis(r.cuda(), f.cuda(), loss, gold=gold)
+            assert abs(out3[0].item() - ref.item()) < 1e-5, (loss, gold)
+            assert (dr.cpu() - rr.grad.view(-1)).abs().max() < 1e-6
+            assert (df.cpu() - ff.grad.view(-1)).abs().max() < 1e-6
+            assert abs(out3[1].item() - torch.sigmoid(r).mean().item()) < 1e-6
+        for rate in (1.0, 0.77, 0.5):
+            ff = f.clone().requires_grad_(True)
+            k = int(rate * 64)
+            ref = O.gen_loss(loss, torch.topk(ff, k, dim=0)[0])
+            ref.backward()
+            out1, df = E.loss_gen(f.cuda(), loss, k=k)
+            assert abs(out1[0].item() - ref.item()) < 1e-5, (loss, rate)
+            assert (df.cpu() - ff.grad.view(-1)).abs().max() < 1e-6
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    (_, _, _, _), (netG, netD, optG, optD) = build("cifar10", "ns")
+    x = torch.rand(4, 3, 32, 32).cuda() * 2 - 1
+    netD.train_step(real_batch=(x, None), netG=netG, optD=optD, log_data=Log(), device='cuda')
+    netD.save_checkpoint(str(tmp_path / "netD"), 7, optD)
+    from diagan.models.predefined_models import get_gan_model
+    _, netD2, _, optD2 = get_gan_model('cifar10', model='sngan', loss_type='ns')
+    netD2.to('cuda')
+    step = netD2.restore_checkpoint(str(tmp_path / "netD" / "netD_7_steps.pth"), optD2)
+    assert step == 7
+    netD.eval(); netD2.eval()
+    assert torch.equal(netD(x), netD2(x))
+    ck = torch.load(str(tmp_path / "netD" / "netD_7_steps.pth"), weights_only=False)
+    assert ck['model_state_dict']['block1.c1.weight'].shape == (128, 3, 3, 3)
+    assert ck['model_state_dict']['l5.weight'].shape == (1, 128)
