@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the SNGAN G+D training step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one global step of LogTrainer.train (diagan-pkg/diagan/trainer/trainer.py:250-299):
+n_dis = 5 discriminator updates + 1 generator update (+ the LR scheduler) at batch 64 PER GPU
+(weak scaling, as stylegan2/train_ffhq.py:393 "batch sizes for each gpus"), on synthetic images that
+are resident in HBM before the timed region.  Default workload: BASELINE.json configs[1]
+(CIFAR-10 SNGAN phase-1 'ns' loss, 32x32).  Prints ONE JSON line on rank 0.
+
+Extra objects on the line:
+  roofline      dominant kernel (most GPU time among the GEMM kernels): algorithmic FLOP / launch
+                time, measured with HIP events around every launch of the timed region
+  cpu_baseline  the CPU restatement (oracle/nets.py, kind "port") timed on this box's host cores,
+                rank 0 at N = 1 only, on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "self-diagnosing-gan_amd"))
+
+import torch
+
+MFMA_F32_PEAK = 157.3e12      # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+HBM_PEAK = 8.0e12
+
+WORKLOADS = {
+    # name: (dataset key, resolution, description)
+    'sngan32': ('cifar10', 32, "CIFAR-10 SNGAN phase-1 ns-loss bs=64, synthetic 32x32"),
+    'sngan64': ('celeba', 64, "CelebA-64 SNGAN phase-1 ns-loss bs=64, synthetic 64x64"),
+}
+
+
+class NullLog:
+    def add_metric(self, *a, **k):
+        pass
+
+
+def build_models(dataset, loss_type, phase, device):
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.utils.settings import set_seed
+    set_seed(1)
+    if phase == 2:
+        netG, netD, netD_drs, optG, optD, optD_drs = get_gan_model(dataset, model='sngan', loss_type=loss_type, drs=True)
+    else:
+        netG, netD, optG, optD = get_gan_model(dataset, model='sngan', loss_type=loss_type)
+        netD_drs = optD_drs = None
+    for n in (netG, netD, netD_drs):
+        if n is not None:
+            n.to(device)
+    return netG, netD, netD_drs, optG, optD, optD_drs
+
+
+def make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, n_dis, num_steps, device):
+    """The body of LogTrainer.train's while-loop without logging / checkpoint I/O."""
+    from diagan.trainer.scheduler import DRS_LRScheduler
+    sched = DRS_LRScheduler('linear', [o for o in (optD, optD_drs, optG) if o is not None], num_steps)
+    log = NullLog()
+    state = dict(step=0, cursor=0)
+
+    def fetch():
+        b = batches[state['cursor'] % len(batches)]
+        state['cursor'] += 1
+        return (b, None)
+
+    def step():
+        for i in range(n_dis):
+            real = fetch()
+            netD.train_step(real_batch=real, netG=netG, optD=optD, log_data=log, global_step=state['step'],
+                            device=device)
+            if netD_drs is not None:
+                netD_drs.train_step(real_batch=fetch(), netG=netG, optD=optD_drs, log_data=log,
+                                    global_step=state['step'], device=device)
+            if i == n_dis - 1:
+                netG.train_step(real_batch=real, netD=netD, optG=optG, log_data=log, global_step=state['step'],
+                                device=device)
+        state['step'] += 1
+        sched.step(log, state['step'])
+
+    return step
+
+
+def cpu_baseline(dataset, res, loss_type, batch, n_dis, budget_s=25.0):
+    """The CPU restatement of the same global step on the host cores this process may use.
+    Bounded sample: D updates and G updates are timed separately (at least one of each, more while
+    the budget lasts) and combined as one global step = n_dis * t_D + t_G."""
+    from oracle import nets as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:                                     # cgroup CPU quota of the box (e.g. "1600000 100000" = 16 cores)
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            avail = max(1, min(avail, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(avail, 64))           # beyond the quota / 64 threads torch CPU convs only oversubscribe
+    torch.set_num_threads(cores)
+    oG, oD, ooptG, ooptD = O.make_pair(dataset, loss_type, seed=1)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(batch, 3, res, res, generator=g) * 2 - 1
+    t_start = time.time()
+    oD.train_step((x, None), oG, ooptD)      # warm-up: thread pool, allocator (not timed)
+    warm = time.time() - t_start
+    td, tg = [], []
+    while True:
+        t0 = time.time(); oD.train_step((x, None), oG, ooptD); td.append(time.time() - t0)
+        t0 = time.time(); oG.train_step((x, None), oD, ooptG); tg.append(time.time() - t0)
+        if time.time() - t_start > budget_s or len(td) >= 5:
+            break
+    t_d, t_g = min(td), min(tg)
+    t_step = n_dis * t_d + t_g
+    return {"value": round(batch / t_step, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/nets.py (torch CPU ops, {cores} threads of {avail} available): best of {len(td)} "
+                      f"D update(s) {t_d:.2f} s and G update(s) {t_g:.2f} s at bs={batch}; one global step = "
+                      f"{n_dis}*t_D + t_G = {t_step:.2f} s (warm-up D update {warm:.1f} s not counted)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="sngan32", choices=sorted(WORKLOADS))
+    ap.add_argument("--phase", type=int, default=1, choices=(1, 2))
+    ap.add_argument("--loss_type", default="ns")
+    ap.add_argument("--batch_size", type=int, default=64)
+    ap.add_argument("--n_dis", type=int, default=5)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_kernel_timer", action="store_true")
+    args = ap.parse_args()
+
+    from diagan.trainer import distributed as dist
+    rank, local_rank, world = dist.init_from_env()
+    if world != args.gpus:
+        if rank == 0 and world > 1:
+            print(f"WARNING: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the device path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dataset, res, desc = WORKLOADS[args.workload]
+
+    netG, netD, netD_drs, optG, optD, optD_drs = build_models(dataset, args.loss_type, args.phase, device)
+    if world > 1:
+        for n in (netG, netD, netD_drs):
+            if n is not None:
+                dist.broadcast_module_(n)
+    gen = torch.Generator().manual_seed(1234 + rank)          # SURVEY §8(d) synthetic inputs
+    pool = 2 * args.n_dis
+    batches = [(torch.rand(args.batch_size, 3, res, res, generator=gen) * 2 - 1).to(device) for _ in range(pool)]
+    step = make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, args.n_dis,
+                            num_steps=50000 if dataset == 'cifar10' else 75000, device=device)
+
+    for _ in range(args.warmup):
+        step()
+    from diagan.ops import conv as C
+    timer = None
+    if not args.no_kernel_timer:
+        timer = C.KernelTimer()
+    dist.synchronize()
+    torch.cuda.synchronize()
+    C.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dist.synchronize()
+    elapsed = time.perf_counter() - t0
+    C.TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return
+
+    images = args.batch_size * args.steps * world
+    line = {
+        "metric": "images/sec (G+D step)",
+        "value": round(images / elapsed, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": desc + (" + D_drs (phase 2)" if args.phase == 2 else ""),
+                   "global_batch": args.batch_size * world, "n_dis": args.n_dis, "loss_type": args.loss_type,
+                   "parallelism": f"dp{world}", "steps_per_s": round(args.steps / elapsed, 3),
+                   "D_updates_per_s": round(args.steps * args.n_dis / elapsed, 3)},
+    }
+    if timer is not None:
+        summ = timer.summary()
+        dom = max(summ.items(), key=lambda kv: kv[1]['seconds'])
+        name, d = dom
+        achieved = d['flop'] / d['seconds'] / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
+            except Exception:
+                traffic = None
+        line["roofline"] = {
+            "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK / 1e12,
+            "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_F32_PEAK, 4), "traffic": traffic,
+            "launches": d['launches'], "avg_launch_us": round(d['seconds'] / d['launches'] * 1e6, 2),
+            "algorithmic_gflop_per_launch": round(d['flop'] / d['launches'] / 1e9, 3),
+            "all_gemm_kernels": {k: {"launches": v['launches'], "tflops": round(v['flop'] / v['seconds'] / 1e12, 2),
+                                     "time_share_of_step": round(v['seconds'] / elapsed, 4)}
+                                 for k, v in sorted(summ.items())},
+        }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(dataset, res, args.loss_type, args.batch_size, args.n_dis)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

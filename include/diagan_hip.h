@@ -77,6 +77,8 @@ int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias
                      int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                      int dr, int off, int up, int Kp, int tile_cfg, void* stream);
 
+int diagan_conv_gemm_pick_cfg(int M, int Co); /* tile config chosen when tile_cfg == 0 (host only) */
+
 /* Weight gradient, split over pixels: slab[s][n][k] = sum_{m in split s} dy[m][n]*pro(x gathered).
  * Replaces the weight half of conv2d / conv_transpose2d backward (errD.backward()/errG.backward()
  * in the train steps, diagan-pkg/diagan/models/topk_models.py:90, mnist.py:126).

@@ -210,6 +210,14 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
 
 using namespace diagan;
 
+// tile selection used when tile_cfg == 0: 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 128x64
+DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
+  int cfg = Co <= 64 ? 2 : 1;
+  const long tiles = (long)cdiv(M, cfg == 2 ? 256 : 128) * cdiv(Co, cfg == 2 ? 64 : 128);
+  if (tiles < 256) cfg = 3;                   // small problems: 64 x 64 tiles to fill the CUs
+  return cfg;
+}
+
 // see include/diagan_hip.h
 DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
                                 const float* residual, int res_relu, const float* mask_src, float mask_slope,
@@ -233,14 +241,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   hipStream_t st = (hipStream_t)stream;
-  // tile selection: 0 = auto
-  int cfg = tile_cfg;
-  if (cfg == 0) {
-    if (Co <= 64) cfg = 2;                    // 256 x 64
-    else cfg = 1;                             // 128 x 128
-    const long tiles = (long)cdiv(a.M, cfg == 2 ? 256 : 128) * cdiv(Co, cfg == 2 ? 64 : 128);
-    if (tiles < 256) cfg = 3;                 // small problems: 64 x 64 tiles to fill the CUs
-  }
+  const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co) : tile_cfg;
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, st);
     case 2: return launch_cfg<256, 64, 4, 1>(a, st);

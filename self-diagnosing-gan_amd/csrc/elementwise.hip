@@ -128,18 +128,42 @@ __global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
   }
 }
 
+// Deterministic combine of the per-split partials: block = 64 channels x 4 split-lanes; lane l sums
+// splits l, l+4, ... and the four lane sums are added in a fixed order.  True for the lanes that own a channel.
+__device__ __forceinline__ bool combine_partials(const double* __restrict__ partials, int splits, int C,
+                                                 double (*red)[64][2], int* c_out, double* s1, double* s2) {
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int k = sl; k < splits; k += 4) { a += partials[(long)k * 2 * C + c]; b += partials[(long)k * 2 * C + C + c]; }
+  red[sl][cl][0] = a;
+  red[sl][cl][1] = b;
+  __syncthreads();
+  *c_out = c;
+  if (sl != 0 || c >= C) return false;
+  *s1 = (red[0][cl][0] + red[1][cl][0]) + (red[2][cl][0] + red[3][cl][0]);
+  *s2 = (red[0][cl][1] + red[1][cl][1]) + (red[2][cl][1] + red[3][cl][1]);
+  return true;
+}
+
 // BatchNorm forward finalize: batch statistics -> affine form + running stats (momentum 0.1, unbiased var)
-__global__ void bn_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                    float* __restrict__ scale_out, float* __restrict__ shift_out, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[4][64][2];
+  int c;
+  double s1 = 0, s2 = 0;
+  if (training) {
+    if (!combine_partials(partials, splits, C, red, &c, &s1, &s2)) return;
+  } else {
+    c = blockIdx.x * 64 + (threadIdx.x & 63);
+    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+  }
   float mean, var;
   if (training) {
-    double s1 = 0, s2 = 0;
-    for (int k = 0; k < splits; ++k) { s1 += partials[(long)k * 2 * C + c]; s2 += partials[(long)k * 2 * C + C + c]; }
     const double m = s1 / (double)M;
     double v = s2 / (double)M - m * m;
     v = v < 0 ? 0 : v;
@@ -161,26 +185,26 @@ __global__ void bn_finalize_kernel(const double* __restrict__ partials, int spli
 }
 
 // BatchNorm backward finalize: dgamma += s2, dbeta += s1, coef = {s1/M, s2/M}
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ coef, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int k = 0; k < splits; ++k) { s1 += partials[(long)k * 2 * C + c]; s2 += partials[(long)k * 2 * C + C + c]; }
+  __shared__ double red[4][64][2];
+  int c;
+  double s1, s2;
+  if (!combine_partials(partials, splits, C, red, &c, &s1, &s2)) return;
   dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
   dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
   coef[c] = (float)(s1 / (double)M);
   coef[C + c] = (float)(s2 / (double)M);
 }
 
-__global__ void colsum_finalize_kernel(const double* __restrict__ partials, int splits, int C, float* __restrict__ out,
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ partials, int splits, int C, float* __restrict__ out,
                                        int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0;
-  for (int k = 0; k < splits; ++k) s += partials[(long)k * 2 * C + c];
-  out[c] = (accumulate ? out[c] : 0.f) + (float)s;
+  __shared__ double red[4][64][2];
+  int c;
+  double s1, s2;
+  if (!combine_partials(partials, splits, C, red, &c, &s1, &s2)) return;
+  out[c] = (accumulate ? out[c] : 0.f) + (float)s1;
 }
 
 // dx = scale * (g' - c1 - xhat*c2) (+ residual)
@@ -404,8 +428,8 @@ static int colred_geometry(long M, int C, int* splits, int* rows_per_split, dim3
   const int C4 = C / 4;
   const int CW = C4 < 64 ? C4 : 64;
   const int gx = cdiv(C4, CW);
-  int s = cdiv(1024, gx);                       // ~4 blocks per CU in total
-  const long max_s = (M + 63) / 64;             // at least 64 rows per split
+  int s = cdiv(512, gx);                        // ~2 blocks per CU in total
+  const long max_s = (M + 255) / 256;           // at least 256 rows per split
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;
   *rows_per_split = (int)((M + s - 1) / s);
@@ -469,7 +493,7 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
     ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0};
     hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(EW_T), 0, ST, a);
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, (const double*)workspace, splits, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits, C,
                      (long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
                      shift_out, training);
   return check_launch("bn_stats");
@@ -488,7 +512,7 @@ DIAGAN_API int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, c
   colred_geometry(M, C, &splits, &rps, &grid);
   ColRedArgs a{x, g, scale, shift, mean, invstd, (double*)workspace, (long)M, C, rps, relu};
   hipLaunchKernelGGL(colred_kernel<1>, grid, dim3(EW_T), 0, ST, a);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, (const double*)workspace, splits,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits,
                      C, (long)M, dgamma, dbeta, coef, accumulate_param_grads);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4))), dim3(EW_T), 0, ST, g, x, scale, shift, mean,
                      invstd, coef, residual, dx, (long)M, C, relu);
@@ -503,7 +527,7 @@ DIAGAN_API int diagan_colsum(const float* x, int64_t M, int C, float* out, int a
   colred_geometry(M, C, &splits, &rps, &grid);
   ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0};
   hipLaunchKernelGGL(colred_kernel<2>, grid, dim3(EW_T), 0, ST, a);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST, (const double*)workspace, splits, C,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits, C,
                      out, accumulate);
   return check_launch("colsum");
 }

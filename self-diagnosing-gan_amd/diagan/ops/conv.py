@@ -11,6 +11,7 @@ from diagan import _native as nat
 
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F] + [I] * 15 + [P])
+nat.register("diagan_conv_gemm_pick_cfg", [I, I])
 nat.register("diagan_conv_wgrad", [P, P, P, I, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_conv_wgrad_splits", [I, I, I])
 nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
@@ -19,6 +20,39 @@ nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
 nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
+TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2>", 2: "conv_gemm_kernel<256,64,4,1>",
+              3: "conv_gemm_kernel<64,64,2,2>", 4: "conv_gemm_kernel<128,64,2,2>"}
+
+
+class KernelTimer:
+    """Optional per-launch HIP-event timing of the GEMM kernels (bench.py's roofline leg).
+    Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.records = []          # (kernel name, flop, start event, stop event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def end(self, name, flop, start):
+        stop = torch.cuda.Event(enable_timing=True)
+        stop.record()
+        self.records.append((name, flop, start, stop))
+
+    def summary(self):
+        """name -> dict(launches, flop, seconds); call after a device synchronize."""
+        out = {}
+        for name, flop, s, e in self.records:
+            d = out.setdefault(name, dict(launches=0, flop=0.0, seconds=0.0))
+            d['launches'] += 1
+            d['flop'] += flop
+            d['seconds'] += s.elapsed_time(e) * 1e-3
+        return out
+
+
+TIMER = None      # set to a KernelTimer by bench.py
 
 
 def round_up(x, m):
@@ -73,9 +107,13 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         if t is not None and t.shape != out.shape:
             raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
     sy, dr, off, up = geo_params
+    t0 = TIMER.begin() if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.current_stream())
+    if t0 is not None:
+        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)
+        TIMER.end(TILE_NAMES[cfg], 2.0 * B * Ho * Wo * Co * R * S * Ci, t0)
     return out
 
 
@@ -131,8 +169,12 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     slab = _slab(dy.device, splits * n_elem + extra)
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
+    t0 = TIMER.begin() if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
+    if t0 is not None:
+        TIMER.end("conv_wgrad_kernel<128,128>" if (Co > 64 and geom.Kp > 64) else "conv_wgrad_kernel<64,64>",
+                  2.0 * M * Co * geom.R * geom.S * Ci, t0)
     if sn is None:
         nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
                  None, None, st)
