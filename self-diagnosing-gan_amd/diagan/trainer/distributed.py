@@ -75,6 +75,26 @@ def all_gather_cat(tensor):
     return torch.cat(out, dim=0)
 
 
+def shard_range(n, rank=None, world=None):
+    """Contiguous index range [lo, hi) of rank `rank` when n items are split over `world` ranks in
+    equal blocks of `per` = ceil(n / world) (the last blocks may be short or empty)."""
+    rank = get_rank() if rank is None else rank
+    world = get_world_size() if world is None else world
+    per = (n + world - 1) // world
+    return min(rank * per, n), min((rank + 1) * per, n), per
+
+
+def gather_row_shards(row, n):
+    """Every rank filled row[lo:hi] for its own shard_range; returns the full row on every rank with
+    ONE all-gather of `per` elements per rank (bit-exact: values are copied, never summed)."""
+    if get_world_size() == 1:
+        return row
+    lo, hi, per = shard_range(n)
+    mine = torch.zeros(per, dtype=row.dtype, device=row.device)
+    mine[: hi - lo] = row[lo:hi]
+    return all_gather_cat(mine)[:n]
+
+
 def reduce_loss_dict(loss_dict):
     """Mean of each scalar over ranks, valid on rank 0 (reference: distributed.py:104-126)."""
     world = get_world_size()

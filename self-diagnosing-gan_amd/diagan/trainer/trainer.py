@@ -100,9 +100,7 @@ class LogTrainer:
         if self.world == 1:
             return self.dataloader, None
         ds = self.dataloader.dataset
-        n = len(ds)
-        per = (n + self.world - 1) // self.world
-        lo, hi = min(self.rank * per, n), min((self.rank + 1) * per, n)
+        lo, hi, per = dist.shard_range(len(ds), self.rank, self.world)
         sub = torch.utils.data.Subset(ds, range(lo, hi))
         loader = torch.utils.data.DataLoader(sub, batch_size=self.dataloader.batch_size, shuffle=False,
                                              num_workers=getattr(self.dataloader, 'num_workers', 0))
@@ -126,11 +124,7 @@ class LogTrainer:
         netD.train()
         record.check_bounds()
         if shard is not None:                     # one all-gather of the contiguous shards
-            lo, hi, per = shard
-            mine = torch.zeros(per, dtype=record.buf.dtype, device=self.device)
-            mine[: hi - lo] = record.buf[row, lo:hi]
-            full = dist.all_gather_cat(mine)[:n_data]
-            record.buf[row].copy_(full)
+            record.buf[row].copy_(dist.gather_row_shards(record.buf[row], n_data))
         return record.buf[row]
 
     # ---- checkpoints --------------------------------------------------------------------------

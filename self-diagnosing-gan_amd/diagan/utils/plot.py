@@ -148,7 +148,7 @@ def calculate_scores(logits, start_epoch=50, end_epoch=75, clip_val=1.5, conf=1,
 
 def print_num_params(netG, netD):
     """plot.py helper used by the CLIs (plot.py:107-110; train_mimicry_phase1.py:74)."""
-    gen_trainable_parameters = sum(p.numel() for p in netG.parameters())
-    disc_trainable_parameters = sum(p.numel() for p in netD.parameters())
+    count = lambda n: n.count_params() if hasattr(n, 'count_params') else sum(p.numel() for p in n.parameters())
+    gen_trainable_parameters, disc_trainable_parameters = count(netG), count(netD)
     print(f'gen_trainable_parameters: {gen_trainable_parameters}, '
           f'disc_trainable_parameters: {disc_trainable_parameters}')

@@ -1,0 +1,71 @@
+"""GPU: phase 1 -> logit record -> scorer -> weighted sampler -> phase 2, through the CLI entry
+points, on a small synthetic dataset.  Checks the on-disk contract the reference's consumers rely on
+(checkpoint names train_mimicry_phase2.py:98-101, logits_netD_eval.pkl layout trainer.py:138-140)."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import scorer as osc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_phase1_then_phase2(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    monkeypatch.setenv("DIAGAN_QUIET", "1")
+    import train_mimicry_phase1 as p1
+    import train_mimicry_phase2 as p2
+    work = str(tmp_path)
+    t1 = p1.main(["--dataset", "cifar10", "--work_dir", work, "--exp_name", "p1", "--loss_type", "ns",
+                  "--num_data", "320", "--max_steps", "40", "--save_steps", "32", "--batch_size", "32"])
+    # snapshot steps: scaled window [28, 32], every step
+    rec = t1.logit_records['netD_eval']
+    assert rec.steps == [28, 29, 30, 31, 32]
+    pkl = os.path.join(work, "p1", "logits_netD_eval.pkl")
+    logits = pickle.load(open(pkl, "rb"))
+    assert list(logits.keys()) == [28, 29, 30, 31, 32]
+    assert all(v.dtype == np.float64 and v.shape == (320,) for v in logits.values())
+    assert all(np.all(v != 0) for v in logits.values())            # every index was written
+    for f in ("checkpoints/netG/netG_32_steps.pth", "checkpoints/netD/netD_32_steps.pth",
+              "checkpoints/netG/netG_40_steps.pth"):
+        assert os.path.exists(os.path.join(work, "p1", f)), f
+    # the record rows equal D(x) recomputed in eval mode from the step-40 weights? (only the last
+    # snapshot at step 32 < 40, so recompute is not possible) -- instead check scorer parity on the record
+    from diagan.utils.plot import calculate_scores
+    sd = calculate_scores(logits, 27, 32)
+    ref = osc.calculate_scores_c(logits, 27, 32)
+    for k in ref:
+        assert np.array_equal(sd[k], ref[k]), k
+
+    t2 = p2.main(["--dataset", "cifar10", "--work_dir", work, "--exp_name", "p2", "--baseline_exp_name", "p1",
+                  "--loss_type", "ns", "--p1_step", "32", "--window", "5", "--num_steps", "36", "--num_data", "320",
+                  "--resample_score", "ldr_conf_0.3_ratio_50", "--batch_size", "32", "--save_steps", "100"])
+    kinds = [e for _, e in t2.events]
+    assert kinds.count('D') == 20 and kinds.count('D_drs') == 20 and kinds.count('G') == 4   # steps 32..35
+    assert os.path.exists(os.path.join(work, "p2", "checkpoints/netD_drs/netD_drs_36_steps.pth"))
+    ck = torch.load(os.path.join(work, "p2", "checkpoints/netD_drs/netD_drs_36_steps.pth"), weights_only=False)
+    assert ck['global_step'] == 36 and 'block1.c1.sn_u' in ck['model_state_dict']
+
+
+def test_logit_record_matches_direct_eval(tmp_path):
+    """_get_logit rows == D(x) of the same weights in eval mode, by dataset index (shuffled loader)."""
+    from diagan.datasets.predefined import get_predefined_dataset
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.trainer.trainer import LogTrainer
+    torch.manual_seed(3)
+    netG, netD, optG, optD = get_gan_model('cifar10', model='sngan', loss_type='hinge')
+    ds = get_predefined_dataset('cifar10', num_data=150)
+    dl = torch.utils.data.DataLoader(ds, batch_size=64, shuffle=True)      # ragged last batch
+    t = LogTrainer(output_path=tmp_path, netD=netD, netG=netG, optD=optD, optG=optG, dataloader=dl, num_steps=1,
+                   log_dir=str(tmp_path), device='cuda')
+    row = t._get_logit(netD, eval_mode=True).cpu().numpy()
+    assert netD.training          # _get_logit restores train mode (trainer.py:155)
+    netD.eval()
+    x = torch.stack([ds[i][0] for i in range(150)]).cuda()
+    direct = netD(x).view(-1).cpu().numpy().astype(np.float64)
+    assert row.dtype == np.float64 and np.array_equal(row, direct)
