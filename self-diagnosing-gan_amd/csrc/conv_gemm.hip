@@ -80,31 +80,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
   const int upm = g.up - 1, ush = g.up >> 1;  // up in {1,2}
 
-  f32x4 ra[AJ], rb[BJ];
+  // Loads are branch-free raw buffer loads: out-of-range elements (padding taps, rows past M / Co)
+  // get an offset beyond num_records and the hardware returns zeros.  The prologue transform is applied
+  // when the registers are written to LDS, i.e. AFTER the MFMAs of the current step, so the global
+  // loads stay in flight under the matrix work instead of being waited for one by one.
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.w), 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
+  constexpr unsigned OOB = 0x7FFFFFF0u;
+  const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
+
+  f32x4 ra[AJ], rb[BJ], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  unsigned a_ok = 0;
   const int nk = g.Kp / BK;
 
   auto load_tiles = [&](int kk) {
     const bool tap_ok = kr < g.R;
     const int dy = kr * g.dr, dx = ks * g.dr;
+    a_ok = 0;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int yn = iy0[j] + dy, xn = ix0[j] + dx;
       const int iy = yn >> ush, ix = xn >> ush;
       const bool ok = tap_ok && yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        v = *reinterpret_cast<const f32x4*>(a.x + ((long)(pix_base[j] + iy * g.Wi + ix) * g.Ci + kc));
-        v = apply_pro(v, a.pro_mode, a.pro_scale, a.pro_shift, kc);
-      }
-      ra[j] = v;
+      const unsigned off = ok ? (unsigned)((pix_base[j] + iy * g.Wi + ix) * g.Ci + kc) * 4u : OOB;
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      a_ok |= (ok ? 1u : 0u) << j;
     }
-    const int kcol = kk * BK + lq * 4;
+    if (affine && tap_ok) {
+      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
+      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
+    }
+    const unsigned kcol = (unsigned)(kk * BK + lq * 4);
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int n = n0 + lrow + 32 * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n < g.Co) v = *reinterpret_cast<const f32x4*>(a.w + (long)n * g.Kp + kcol);
-      rb[j] = v;
+      const unsigned n = (unsigned)(n0 + lrow + 32 * j);
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (n * g.Kp + kcol) * 4u, 0, 0));
     }
     // advance (tap, c) to the next K-step
     kc += BK;
@@ -116,7 +128,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
       const int row = lrow + 32 * j;
-      *reinterpret_cast<f32x4*>(Ad + row * BK + ((lq ^ ((row >> 1) & 7)) << 2)) = ra[j];
+      f32x4 v = ra[j];
+      if (a.pro_mode != PRO_NONE) {
+        if (affine) v = v * psc + psh;
+        if (a.pro_mode == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        } else if (a.pro_mode != PRO_AFFINE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (affine && !((a_ok >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // padding is zero AFTER the transform
+      }
+      *reinterpret_cast<f32x4*>(Ad + row * BK + ((lq ^ ((row >> 1) & 7)) << 2)) = v;
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
@@ -234,7 +258,9 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "conv_gemm: bad pro_mode %d", pro_mode);
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift),
              "conv_gemm: affine prologue needs scale/shift");
-  DG_REQUIRE((long)B * Ho * Wo < (1L << 31) && (long)B * Hi * Wi < (1L << 31), "conv_gemm: too many pixels");
+  DG_REQUIRE((long)B * Ho * Wo * Co * 4 < (1L << 31) && (long)B * Hi * Wi * Ci * 4 < (1L << 31) &&
+                 (long)Co * Kp * 4 < (1L << 31),
+             "conv_gemm: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_src = mask_src;
   a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.mask_slope = mask_slope; a.out_scale = out_scale;

@@ -85,33 +85,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
   const int upm = g.up - 1, ush = g.up >> 1;
 
+  // branch-free raw buffer loads (out-of-range -> zeros); prologue applied at LDS-store time so the
+  // loads stay in flight under the MFMAs (see conv_gemm.hip)
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  constexpr unsigned OOB = 0x7FFFFFF0u;
+  const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (affine && b_ok) {
+    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
+    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
+  }
   f32x4 ra[AJ], rb[BJ];
+  unsigned bmask = 0;
   auto load_tiles = [&](int step) {
     const int mb = step * BK;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int m = mb + ap + APR * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok && m < a.M) v = *reinterpret_cast<const f32x4*>(a.dy + (long)m * g.Co + an);
-      ra[j] = v;
+      const unsigned m = (unsigned)(mb + ap + APR * j);      // rows past M fall outside num_records
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            ysrc, a_ok ? (m * g.Co + an) * 4u : OOB, 0, 0));
     }
+    bmask = 0;
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       const int m = mb + bp + BPR * j;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (b_ok && m < a.M) {
-        const unsigned t = fdiv((unsigned)m, a.dWo);
-        const int ox = m - (int)t * g.Wo;
-        const unsigned b = fdiv(t, a.dHo);
-        const int oy = (int)t - (int)b * g.Ho;
-        const int yn = oy * g.sy + dyo, xn = ox * g.sy + dxo;
-        const int iy = yn >> ush, ix = xn >> ush;
-        if (yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi) {
-          v = *reinterpret_cast<const f32x4*>(a.x + ((long)((int)b * g.Hi * g.Wi + iy * g.Wi + ix) * g.Ci + kc));
-          v = apply_pro(v, a.pro_mode, a.pro_scale, a.pro_shift, kc);
-        }
-      }
-      rb[j] = v;
+      const unsigned t = fdiv((unsigned)m, a.dWo);
+      const int ox = m - (int)t * g.Wo;
+      const unsigned b = fdiv(t, a.dHo);
+      const int oy = (int)t - (int)b * g.Ho;
+      const int yn = oy * g.sy + dyo, xn = ox * g.sy + dxo;
+      const int iy = yn >> ush, ix = xn >> ush;
+      const bool ok = b_ok && m < a.M && yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi;
+      const unsigned off = ok ? (unsigned)(((int)b * g.Hi * g.Wi + iy * g.Wi + ix) * g.Ci + kc) * 4u : OOB;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      bmask |= (ok ? 1u : 0u) << j;
     }
   };
   auto store_tiles = [&](int buf) {
@@ -119,8 +129,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < AJ; ++j)
       *reinterpret_cast<f32x4*>(&As[buf][(ap + APR * j) * BNn + ac * 4]) = ra[j];
 #pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[buf][(bp + BPR * j) * BNk + bc * 4]) = rb[j];
+    for (int j = 0; j < BJ; ++j) {
+      f32x4 v = rb[j];
+      if (a.pro_mode != PRO_NONE) {
+        if (affine) v = v * psc + psh;
+        if (a.pro_mode == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        } else if (a.pro_mode != PRO_AFFINE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (affine && !((bmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      *reinterpret_cast<f32x4*>(&Bs[buf][(bp + BPR * j) * BNk + bc * 4]) = v;
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -216,7 +239,8 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   DG_REQUIRE(dr == 1 || dr == -1, "conv_wgrad: dr must be +-1");
   DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_wgrad: bad Kp=%d", Kp);
   DG_REQUIRE(splits >= 1, "conv_wgrad: splits=%d", splits);
-  DG_REQUIRE((long)B * Ho * Wo < (1L << 31) && (long)B * Hi * Wi < (1L << 31), "conv_wgrad: too many pixels");
+  DG_REQUIRE((long)B * Ho * Wo * Co * 4 < (1L << 31) && (long)B * Hi * Wi * Ci * 4 < (1L << 31),
+             "conv_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   WgradArgs a;
   a.dy = dy; a.x = x; a.slab = slab; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_mode = pro_mode;
   a.M = B * Ho * Wo;
