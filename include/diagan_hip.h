@@ -105,6 +105,22 @@ int diagan_sn_power_iter(const float* W, float* u_buffer, float* sigma_buffer, f
                          float* v_out, float* state, float* work, int Co, int Kp, float eps,
                          int update_buffers, void* stream);
 
+/* All SN layers of one network in four launches.  table_dev: device array of n_layers descriptors. */
+typedef struct {
+  const float* W;    /* master weight [Co][Kp] */
+  float* u_buf;      /* module buffer sn_u [Co] (updated iff update_buffers) */
+  float* sigma_buf;  /* module buffer sn_sigma [1] */
+  float* u_out;      /* [Co] u' of this forward */
+  float* v_out;      /* [Kp] v of this forward */
+  float* state;      /* {sigma, 1/sigma} */
+  float* work;       /* 8*Kp + Co floats */
+  float* Wf;         /* [Co][Kp] = W/sigma, or NULL */
+  float* Wd;         /* [Ci][Kd] data-gradient operand / sigma, or NULL */
+  int Co, Ci, RS, Kp, Kd, pad;
+} diagan_sn_layer;
+int diagan_sn_prepare_batched(const void* table_dev, int n_layers, int max_Co, int max_Ci, int max_RS,
+                              int max_Kp, float eps, int update_buffers, int write_wd, void* stream);
+
 /* GEMM operand packing: Wf = W*inv (same [Co][Kp] layout), Wd[ci][(rs)*Co+co] = W[co][(rs)*Ci+ci]*inv
  * (data-gradient operand, row length Kd).  inv_sigma: device float* or NULL (= 1). */
 int diagan_pack_weights(const float* W, const float* inv_sigma, float* Wf, float* Wd, int Co, int Ci,

@@ -174,3 +174,137 @@ DIAGAN_API int diagan_sn_grad_fix(const float* G, const double* dot_partials, in
                      dot_partials, nparts, u, v, state, grad, Co, Kp, accumulate);
   return check_launch("sn_grad_fix");
 }
+
+// ================================================================================================
+// Batched spectral-norm preparation: ALL SN layers of a network in 4 launches (instead of 4 per
+// layer).  blockIdx.z selects the layer through a device-resident descriptor table.
+// ================================================================================================
+namespace diagan {
+
+struct SnLayer {          // mirrored by diagan_sn_layer in include/diagan_hip.h (96 bytes)
+  const float* W;         // master weight [Co][Kp]
+  float* u_buf;           // module buffer sn_u [Co]
+  float* sigma_buf;       // module buffer sn_sigma [1]
+  float* u_out;           // [Co]  u' of this forward (kept for the backward)
+  float* v_out;           // [Kp]  v  of this forward
+  float* state;           // {sigma, 1/sigma}
+  float* work;            // [SN_RSPLIT*Kp + Co] scratch
+  float* Wf;              // [Co][Kp] scaled forward operand or NULL
+  float* Wd;              // [Ci][Kd] scaled data-gradient operand or NULL
+  int Co, Ci, RS, Kp, Kd, pad;
+};
+constexpr int SN_RSPLIT = 8;
+constexpr int SN_MAX_KP = 9216;
+
+// vpart[r][k] = sum_{n in row chunk r} u[n] W[n][k]
+__global__ __launch_bounds__(256) void sn_cols_batched_kernel(const SnLayer* __restrict__ tab) {
+  const SnLayer L = tab[blockIdx.z];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= L.Kp) return;
+  const int per = (L.Co + SN_RSPLIT - 1) / SN_RSPLIT;
+  const int n0 = blockIdx.y * per, n1 = min(n0 + per, L.Co);
+  float s = 0.f;
+  for (int n = n0; n < n1; ++n) s = fmaf(L.u_buf[n], L.W[(long)n * L.Kp + k], s);
+  L.work[(long)blockIdx.y * L.Kp + k] = s;
+}
+
+// v_raw = sum_r vpart[r] (into LDS; block 0 also stores it to v_out); t_raw[n] = W[n] . v_raw, 16 rows/block
+__global__ __launch_bounds__(256) void sn_rows_batched_kernel(const SnLayer* __restrict__ tab) {
+  __shared__ float vs[SN_MAX_KP];
+  const SnLayer L = tab[blockIdx.z];
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= L.Co) return;
+  for (int k = threadIdx.x; k < L.Kp; k += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < SN_RSPLIT; ++r) s += L.work[(long)r * L.Kp + k];
+    vs[k] = s;
+    if (blockIdx.x == 0) L.v_out[k] = s;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* t_raw = L.work + (long)SN_RSPLIT * L.Kp;
+  for (int i = 0; i < 4; ++i) {
+    const int n = row0 + wave * 4 + i;
+    if (n >= L.Co) break;
+    float s = 0.f;
+    for (int k = lane * 4; k < L.Kp; k += 256) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(L.W + (long)n * L.Kp + k);
+      s += w[0] * vs[k] + w[1] * vs[k + 1] + w[2] * vs[k + 2] + w[3] * vs[k + 3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) t_raw[n] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void sn_finalize_batched_kernel(const SnLayer* __restrict__ tab, float eps,
+                                                                  int update_buffers) {
+  __shared__ float red[4];
+  const SnLayer L = tab[blockIdx.z];
+  const float* t_raw = L.work + (long)SN_RSPLIT * L.Kp;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < L.Kp; k += 256) { const float v = L.v_out[k]; s += v * v; }
+  const float nv = fmaxf(sqrtf(block_sum_256(s, red)), eps);
+  for (int k = threadIdx.x; k < L.Kp; k += 256) L.v_out[k] = L.v_out[k] / nv;
+  s = 0.f;
+  for (int n = threadIdx.x; n < L.Co; n += 256) { const float t = t_raw[n] / nv; s += t * t; }
+  const float nt = fmaxf(sqrtf(block_sum_256(s, red)), eps);
+  s = 0.f;
+  for (int n = threadIdx.x; n < L.Co; n += 256) {
+    const float t = t_raw[n] / nv;
+    const float un = t / nt;
+    L.u_out[n] = un;
+    if (update_buffers) L.u_buf[n] = un;
+    s += un * t;
+  }
+  const float sigma = block_sum_256(s, red);
+  if (threadIdx.x == 0) {
+    L.state[0] = sigma;
+    L.state[1] = 1.f / sigma;
+    if (update_buffers) L.sigma_buf[0] = sigma;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_batched_kernel(const SnLayer* __restrict__ tab, int max_rs, int write_wd) {
+  __shared__ float tile[32][33];
+  const SnLayer L = tab[blockIdx.z / max_rs];
+  const int tap = blockIdx.z % max_rs;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  if (tap >= L.RS || co0 >= L.Co || ci0 >= L.Ci || (!L.Wf && !(L.Wd && write_wd))) return;
+  const float inv = L.state[1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    float v = 0.f;
+    if (co < L.Co && ci < L.Ci) {
+      v = L.W[(long)co * L.Kp + tap * L.Ci + ci] * inv;
+      if (L.Wf) L.Wf[(long)co * L.Kp + tap * L.Ci + ci] = v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (L.Wd && write_wd) {
+    for (int r = ty; r < 32; r += 8) {
+      const int ci = ci0 + r, co = co0 + tx;
+      if (ci < L.Ci && co < L.Co) L.Wd[(long)ci * L.Kd + tap * L.Co + co] = tile[tx][r];
+    }
+  }
+}
+
+}  // namespace diagan
+
+DIAGAN_API int diagan_sn_prepare_batched(const void* table_dev, int n_layers, int max_Co, int max_Ci, int max_RS,
+                                         int max_Kp, float eps, int update_buffers, int write_wd, void* stream) {
+  DG_REQUIRE(table_dev && n_layers > 0 && max_Co > 0 && max_Ci > 0 && max_RS > 0 && max_Kp > 0,
+             "sn_prepare_batched: bad args");
+  DG_REQUIRE(max_Kp <= SN_MAX_KP, "sn_prepare_batched: Kp=%d exceeds the LDS-resident limit %d", max_Kp, SN_MAX_KP);
+  static_assert(sizeof(SnLayer) == 96, "descriptor layout");
+  hipStream_t st = (hipStream_t)stream;
+  const SnLayer* tab = (const SnLayer*)table_dev;
+  hipLaunchKernelGGL(sn_cols_batched_kernel, dim3(cdiv(max_Kp, 256), SN_RSPLIT, n_layers), dim3(256), 0, st, tab);
+  hipLaunchKernelGGL(sn_rows_batched_kernel, dim3(cdiv(max_Co, 16), 1, n_layers), dim3(256), 0, st, tab);
+  hipLaunchKernelGGL(sn_finalize_batched_kernel, dim3(1, 1, n_layers), dim3(256), 0, st, tab, eps, update_buffers);
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(cdiv(max_Ci, 32), cdiv(max_Co, 32), n_layers * max_RS), dim3(256), 0,
+                     st, tab, max_RS, write_wd);
+  return check_launch("sn_prepare_batched");
+}

@@ -146,7 +146,8 @@ class BaseDiscriminator(BaseModel):
         out_real, ctx_r = self.forward_nhwc(self.to_nhwc(real_images), self.training, save=True, need_dgrad=True,
                                             need_in_dgrad=False)
         fake, _ = netG.generate_images_nhwc(batch_size, device=device, noise=noise, save=False)   # .detach()
-        out_fake, ctx_f = self.forward_nhwc(fake, self.training, save=True, need_dgrad=True, need_in_dgrad=False)
+        out_fake, ctx_f = self.forward_nhwc(fake, self.training, save=True, need_dgrad=True, need_in_dgrad=False,
+                                            slot=1)
         out3, d_real, d_fake = E.loss_dis(out_real, out_fake, self.loss_type, gold=self.use_gold)
         self.backward_nhwc(ctx_r, d_real, need_wgrad=True, need_gx=False)
         self.backward_nhwc(ctx_f, d_fake, need_wgrad=True, need_gx=False)

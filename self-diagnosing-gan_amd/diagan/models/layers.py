@@ -99,10 +99,13 @@ class ConvLayer(nn.Module):
 
     # ---- compute ----
     class Ctx:
-        __slots__ = ("wf", "wd", "u", "v", "state")
+        __slots__ = ("wf", "wd", "u", "v", "state", "_keep")
 
-    def prepare(self, training, need_dgrad=True):
-        """Per-forward operand preparation.  SN layers: one power iteration + scaled packing."""
+    def prepare(self, training, need_dgrad=True, slot=None):
+        """Per-forward operand preparation.  SN layers: one power iteration + scaled packing (done for
+        the whole network at once by SNBatch when `slot` is given)."""
+        if self.sn and slot is not None:
+            return self._slot_ctx[slot]
         ctx = ConvLayer.Ctx()
         g = self.geom
         dev = self.weight.device
@@ -272,12 +275,16 @@ class HeadLinear(nn.Module):
             sd[k] = torch.cat([sd[k].to(torch.float32), torch.zeros(3, device=sd[k].device)])
 
     class Ctx:
-        __slots__ = ("u", "v", "state", "x", "pooled")
+        __slots__ = ("u", "v", "state", "x", "pooled", "_keep")
 
-    def fwd(self, x, training):
+    def fwd(self, x, training, slot=None):
         ctx = HeadLinear.Ctx()
         inv = None
-        if self.sn:
+        if self.sn and slot is not None:
+            pre = self._slot_ctx[slot]
+            ctx.u, ctx.v, ctx.state = pre.u, pre.v, pre.state
+            inv = ctx.state[1:]
+        elif self.sn:
             ctx.u, ctx.v, ctx.state = C.sn_power_iter(self.weight.data, self.sn_u.view(-1), self.sn_sigma,
                                                       training=training)
             inv = ctx.state[1:]
@@ -297,6 +304,61 @@ class HeadLinear(nn.Module):
             else:
                 self.weight.grad.view(-1).add_(G)
         return gx
+
+
+class SNBatch:
+    """All spectral-norm layers of one network prepared in 4 launches (diagan_sn_prepare_batched).
+
+    Two context slots per layer: a D update runs two forwards (real, fake) before its backward, and each
+    forward's (u, v, sigma, Wf, Wd) must survive until that forward's backward."""
+
+    def __init__(self, net, layers, n_slots=2):
+        import numpy as np
+        from diagan import _native as nat
+        self.net, self.layers, self.nat = net, layers, nat
+        dev = net.flat_params.device
+        self.flat_id = id(net.flat_params)
+        desc = np.dtype([('p', np.uint64, 9), ('i', np.int32, 6)])
+        self.tables = []
+        f32 = dict(dtype=torch.float32, device=dev)
+        dims = []
+        for slot in range(n_slots):
+            tab = np.zeros(len(layers), dtype=desc)
+            for li, m in enumerate(layers):
+                if isinstance(m, ConvLayer):
+                    g = m.geom
+                    Co, Ci, RS, Kp, Kd = g.Co, g.Ci, g.R * g.S, g.Kp, g.Kd
+                    wf, wd = torch.zeros((Co, Kp), **f32), torch.zeros((Ci, Kd), **f32)
+                    ctx = ConvLayer.Ctx()
+                else:                                   # HeadLinear: [1][C], used with inv_sigma only
+                    Co, Ci, RS, Kp, Kd = 1, m.in_ch, 1, m.in_ch, 0
+                    wf = wd = None
+                    ctx = HeadLinear.Ctx()
+                ctx.u, ctx.v, ctx.state = torch.zeros(Co, **f32), torch.zeros(Kp, **f32), torch.ones(2, **f32)
+                if isinstance(m, ConvLayer):
+                    ctx.wf, ctx.wd = wf, wd
+                work = torch.zeros(8 * Kp + Co, **f32)
+                ctx._keep = (work,)
+                if not hasattr(m, '_slot_ctx') or m._slot_ctx is None or len(m._slot_ctx) != n_slots:
+                    m._slot_ctx = [None] * n_slots
+                m._slot_ctx[slot] = ctx
+                ptrs = [m.weight.data.data_ptr(), m.sn_u.data_ptr(), m.sn_sigma.data_ptr(), ctx.u.data_ptr(),
+                        ctx.v.data_ptr(), ctx.state.data_ptr(), work.data_ptr(),
+                        wf.data_ptr() if wf is not None else 0, wd.data_ptr() if wd is not None else 0]
+                tab[li]['p'] = ptrs
+                tab[li]['i'] = [Co, Ci, RS, Kp, Kd, 0]
+                dims.append((Co, Ci, RS, Kp))
+            self.tables.append(torch.from_numpy(tab.view(np.uint8).copy()).to(dev))
+        self.max = [max(d[k] for d in dims) for k in range(4)]
+
+    def stale(self):
+        return self.flat_id != id(self.net.flat_params)
+
+    def run(self, slot, training, write_wd):
+        nat = self.nat
+        nat.call("diagan_sn_prepare_batched", self.tables[slot].data_ptr(), len(self.layers), self.max[0],
+                 self.max[1], self.max[2], self.max[3], 1e-12, 1 if training else 0, 1 if write_wd else 0,
+                 nat.current_stream())
 
 
 class FlatNet(nn.Module):

@@ -16,7 +16,7 @@ import math
 import torch.nn as nn
 
 from diagan.models.base import BaseDiscriminator, BaseGenerator
-from diagan.models.layers import BatchNorm, ConvLayer, HeadLinear, LatentLinear
+from diagan.models.layers import BatchNorm, ConvLayer, HeadLinear, LatentLinear, SNBatch
 from diagan.ops import conv as C
 from diagan.ops import eltwise as E
 
@@ -100,12 +100,12 @@ class DBlock(nn.Module):
             self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0, sn=True)
             self.c_sc.xavier_(1.0)
 
-    def forward(self, x, training, save=True, need_dgrad=True):
-        k1 = self.c1.prepare(training, need_dgrad)
-        k2 = self.c2.prepare(training, need_dgrad)
+    def forward(self, x, training, save=True, need_dgrad=True, slot=None):
+        k1 = self.c1.prepare(training, need_dgrad, slot)
+        k2 = self.c2.prepare(training, need_dgrad, slot)
         h1 = self.c1.fwd(k1, x, pro=RELU)
         if self.learnable_sc:
-            ksc = self.c_sc.prepare(training, need_dgrad)
+            ksc = self.c_sc.prepare(training, need_dgrad, slot)
             sc = self.c_sc.fwd(ksc, x, pro=RELU)
             h2 = self.c2.fwd(k2, h1, pro=RELU, residual=sc)
         else:
@@ -144,10 +144,10 @@ class DBlockOptimized(nn.Module):
         self.c2.xavier_(math.sqrt(2.0))
         self.c_sc.xavier_(1.0)
 
-    def forward(self, x, training, save=True, need_dgrad=True, need_in_dgrad=False):
-        k1 = self.c1.prepare(training, need_dgrad and need_in_dgrad)
-        k2 = self.c2.prepare(training, need_dgrad)
-        ksc = self.c_sc.prepare(training, need_dgrad and need_in_dgrad)
+    def forward(self, x, training, save=True, need_dgrad=True, need_in_dgrad=False, slot=None):
+        k1 = self.c1.prepare(training, need_dgrad and need_in_dgrad, slot)
+        k2 = self.c2.prepare(training, need_dgrad, slot)
+        ksc = self.c_sc.prepare(training, need_dgrad and need_in_dgrad, slot)
         h1 = self.c1.fwd(k1, x)
         xp = E.avgpool2(x)
         sc = self.c_sc.fwd(ksc, xp)
@@ -261,14 +261,25 @@ class SNGANBaseDiscriminator(BaseDiscriminator):
     def _blocks(self):
         raise NotImplementedError
 
-    def forward_nhwc(self, x, training, save=True, need_dgrad=True, need_in_dgrad=True):
+    def _sn_prepare(self, slot, training, need_dgrad):
+        """Spectral norm of every layer of the network for this forward: 4 launches in total."""
+        sb = getattr(self, '_sn_batch', None)
+        if sb is None or sb.stale():
+            layers = [m for m in self.modules() if isinstance(m, ConvLayer) and m.sn] + [self._head]
+            sb = SNBatch(self, layers)
+            object.__setattr__(self, '_sn_batch', sb)
+        sb.run(slot, training, need_dgrad)
+
+    def forward_nhwc(self, x, training, save=True, need_dgrad=True, need_in_dgrad=True, slot=0):
+        self._sn_prepare(slot, training, need_dgrad)
         blocks = self._blocks()
-        h, c0 = blocks[0].forward(x, training, save=save, need_dgrad=need_dgrad, need_in_dgrad=need_in_dgrad)
+        h, c0 = blocks[0].forward(x, training, save=save, need_dgrad=need_dgrad, need_in_dgrad=need_in_dgrad,
+                                  slot=slot)
         bctx = [c0]
         for blk in blocks[1:]:
-            h, c = blk.forward(h, training, save=save, need_dgrad=need_dgrad)
+            h, c = blk.forward(h, training, save=save, need_dgrad=need_dgrad, slot=slot)
             bctx.append(c)
-        hctx, logit = self._head.fwd(h, training)
+        hctx, logit = self._head.fwd(h, training, slot=slot)
         return logit, (dict(bctx=bctx, hctx=hctx) if save else None)
 
     def backward_nhwc(self, ctx, dlogit, need_wgrad=True, need_gx=False):

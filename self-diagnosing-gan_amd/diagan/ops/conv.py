@@ -16,6 +16,7 @@ nat.register("diagan_conv_wgrad", [P, P, P, I, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_conv_wgrad_splits", [I, I, I])
 nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
 nat.register("diagan_sn_power_iter", [P, P, P, P, P, P, P, I, I, F, I, P])
+nat.register("diagan_sn_prepare_batched", [P, I, I, I, I, I, F, I, I, P])
 nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
 nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
 
