@@ -236,10 +236,12 @@ using namespace diagan;
 
 // tile selection used when tile_cfg == 0: 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 128x64
 DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
-  int cfg = Co <= 64 ? 2 : 1;
-  const long tiles = (long)cdiv(M, cfg == 2 ? 256 : 128) * cdiv(Co, cfg == 2 ? 64 : 128);
-  if (tiles < 256) cfg = 3;                   // small problems: 64 x 64 tiles to fill the CUs
-  return cfg;
+  // measured on MI355X (tools/bench_conv.py, SWEEP=1): the 64x64 tile (5 blocks/CU) is within ~5 % of
+  // the 128x128 tile everywhere and far better on small grids and narrow outputs; 128x128 wins by
+  // 5-10 % once it has >= 512 tiles (2 resident blocks on every CU) and wastes no columns.
+  const long tiles128 = (long)cdiv(M, 128) * cdiv(Co, 128);
+  if (Co % 128 == 0 && tiles128 >= 512) return 1;
+  return 3;
 }
 
 // see include/diagan_hip.h

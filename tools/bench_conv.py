@@ -25,6 +25,11 @@ SHAPES = [
     ("D64.b2.c2", 64, 32, 32, 64, 128, 3),
     ("D64.b5.c2", 64, 4, 4, 512, 1024, 3),
     ("D64.b3.sc", 64, 16, 16, 128, 256, 1),
+    ("D32.b3.c1", 64, 8, 8, 128, 128, 3),
+    ("G32.b2.c1", 64, 8, 8, 256, 256, 3),
+    ("G32.b2.sc", 64, 8, 8, 256, 256, 1),
+    ("G32.b4.sc", 64, 32, 32, 256, 256, 1),
+    ("D32.b2.sc", 64, 16, 16, 128, 128, 1),
 ]
 
 
