@@ -239,9 +239,15 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
   // measured on MI355X (tools/bench_conv.py, SWEEP=1): the 64x64 tile (5 blocks/CU) is within ~5 % of
   // the 128x128 tile everywhere and far better on small grids and narrow outputs; 128x128 wins by
   // 5-10 % once it has >= 512 tiles (2 resident blocks on every CU) and wastes no columns.
-  const long tiles128 = (long)cdiv(M, 128) * cdiv(Co, 128);
-  if (Co % 128 == 0 && tiles128 >= 512) return 1;
-  return 3;
+  // Blocks run a whole K loop, so a partially filled last round of blocks costs a full round
+  // ("wave quantisation"): weigh each tile shape by tiles / (rounds * resident slots).
+  const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128), t64 = (long)cdiv(M, 64) * cdiv(Co, 64);
+  const long s128 = 256 * 2, s64 = 256 * 5;     // resident workgroups (LDS-limited)
+  const double q128 = (double)t128 / (double)(cdiv(t128, s128) * s128);
+  const double q64 = (double)t64 / (double)(cdiv(t64, s64) * s64);
+  const double waste128 = (double)M * Co / ((double)t128 * 128 * 128);
+  const double waste64 = (double)M * Co / ((double)t64 * 64 * 64);
+  return 1.08 * q128 * waste128 > q64 * waste64 ? 1 : 3;
 }
 
 // see include/diagan_hip.h

@@ -14,6 +14,7 @@
 //
 // Roofline: MFMA fp32 (algorithmic FLOP = 2*M*Co*K).
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace diagan {
 
@@ -250,7 +251,8 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   const int total_steps = cdiv(a.M, 32);
   a.steps_per_split = cdiv(total_steps, splits);
   hipStream_t st = (hipStream_t)stream;
-  if (Co <= 64 || Kp <= 64) {
+  static const int force64 = getenv("DIAGAN_WGRAD_TILE64") ? atoi(getenv("DIAGAN_WGRAD_TILE64")) : 0;
+  if (Co <= 64 || Kp <= 64 || force64) {
     const int tiles = cdiv(Co, 64) * cdiv(Kp, 64);
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3(tiles, splits), dim3(256), 0, st, a);
   } else {
@@ -262,9 +264,11 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
 
 // how many splits conv_wgrad should use for this problem (host-side heuristic, no device work)
 DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
-  const int tiles = (Co <= 64 || Kp <= 64) ? cdiv(Co, 64) * cdiv(Kp, 64) : cdiv(Co, 128) * cdiv(Kp, 128);
+  static const int force64 = getenv("DIAGAN_WGRAD_TILE64") ? atoi(getenv("DIAGAN_WGRAD_TILE64")) : 0;
+  const int tiles = (Co <= 64 || Kp <= 64 || force64) ? cdiv(Co, 64) * cdiv(Kp, 64) : cdiv(Co, 128) * cdiv(Kp, 128);
   const int total_steps = cdiv(M, 32);
-  int splits = cdiv(512, tiles);                 // ~2 workgroups per CU
+  int splits = 512 / tiles;                      // <= 2 resident workgroups per CU: ONE round of blocks
+                                                 // (540 blocks on 512 slots would cost a second, nearly empty round)
   if (splits > total_steps / 4) splits = total_steps / 4;  // at least 4 K-steps per split
   if (splits < 1) splits = 1;
   if (splits > 256) splits = 256;
