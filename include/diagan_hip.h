@@ -82,12 +82,29 @@ int diagan_conv_gemm_pick_cfg(int M, int Co); /* tile config chosen when tile_cf
 /* Weight gradient, split over pixels: slab[s][n][k] = sum_{m in split s} dy[m][n]*pro(x gathered).
  * Replaces the weight half of conv2d / conv_transpose2d backward (errD.backward()/errG.backward()
  * in the train steps, diagan-pkg/diagan/models/topk_models.py:90, mnist.py:126).
- * dy NHWC [B,Ho,Wo,Co] (Co % 4 == 0), slab [splits][Co][Kp]. */
-int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, const float* pro_scale,
-                      const float* pro_shift, int pro_mode, int B, int Hi, int Wi, int Ci, int Ho,
+ * dy NHWC [B,Ho,Wo,Co] (Co % 4 == 0), slab [splits][slab_stride] (slab_stride >= Co*Kp).
+ * bias_off >= 0: the bias gradient partials sum_m dy[m][n] are written to slab[s][bias_off + n]. */
+int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t slab_stride,
+                      int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B, int Hi, int Wi, int Ci, int Ho,
                       int Wo, int Co, int R, int S, int sy, int dr, int off, int up, int Kp,
                       void* stream);
 int diagan_conv_wgrad_splits(int M, int Co, int Kp); /* host heuristic: number of splits */
+
+/* Deferred epilogue of a whole backward pass, all layers in two launches: per layer
+ * G = sum_s slab[s] (fixed order); plain layers: grad += G; spectral-norm layers:
+ * grad += (G - <G,W>/sigma u^T v)/sigma on the weight part, grad += G on the bias part. */
+typedef struct {
+  float* slab;        /* [splits][stride] */
+  float* grad;        /* weight gradient [Co*Kp] followed by the bias gradient */
+  const float* W;     /* master weight for SN layers, NULL otherwise */
+  const float* u;     /* SN context of the matching forward */
+  const float* v;
+  const float* state; /* {sigma, 1/sigma} */
+  double* partials;   /* ceil(n_elem/1024) doubles (SN layers) */
+  int64_t stride;
+  int splits, n_elem, n_w, Kp;
+} diagan_wgrad_layer;
+int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t max_elem, int any_sn, void* stream);
 
 /* out (+)= sum_s slab[s]; if w: dot_partials[block] = partial <sum, w> (fp64, for the SN backward);
  * ceil(n_elem/1024) partials. */

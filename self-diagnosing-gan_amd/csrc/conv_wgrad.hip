@@ -47,6 +47,8 @@ struct WgradArgs {
   int pro_mode;
   int M;
   int steps_per_split;    // K-steps (of 32 pixels) per split
+  long slab_stride;       // floats between consecutive split slabs (>= Co*Kp)
+  long bias_off;          // >= 0: column sums of dy (bias gradient) go to slab[split][bias_off + n]
   ConvGeom g;
   FastDiv dWo, dHo;
 };
@@ -156,6 +158,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int fi = lane & 31, fh = lane >> 5;
+  const bool do_bias = a.bias_off >= 0 && k0 == 0 && tid < BNn;
+  float bsum = 0.f;
   if (step0 < step1) {
     load_tiles(step0);
     store_tiles(0);
@@ -180,11 +184,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+    if (do_bias) {  // bias gradient: column sums of this step's dy tile (only the k0 == 0 tile column)
+#pragma unroll 8
+      for (int p = 0; p < BK; ++p) bsum += Ac[p * BNn + tid];
+    }
     if (step + 1 < step1) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
-  float* out = a.slab + (long)split * g.Co * g.Kp;
+  float* out = a.slab + (long)split * a.slab_stride;
+  if (do_bias && n0 + tid < g.Co) out[a.bias_off + n0 + tid] = bsum;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -225,12 +234,97 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+
+// ---- deferred, batched epilogue of a whole backward pass --------------------------------------
+// One descriptor per parameterised layer; blockIdx.z selects the layer.
+struct WgFinish {          // mirrored by diagan_wgrad_layer in include/diagan_hip.h (80 bytes)
+  float* slab;             // [splits][stride]: weight partials (+ bias partials at bias_off)
+  float* grad;             // flat gradient region of the layer: weight [Co*Kp] then bias
+  const float* W;          // master weight (SN layers) or NULL
+  const float* u;          // SN: u', v, state of the forward this backward belongs to
+  const float* v;
+  const float* state;
+  double* partials;        // SN: one fp64 partial of <G, W> per block of phase A
+  long stride;
+  int splits, n_elem, n_w, Kp;   // n_elem = Co*Kp (+ Co if bias), n_w = Co*Kp
+};
+
+// phase A: G = sum over splits (fixed order).  non-SN layers: grad += G.  SN layers: G kept in
+// slab[0] and the block's partial of <G, W> is written.
+__global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab) {
+  const WgFinish L = tab[blockIdx.z];
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool sn = L.W != nullptr;
+  if ((long)blockIdx.x * 1024 >= L.n_elem) return;
+  double dot = 0.0;
+  if (i < L.n_elem) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(L.slab + i);
+    for (int k = 1; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(L.slab + (long)k * L.stride + i);
+    if (sn) {
+      if (i < L.n_w) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + i);
+        dot = (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
+      }
+      *reinterpret_cast<f32x4*>(L.slab + i) = s;
+    } else {
+      *reinterpret_cast<f32x4*>(L.grad + i) += s;
+    }
+  }
+  if (sn) {
+    __shared__ double red[4];
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) L.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// phase B (SN layers): grad += (G - <G,W>/sigma * u^T v) / sigma ; bias part: grad += G
+__global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab) {
+  const WgFinish L = tab[blockIdx.z];
+  if (L.W == nullptr || (long)blockIdx.x * 1024 >= L.n_elem) return;
+  __shared__ double sdot;
+  if (threadIdx.x == 0) {
+    const int nparts = (L.n_elem + 1023) / 1024;
+    double d = 0.0;
+    for (int k = 0; k < nparts; ++k) d += L.partials[k];
+    sdot = d;
+  }
+  __syncthreads();
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= L.n_elem) return;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(L.slab + i);
+  f32x4 o;
+  if (i < L.n_w) {
+    const float inv = L.state[1];
+    const float coef = (float)(sdot * (double)inv);
+    const int n = (int)(i / L.Kp), k = (int)(i - (long)n * L.Kp);
+    const f32x4 vv = *reinterpret_cast<const f32x4*>(L.v + k);
+    o = (g - (L.u[n] * coef) * vv) * inv;
+  } else {
+    o = g;
+  }
+  *reinterpret_cast<f32x4*>(L.grad + i) += o;
+}
+
 }  // namespace diagan
 
 using namespace diagan;
 
-DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits,
-                                 const float* pro_scale, const float* pro_shift, int pro_mode, int B,
+DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t max_elem, int any_sn,
+                                           void* stream) {
+  DG_REQUIRE(table_dev && n_layers > 0 && max_elem > 0, "wgrad_finish_batched: bad args");
+  static_assert(sizeof(WgFinish) == 80, "descriptor layout");
+  const WgFinish* tab = (const WgFinish*)table_dev;
+  const int blocks = cdiv(max_elem, 1024);
+  hipLaunchKernelGGL(wgrad_finish_a_kernel, dim3(blocks, 1, n_layers), dim3(256), 0, (hipStream_t)stream, tab);
+  if (any_sn)
+    hipLaunchKernelGGL(wgrad_finish_b_kernel, dim3(blocks, 1, n_layers), dim3(256), 0, (hipStream_t)stream, tab);
+  return check_launch("wgrad_finish_batched");
+}
+
+DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t slab_stride,
+                                 int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
                                  int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                  int dr, int off, int up, int Kp, void* stream) {
   DG_REQUIRE(dy && x && slab, "conv_wgrad: null tensor");
@@ -240,6 +334,8 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   DG_REQUIRE(dr == 1 || dr == -1, "conv_wgrad: dr must be +-1");
   DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_wgrad: bad Kp=%d", Kp);
   DG_REQUIRE(splits >= 1, "conv_wgrad: splits=%d", splits);
+  DG_REQUIRE(slab_stride >= (int64_t)Co * Kp && (bias_off < 0 || bias_off + Co <= slab_stride),
+             "conv_wgrad: slab_stride=%ld too small for Co*Kp=%ld (+bias)", (long)slab_stride, (long)Co * Kp);
   DG_REQUIRE((long)B * Ho * Wo * Co * 4 < (1L << 31) && (long)B * Hi * Wi * Ci * 4 < (1L << 31),
              "conv_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   WgradArgs a;
@@ -250,6 +346,8 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   a.dHo = make_fastdiv((unsigned)Ho);
   const int total_steps = cdiv(a.M, 32);
   a.steps_per_split = cdiv(total_steps, splits);
+  a.slab_stride = slab_stride;
+  a.bias_off = bias_off;
   hipStream_t st = (hipStream_t)stream;
   static const int force64 = getenv("DIAGAN_WGRAD_TILE64") ? atoi(getenv("DIAGAN_WGRAD_TILE64")) : 0;
   if (Co <= 64 || Kp <= 64 || force64) {

@@ -136,6 +136,10 @@ class ConvLayer(nn.Module):
                 ctx.wd = self._wd
         return ctx
 
+    def _slot_ctx_or_none(self, slot):
+        sc = getattr(self, '_slot_ctx', None)
+        return sc[slot] if sc is not None else None
+
     def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0):
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu)
@@ -144,8 +148,14 @@ class ConvLayer(nn.Module):
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
                             mask_slope=mask_slope)
 
-    def wgrad(self, ctx, dy, x, pro=None):
-        """Accumulates into weight.grad / bias.grad (views of the net's flat gradient buffer)."""
+    def wgrad(self, ctx, dy, x, pro=None, slot=0):
+        """Accumulates into weight.grad / bias.grad (views of the net's flat gradient buffer).
+        Inside a network the split-K partials go to a per-layer slab and are reduced for all layers at
+        once by WgradBatch.finish(); standalone layers reduce immediately."""
+        net = getattr(self, '_net', None)
+        if net is not None and (not self.sn or ctx is self._slot_ctx_or_none(slot)):
+            net.wgrad_batch.launch(self, slot, dy, x, pro, ctx if self.sn else None)
+            return
         sn = (self.weight.data, ctx.u, ctx.v, ctx.state) if self.sn else None
         C.conv_wgrad(self.geom, dy, x, self.weight.grad, accumulate=True, pro=pro, sn=sn)
         if self.bias is not None:
@@ -234,9 +244,15 @@ class LatentLinear(nn.Module):
         y = C.conv_fwd(self.geom, x, self.weight.data, bias=self.bias.data)
         return x, y.view(B, self.bw, self.bw, self.ch)
 
-    def wgrad(self, x, dy):
+    sn = False
+
+    def wgrad(self, x, dy, slot=0):
         B = x.shape[0]
         dy2 = dy.reshape(B, 1, 1, -1)
+        net = getattr(self, '_net', None)
+        if net is not None:
+            net.wgrad_batch.launch(self, slot, dy2, x, None, None)
+            return
         C.conv_wgrad(self.geom, dy2, x, self.weight.grad, accumulate=True)
         E.colsum(dy2, self.bias.grad, accumulate=True)
 
@@ -361,6 +377,79 @@ class SNBatch:
                  nat.current_stream())
 
 
+class WgradBatch:
+    """Deferred weight-gradient epilogue of one network.
+
+    Every parameterised GEMM layer owns one split-K slab per context slot; conv_wgrad_kernel writes its
+    partials (weights and, fused, the bias column sums) there during the backward pass, and finish()
+    reduces all layers in two launches (diagan_wgrad_finish_batched), including the spectral-norm
+    correction.  Replaces 4-5 small launches per layer per pass."""
+
+    def __init__(self, net):
+        self.net = net
+        self.entries = {}        # (layer, slot) -> dict
+        self.launched = {}       # slot -> list of layers launched in the current pass
+        self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, max_elem, any_sn)
+        self.flat_id = None
+
+    def _entry(self, layer, slot, M):
+        if self.flat_id != id(self.net.flat_grads):          # gradient slab was re-allocated
+            self.entries.clear(), self.tables.clear()
+            self.flat_id = id(self.net.flat_grads)
+        e = self.entries.get((layer, slot))
+        if e is None or e['M'] != M:
+            g = layer.geom
+            n_w = g.Co * g.Kp
+            has_bias = layer.bias is not None
+            n_b = layer.bias.numel() if has_bias else 0
+            if has_bias and layer.bias.grad.data_ptr() != layer.weight.grad.data_ptr() + 4 * n_w:
+                raise RuntimeError("bias gradient does not follow the weight gradient in the flat slab")
+            stride = n_w + n_b
+            splits = C.wgrad_splits(M, g.Co, g.Kp)
+            dev = layer.weight.device
+            e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, bias_off=n_w if has_bias else -1,
+                     slab=torch.empty(splits * stride, dtype=torch.float32, device=dev),
+                     partials=torch.empty((stride + 1023) // 1024, dtype=torch.float64, device=dev))
+            self.entries[(layer, slot)] = e
+            self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
+        return e
+
+    def launch(self, layer, slot, dy, x, pro, sn_ctx):
+        M = dy.numel() // dy.shape[-1]
+        e = self._entry(layer, slot, M)
+        e['sn_ctx'] = sn_ctx
+        C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro)
+        self.launched.setdefault(slot, []).append(layer)
+
+    def finish(self, slot):
+        import numpy as np
+        from diagan import _native as nat
+        layers = self.launched.pop(slot, [])
+        if not layers:
+            return
+        key = (slot, tuple(id(l) for l in layers))
+        t = self.tables.get(key)
+        if t is None:
+            desc = np.dtype([('p', np.uint64, 7), ('stride', np.int64), ('i', np.int32, 4)])
+            tab = np.zeros(len(layers), dtype=desc)
+            any_sn, max_elem = 0, 0
+            for li, layer in enumerate(layers):
+                e = self.entries[(layer, slot)]
+                c = e['sn_ctx']
+                sn = c is not None
+                any_sn |= int(sn)
+                max_elem = max(max_elem, e['n_elem'])
+                tab[li]['p'] = [e['slab'].data_ptr(), layer.weight.grad.data_ptr(),
+                                layer.weight.data.data_ptr() if sn else 0, c.u.data_ptr() if sn else 0,
+                                c.v.data_ptr() if sn else 0, c.state.data_ptr() if sn else 0,
+                                e['partials'].data_ptr()]
+                tab[li]['stride'] = e['stride']
+                tab[li]['i'] = [e['splits'], e['n_elem'], e['n_w'], layer.geom.Kp]
+            t = (torch.from_numpy(tab.view(np.uint8).copy()).to(layers[0].weight.device), len(layers), max_elem, any_sn)
+            self.tables[key] = t
+        nat.call("diagan_wgrad_finish_batched", t[0].data_ptr(), t[1], t[2], t[3], nat.current_stream())
+
+
 class FlatNet(nn.Module):
     """Base of the engine's networks: owns the flat parameter / gradient buffers."""
 
@@ -369,6 +458,7 @@ class FlatNet(nn.Module):
         self.param_version = 0        # bumped whenever parameters change (optimizer step, load)
         self._flat = None
         self._flat_grad = None
+        object.__setattr__(self, 'wgrad_batch', WgradBatch(self))
 
     def _link_layers(self):
         for m in self.modules():

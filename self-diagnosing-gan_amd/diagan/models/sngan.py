@@ -112,20 +112,20 @@ class DBlock(nn.Module):
             ksc = None
             h2 = self.c2.fwd(k2, h1, pro=RELU, residual=x, res_relu=True)
         out = E.avgpool2(h2) if self.downsample else h2
-        ctx = dict(x=x, h1=h1, k1=k1, k2=k2, ksc=ksc) if save else {}
+        ctx = dict(x=x, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=slot or 0) if save else {}
         return out, ctx
 
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
-        x, h1 = ctx['x'], ctx['h1']
+        x, h1, slot = ctx['x'], ctx['h1'], ctx['slot']
         hw = x.shape[1:3]
         g_full = E.avgpool2_bwd(gout) if self.downsample else gout
         if need_wgrad:
-            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU)
+            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
         g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
         if need_wgrad:
-            self.c1.wgrad(ctx['k1'], g_h1, x, pro=RELU)
+            self.c1.wgrad(ctx['k1'], g_h1, x, pro=RELU, slot=slot)
             if self.learnable_sc:
-                self.c_sc.wgrad(ctx['ksc'], g_full, x, pro=RELU)
+                self.c_sc.wgrad(ctx['ksc'], g_full, x, pro=RELU, slot=slot)
         if not need_gx:
             return None
         if self.learnable_sc:
@@ -153,19 +153,19 @@ class DBlockOptimized(nn.Module):
         sc = self.c_sc.fwd(ksc, xp)
         h2 = self.c2.fwd(k2, h1, pro=RELU)
         out = E.avgpool2(h2, residual=sc)
-        ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc) if save else {}
+        ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=slot or 0) if save else {}
         return out, ctx
 
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
-        x, xp, h1 = ctx['x'], ctx['xp'], ctx['h1']
+        x, xp, h1, slot = ctx['x'], ctx['xp'], ctx['h1'], ctx['slot']
         hw = x.shape[1:3]
         g_full = E.avgpool2_bwd(gout)
         if need_wgrad:
-            self.c_sc.wgrad(ctx['ksc'], gout, xp)
-            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU)
+            self.c_sc.wgrad(ctx['ksc'], gout, xp, slot=slot)
+            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
         g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
         if need_wgrad:
-            self.c1.wgrad(ctx['k1'], g_h1, x)
+            self.c1.wgrad(ctx['k1'], g_h1, x, slot=slot)
         if not need_gx:
             return None
         g_xp = self.c_sc.dgrad(ctx['ksc'], gout, xp.shape[1:3])
@@ -202,6 +202,7 @@ class SNGANBaseGenerator(BaseGenerator):
         for blk, c in zip(reversed(self._blocks()), reversed(ctx['bctx'])):
             g = blk.backward(c, g)
         self.l1.wgrad(ctx['x0'], g)
+        self.wgrad_batch.finish(0)
 
 
 class SNGANGenerator32(SNGANBaseGenerator):
@@ -280,13 +281,15 @@ class SNGANBaseDiscriminator(BaseDiscriminator):
             h, c = blk.forward(h, training, save=save, need_dgrad=need_dgrad, slot=slot)
             bctx.append(c)
         hctx, logit = self._head.fwd(h, training, slot=slot)
-        return logit, (dict(bctx=bctx, hctx=hctx) if save else None)
+        return logit, (dict(bctx=bctx, hctx=hctx, slot=slot) if save else None)
 
     def backward_nhwc(self, ctx, dlogit, need_wgrad=True, need_gx=False):
         g = self._head.bwd(ctx['hctx'], dlogit, need_wgrad=need_wgrad)
         blocks = self._blocks()
         for i in range(len(blocks) - 1, -1, -1):
             g = blocks[i].backward(ctx['bctx'][i], g, need_wgrad=need_wgrad, need_gx=(need_gx or i > 0))
+        if need_wgrad:
+            self.wgrad_batch.finish(ctx['slot'])
         return g
 
 

@@ -12,7 +12,8 @@ from diagan import _native as nat
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F] + [I] * 15 + [P])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I])
-nat.register("diagan_conv_wgrad", [P, P, P, I, P, P, I] + [I] * 14 + [P])
+nat.register("diagan_conv_wgrad", [P, P, P, I, I64, I64, P, P, I] + [I] * 14 + [P])
+nat.register("diagan_wgrad_finish_batched", [P, I, I64, I, P])
 nat.register("diagan_conv_wgrad_splits", [I, I, I])
 nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
 nat.register("diagan_sn_power_iter", [P, P, P, P, P, P, P, I, I, F, I, P])
@@ -171,7 +172,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
     t0 = TIMER.begin() if TIMER is not None else None
-    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, nat.ptr(scale), nat.ptr(shift),
+    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
         TIMER.end("conv_wgrad_kernel<128,128>" if (Co > 64 and geom.Kp > 64) else "conv_wgrad_kernel<64,64>",
@@ -189,6 +190,26 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
         nat.call("diagan_sn_grad_fix", G.data_ptr(), nat.ptr(parts), nparts, nat.ptr(u), nat.ptr(v),
                  nat.ptr(state), nat.ptr(grad), Co, geom.Kp, 1 if accumulate else 0, st)
     return grad
+
+
+def wgrad_splits(M, Co, Kp):
+    return nat.fn("diagan_conv_wgrad_splits")(M, Co, Kp)
+
+
+def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None):
+    """Split-K weight (+bias) gradient partials into a caller-owned slab [splits][stride]; the sum over
+    splits is done later for all layers at once (diagan_wgrad_finish_batched)."""
+    B, Ho, Wo, Co = dy.shape
+    _, Hi, Wi, Ci = x.shape
+    mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
+    sy, dr, off, up = geom.fwd_params()
+    t0 = TIMER.begin() if TIMER is not None else None
+    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, stride, bias_off, nat.ptr(scale),
+             nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
+             nat.current_stream())
+    if t0 is not None:
+        TIMER.end("conv_wgrad_kernel<128,128>" if (Co > 64 and geom.Kp > 64) else "conv_wgrad_kernel<64,64>",
+                  2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0)
 
 
 def sn_power_iter(W, u_buffer, sigma_buffer, training=True, eps=1e-12):
