@@ -70,10 +70,14 @@ int diagan_logit_scatter(const float* logit, const int64_t* idx, int64_t n, void
  *   epi: + bias[n], + residual (or max(residual,0) if res_relu), then (mask_src > 0 ? v : mask_slope*v).
  * Replaces F.conv2d / nn.ConvTranspose2d forward and their input gradient
  * (SNGAN blocks: SURVEY §8 a2-a7; DCGAN: diagan-pkg/diagan/models/mnist.py:55-71,163-190).
- * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto. */
+ * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto.
+ * scale0/scale1 (device scalars, optional): pixel rows m < scale_split are scaled by *scale0, the rest
+ * by *scale1 instead of out_scale -- two forwards of one spectral-norm layer (different sigma) batched
+ * into one GEMM on the un-normalised weight. */
 int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
                      const float* residual, int res_relu, const float* mask_src, float mask_slope,
                      const float* pro_scale, const float* pro_shift, int pro_mode, float out_scale,
+                     const float* scale0, const float* scale1, int scale_split,
                      int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                      int dr, int off, int up, int Kp, int tile_cfg, void* stream);
 
@@ -83,8 +87,10 @@ int diagan_conv_gemm_pick_cfg(int M, int Co); /* tile config chosen when tile_cf
  * Replaces the weight half of conv2d / conv_transpose2d backward (errD.backward()/errG.backward()
  * in the train steps, diagan-pkg/diagan/models/topk_models.py:90, mnist.py:126).
  * dy NHWC [B,Ho,Wo,Co] (Co % 4 == 0), slab [splits][slab_stride] (slab_stride >= Co*Kp).
+ * segments: the pixel range is cut into `segments` equal parts and no split straddles a part
+ * (splits % segments == 0), so each batched forward's gradient can be reduced separately.
  * bias_off >= 0: the bias gradient partials sum_m dy[m][n] are written to slab[s][bias_off + n]. */
-int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t slab_stride,
+int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int segments, int64_t slab_stride,
                       int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B, int Hi, int Wi, int Ci, int Ho,
                       int Wo, int Co, int R, int S, int sy, int dr, int off, int up, int Kp,
                       void* stream);
@@ -94,15 +100,16 @@ int diagan_conv_wgrad_splits(int M, int Co, int Kp); /* host heuristic: number o
  * G = sum_s slab[s] (fixed order); plain layers: grad += G; spectral-norm layers:
  * grad += (G - <G,W>/sigma u^T v)/sigma on the weight part, grad += G on the bias part. */
 typedef struct {
-  float* slab;        /* [splits][stride] */
-  float* grad;        /* weight gradient [Co*Kp] followed by the bias gradient */
-  const float* W;     /* master weight for SN layers, NULL otherwise */
-  const float* u;     /* SN context of the matching forward */
-  const float* v;
-  const float* state; /* {sigma, 1/sigma} */
-  double* partials;   /* ceil(n_elem/1024) doubles (SN layers) */
+  float* slab[2];        /* per context: [splits][stride] */
+  const float* u[2];     /* SN context of the forward each slab belongs to */
+  const float* v[2];
+  const float* state[2]; /* {sigma, 1/sigma} */
+  double* partials[2];   /* ceil(n_elem/1024) doubles each (SN layers) */
+  float* grad;           /* weight gradient [Co*Kp] followed by the bias gradient */
+  const float* W;        /* master weight for SN layers, NULL otherwise */
   int64_t stride;
-  int splits, n_elem, n_w, Kp;
+  int splits, n_elem, n_w, Kp;  /* splits per context */
+  int nctx, pad;         /* 1, or 2 when the backward covered two batched forwards */
 } diagan_wgrad_layer;
 int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t max_elem, int any_sn, void* stream);
 
@@ -137,6 +144,10 @@ typedef struct {
 } diagan_sn_layer;
 int diagan_sn_prepare_batched(const void* table_dev, int n_layers, int max_Co, int max_Ci, int max_RS,
                               int max_Kp, float eps, int update_buffers, int write_wd, void* stream);
+/* write_wd: 1 pack Wf and Wd, 0 pack Wf only, -1 power iteration only.  diagan_pack_batched runs the
+ * packing step alone (scale = state[1] of each descriptor). */
+int diagan_pack_batched(const void* table_dev, int n_layers, int max_Co, int max_Ci, int max_RS, int write_wd,
+                        void* stream);
 
 /* GEMM operand packing: Wf = W*inv (same [Co][Kp] layout), Wd[ci][(rs)*Co+co] = W[co][(rs)*Ci+ci]*inv
  * (data-gradient operand, row length Kd).  inv_sigma: device float* or NULL (= 1). */
@@ -193,12 +204,13 @@ int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int W, int C, 
 
 /* SNGAN discriminator head: pooled = sum_hw relu(x); logit = inv_sigma * pooled.w + bias
  * (torch.sum(activation(h), dim=(2,3)) -> SNLinear(C, 1)). */
-int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* bias, float* pooled,
-                    float* logit, int B, int HW, int C, void* stream);
-/* gx = dlogit*w*inv_sigma*(x>0) (if gx); G[c] = sum_b dlogit*pooled, dot = <G,w>, dbias (if G). */
-int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* x,
-                    const float* pooled, float* gx, float* G, double* dot, float* dbias, int accumulate_bias,
-                    int B, int HW, int C, void* stream);
+int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* inv_sigma1, int split_b,
+                    const float* bias, float* pooled, float* logit, int B, int HW, int C, void* stream);
+/* inv_sigma1 (optional): samples b >= split_b use *inv_sigma1 (second batched forward).
+ * gx = dlogit*w*inv_sigma*(x>0) (if gx); G[c] = sum_b dlogit*pooled, dot = <G,w>, dbias (if G). */
+int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* inv_sigma1, int split_b,
+                    const float* x, const float* pooled, float* gx, float* G, double* dot, float* dbias,
+                    int accumulate_bias, int B, int HW, int C, void* stream);
 
 int diagan_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 

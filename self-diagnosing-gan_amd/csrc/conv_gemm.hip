@@ -33,6 +33,9 @@ struct ConvGemmArgs {
   const float* pro_shift;
   float mask_slope;       // 0 for ReLU backward, 0.2 for LeakyReLU backward
   float out_scale;        // multiplies the accumulator before bias/residual (1.0 normally)
+  const float* scale0;    // optional device scalars: rows m < scale_split use *scale0, the others *scale1
+  const float* scale1;    // (two forwards with different spectral-norm sigmas batched into one GEMM)
+  int scale_split;
   int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
   int pro_mode;
   int M;                  // B*Ho*Wo
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     __syncthreads();
   }
 
+  const float sc0 = a.scale0 ? a.scale0[0] : 1.f, sc1 = a.scale1 ? a.scale1[0] : 1.f;
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -207,7 +211,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         const int m = m0 + wm * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (m >= a.M) continue;
         const long o = (long)m * g.Co + n;
-        float v = acc[i][j][e] * a.out_scale + bv;
+        const float sc = a.scale0 ? (m < a.scale_split ? sc0 : sc1) : a.out_scale;
+        float v = acc[i][j][e] * sc + bv;
         if (a.residual) { const float r = a.residual[o]; v += a.res_relu ? fmaxf(r, 0.f) : r; }
         if (a.mask_src) v = a.mask_src[o] > 0.f ? v : v * a.mask_slope;
         a.y[o] = v;
@@ -254,7 +259,8 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
 DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
                                 const float* residual, int res_relu, const float* mask_src, float mask_slope,
                                 const float* pro_scale, const float* pro_shift, int pro_mode,
-                                float out_scale, int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
+                                float out_scale, const float* scale0, const float* scale1, int scale_split,
+                                int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                 int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
                                 void* stream) {
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
@@ -272,6 +278,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   ConvGemmArgs a;
   a.x = x; a.w = w; a.y = y; a.bias = bias; a.residual = residual; a.mask_src = mask_src;
   a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.mask_slope = mask_slope; a.out_scale = out_scale;
+  a.scale0 = scale0; a.scale1 = scale1; a.scale_split = scale_split;
+  DG_REQUIRE(!scale0 || scale1, "conv_gemm: scale0 and scale1 must be given together");
   a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   hipStream_t st = (hipStream_t)stream;

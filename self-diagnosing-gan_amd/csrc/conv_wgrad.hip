@@ -47,6 +47,8 @@ struct WgradArgs {
   int pro_mode;
   int M;
   int steps_per_split;    // K-steps (of 32 pixels) per split
+  int seg_steps;          // K-steps per pixel segment (total steps when there is one segment)
+  int splits_per_seg;     // splits never straddle a segment (= one of several batched forwards)
   long slab_stride;       // floats between consecutive split slabs (>= Co*Kp)
   long bias_off;          // >= 0: column sums of dy (bias gradient) go to slab[split][bias_off + n]
   ConvGeom g;
@@ -71,9 +73,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
   const int split = blockIdx.y;
-  const int step0 = split * a.steps_per_split;
-  const int total_steps = (a.M + BK - 1) / BK;
-  const int step1 = min(step0 + a.steps_per_split, total_steps);
+  const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
+  const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
+  const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
 
   // A' loader (dy rows): fixed channel chunk, pixel rows ap + APR*j
   const int ac = tid % AC, ap = tid / AC;
@@ -236,73 +238,84 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 
 // ---- deferred, batched epilogue of a whole backward pass --------------------------------------
-// One descriptor per parameterised layer; blockIdx.z selects the layer.
-struct WgFinish {          // mirrored by diagan_wgrad_layer in include/diagan_hip.h (80 bytes)
-  float* slab;             // [splits][stride]: weight partials (+ bias partials at bias_off)
+// One descriptor per parameterised layer; blockIdx.z selects the layer.  A layer whose backward
+// covered two batched forwards (nctx == 2) has two slab halves, each with its own SN context; both
+// contributions are added by the same thread (no two writers per gradient element).
+struct WgFinish {          // mirrored by diagan_wgrad_layer in include/diagan_hip.h (120 bytes)
+  float* slab[2];          // [splits][stride] per context: weight partials (+ bias partials)
+  const float* u[2];       // SN: u', v, state of the forward each context belongs to
+  const float* v[2];
+  const float* state[2];
+  double* partials[2];     // SN: one fp64 partial of <G, W> per block of phase A, per context
   float* grad;             // flat gradient region of the layer: weight [Co*Kp] then bias
   const float* W;          // master weight (SN layers) or NULL
-  const float* u;          // SN: u', v, state of the forward this backward belongs to
-  const float* v;
-  const float* state;
-  double* partials;        // SN: one fp64 partial of <G, W> per block of phase A
   long stride;
-  int splits, n_elem, n_w, Kp;   // n_elem = Co*Kp (+ Co if bias), n_w = Co*Kp
+  int splits, n_elem, n_w, Kp;   // splits per context; n_elem = Co*Kp (+ Co if bias), n_w = Co*Kp
+  int nctx, pad;
 };
 
-// phase A: G = sum over splits (fixed order).  non-SN layers: grad += G.  SN layers: G kept in
-// slab[0] and the block's partial of <G, W> is written.
+// phase A: G_c = sum over the splits of context c (fixed order).  plain layers: grad += sum_c G_c.
+// SN layers: G_c kept in slab[c][0..] and the block's partial of <G_c, W> is written.
 __global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab) {
   const WgFinish L = tab[blockIdx.z];
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const bool sn = L.W != nullptr;
   if ((long)blockIdx.x * 1024 >= L.n_elem) return;
-  double dot = 0.0;
-  if (i < L.n_elem) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(L.slab + i);
-    for (int k = 1; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(L.slab + (long)k * L.stride + i);
-    if (sn) {
-      if (i < L.n_w) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + i);
-        dot = (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
+  __shared__ double red[4];
+  f32x4 total = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < L.nctx; ++c) {
+    double dot = 0.0;
+    if (i < L.n_elem) {
+      float* sl = L.slab[c];
+      f32x4 s = *reinterpret_cast<const f32x4*>(sl + i);
+      for (int k = 1; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + i);
+      if (sn) {
+        if (i < L.n_w) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + i);
+          dot = (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
+        }
+        *reinterpret_cast<f32x4*>(sl + i) = s;
+      } else {
+        total += s;
       }
-      *reinterpret_cast<f32x4*>(L.slab + i) = s;
-    } else {
-      *reinterpret_cast<f32x4*>(L.grad + i) += s;
+    }
+    if (sn) {
+      dot = wave_sum(dot);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+      __syncthreads();
+      if (threadIdx.x == 0) L.partials[c][blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
   }
-  if (sn) {
-    __shared__ double red[4];
-    dot = wave_sum(dot);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) L.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-  }
+  if (!sn && i < L.n_elem) *reinterpret_cast<f32x4*>(L.grad + i) += total;
 }
 
-// phase B (SN layers): grad += (G - <G,W>/sigma * u^T v) / sigma ; bias part: grad += G
+// phase B (SN layers): grad += sum_c (G_c - <G_c,W>/sigma_c * u_c^T v_c) / sigma_c ; bias part: += G_c
 __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab) {
   const WgFinish L = tab[blockIdx.z];
   if (L.W == nullptr || (long)blockIdx.x * 1024 >= L.n_elem) return;
-  __shared__ double sdot;
-  if (threadIdx.x == 0) {
+  __shared__ double sdot[2];
+  if (threadIdx.x < L.nctx) {
     const int nparts = (L.n_elem + 1023) / 1024;
     double d = 0.0;
-    for (int k = 0; k < nparts; ++k) d += L.partials[k];
-    sdot = d;
+    for (int k = 0; k < nparts; ++k) d += L.partials[threadIdx.x][k];   // fixed order: deterministic
+    sdot[threadIdx.x] = d;
   }
   __syncthreads();
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= L.n_elem) return;
-  const f32x4 g = *reinterpret_cast<const f32x4*>(L.slab + i);
-  f32x4 o;
-  if (i < L.n_w) {
-    const float inv = L.state[1];
-    const float coef = (float)(sdot * (double)inv);
-    const int n = (int)(i / L.Kp), k = (int)(i - (long)n * L.Kp);
-    const f32x4 vv = *reinterpret_cast<const f32x4*>(L.v + k);
-    o = (g - (L.u[n] * coef) * vv) * inv;
-  } else {
-    o = g;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < L.nctx; ++c) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(L.slab[c] + i);
+    if (i < L.n_w) {
+      const float inv = L.state[c][1];
+      const float coef = (float)(sdot[c] * (double)inv);
+      const int n = (int)(i / L.Kp), k = (int)(i - (long)n * L.Kp);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(L.v[c] + k);
+      o += (g - (L.u[c][n] * coef) * vv) * inv;
+    } else {
+      o += g;
+    }
   }
   *reinterpret_cast<f32x4*>(L.grad + i) += o;
 }
@@ -314,7 +327,7 @@ using namespace diagan;
 DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t max_elem, int any_sn,
                                            void* stream) {
   DG_REQUIRE(table_dev && n_layers > 0 && max_elem > 0, "wgrad_finish_batched: bad args");
-  static_assert(sizeof(WgFinish) == 80, "descriptor layout");
+  static_assert(sizeof(WgFinish) == 128, "descriptor layout");
   const WgFinish* tab = (const WgFinish*)table_dev;
   const int blocks = cdiv(max_elem, 1024);
   hipLaunchKernelGGL(wgrad_finish_a_kernel, dim3(blocks, 1, n_layers), dim3(256), 0, (hipStream_t)stream, tab);
@@ -323,8 +336,8 @@ DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, 
   return check_launch("wgrad_finish_batched");
 }
 
-DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int64_t slab_stride,
-                                 int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
+DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int segments,
+                                 int64_t slab_stride, int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
                                  int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                  int dr, int off, int up, int Kp, void* stream) {
   DG_REQUIRE(dy && x && slab, "conv_wgrad: null tensor");
@@ -345,7 +358,11 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
   const int total_steps = cdiv(a.M, 32);
-  a.steps_per_split = cdiv(total_steps, splits);
+  DG_REQUIRE(segments >= 1 && splits % segments == 0, "conv_wgrad: splits=%d not a multiple of segments=%d", splits, segments);
+  DG_REQUIRE(segments == 1 || (a.M % (32 * segments)) == 0, "conv_wgrad: %d pixels do not split into %d segments of whole K-steps", a.M, segments);
+  a.seg_steps = cdiv(total_steps, segments);
+  a.splits_per_seg = splits / segments;
+  a.steps_per_split = cdiv(a.seg_steps, a.splits_per_seg);
   a.slab_stride = slab_stride;
   a.bias_off = bias_off;
   hipStream_t st = (hipStream_t)stream;

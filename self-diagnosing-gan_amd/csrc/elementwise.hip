@@ -363,28 +363,31 @@ __global__ __launch_bounds__(EW_T) void relu_sumpool_kernel(const float* __restr
 
 // logit[b] = inv_sigma * sum_c pooled[b][c]*w[c] + bias        (one wave per sample)
 __global__ void head_linear_kernel(const float* __restrict__ pooled, const float* __restrict__ w,
-                                   const float* __restrict__ inv_sigma, const float* __restrict__ bias,
-                                   float* __restrict__ logit, int B, int C) {
+                                   const float* __restrict__ inv_sigma, const float* __restrict__ inv_sigma1,
+                                   int split_b, const float* __restrict__ bias, float* __restrict__ logit, int B,
+                                   int C) {
   const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (b >= B) return;
   float s = 0.f;
   for (int c = lane; c < C; c += 64) s = fmaf(pooled[(long)b * C + c], w[c], s);
   s = wave_sum(s);
-  if (lane == 0) logit[b] = s * (inv_sigma ? inv_sigma[0] : 1.f) + (bias ? bias[0] : 0.f);
+  const float* ip = (inv_sigma1 && b >= split_b) ? inv_sigma1 : inv_sigma;
+  if (lane == 0) logit[b] = s * (ip ? ip[0] : 1.f) + (bias ? bias[0] : 0.f);
 }
 
 // gx[b,hw,c] = dlogit[b] * w[c] * inv_sigma * (x > 0)
 __global__ void head_bwd_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
-                                const float* __restrict__ inv_sigma, const float* __restrict__ x,
-                                float* __restrict__ gx, long n4, int HW, int C) {
+                                const float* __restrict__ inv_sigma, const float* __restrict__ inv_sigma1,
+                                int split_b, const float* __restrict__ x, float* __restrict__ gx, long n4, int HW,
+                                int C) {
   const int C4 = C >> 2;
-  const float inv = inv_sigma ? inv_sigma[0] : 1.f;
+  const float inv0 = inv_sigma ? inv_sigma[0] : 1.f, inv1 = inv_sigma1 ? inv_sigma1[0] : inv0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
     const long b = i / ((long)C4 * HW);
     const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
     const f32x4 wv = reinterpret_cast<const f32x4*>(w)[c4];
-    const float d = dlogit[b] * inv;
+    const float d = dlogit[b] * (b >= split_b ? inv1 : inv0);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = xv[e] > 0.f ? d * wv[e] : 0.f;
@@ -568,22 +571,25 @@ DIAGAN_API int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int
   return check_launch("avgpool2_bwd");
 }
 
-DIAGAN_API int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* bias,
-                               float* pooled, float* logit, int B, int HW, int C, void* stream) {
+DIAGAN_API int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* inv_sigma1,
+                               int split_b, const float* bias, float* pooled, float* logit, int B, int HW, int C,
+                               void* stream) {
   DG_REQUIRE(x && w && pooled && logit && B > 0 && HW > 0 && C > 0 && (C & 3) == 0, "head_fwd: bad args");
   const int C4 = C / 4, CW = C4 < 64 ? C4 : 64;
   hipLaunchKernelGGL(relu_sumpool_kernel, dim3(cdiv(C4, CW), B), dim3(EW_T), 0, ST, x, pooled, HW, C);
-  hipLaunchKernelGGL(head_linear_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ST, pooled, w, inv_sigma, bias, logit, B, C);
+  hipLaunchKernelGGL(head_linear_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ST, pooled, w, inv_sigma, inv_sigma1,
+                     inv_sigma1 ? split_b : B, bias, logit, B, C);
   return check_launch("head_fwd");
 }
 
-DIAGAN_API int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* x,
-                               const float* pooled, float* gx, float* G, double* dot, float* dbias,
-                               int accumulate_bias, int B, int HW, int C, void* stream) {
+DIAGAN_API int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* inv_sigma1,
+                               int split_b, const float* x, const float* pooled, float* gx, float* G, double* dot,
+                               float* dbias, int accumulate_bias, int B, int HW, int C, void* stream) {
   DG_REQUIRE(dlogit && w && x && B > 0 && HW > 0 && C > 0 && (C & 3) == 0, "head_bwd: bad args");
   if (gx) {
     const long n4 = (long)B * HW * C / 4;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, dlogit, w, inv_sigma, x, gx, n4, HW, C);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, dlogit, w, inv_sigma, inv_sigma1,
+                       inv_sigma1 ? split_b : B, x, gx, n4, HW, C);
   }
   if (G) {
     DG_REQUIRE(pooled && dot, "head_bwd: weight gradient needs pooled and dot");

@@ -304,7 +304,18 @@ DIAGAN_API int diagan_sn_prepare_batched(const void* table_dev, int n_layers, in
   hipLaunchKernelGGL(sn_cols_batched_kernel, dim3(cdiv(max_Kp, 256), SN_RSPLIT, n_layers), dim3(256), 0, st, tab);
   hipLaunchKernelGGL(sn_rows_batched_kernel, dim3(cdiv(max_Co, 16), 1, n_layers), dim3(256), 0, st, tab);
   hipLaunchKernelGGL(sn_finalize_batched_kernel, dim3(1, 1, n_layers), dim3(256), 0, st, tab, eps, update_buffers);
-  hipLaunchKernelGGL(pack_batched_kernel, dim3(cdiv(max_Ci, 32), cdiv(max_Co, 32), n_layers * max_RS), dim3(256), 0,
-                     st, tab, max_RS, write_wd);
+  if (write_wd >= 0)      // write_wd < 0: power iteration only (operands are packed elsewhere)
+    hipLaunchKernelGGL(pack_batched_kernel, dim3(cdiv(max_Ci, 32), cdiv(max_Co, 32), n_layers * max_RS), dim3(256), 0,
+                       st, tab, max_RS, write_wd);
   return check_launch("sn_prepare_batched");
+}
+
+// Operand packing alone for a table of layers (scale = table state[1]; used with a unit-scale state to
+// produce the un-normalised data-gradient operand shared by two batched forwards).
+DIAGAN_API int diagan_pack_batched(const void* table_dev, int n_layers, int max_Co, int max_Ci, int max_RS,
+                                   int write_wd, void* stream) {
+  DG_REQUIRE(table_dev && n_layers > 0 && max_Co > 0 && max_Ci > 0 && max_RS > 0, "pack_batched: bad args");
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(cdiv(max_Ci, 32), cdiv(max_Co, 32), n_layers * max_RS), dim3(256), 0,
+                     (hipStream_t)stream, (const SnLayer*)table_dev, max_RS, write_wd);
+  return check_launch("pack_batched");
 }

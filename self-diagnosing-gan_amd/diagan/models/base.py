@@ -72,12 +72,12 @@ class BaseGenerator(BaseModel):
             noise = torch.randn((num_images, self.nz), device=device)
         return self.forward(noise)
 
-    def generate_images_nhwc(self, num_images, device=None, noise=None, save=False):
+    def generate_images_nhwc(self, num_images, device=None, noise=None, save=False, out=None):
         if device is None:
             device = self.device
         if noise is None:
             noise = torch.randn((num_images, self.nz), device=device)
-        return self.forward_nhwc(noise, self.training, save=save)
+        return self.forward_nhwc(noise, self.training, save=save, out=out)
 
     def compute_gan_loss(self, output):
         k = None
@@ -143,14 +143,27 @@ class BaseDiscriminator(BaseModel):
         self.zero_grad()
         real_images = real_batch[0]
         batch_size = real_images.shape[0]
-        out_real, ctx_r = self.forward_nhwc(self.to_nhwc(real_images), self.training, save=True, need_dgrad=True,
-                                            need_in_dgrad=False)
-        fake, _ = netG.generate_images_nhwc(batch_size, device=device, noise=noise, save=False)   # .detach()
-        out_fake, ctx_f = self.forward_nhwc(fake, self.training, save=True, need_dgrad=True, need_in_dgrad=False,
-                                            slot=1)
-        out3, d_real, d_fake = E.loss_dis(out_real, out_fake, self.loss_type, gold=self.use_gold)
-        self.backward_nhwc(ctx_r, d_real, need_wgrad=True, need_gx=False)
-        self.backward_nhwc(ctx_f, d_fake, need_wgrad=True, need_gx=False)
+        if getattr(self, 'pair_forward', False) and self.training:
+            # D(real) and D(fake) as ONE batched pass: the two forwards differ only by their spectral-norm
+            # sigma (u is still advanced twice), which is applied per half of the batch in the GEMM epilogue.
+            B, _, H, W = real_images.shape
+            x_all = torch.empty((2 * B, H, W, self.in_channels_padded), dtype=torch.float32, device=real_images.device)
+            E.nchw_to_nhwc(real_images.to(dtype=torch.float32), self.in_channels_padded, out=x_all[:B])
+            netG.generate_images_nhwc(batch_size, device=device, noise=noise, save=False, out=x_all[B:])   # .detach()
+            out_all, ctx = self.forward_nhwc(x_all, True, save=True, need_dgrad=True, need_in_dgrad=False, slot='pair')
+            dl = torch.empty(2 * B, dtype=torch.float32, device=x_all.device)
+            out3, _, _ = E.loss_dis(out_all[:B], out_all[B:], self.loss_type, gold=self.use_gold, d_real=dl[:B],
+                                    d_fake=dl[B:])
+            self.backward_nhwc(ctx, dl, need_wgrad=True, need_gx=False)
+        else:
+            out_real, ctx_r = self.forward_nhwc(self.to_nhwc(real_images), self.training, save=True, need_dgrad=True,
+                                                need_in_dgrad=False)
+            fake, _ = netG.generate_images_nhwc(batch_size, device=device, noise=noise, save=False)   # .detach()
+            out_fake, ctx_f = self.forward_nhwc(fake, self.training, save=True, need_dgrad=True, need_in_dgrad=False,
+                                                slot=1)
+            out3, d_real, d_fake = E.loss_dis(out_real, out_fake, self.loss_type, gold=self.use_gold)
+            self.backward_nhwc(ctx_r, d_real, need_wgrad=True, need_gx=False)
+            self.backward_nhwc(ctx_f, d_fake, need_wgrad=True, need_gx=False)
         self.sync_grads()
         optD.step()
         # device scalars: no host sync here (the reference calls .item() three times per D step)

@@ -99,11 +99,17 @@ class ConvLayer(nn.Module):
 
     # ---- compute ----
     class Ctx:
-        __slots__ = ("wf", "wd", "u", "v", "state", "_keep")
+        __slots__ = ("wf", "wd", "u", "v", "state", "_keep", "row_scale", "pair")
+
+        def __init__(self):
+            self.row_scale = None      # (inv_sigma0, inv_sigma1): two forwards batched into one GEMM
+            self.pair = None           # their two per-forward SN contexts
 
     def prepare(self, training, need_dgrad=True, slot=None):
         """Per-forward operand preparation.  SN layers: one power iteration + scaled packing (done for
         the whole network at once by SNBatch when `slot` is given)."""
+        if self.sn and slot == 'pair':
+            return self._pair_ctx
         if self.sn and slot is not None:
             return self._slot_ctx[slot]
         ctx = ConvLayer.Ctx()
@@ -138,21 +144,24 @@ class ConvLayer(nn.Module):
 
     def _slot_ctx_or_none(self, slot):
         sc = getattr(self, '_slot_ctx', None)
-        return sc[slot] if sc is not None else None
+        return sc[slot] if (sc is not None and isinstance(slot, int)) else None
 
     def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0):
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
-                          residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu)
+                          residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale)
 
     def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
-                            mask_slope=mask_slope)
+                            mask_slope=mask_slope, row_scale=ctx.row_scale)
 
     def wgrad(self, ctx, dy, x, pro=None, slot=0):
         """Accumulates into weight.grad / bias.grad (views of the net's flat gradient buffer).
         Inside a network the split-K partials go to a per-layer slab and are reduced for all layers at
         once by WgradBatch.finish(); standalone layers reduce immediately."""
         net = getattr(self, '_net', None)
+        if net is not None and self.sn and slot == 'pair':
+            net.wgrad_batch.launch(self, slot, dy, x, pro, ctx.pair, segments=2)
+            return
         if net is not None and (not self.sn or ctx is self._slot_ctx_or_none(slot)):
             net.wgrad_batch.launch(self, slot, dy, x, pro, ctx if self.sn else None)
             return
@@ -291,11 +300,20 @@ class HeadLinear(nn.Module):
             sd[k] = torch.cat([sd[k].to(torch.float32), torch.zeros(3, device=sd[k].device)])
 
     class Ctx:
-        __slots__ = ("u", "v", "state", "x", "pooled", "_keep")
+        __slots__ = ("u", "v", "state", "x", "pooled", "_keep", "pair")
+
+        def __init__(self):
+            self.pair = None
 
     def fwd(self, x, training, slot=None):
         ctx = HeadLinear.Ctx()
         inv = None
+        if self.sn and slot == 'pair':
+            p0, p1 = self._slot_ctx[0], self._slot_ctx[1]
+            ctx.pair = (p0, p1)
+            ctx.x = x
+            ctx.pooled, logit = E.head_fwd(x, self.weight.data, p0.state[1:], self.bias.data, inv_sigma1=p1.state[1:])
+            return ctx, logit
         if self.sn and slot is not None:
             pre = self._slot_ctx[slot]
             ctx.u, ctx.v, ctx.state = pre.u, pre.v, pre.state
@@ -309,6 +327,19 @@ class HeadLinear(nn.Module):
         return ctx, logit
 
     def bwd(self, ctx, dlogit, need_wgrad=True):
+        if ctx.pair is not None:
+            from diagan import _native as nat
+            p0, p1 = ctx.pair
+            gx, _, _ = E.head_bwd(dlogit, self.weight.data, p0.state[1:], ctx.x, ctx.pooled, need_gx=True,
+                                  need_wgrad=False, inv_sigma1=p1.state[1:])
+            if need_wgrad:
+                h = dlogit.numel() // 2
+                for p, sl in ((p0, slice(0, h)), (p1, slice(h, 2 * h))):
+                    _, G, dot = E.head_bwd(dlogit[sl], self.weight.data, None, ctx.x[sl], ctx.pooled[sl], need_gx=False,
+                                           need_wgrad=True, dbias=self.bias.grad)
+                    nat.call("diagan_sn_grad_fix", nat.ptr(G), nat.ptr(dot), 1, nat.ptr(p.u), nat.ptr(p.v),
+                             nat.ptr(p.state), nat.ptr(self.weight.grad), 1, self.in_ch, 1, nat.current_stream())
+            return gx
         inv = ctx.state[1:] if self.sn else None
         gx, G, dot = E.head_bwd(dlogit, self.weight.data, inv, ctx.x, ctx.pooled, need_gx=True,
                                 need_wgrad=need_wgrad, dbias=self.bias.grad if need_wgrad else None)
@@ -366,14 +397,46 @@ class SNBatch:
                 dims.append((Co, Ci, RS, Kp))
             self.tables.append(torch.from_numpy(tab.view(np.uint8).copy()).to(dev))
         self.max = [max(d[k] for d in dims) for k in range(4)]
+        # "pair" mode: two forwards (different sigma) batched into one GEMM on the UN-normalised weight:
+        # forward operand = master weight, data-gradient operand = un-normalised transpose pack (made
+        # once per parameter update), per-forward 1/sigma applied in the GEMM epilogue.
+        convs = [m for m in layers if isinstance(m, ConvLayer)]
+        self.unit = torch.ones(2, **f32)
+        ptab = np.zeros(len(convs), dtype=desc)
+        for li, m in enumerate(convs):
+            g = m.geom
+            wd_raw = torch.zeros((g.Ci, g.Kd), **f32)
+            pc = ConvLayer.Ctx()
+            pc.wf, pc.wd = m.weight.data, wd_raw
+            pc.u = pc.v = pc.state = None
+            pc.row_scale = (m._slot_ctx[0].state[1:], m._slot_ctx[1].state[1:])
+            pc.pair = (m._slot_ctx[0], m._slot_ctx[1])
+            m._pair_ctx = pc
+            ptab[li]['p'] = [m.weight.data.data_ptr(), 0, 0, 0, 0, self.unit.data_ptr(), 0, 0, wd_raw.data_ptr()]
+            ptab[li]['i'] = [g.Co, g.Ci, g.R * g.S, g.Kp, g.Kd, 0]
+        self.pair_table = torch.from_numpy(ptab.view(np.uint8).copy()).to(dev)
+        self.n_convs = len(convs)
+        self.pair_version = None
 
     def stale(self):
         return self.flat_id != id(self.net.flat_params)
 
+    def run_pair(self, training, need_dgrad):
+        """Power iterations of BOTH forwards (u is advanced twice, as two sequential forwards would),
+        no operand packing; the shared un-normalised data-gradient operand is refreshed when stale."""
+        self.run(0, training, -1)
+        self.run(1, training, -1)
+        if need_dgrad and self.pair_version != self.net.param_version:
+            nat = self.nat
+            nat.call("diagan_pack_batched", self.pair_table.data_ptr(), self.n_convs, self.max[0], self.max[1],
+                     self.max[2], 1, nat.current_stream())
+            self.pair_version = self.net.param_version
+
     def run(self, slot, training, write_wd):
         nat = self.nat
         nat.call("diagan_sn_prepare_batched", self.tables[slot].data_ptr(), len(self.layers), self.max[0],
-                 self.max[1], self.max[2], self.max[3], 1e-12, 1 if training else 0, 1 if write_wd else 0,
+                 self.max[1], self.max[2], self.max[3], 1e-12, 1 if training else 0,
+                 write_wd if isinstance(write_wd, int) and not isinstance(write_wd, bool) else (1 if write_wd else 0),
                  nat.current_stream())
 
 
@@ -392,7 +455,7 @@ class WgradBatch:
         self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, max_elem, any_sn)
         self.flat_id = None
 
-    def _entry(self, layer, slot, M):
+    def _entry(self, layer, slot, M, segments=1):
         if self.flat_id != id(self.net.flat_grads):          # gradient slab was re-allocated
             self.entries.clear(), self.tables.clear()
             self.flat_id = id(self.net.flat_grads)
@@ -405,20 +468,24 @@ class WgradBatch:
             if has_bias and layer.bias.grad.data_ptr() != layer.weight.grad.data_ptr() + 4 * n_w:
                 raise RuntimeError("bias gradient does not follow the weight gradient in the flat slab")
             stride = n_w + n_b
-            splits = C.wgrad_splits(M, g.Co, g.Kp)
+            splits = max(segments, C.wgrad_splits(M, g.Co, g.Kp) // segments * segments)
             dev = layer.weight.device
             e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, bias_off=n_w if has_bias else -1,
+                     segments=segments,
                      slab=torch.empty(splits * stride, dtype=torch.float32, device=dev),
-                     partials=torch.empty((stride + 1023) // 1024, dtype=torch.float64, device=dev))
+                     partials=torch.empty((segments, (stride + 1023) // 1024), dtype=torch.float64, device=dev))
             self.entries[(layer, slot)] = e
             self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
         return e
 
-    def launch(self, layer, slot, dy, x, pro, sn_ctx):
+    def launch(self, layer, slot, dy, x, pro, sn_ctx, segments=1):
+        """sn_ctx: None (plain layer), one SN context, or a tuple of `segments` contexts (one per
+        batched forward; the pixel range is cut accordingly and each part gets its own correction)."""
         M = dy.numel() // dy.shape[-1]
-        e = self._entry(layer, slot, M)
+        e = self._entry(layer, slot, M, segments)
         e['sn_ctx'] = sn_ctx
-        C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro)
+        C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro,
+                          segments=segments)
         self.launched.setdefault(slot, []).append(layer)
 
     def finish(self, slot):
@@ -430,21 +497,30 @@ class WgradBatch:
         key = (slot, tuple(id(l) for l in layers))
         t = self.tables.get(key)
         if t is None:
-            desc = np.dtype([('p', np.uint64, 7), ('stride', np.int64), ('i', np.int32, 4)])
+            desc = np.dtype([('p', np.uint64, 12), ('stride', np.int64), ('i', np.int32, 6)])
             tab = np.zeros(len(layers), dtype=desc)
             any_sn, max_elem = 0, 0
             for li, layer in enumerate(layers):
                 e = self.entries[(layer, slot)]
                 c = e['sn_ctx']
-                sn = c is not None
-                any_sn |= int(sn)
                 max_elem = max(max_elem, e['n_elem'])
-                tab[li]['p'] = [e['slab'].data_ptr(), layer.weight.grad.data_ptr(),
-                                layer.weight.data.data_ptr() if sn else 0, c.u.data_ptr() if sn else 0,
-                                c.v.data_ptr() if sn else 0, c.state.data_ptr() if sn else 0,
-                                e['partials'].data_ptr()]
-                tab[li]['stride'] = e['stride']
-                tab[li]['i'] = [e['splits'], e['n_elem'], e['n_w'], layer.geom.Kp]
+                ctxs = list(c) if isinstance(c, tuple) else [c]
+                nctx = len(ctxs)
+                per = e['splits'] // nctx                  # splits of each batched forward
+                sn = ctxs[0] is not None
+                any_sn |= int(sn)
+                pp = [0] * 12
+                for pi, cc in enumerate(ctxs):
+                    pp[0 + pi] = e['slab'].data_ptr() + 4 * pi * per * e['stride']
+                    if sn:
+                        pp[2 + pi], pp[4 + pi], pp[6 + pi] = cc.u.data_ptr(), cc.v.data_ptr(), cc.state.data_ptr()
+                    pp[8 + pi] = e['partials'][pi].data_ptr()
+                if not sn and nctx > 1:                    # plain layer: one context over all splits
+                    nctx, per = 1, e['splits']
+                pp[10] = layer.weight.grad.data_ptr()
+                pp[11] = layer.weight.data.data_ptr() if sn else 0
+                tab[li]['p'], tab[li]['stride'] = pp, e['stride']
+                tab[li]['i'] = [per, e['n_elem'], e['n_w'], layer.geom.Kp, nctx, 0]
             t = (torch.from_numpy(tab.view(np.uint8).copy()).to(layers[0].weight.device), len(layers), max_elem, any_sn)
             self.tables[key] = t
         nat.call("diagan_wgrad_finish_batched", t[0].data_ptr(), t[1], t[2], t[3], nat.current_stream())

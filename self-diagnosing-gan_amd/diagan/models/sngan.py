@@ -112,7 +112,7 @@ class DBlock(nn.Module):
             ksc = None
             h2 = self.c2.fwd(k2, h1, pro=RELU, residual=x, res_relu=True)
         out = E.avgpool2(h2) if self.downsample else h2
-        ctx = dict(x=x, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=slot or 0) if save else {}
+        ctx = dict(x=x, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=0 if slot is None else slot) if save else {}
         return out, ctx
 
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
@@ -153,7 +153,7 @@ class DBlockOptimized(nn.Module):
         sc = self.c_sc.fwd(ksc, xp)
         h2 = self.c2.fwd(k2, h1, pro=RELU)
         out = E.avgpool2(h2, residual=sc)
-        ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=slot or 0) if save else {}
+        ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=0 if slot is None else slot) if save else {}
         return out, ctx
 
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
@@ -179,7 +179,7 @@ class SNGANBaseGenerator(BaseGenerator):
     def _blocks(self):
         raise NotImplementedError
 
-    def forward_nhwc(self, z, training, save=True):
+    def forward_nhwc(self, z, training, save=True, out=None):
         z = z.to(dtype=self.l1.weight.dtype)
         x0, h = self.l1.fwd(z)
         bctx = []
@@ -189,7 +189,7 @@ class SNGANBaseGenerator(BaseGenerator):
         bn = self._last_bn.stats(h, training)
         k = self._last_conv.prepare(training, need_dgrad=save)
         y_pre = self._last_conv.fwd(k, h, pro=_bn_pro(bn))
-        y = E.tanh_fwd(y_pre)
+        y = E.tanh_fwd(y_pre, out=out)
         ctx = dict(x0=x0, bctx=bctx, h=h, bn=bn, k=k, y=y) if save else None
         return y, ctx
 
@@ -258,6 +258,7 @@ class SNGANGenerator64(SNGANBaseGenerator):
 
 class SNGANBaseDiscriminator(BaseDiscriminator):
     in_channels_padded = 4
+    pair_forward = True     # no BatchNorm in D: D(real) and D(fake) can share one batched pass
 
     def _blocks(self):
         raise NotImplementedError
@@ -269,7 +270,10 @@ class SNGANBaseDiscriminator(BaseDiscriminator):
             layers = [m for m in self.modules() if isinstance(m, ConvLayer) and m.sn] + [self._head]
             sb = SNBatch(self, layers)
             object.__setattr__(self, '_sn_batch', sb)
-        sb.run(slot, training, need_dgrad)
+        if slot == 'pair':
+            sb.run_pair(training, need_dgrad)
+        else:
+            sb.run(slot, training, 1 if need_dgrad else 0)
 
     def forward_nhwc(self, x, training, save=True, need_dgrad=True, need_in_dgrad=True, slot=0):
         self._sn_prepare(slot, training, need_dgrad)

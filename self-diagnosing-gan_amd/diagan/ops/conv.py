@@ -10,9 +10,10 @@ import torch
 from diagan import _native as nat
 
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
-nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F] + [I] * 15 + [P])
+nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I])
-nat.register("diagan_conv_wgrad", [P, P, P, I, I64, I64, P, P, I] + [I] * 14 + [P])
+nat.register("diagan_conv_wgrad", [P, P, P, I, I, I64, I64, P, P, I] + [I] * 14 + [P])
+nat.register("diagan_pack_batched", [P, I, I, I, I, I, P])
 nat.register("diagan_wgrad_finish_batched", [P, I, I64, I, P])
 nat.register("diagan_conv_wgrad_splits", [I, I, I])
 nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
@@ -96,7 +97,7 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False):
+          res_relu=False, row_scale=None):
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
     mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
@@ -112,6 +113,8 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     t0 = TIMER.begin() if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
+             nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
+             (B // 2) * Ho * Wo if row_scale else 0,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.current_stream())
     if t0 is not None:
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)
@@ -119,7 +122,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     return out
 
 
-def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False):
+def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
@@ -128,10 +131,11 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, 1.0,
-                 tile_cfg, res_relu=res_relu)
+                 tile_cfg, res_relu=res_relu, row_scale=row_scale)
 
 
-def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0):
+def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,
+               row_scale=None):
     """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci]."""
     B, Ho, Wo, Co = dy.shape
     if Co != geom.Co:
@@ -140,7 +144,7 @@ def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0
     if out is None:
         out = torch.empty((B, Hi, Wi, geom.Ci), dtype=torch.float32, device=dy.device)
     return _gemm(dy, wd, out, geom.dgrad_params(), geom.R, geom.S, geom.Kd, None, residual, mask_src, mask_slope,
-                 None, 1.0, tile_cfg)
+                 None, 1.0, tile_cfg, row_scale=row_scale)
 
 
 _slabs = {}
@@ -172,7 +176,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
     t0 = TIMER.begin() if TIMER is not None else None
-    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
+    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
         TIMER.end("conv_wgrad_kernel<128,128>" if (Co > 64 and geom.Kp > 64) else "conv_wgrad_kernel<64,64>",
@@ -196,7 +200,7 @@ def wgrad_splits(M, Co, Kp):
     return nat.fn("diagan_conv_wgrad_splits")(M, Co, Kp)
 
 
-def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None):
+def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segments=1):
     """Split-K weight (+bias) gradient partials into a caller-owned slab [splits][stride]; the sum over
     splits is done later for all layers at once (diagan_wgrad_finish_batched)."""
     B, Ho, Wo, Co = dy.shape
@@ -204,7 +208,7 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None):
     mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
     sy, dr, off, up = geom.fwd_params()
     t0 = TIMER.begin() if TIMER is not None else None
-    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, stride, bias_off, nat.ptr(scale),
+    nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
     if t0 is not None:

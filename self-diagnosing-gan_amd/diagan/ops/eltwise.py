@@ -18,8 +18,8 @@ nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, P])
 nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
 nat.register("diagan_avgpool2", [P, P, I, I, I, I, P, P])
 nat.register("diagan_avgpool2_bwd", [P, P, I, I, I, I, P, P])
-nat.register("diagan_head_fwd", [P, P, P, P, P, P, I, I, I, P])
-nat.register("diagan_head_bwd", [P, P, P, P, P, P, P, P, P, I, I, I, I, P])
+nat.register("diagan_head_fwd", [P, P, P, P, I, P, P, P, I, I, I, P])
+nat.register("diagan_head_bwd", [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P])
 nat.register("diagan_add", [P, P, P, I64, P])
 nat.register("diagan_loss_dis", [P, I, P, I, I, I, P, P, P, P])
 nat.register("diagan_loss_gen", [P, I, I, I, P, P, P])
@@ -51,9 +51,10 @@ def _colred_ws(dev, M, C):
     return _workspace(dev, fn(M, C))
 
 
-def nchw_to_nhwc(x, Cp):
+def nchw_to_nhwc(x, Cp, out=None):
     B, C, H, W = x.shape
-    out = _f32((B, H, W, Cp), x.device)
+    if out is None:
+        out = _f32((B, H, W, Cp), x.device)
     nat.call("diagan_nchw_to_nhwc", ptr(x.contiguous()), ptr(out), B, C, H, W, Cp, st())
     return out
 
@@ -65,8 +66,8 @@ def nhwc_to_nchw(x, C):
     return out
 
 
-def tanh_fwd(x):
-    y = torch.empty_like(x)
+def tanh_fwd(x, out=None):
+    y = torch.empty_like(x) if out is None else out
     nat.call("diagan_tanh_fwd", ptr(x), ptr(y), x.numel(), st())
     return y
 
@@ -141,21 +142,24 @@ def avgpool2_bwd(g, residual=None):
     return out
 
 
-def head_fwd(x, w, inv_sigma, bias):
+def head_fwd(x, w, inv_sigma, bias, inv_sigma1=None):
+    """inv_sigma1: second half of the batch uses it (two forwards batched into one)."""
     B, H, W, C = x.shape
     pooled = _f32((B, C), x.device)
     logit = _f32((B, 1), x.device)
-    nat.call("diagan_head_fwd", ptr(x), ptr(w), ptr(inv_sigma), ptr(bias), ptr(pooled), ptr(logit), B, H * W, C, st())
+    nat.call("diagan_head_fwd", ptr(x), ptr(w), ptr(inv_sigma), ptr(inv_sigma1), B // 2, ptr(bias), ptr(pooled),
+             ptr(logit), B, H * W, C, st())
     return pooled, logit
 
 
-def head_bwd(dlogit, w, inv_sigma, x, pooled, need_gx=True, need_wgrad=True, dbias=None, accumulate_bias=True):
+def head_bwd(dlogit, w, inv_sigma, x, pooled, need_gx=True, need_wgrad=True, dbias=None, accumulate_bias=True,
+             inv_sigma1=None):
     B, H, W, C = x.shape
     gx = torch.empty_like(x) if need_gx else None
     G = _f32((C,), x.device) if need_wgrad else None
     dot = torch.empty(1, dtype=torch.float64, device=x.device) if need_wgrad else None
-    nat.call("diagan_head_bwd", ptr(dlogit), ptr(w), ptr(inv_sigma), ptr(x), ptr(pooled), ptr(gx), ptr(G), ptr(dot),
-             ptr(dbias), 1 if accumulate_bias else 0, B, H * W, C, st())
+    nat.call("diagan_head_bwd", ptr(dlogit), ptr(w), ptr(inv_sigma), ptr(inv_sigma1), B // 2, ptr(x), ptr(pooled),
+             ptr(gx), ptr(G), ptr(dot), ptr(dbias), 1 if accumulate_bias else 0, B, H * W, C, st())
     return gx, G, dot
 
 
@@ -165,11 +169,11 @@ def add(a, b):
     return out
 
 
-def loss_dis(out_real, out_fake, loss_type, gold=False, need_grad=True):
+def loss_dis(out_real, out_fake, loss_type, gold=False, need_grad=True, d_real=None, d_fake=None):
     dev = out_real.device
     nr, nf = out_real.numel(), out_fake.numel()
-    d_real = _f32((nr,), dev) if need_grad else None
-    d_fake = _f32((nf,), dev) if need_grad else None
+    if need_grad and d_real is None:
+        d_real, d_fake = _f32((nr,), dev), _f32((nf,), dev)
     out3 = _f32((3,), dev)
     nat.call("diagan_loss_dis", ptr(out_real), nr, ptr(out_fake), nf, LOSS_TYPES[loss_type], 1 if gold else 0,
              ptr(d_real), ptr(d_fake), ptr(out3), st())

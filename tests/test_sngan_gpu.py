@@ -182,6 +182,32 @@ def test_discriminator_backward_isolated():
             relclose(gr[k], p.grad, 1e-4, f"D grad {k}")
 
 
+def test_pair_forward_equals_two_pass():
+    """The batched real+fake D pass (one GEMM per layer, per-half 1/sigma in the epilogue) gives the same
+    update as two sequential forwards: same losses, same gradients, same SN buffers."""
+    import copy
+    (_, _, _, _), (netG, netD, optG, optD) = build("cifar10", "hinge")
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(8, 3, 32, 32, generator=g) * 2 - 1).cuda()
+    z = torch.randn(8, 128, generator=g).cuda()
+    sd = copy.deepcopy(netD.state_dict())
+    sdG = copy.deepcopy(netG.state_dict())
+    res = {}
+    for mode in (True, False):
+        netD.load_state_dict(sd)
+        netG.load_state_dict(sdG)
+        netD.pair_forward = mode
+        log = netD.train_step(real_batch=(x, None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=z)
+        res[mode] = (log.m['errD'].item(), {k: v.clone() for k, v in netD.export_grads().items()},
+                     {k: v.clone() for k, v in netD.state_dict().items() if 'sn_' in k})
+    netD.pair_forward = True
+    assert abs(res[True][0] - res[False][0]) < 1e-5
+    for k in res[True][1]:
+        relclose(res[True][1][k], res[False][1][k], 1e-4, f"grad {k}")
+    for k in res[True][2]:
+        relclose(res[True][2][k], res[False][2][k], 1e-6, k)
+
+
 def test_topk_and_gold_losses_vs_oracle():
     from diagan.ops import eltwise as E
     g = torch.Generator().manual_seed(5)
