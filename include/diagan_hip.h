@@ -181,9 +181,12 @@ int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const 
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                     void* workspace, void* stream);
 
-/* Backward of [BatchNorm -> optional ReLU]: dx (+ residual), dgamma/dbeta (+)=.  coef: 2*C floats. */
+/* Backward of [BatchNorm -> optional (Leaky)ReLU -> optional dropout]: dx (+ residual), dgamma/dbeta (+)=.
+ * relu != 0: g' = g * drop * (y > 0 ? 1 : slope), y = scale*x+shift (slope 0 = ReLU).  coef: 2*C floats.
+ * batch_stats = 0: eval-mode BatchNorm (running statistics): dx = scale * g'. */
 int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, const float* scale, const float* shift,
-                  const float* mean, const float* invstd, int relu, float* dgamma, float* dbeta,
+                  const float* mean, const float* invstd, int batch_stats, int relu, float slope,
+                  const float* drop, float* dgamma, float* dbeta,
                   int accumulate_param_grads, const float* residual, float* dx, float* coef,
                   void* workspace, void* stream);
 
@@ -211,6 +214,19 @@ int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, cons
 int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma, const float* inv_sigma1, int split_b,
                     const float* x, const float* pooled, float* gx, float* G, double* dot, float* dbias,
                     int accumulate_bias, int B, int HW, int C, void* stream);
+
+/* DCGAN discriminator activations (diagan-pkg/diagan/models/mnist.py:163-190): out = act(x*scale+shift)*drop,
+ * act(v) = v > 0 ? v : slope*v (LeakyReLU 0.2), drop = dropout mask scaled by 1/(1-p) or NULL; and the
+ * backward of the un-normalised first layer. */
+int diagan_act_fwd(const float* x, const float* scale, const float* shift, float slope, const float* drop,
+                   float* out, int64_t M, int C, void* stream);
+int diagan_act_bwd(const float* g, const float* x, float slope, const float* drop, float* out, int64_t n,
+                   void* stream);
+/* nn.Linear(C, 1) (mnist.py:191 out_d): logit = x.w + bias; dw += dlogit^T x, dbias += sum dlogit;
+ * input gradient gx[b][j] = dlogit[b]*w[j]. */
+int diagan_linear1_fwd(const float* x, const float* w, const float* bias, float* logit, int B, int C, void* stream);
+int diagan_linear1_wgrad(const float* dlogit, const float* x, float* dw, float* dbias, int B, int C, void* stream);
+int diagan_linear1_bwd_input(const float* dlogit, const float* w, float* gx, int B, int C, void* stream);
 
 int diagan_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 

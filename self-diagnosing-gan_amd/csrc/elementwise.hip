@@ -70,7 +70,9 @@ struct ColRedArgs {
   long M;
   int C;
   int rows_per_split;
-  int relu;            // MODE 1: mask g by (scale*x+shift > 0)
+  int relu;            // MODE 1: g' = g * (y > 0 ? 1 : slope) with y = scale*x+shift (ReLU: slope 0)
+  float slope;
+  const float* drop;   // MODE 1: optional dropout mask (already scaled by 1/(1-p)), multiplies g
 };
 
 template <int MODE>
@@ -104,10 +106,11 @@ __global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
       } else {
         f32x4 gv = reinterpret_cast<const f32x4*>(a.g)[r * C4 + c4];
         const f32x4 xh = (xv - mu) * is;
+        if (a.drop) gv *= reinterpret_cast<const f32x4*>(a.drop)[r * C4 + c4];
         if (a.relu) {
           const f32x4 y = xv * sc + sh;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : 0.f;
+          for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : gv[e] * a.slope;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s1[e] += gv[e]; s2[e] += (double)gv[e] * xh[e]; }
@@ -187,15 +190,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 // BatchNorm backward finalize: dgamma += s2, dbeta += s1, coef = {s1/M, s2/M}
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ partials, int splits, int C, long M,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef, int accumulate) {
+                                       float* __restrict__ coef, int accumulate, int batch_stats) {
   __shared__ double red[4][64][2];
   int c;
   double s1, s2;
   if (!combine_partials(partials, splits, C, red, &c, &s1, &s2)) return;
   dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
   dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-  coef[c] = (float)(s1 / (double)M);
-  coef[C + c] = (float)(s2 / (double)M);
+  // eval-mode BatchNorm (running statistics) is a fixed affine map: no mean / variance terms
+  coef[c] = batch_stats ? (float)(s1 / (double)M) : 0.f;
+  coef[C + c] = batch_stats ? (float)(s2 / (double)M) : 0.f;
 }
 
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const double* __restrict__ partials, int splits, int C, float* __restrict__ out,
@@ -212,7 +216,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ coef, const float* __restrict__ residual,
-                                    float* __restrict__ out, long M, int C, int relu) {
+                                    float* __restrict__ out, long M, int C, int relu, float slope,
+                                    const float* __restrict__ drop) {
   const int C4 = C >> 2;
   const long n4 = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -224,11 +229,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
     const f32x4 k1 = reinterpret_cast<const f32x4*>(coef)[c4];
     const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + C)[c4];
+    if (drop) gv *= reinterpret_cast<const f32x4*>(drop)[i];
     if (relu) {
       const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
       const f32x4 y = xv * sc + sh;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : 0.f;
+      for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : gv[e] * slope;
     }
     f32x4 o = sc * (gv - k1 - (xv - mu) * is * k2);
     if (residual) o += reinterpret_cast<const f32x4*>(residual)[i];
@@ -421,6 +427,60 @@ __global__ __launch_bounds__(EW_T) void head_wgrad_kernel(const float* __restric
   }
 }
 
+// a = act(x*scale[c]+shift[c]) * drop ; act: v > 0 ? v : slope*v   (slope 0 ReLU, 0.2 LeakyReLU, 1 identity)
+__global__ void act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                               const float* __restrict__ shift, float slope, const float* __restrict__ drop,
+                               float* __restrict__ out, long n4, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (scale) {
+      const int c4 = (int)(i % C4);
+      v = v * reinterpret_cast<const f32x4*>(scale)[c4] + reinterpret_cast<const f32x4*>(shift)[c4];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    if (drop) v *= reinterpret_cast<const f32x4*>(drop)[i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
+// backward of act(x)*drop without BatchNorm: gx = g * drop * (x > 0 ? 1 : slope)
+__global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, float slope,
+                               const float* __restrict__ drop, float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    if (drop) gv *= reinterpret_cast<const f32x4*>(drop)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gv[e] = xv[e] > 0.f ? gv[e] : gv[e] * slope;
+    reinterpret_cast<f32x4*>(out)[i] = gv;
+  }
+}
+
+// dw[c] += sum_b dlogit[b]*x[b][c] ; dbias += sum_b dlogit[b]     (weight gradient of a Linear(C, 1))
+__global__ __launch_bounds__(EW_T) void linear1_wgrad_kernel(const float* __restrict__ dlogit, const float* __restrict__ x,
+                                                             float* __restrict__ dw, float* __restrict__ dbias, int B,
+                                                             int C) {
+  const int c = blockIdx.x * EW_T + threadIdx.x;
+  if (c < C) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(dlogit[b], x[(long)b * C + c], s);
+    dw[c] += s;
+  }
+  if (dbias && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dlogit[b];
+    dbias[0] += s;
+  }
+}
+
+// gx[b][j] = dlogit[b] * w[j]   (input gradient of a Linear(C, 1))
+__global__ void linear1_bwd_input_kernel(const float* __restrict__ dlogit, const float* __restrict__ w,
+                                         float* __restrict__ gx, long n4, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+    reinterpret_cast<f32x4*>(gx)[i] = reinterpret_cast<const f32x4*>(w)[i % C4] * dlogit[i / C4];
+}
+
 // out = a + b (float4)
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
@@ -493,7 +553,7 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
   if (training) {
     DG_REQUIRE(workspace, "bn_stats: workspace required in training mode");
     colred_geometry(M, C, &splits, &rps, &grid);
-    ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0};
+    ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr};
     hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(EW_T), 0, ST, a);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits, C,
@@ -504,7 +564,8 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
 
 // dx = BN_backward(relu_backward(g)); dgamma/dbeta (+)=.  coef: 2*C floats scratch.
 DIAGAN_API int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, const float* scale, const float* shift,
-                             const float* mean, const float* invstd, int relu, float* dgamma, float* dbeta,
+                             const float* mean, const float* invstd, int batch_stats, int relu, float slope,
+                             const float* drop, float* dgamma, float* dbeta,
                              int accumulate_param_grads, const float* residual, float* dx, float* coef,
                              void* workspace, void* stream) {
   DG_REQUIRE(g && x && scale && shift && mean && invstd && dgamma && dbeta && dx && coef && workspace,
@@ -513,12 +574,12 @@ DIAGAN_API int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, c
   int splits, rps;
   dim3 grid;
   colred_geometry(M, C, &splits, &rps, &grid);
-  ColRedArgs a{x, g, scale, shift, mean, invstd, (double*)workspace, (long)M, C, rps, relu};
+  ColRedArgs a{x, g, scale, shift, mean, invstd, (double*)workspace, (long)M, C, rps, relu, slope, drop};
   hipLaunchKernelGGL(colred_kernel<1>, grid, dim3(EW_T), 0, ST, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits,
-                     C, (long)M, dgamma, dbeta, coef, accumulate_param_grads);
+                     C, (long)M, dgamma, dbeta, coef, accumulate_param_grads, batch_stats);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4))), dim3(EW_T), 0, ST, g, x, scale, shift, mean,
-                     invstd, coef, residual, dx, (long)M, C, relu);
+                     invstd, coef, residual, dx, (long)M, C, relu, slope, drop);
   return check_launch("bn_bwd");
 }
 
@@ -528,7 +589,7 @@ DIAGAN_API int diagan_colsum(const float* x, int64_t M, int C, float* out, int a
   int splits, rps;
   dim3 grid;
   colred_geometry(M, C, &splits, &rps, &grid);
-  ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0};
+  ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr};
   hipLaunchKernelGGL(colred_kernel<2>, grid, dim3(EW_T), 0, ST, a);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits, C,
                      out, accumulate);
@@ -597,6 +658,44 @@ DIAGAN_API int diagan_head_bwd(const float* dlogit, const float* w, const float*
                        accumulate_bias);
   }
   return check_launch("head_bwd");
+}
+
+DIAGAN_API int diagan_act_fwd(const float* x, const float* scale, const float* shift, float slope, const float* drop,
+                              float* out, int64_t M, int C, void* stream) {
+  DG_REQUIRE(x && out && M > 0 && C > 0 && (C & 3) == 0, "act_fwd: bad args");
+  DG_REQUIRE(!scale == !shift, "act_fwd: scale and shift must be given together");
+  const long n4 = M * (C / 4);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, x, scale, shift, slope, drop, out, n4, C / 4);
+  return check_launch("act_fwd");
+}
+
+DIAGAN_API int diagan_act_bwd(const float* g, const float* x, float slope, const float* drop, float* out, int64_t n,
+                              void* stream) {
+  DG_REQUIRE(g && x && out && n > 0 && (n & 3) == 0, "act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_T), 0, ST, g, x, slope, drop, out, (long)(n / 4));
+  return check_launch("act_bwd");
+}
+
+DIAGAN_API int diagan_linear1_fwd(const float* x, const float* w, const float* bias, float* logit, int B, int C,
+                                  void* stream) {
+  DG_REQUIRE(x && w && logit && B > 0 && C > 0, "linear1_fwd: bad args");
+  hipLaunchKernelGGL(head_linear_kernel, dim3(cdiv(B, 4)), dim3(256), 0, ST, x, w, (const float*)nullptr,
+                     (const float*)nullptr, B, bias, logit, B, C);
+  return check_launch("linear1_fwd");
+}
+
+DIAGAN_API int diagan_linear1_wgrad(const float* dlogit, const float* x, float* dw, float* dbias, int B, int C,
+                                    void* stream) {
+  DG_REQUIRE(dlogit && x && dw && B > 0 && C > 0, "linear1_wgrad: bad args");
+  hipLaunchKernelGGL(linear1_wgrad_kernel, dim3(cdiv(C, EW_T)), dim3(EW_T), 0, ST, dlogit, x, dw, dbias, B, C);
+  return check_launch("linear1_wgrad");
+}
+
+DIAGAN_API int diagan_linear1_bwd_input(const float* dlogit, const float* w, float* gx, int B, int C, void* stream) {
+  DG_REQUIRE(dlogit && w && gx && B > 0 && C > 0 && (C & 3) == 0, "linear1_bwd_input: bad args");
+  const long n4 = (long)B * (C / 4);
+  hipLaunchKernelGGL(linear1_bwd_input_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, dlogit, w, gx, n4, C / 4);
+  return check_launch("linear1_bwd_input");
 }
 
 DIAGAN_API int diagan_add(const float* a, const float* b, float* out, int64_t n, void* stream) {

@@ -189,8 +189,9 @@ class BatchNorm(nn.Module):
         return E.bn_stats(x, self.weight.data, self.bias.data, self.running_mean, self.running_var, training,
                           self.eps, self.momentum)
 
-    def bwd(self, g, x, ctx, relu, residual=None):
-        return E.bn_bwd(g, x, ctx, relu, self.weight.grad, self.bias.grad, True, residual=residual)
+    def bwd(self, g, x, ctx, relu, residual=None, slope=0.0, drop=None):
+        return E.bn_bwd(g, x, ctx, relu, self.weight.grad, self.bias.grad, True, residual=residual, slope=slope,
+                        drop=drop)
 
 
 class LatentLinear(nn.Module):
@@ -349,7 +350,7 @@ class HeadLinear(nn.Module):
                 nat.call("diagan_sn_grad_fix", nat.ptr(G), nat.ptr(dot), 1, nat.ptr(ctx.u), nat.ptr(ctx.v),
                          nat.ptr(ctx.state), nat.ptr(self.weight.grad), 1, self.in_ch, 1, nat.current_stream())
             else:
-                self.weight.grad.view(-1).add_(G)
+                E.add(self.weight.grad.view(-1), G, out=self.weight.grad.view(-1))
         return gx
 
 
@@ -608,6 +609,9 @@ class FlatNet(nn.Module):
             elif isinstance(m, BatchNorm):
                 out[pre + 'weight'] = m.weight.grad.clone()
                 out[pre + 'bias'] = m.bias.grad.clone()
+            elif hasattr(m, '_unperm') and hasattr(m, 'hw'):        # OutLinear
+                out[pre + 'weight'] = m._unperm(m.weight.grad)
+                out[pre + 'bias'] = m.bias.grad[:1].clone()
         return out
 
     def count_params(self):

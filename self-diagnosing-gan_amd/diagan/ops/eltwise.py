@@ -12,7 +12,12 @@ nat.register("diagan_tanh_fwd", [P, P, I64, P])
 nat.register("diagan_tanh_bwd", [P, P, P, I64, P])
 nat.register("diagan_colred_workspace", [I64, I])
 nat.register("diagan_bn_stats", [P, I64, I, P, P, F, F, P, P, I, P, P, P, P, P, P])
-nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, P, P, I, P, P, P, P, P])
+nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, I, F, P, P, P, I, P, P, P, P, P])
+nat.register("diagan_act_fwd", [P, P, P, F, P, P, I64, I, P])
+nat.register("diagan_act_bwd", [P, P, F, P, P, I64, P])
+nat.register("diagan_linear1_bwd_input", [P, P, P, I, I, P])
+nat.register("diagan_linear1_fwd", [P, P, P, P, I, I, P])
+nat.register("diagan_linear1_wgrad", [P, P, P, P, I, I, P])
 nat.register("diagan_colsum", [P, I64, I, P, I, P, P])
 nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, P])
 nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
@@ -79,7 +84,7 @@ def tanh_bwd(y, g):
 
 
 class BNCtx:
-    __slots__ = ("mean", "invstd", "scale", "shift", "M", "C")
+    __slots__ = ("mean", "invstd", "scale", "shift", "M", "C", "training")
 
 
 def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1):
@@ -88,6 +93,7 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mome
     buf = _f32((4, C), x.device)
     ctx = BNCtx()
     ctx.mean, ctx.invstd, ctx.scale, ctx.shift, ctx.M, ctx.C = buf[0], buf[1], buf[2], buf[3], M, C
+    ctx.training = bool(training)
     ws = _colred_ws(x.device, M, C) if training else None
     nat.call("diagan_bn_stats", ptr(x), M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
              ptr(running_var), 1 if training else 0, ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale),
@@ -95,12 +101,13 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mome
     return ctx
 
 
-def bn_bwd(g, x, ctx, relu, dgamma, dbeta, accumulate, residual=None):
+def bn_bwd(g, x, ctx, relu, dgamma, dbeta, accumulate, residual=None, slope=0.0, drop=None):
     dx = torch.empty_like(x)
     coef = _f32((2 * ctx.C,), x.device)
     ws = _colred_ws(x.device, ctx.M, ctx.C)
     nat.call("diagan_bn_bwd", ptr(g), ptr(x), ctx.M, ctx.C, ptr(ctx.scale), ptr(ctx.shift), ptr(ctx.mean),
-             ptr(ctx.invstd), 1 if relu else 0, ptr(dgamma), ptr(dbeta), 1 if accumulate else 0, ptr(residual),
+             ptr(ctx.invstd), 1 if ctx.training else 0, 1 if relu else 0, slope, ptr(drop), ptr(dgamma), ptr(dbeta), 1 if accumulate else 0,
+             ptr(residual),
              ptr(dx), ptr(coef), ptr(ws), st())
     return dx
 
@@ -163,8 +170,39 @@ def head_bwd(dlogit, w, inv_sigma, x, pooled, need_gx=True, need_wgrad=True, dbi
     return gx, G, dot
 
 
-def add(a, b):
-    out = torch.empty_like(a)
+def act_fwd(x, slope, scale=None, shift=None, drop=None):
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    nat.call("diagan_act_fwd", ptr(x), ptr(scale), ptr(shift), slope, ptr(drop), ptr(out), x.numel() // C, C, st())
+    return out
+
+
+def act_bwd(g, x, slope, drop=None):
+    out = torch.empty_like(x)
+    nat.call("diagan_act_bwd", ptr(g), ptr(x), slope, ptr(drop), ptr(out), x.numel(), st())
+    return out
+
+
+def linear1_fwd(x, w, bias):
+    B, C = x.shape
+    logit = _f32((B, 1), x.device)
+    nat.call("diagan_linear1_fwd", ptr(x), ptr(w), ptr(bias), ptr(logit), B, C, st())
+    return logit
+
+
+def linear1_wgrad(dlogit, x, dw, dbias):
+    B, C = x.shape
+    nat.call("diagan_linear1_wgrad", ptr(dlogit), ptr(x), ptr(dw), ptr(dbias), B, C, st())
+
+
+def linear1_bwd_input(dlogit, w, B, C):
+    gx = _f32((B, C), w.device)
+    nat.call("diagan_linear1_bwd_input", ptr(dlogit), ptr(w), ptr(gx), B, C, st())
+    return gx
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
     nat.call("diagan_add", ptr(a), ptr(b), ptr(out), a.numel(), st())
     return out
 
