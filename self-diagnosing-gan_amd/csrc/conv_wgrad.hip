@@ -294,14 +294,22 @@ __global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __r
 __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab) {
   const WgFinish L = tab[blockIdx.z];
   if (L.W == nullptr || (long)blockIdx.x * 1024 >= L.n_elem) return;
+  // <G_c, W> = sum of the phase-A partials, reduced by the whole block in a fixed pattern (deterministic)
   __shared__ double sdot[2];
-  if (threadIdx.x < L.nctx) {
-    const int nparts = (L.n_elem + 1023) / 1024;
+  __shared__ double red[256];
+  const int nparts = (L.n_elem + 1023) / 1024;
+  for (int c = 0; c < L.nctx; ++c) {
     double d = 0.0;
-    for (int k = 0; k < nparts; ++k) d += L.partials[threadIdx.x][k];   // fixed order: deterministic
-    sdot[threadIdx.x] = d;
+    for (int k = threadIdx.x; k < nparts; k += 256) d += L.partials[c][k];
+    red[threadIdx.x] = d;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sdot[c] = red[0];
+    __syncthreads();
   }
-  __syncthreads();
   const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= L.n_elem) return;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
