@@ -145,8 +145,9 @@ def main():
             print(f"WARNING: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the device path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real multi-GPU node
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dataset, res, desc = WORKLOADS[args.workload]
 
     netG, netD, netD_drs, optG, optD, optD_drs = build_models(dataset, args.loss_type, args.phase, device)

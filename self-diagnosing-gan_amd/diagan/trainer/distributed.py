@@ -33,10 +33,10 @@ def init_from_env(backend=None):
     if world > 1 and not is_dist():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+        if backend is None:      # DIAGAN_DIST_BACKEND=gloo: functional test of the N>1 path on a 1-GPU box
+            backend = os.environ.get("DIAGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
         synchronize()
     return rank, local_rank, world

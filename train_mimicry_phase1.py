@@ -81,7 +81,7 @@ def main(argv=None):
     set_seed(args.seed)
     if not torch.cuda.is_available():
         raise SystemExit("the Dia-GAN engine needs an MI355X (no CPU fallback)")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", (local_rank % torch.cuda.device_count()) if world > 1 else 0)
     torch.cuda.set_device(device)
 
     netG, netD, optG, optD = get_gan_model(dataset_name=args.dataset, model=args.model, loss_type=args.loss_type,
