@@ -79,7 +79,12 @@ int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias
                      const float* pro_scale, const float* pro_shift, int pro_mode, float out_scale,
                      const float* scale0, const float* scale1, int scale_split,
                      int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
-                     int dr, int off, int up, int Kp, int tile_cfg, void* stream);
+                     int dr, int off, int up, int Kp, int tile_cfg, float* splitk_ws, int64_t splitk_ws_floats,
+                     void* stream);
+/* splitk_ws (optional scratch, splitk_ws_floats floats): lets small-output / long-K problems split the K
+ * loop over several workgroups (deterministic two-stage reduction); diagan_conv_gemm_pick_ksplit tells
+ * the factor that would be used (1 = none). */
+int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 
 int diagan_conv_gemm_pick_cfg(int M, int Co); /* tile config chosen when tile_cfg == 0 (host only) */
 

@@ -36,6 +36,8 @@ struct ConvGemmArgs {
   const float* scale0;    // optional device scalars: rows m < scale_split use *scale0, the others *scale1
   const float* scale1;    // (two forwards with different spectral-norm sigmas batched into one GEMM)
   int scale_split;
+  float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel)
+  int ksplit;             // number of K splits (gridDim.y); 1 = no split
   int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
   int pro_mode;
   int M;                  // B*Ho*Wo
@@ -78,9 +80,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       ix0[j] = -(1 << 28);
     }
   }
+  // K-step range of this workgroup (split-K over gridDim.y for problems with few output tiles)
+  const int nk_all = g.Kp / 32;
+  const int k_per = (nk_all + a.ksplit - 1) / a.ksplit;
+  const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk_all);
   // (tap, c) of this thread's chunk, advanced incrementally by 32 channels per K-step
-  int kc = lq * 4, kr = 0, ks = 0;
-  while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
+  int kc, kr, ks;
+  {
+    const int kflat = k_begin * 32 + lq * 4, tap = kflat / g.Ci;
+    kc = kflat - tap * g.Ci;
+    kr = tap / g.S;
+    ks = tap - kr * g.S;
+  }
   const int upm = g.up - 1, ush = g.up >> 1;  // up in {1,2}
 
   // Loads are branch-free raw buffer loads: out-of-range elements (padding taps, rows past M / Co)
@@ -96,7 +107,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
 
   f32x4 ra[AJ], rb[BJ], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   unsigned a_ok = 0;
-  const int nk = g.Kp / BK;
 
   auto load_tiles = [&](int kk) {
     const bool tap_ok = kr < g.R;
@@ -162,13 +172,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
 
   const int fi = lane & 31, fh = lane >> 5;
 
-  load_tiles(0);
-  store_tiles(0);
+  if (k_begin < k_end) {
+    load_tiles(k_begin);
+    store_tiles(0);
+  }
   __syncthreads();
 
-  for (int kk = 0; kk < nk; ++kk) {
-    const int cur = kk & 1;
-    if (kk + 1 < nk) load_tiles(kk + 1);  // global loads in flight under the MFMAs below
+  for (int kk = k_begin; kk < k_end; ++kk) {
+    const int cur = (kk - k_begin) & 1;
+    if (kk + 1 < k_end) load_tiles(kk + 1);  // global loads in flight under the MFMAs below
     const float* Ac = As + cur * BM * BK;
     const float* Bc = Bs + cur * BN * BK;
 #pragma unroll
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    if (kk + 1 < nk) store_tiles(cur ^ 1);
+    if (kk + 1 < k_end) store_tiles(cur ^ 1);
     __syncthreads();
   }
 
@@ -211,6 +223,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         const int m = m0 + wm * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (m >= a.M) continue;
         const long o = (long)m * g.Co + n;
+        if (a.ksplit > 1) {
+          a.slab[(long)blockIdx.y * a.M * g.Co + o] = acc[i][j][e];
+          continue;
+        }
         const float sc = a.scale0 ? (m < a.scale_split ? sc0 : sc1) : a.out_scale;
         float v = acc[i][j][e] * sc + bv;
         if (a.residual) { const float r = a.residual[o]; v += a.res_relu ? fmaxf(r, 0.f) : r; }
@@ -218,6 +234,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         a.y[o] = v;
       }
     }
+  }
+}
+
+// split-K second stage: y = epi(sum_s slab[s]) (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs a) {
+  const int C4 = a.g.Co >> 2;
+  const long n4 = (long)a.M * C4;
+  const float sc0 = a.scale0 ? a.scale0[0] : 1.f, sc1 = a.scale1 ? a.scale1[0] : 1.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int m = (int)(i / C4);
+    f32x4 s = reinterpret_cast<const f32x4*>(a.slab)[i];
+    for (int k = 1; k < a.ksplit; ++k) s += reinterpret_cast<const f32x4*>(a.slab)[(long)k * n4 + i];
+    const float sc = a.scale0 ? (m < a.scale_split ? sc0 : sc1) : a.out_scale;
+    s *= sc;
+    if (a.bias) s += reinterpret_cast<const f32x4*>(a.bias)[c4];
+    if (a.residual) {
+      f32x4 r = reinterpret_cast<const f32x4*>(a.residual)[i];
+      if (a.res_relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+      }
+      s += r;
+    }
+    if (a.mask_src) {
+      const f32x4 ms = reinterpret_cast<const f32x4*>(a.mask_src)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = ms[e] > 0.f ? s[e] : s[e] * a.mask_slope;
+    }
+    reinterpret_cast<f32x4*>(a.y)[i] = s;
   }
 }
 
@@ -231,7 +277,12 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit), dim3(256), lds, st, a);
+  if (a.ksplit > 1) {
+    long blocks = ((long)a.M * (a.g.Co / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+  }
   return check_launch("conv_gemm");
 }
 
@@ -255,6 +306,20 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
   return 1.08 * q128 * waste128 > q64 * waste64 ? 1 : 3;
 }
 
+// Split-K factor for the 64x64 tile: problems with fewer than ~2 tiles per CU and a long K loop are
+// latency bound (one workgroup per CU cannot hide its own global loads); splitting K across
+// gridDim.y fills the 1280 resident slots.  Returns 1 when not worthwhile.
+DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
+  if (cfg != 3 || (Co & 3)) return 1;
+  const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
+  const int nk = Kp / 32;
+  if (tiles > 512 || nk < 16) return 1;
+  long s = 1280 / tiles;
+  if (s > nk / 8) s = nk / 8;       // at least 8 K-steps per split
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int)s;
+}
+
 // see include/diagan_hip.h
 DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
                                 const float* residual, int res_relu, const float* mask_src, float mask_slope,
@@ -262,7 +327,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                                 float out_scale, const float* scale0, const float* scale1, int scale_split,
                                 int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                 int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
-                                void* stream) {
+                                float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
@@ -284,6 +349,12 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   hipStream_t st = (hipStream_t)stream;
   const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co) : tile_cfg;
+  a.slab = splitk_ws;
+  a.ksplit = 1;
+  if (splitk_ws) {
+    const int ks = diagan_conv_gemm_pick_ksplit(a.M, Co, Kp, cfg);
+    if (ks > 1 && (int64_t)ks * a.M * Co <= splitk_ws_floats) a.ksplit = ks;
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2>(a, st);
     case 2: return launch_cfg<256, 64, 4, 1>(a, st);

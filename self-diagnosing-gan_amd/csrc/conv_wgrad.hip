@@ -344,6 +344,13 @@ DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, 
   return check_launch("wgrad_finish_batched");
 }
 
+// tile (rows of Co x columns of packed k) of the weight-gradient GEMM
+static void wgrad_tile(int Co, int Kp, int* bn, int* bk) {
+  *bn = Co <= 64 ? 64 : 128;
+  *bk = Kp <= 64 ? 64 : 128;
+  if (*bn == 128 && *bk == 64) *bn = 64;   // no <128,64> instantiation
+}
+
 DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int segments,
                                  int64_t slab_stride, int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
                                  int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
@@ -374,21 +381,23 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   a.slab_stride = slab_stride;
   a.bias_off = bias_off;
   hipStream_t st = (hipStream_t)stream;
-  static const int force64 = getenv("DIAGAN_WGRAD_TILE64") ? atoi(getenv("DIAGAN_WGRAD_TILE64")) : 0;
-  if (Co <= 64 || Kp <= 64 || force64) {
-    const int tiles = cdiv(Co, 64) * cdiv(Kp, 64);
+  int bn, bk;
+  wgrad_tile(Co, Kp, &bn, &bk);
+  const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
+  if (bn == 64 && bk == 64)
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3(tiles, splits), dim3(256), 0, st, a);
-  } else {
-    const int tiles = cdiv(Co, 128) * cdiv(Kp, 128);
+  else if (bn == 64)
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), dim3(tiles, splits), dim3(256), 0, st, a);
+  else
     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3(tiles, splits), dim3(256), 0, st, a);
-  }
   return check_launch("conv_wgrad");
 }
 
 // how many splits conv_wgrad should use for this problem (host-side heuristic, no device work)
 DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
-  static const int force64 = getenv("DIAGAN_WGRAD_TILE64") ? atoi(getenv("DIAGAN_WGRAD_TILE64")) : 0;
-  const int tiles = (Co <= 64 || Kp <= 64 || force64) ? cdiv(Co, 64) * cdiv(Kp, 64) : cdiv(Co, 128) * cdiv(Kp, 128);
+  int bn, bk;
+  wgrad_tile(Co, Kp, &bn, &bk);
+  const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
   const int total_steps = cdiv(M, 32);
   int splits = 512 / tiles;                      // <= 2 resident workgroups per CU: ONE round of blocks
                                                  // (540 blocks on 512 slots would cost a second, nearly empty round)

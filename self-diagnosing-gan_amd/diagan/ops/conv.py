@@ -10,7 +10,8 @@ import torch
 from diagan import _native as nat
 
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
-nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P])
+nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P])
+nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I])
 nat.register("diagan_conv_wgrad", [P, P, P, I, I, I64, I64, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_pack_batched", [P, I, I, I, I, I, P])
@@ -39,16 +40,26 @@ class KernelTimer:
         ev.record()
         return ev
 
-    def end(self, name, flop, start):
+    def end(self, name, flop, start, shape=None):
         stop = torch.cuda.Event(enable_timing=True)
         stop.record()
-        self.records.append((name, flop, start, stop))
+        self.records.append((name, flop, start, stop, shape))
 
     def summary(self):
         """name -> dict(launches, flop, seconds); call after a device synchronize."""
         out = {}
-        for name, flop, s, e in self.records:
+        for name, flop, s, e, _ in self.records:
             d = out.setdefault(name, dict(launches=0, flop=0.0, seconds=0.0))
+            d['launches'] += 1
+            d['flop'] += flop
+            d['seconds'] += s.elapsed_time(e) * 1e-3
+        return out
+
+    def by_shape(self):
+        """(kernel, M, N, K, tag) -> dict(launches, flop, seconds)"""
+        out = {}
+        for name, flop, s, e, shape in self.records:
+            d = out.setdefault((name,) + tuple(shape or ()), dict(launches=0, flop=0.0, seconds=0.0))
             d['launches'] += 1
             d['flop'] += flop
             d['seconds'] += s.elapsed_time(e) * 1e-3
@@ -110,16 +121,33 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         if t is not None and t.shape != out.shape:
             raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
     sy, dr, off, up = geo_params
+    ws = _splitk_ws(x.device)
     t0 = TIMER.begin() if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
              (B // 2) * Ho * Wo if row_scale else 0,
-             B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.current_stream())
+             B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
+             nat.current_stream())
     if t0 is not None:
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)
-        TIMER.end(TILE_NAMES[cfg], 2.0 * B * Ho * Wo * Co * R * S * Ci, t0)
+        TIMER.end(TILE_NAMES[cfg], 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
+                  (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}{'+res' if residual is not None else ''}"
+                                               f"{'+mask' if mask_src is not None else ''}{'+up' if up > 1 else ''}"))
     return out
+
+
+_skws = {}
+
+
+def _splitk_ws(dev):
+    """Scratch for the split-K path of small problems (consumed by the second-stage kernel on the same
+    stream right after it is written)."""
+    w = _skws.get(dev.index)
+    if w is None:
+        w = torch.empty(16 << 20, dtype=torch.float32, device=dev)      # 64 MiB
+        _skws[dev.index] = w
+    return w
 
 
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None):
@@ -179,8 +207,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
-        TIMER.end("conv_wgrad_kernel<128,128>" if (Co > 64 and geom.Kp > 64) else "conv_wgrad_kernel<64,64>",
-                  2.0 * M * Co * geom.R * geom.S * Ci, t0)
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp), 2.0 * M * Co * geom.R * geom.S * Ci, t0)
     if sn is None:
         nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
                  None, None, st)
@@ -212,8 +239,15 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
     if t0 is not None:
-        TIMER.end("conv_wgrad_kernel<128,128>" if (Co > 64 and geom.Kp > 64) else "conv_wgrad_kernel<64,64>",
-                  2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0)
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp), 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
+                  (B * Ho * Wo, Co, geom.R * geom.S * Ci, f"pro{mode}"))
+
+
+def _wgrad_kernel_name(Co, Kp):
+    bn, bk = (64 if Co <= 64 else 128), (64 if Kp <= 64 else 128)
+    if bn == 128 and bk == 64:
+        bn = 64
+    return f"conv_wgrad_kernel<{bn},{bk}>"
 
 
 def sn_power_iter(W, u_buffer, sigma_buffer, training=True, eps=1e-12):

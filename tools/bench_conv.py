@@ -30,6 +30,9 @@ SHAPES = [
     ("G32.b2.sc", 64, 8, 8, 256, 256, 1),
     ("G32.b4.sc", 64, 32, 32, 256, 256, 1),
     ("D32.b2.sc", 64, 16, 16, 128, 128, 1),
+    ("D32.b3.pair", 128, 8, 8, 128, 128, 3),
+    ("D64.b5.pair", 128, 4, 4, 512, 1024, 3),
+    ("D64.b4.pair", 128, 8, 8, 256, 512, 3),
 ]
 
 
