@@ -86,6 +86,14 @@ int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias
  * the factor that would be used (1 = none). */
 int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 
+/* 3x3 / stride 1 / pad 1 convolution (or its data-gradient) to FOUR output channels, Ci in {64,128,256}:
+ * lane-parallel reduction instead of the matrix cores (generator's last conv, D's first-layer dgrad).
+ * Same prologue / bias / residual semantics as diagan_conv_gemm. */
+int diagan_conv3x3_co4_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up);
+int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bias, const float* residual,
+                       const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W, int Ci,
+                       int dr, int off, int Kp, void* stream);
+
 int diagan_conv_gemm_pick_cfg(int M, int Co); /* tile config chosen when tile_cfg == 0 (host only) */
 
 /* Weight gradient, split over pixels: slab[s][n][k] = sum_{m in split s} dy[m][n]*pro(x gathered).

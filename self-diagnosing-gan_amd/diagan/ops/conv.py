@@ -13,6 +13,8 @@ P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I])
+nat.register("diagan_conv3x3_co4_supported", [I] * 8)
+nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P])
 nat.register("diagan_conv_wgrad", [P, P, P, I, I, I64, I64, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_pack_batched", [P, I, I, I, I, I, P])
 nat.register("diagan_wgrad_finish_batched", [P, I, I64, I, P])
@@ -121,6 +123,15 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         if t is not None and t.shape != out.shape:
             raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
     sy, dr, off, up = geo_params
+    if (mask_src is None and row_scale is None and out_scale == 1.0 and not res_relu and tile_cfg == 0
+            and nat.fn("diagan_conv3x3_co4_supported")(Ci, Co, R, S, sy, dr, off, up)):
+        t0 = TIMER.begin() if TIMER is not None else None
+        nat.call("diagan_conv3x3_co4", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
+                 nat.ptr(scale), nat.ptr(shift), mode, B, Hi, Wi, Ci, dr, off, Kp, nat.current_stream())
+        if t0 is not None:
+            TIMER.end("conv3x3_co4_kernel", 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
+                      (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}"))
+        return out
     ws = _splitk_ws(x.device)
     t0 = TIMER.begin() if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),

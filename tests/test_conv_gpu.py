@@ -128,6 +128,42 @@ def test_dgrad_and_wgrad(case):
         assert torch.all(grad[:, R * R * Ci:] == 0.5)
 
 
+@pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
+@pytest.mark.parametrize("pro", [0, 2])
+def test_small_co_kernel_fwd_and_dgrad(Ci, H, W, B, pro):
+    """conv3x3_co4 (4 output channels, lane-parallel): the generator's last conv and D's first-layer dgrad."""
+    from diagan.ops import conv as C
+    g = torch.Generator().manual_seed(Ci + pro)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(3, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias = torch.randn(3, generator=g)
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    geom = C.Geom("conv", Ci, 4, 3, 3, 1, 1)
+    wp = torch.zeros(4, geom.Kp)
+    wp[:3] = C.pack_oihw(w, geom.Kp)
+    b4 = torch.zeros(4)
+    b4[:3] = bias
+    ref = F.conv2d(ref_pro(x, pro, scale, shift), w, bias, padding=1)
+    res = torch.randn(B, 4, H, W, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp.cuda(), bias=b4.cuda(), residual=nhwc(res).cuda(),
+                   pro=(pro, scale.cuda(), shift.cuda()))
+    close(nchw(y)[:, :3], ref + res[:, :3])
+    assert torch.equal(nchw(y)[:, 3].cpu(), res[:, 3])            # padded channel: zero weights, zero bias
+    if pro == 0:
+        # data-gradient of a conv FROM 4 (RGB+pad) channels TO Ci: output has 4 channels
+        geom2 = C.Geom("conv", 4, Ci, 3, 3, 1, 1)
+        w2 = torch.randn(Ci, 3, 3, 3, generator=g) / 27 ** 0.5
+        xi = torch.randn(B, 3, H, W, generator=g, requires_grad=True)
+        yo = F.conv2d(xi, w2, None, padding=1)
+        dy = torch.randn(yo.shape, generator=g)
+        yo.backward(dy)
+        wp2 = C.pack_oihw(w2, geom2.Kp, ci_pad=4).cuda()
+        wd = torch.zeros((4, geom2.Kd), device="cuda")
+        C.pack_weights(wp2, Ci, 4, 9, geom2.Kp, geom2.Kd, Wd=wd)
+        dx = C.conv_dgrad(geom2, nhwc(dy).cuda(), wd, (H, W))
+        close(nchw(dx)[:, :3], xi.grad)
+
+
 def test_full_size_sngan32_g_block4():
     """BASELINE configs[1] dominant GEMM: M=65536, N=256, K=2304 (SNGAN G-32 block4.c1)."""
     from diagan.ops import conv as C
