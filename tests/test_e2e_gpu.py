@@ -68,4 +68,7 @@ def test_logit_record_matches_direct_eval(tmp_path):
     netD.eval()
     x = torch.stack([ds[i][0] for i in range(150)]).cuda()
     direct = netD(x).view(-1).cpu().numpy().astype(np.float64)
-    assert row.dtype == np.float64 and np.array_equal(row, direct)
+    # batch 64 (+ ragged 22) vs one batch of 150: tile / split-K choices depend on M, so the fp32
+    # summation order may differ -> equal to rounding, placed at exactly the right indices
+    assert row.dtype == np.float64
+    np.testing.assert_allclose(row, direct, rtol=2e-6, atol=2e-6)
