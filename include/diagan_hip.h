@@ -80,7 +80,10 @@ int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias
                      const float* scale0, const float* scale1, int scale_split,
                      int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                      int dr, int off, int up, int Kp, int tile_cfg, float* splitk_ws, int64_t splitk_ws_floats,
-                     void* stream);
+                     float* stat_partials, void* stream);
+/* stat_partials (optional, [ceil(M/BM)][2][Co] floats, BM = 128 for tile_cfg 1 else 64): the epilogue also
+ * writes per-tile column sums of y and y^2 -- the BatchNorm statistics of the layer that consumes y
+ * (diagan_bn_stats_fused), so the activation is not re-read; disables split-K. */
 /* splitk_ws (optional scratch, splitk_ws_floats floats): lets small-output / long-K problems split the K
  * loop over several workgroups (deterministic two-stage reduction); diagan_conv_gemm_pick_ksplit tells
  * the factor that would be used (1 = none). */
@@ -193,6 +196,11 @@ int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const 
                     float momentum, float* running_mean, float* running_var, int training,
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                     void* workspace, void* stream);
+
+/* BatchNorm (training mode) from the per-tile sums written by diagan_conv_gemm(stat_partials). */
+int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M, int C, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
+                          float* invstd_out, float* scale_out, float* shift_out, void* stream);
 
 /* Backward of [BatchNorm -> optional (Leaky)ReLU -> optional dropout]: dx (+ residual), dgamma/dbeta (+)=.
  * relu != 0: g' = g * drop * (y > 0 ? 1 : slope), y = scale*x+shift (slope 0 = ReLU).  coef: 2*C floats.

@@ -36,6 +36,7 @@ struct ConvGemmArgs {
   const float* scale0;    // optional device scalars: rows m < scale_split use *scale0, the others *scale1
   const float* scale1;    // (two forwards with different spectral-norm sigmas batched into one GEMM)
   int scale_split;
+  float* stat_partials;   // optional [tiles_m][2][Co]: per-tile column sums of y and y*y (fused BatchNorm statistics)
   float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel)
   int ksplit;             // number of K splits (gridDim.y); 1 = no split
   int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
@@ -210,6 +211,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   }
 
   const float sc0 = a.scale0 ? a.scale0[0] : 1.f, sc1 = a.scale1 ? a.scale1[0] : 1.f;
+  float cs1[TN], cs2[TN];   // fused BatchNorm statistics: column sums of the stored values
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -232,7 +236,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         if (a.residual) { const float r = a.residual[o]; v += a.res_relu ? fmaxf(r, 0.f) : r; }
         if (a.mask_src) v = a.mask_src[o] > 0.f ? v : v * a.mask_slope;
         a.y[o] = v;
+        if (a.stat_partials) {
+          cs1[j] += v;
+          cs2[j] = fmaf(v, v, cs2[j]);
+        }
       }
+    }
+  }
+  if (a.stat_partials) {
+    // combine the two half-waves (same column), then the WM wave rows through LDS (tiles are done with it)
+    float* red = smem;  // [WM][BN][2]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      cs1[j] += __shfl_xor(cs1[j], 32, 64);
+      cs2[j] += __shfl_xor(cs2[j], 32, 64);
+      if (fh == 0) {
+        const int col = wn * (TN * 32) + j * 32 + fi;
+        red[(wm * BN + col) * 2 + 0] = cs1[j];
+        red[(wm * BN + col) * 2 + 1] = cs2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < g.Co) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { t1 += red[(w * BN + tid) * 2]; t2 += red[(w * BN + tid) * 2 + 1]; }
+      float* p = a.stat_partials + (long)(tile / tiles_n) * 2 * g.Co;
+      p[n0 + tid] = t1;
+      p[g.Co + n0 + tid] = t2;
     }
   }
 }
@@ -327,7 +358,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                                 float out_scale, const float* scale0, const float* scale1, int scale_split,
                                 int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                 int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
-                                float* splitk_ws, int64_t splitk_ws_floats, void* stream) {
+                                float* splitk_ws, int64_t splitk_ws_floats, float* stat_partials, void* stream) {
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
@@ -351,7 +382,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co) : tile_cfg;
   a.slab = splitk_ws;
   a.ksplit = 1;
-  if (splitk_ws) {
+  a.stat_partials = stat_partials;
+  if (splitk_ws && !stat_partials) {
     const int ks = diagan_conv_gemm_pick_ksplit(a.M, Co, Kp, cfg);
     if (ks > 1 && (int64_t)ks * a.M * Co <= splitk_ws_floats) a.ksplit = ks;
   }

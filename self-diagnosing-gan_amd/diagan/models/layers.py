@@ -150,6 +150,18 @@ class ConvLayer(nn.Module):
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale)
 
+    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None):
+        """Forward + the BatchNorm statistics of the layer that consumes the output, taken from the GEMM
+        epilogue's per-tile sums (no second pass over the activation).  Returns (y, bn context)."""
+        if not training:
+            y = self.fwd(ctx, x, pro=pro, residual=residual)
+            return y, bn.stats(y, False)
+        y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
+                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True)
+        if stats is None:
+            return y, bn.stats(y, True)
+        return y, bn.stats_fused(stats[0], stats[1], y.numel() // y.shape[-1])
+
     def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
                             mask_slope=mask_slope, row_scale=ctx.row_scale)
@@ -188,6 +200,11 @@ class BatchNorm(nn.Module):
             self.num_batches_tracked += 1
         return E.bn_stats(x, self.weight.data, self.bias.data, self.running_mean, self.running_var, training,
                           self.eps, self.momentum)
+
+    def stats_fused(self, partials, tiles, M):
+        self.num_batches_tracked += 1
+        return E.bn_stats_fused(partials, tiles, M, self.weight.data, self.bias.data, self.running_mean,
+                                self.running_var, self.eps, self.momentum)
 
     def bwd(self, g, x, ctx, relu, residual=None, slope=0.0, drop=None):
         return E.bn_bwd(g, x, ctx, relu, self.weight.grad, self.bias.grad, True, residual=residual, slope=slope,

@@ -43,16 +43,18 @@ class GBlock(nn.Module):
             self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0)
             self.c_sc.xavier_(1.0)
 
-    def forward(self, x, training, save=True, need_dgrad=True):
+    def forward(self, x, training, save=True, need_dgrad=True, bn1=None, next_bn=None):
+        """bn1: statistics of x if the producer already reduced them; next_bn: the BatchNorm module that will
+        consume this block's output (its statistics are then taken from the last conv's epilogue)."""
         ctx = {}
-        bn1 = self.b1.stats(x, training)
+        if bn1 is None:
+            bn1 = self.b1.stats(x, training)
         if self.upsample:
             c1_in, c1_pro = E.upsample2x(x, pro=_bn_pro(bn1)), None
         else:
             c1_in, c1_pro = x, _bn_pro(bn1)
         k1 = self.c1.prepare(training, need_dgrad)
-        h1 = self.c1.fwd(k1, c1_in, pro=c1_pro)
-        bn2 = self.b2.stats(h1, training)
+        h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro)
         if self.learnable_sc:
             sc_in = E.upsample2x(x) if self.upsample else x
             ksc = self.c_sc.prepare(training, need_dgrad)
@@ -60,10 +62,14 @@ class GBlock(nn.Module):
         else:
             sc_in, ksc, sc = None, None, x
         k2 = self.c2.prepare(training, need_dgrad)
-        out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc)
+        bn_out = None
+        if next_bn is not None:
+            out, bn_out = self.c2.fwd_bn(k2, h1, next_bn, training, pro=_bn_pro(bn2), residual=sc)
+        else:
+            out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc)
         if save:
             ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, sc_in=sc_in, ksc=ksc, k2=k2)
-        return out, ctx
+        return out, ctx, bn_out
 
     def backward(self, ctx, gout):
         x, h1 = ctx['x'], ctx['h1']
@@ -183,10 +189,12 @@ class SNGANBaseGenerator(BaseGenerator):
         z = z.to(dtype=self.l1.weight.dtype)
         x0, h = self.l1.fwd(z)
         bctx = []
-        for blk in self._blocks():
-            h, c = blk.forward(h, training, save=save, need_dgrad=save)
+        blocks = self._blocks()
+        bn = None
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1].b1 if i + 1 < len(blocks) else self._last_bn
+            h, c, bn = blk.forward(h, training, save=save, need_dgrad=save, bn1=bn, next_bn=nxt)
             bctx.append(c)
-        bn = self._last_bn.stats(h, training)
         k = self._last_conv.prepare(training, need_dgrad=save)
         y_pre = self._last_conv.fwd(k, h, pro=_bn_pro(bn))
         y = E.tanh_fwd(y_pre, out=out)

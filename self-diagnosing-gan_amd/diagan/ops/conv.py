@@ -10,7 +10,7 @@ import torch
 from diagan import _native as nat
 
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
-nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P])
+nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I])
 nat.register("diagan_conv3x3_co4_supported", [I] * 8)
@@ -110,7 +110,9 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None):
+          res_relu=False, row_scale=None, want_stats=False):
+    """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
+    (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
     mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
@@ -123,8 +125,9 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         if t is not None and t.shape != out.shape:
             raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
     sy, dr, off, up = geo_params
+    stats = None
     if (mask_src is None and row_scale is None and out_scale == 1.0 and not res_relu and tile_cfg == 0
-            and nat.fn("diagan_conv3x3_co4_supported")(Ci, Co, R, S, sy, dr, off, up)):
+            and not want_stats and nat.fn("diagan_conv3x3_co4_supported")(Ci, Co, R, S, sy, dr, off, up)):
         t0 = TIMER.begin() if TIMER is not None else None
         nat.call("diagan_conv3x3_co4", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
                  nat.ptr(scale), nat.ptr(shift), mode, B, Hi, Wi, Ci, dr, off, Kp, nat.current_stream())
@@ -133,19 +136,26 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
                       (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}"))
         return out
     ws = _splitk_ws(x.device)
+    if want_stats:
+        M = B * Ho * Wo
+        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co)
+        if nat.fn("diagan_conv_gemm_pick_ksplit")(M, Co, Kp, cfg) == 1:
+            tiles = (M + (127 if cfg == 1 else 63)) // (128 if cfg == 1 else 64)
+            stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
+            tile_cfg = cfg
     t0 = TIMER.begin() if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
              (B // 2) * Ho * Wo if row_scale else 0,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
-             nat.current_stream())
+             nat.ptr(stats[0]) if stats else None, nat.current_stream())
     if t0 is not None:
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)
         TIMER.end(TILE_NAMES[cfg], 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                   (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}{'+res' if residual is not None else ''}"
                                                f"{'+mask' if mask_src is not None else ''}{'+up' if up > 1 else ''}"))
-    return out
+    return (out, stats) if want_stats else out
 
 
 _skws = {}
@@ -161,7 +171,8 @@ def _splitk_ws(dev):
     return w
 
 
-def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None):
+def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
+             want_stats=False):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
@@ -170,7 +181,7 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, 1.0,
-                 tile_cfg, res_relu=res_relu, row_scale=row_scale)
+                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,

@@ -12,6 +12,7 @@ nat.register("diagan_tanh_fwd", [P, P, I64, P])
 nat.register("diagan_tanh_bwd", [P, P, P, I64, P])
 nat.register("diagan_colred_workspace", [I64, I])
 nat.register("diagan_bn_stats", [P, I64, I, P, P, F, F, P, P, I, P, P, P, P, P, P])
+nat.register("diagan_bn_stats_fused", [P, I, I64, I, P, P, F, F, P, P, P, P, P, P, P])
 nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, I, F, P, P, P, I, P, P, P, P, P])
 nat.register("diagan_act_fwd", [P, P, P, F, P, P, I64, I, P])
 nat.register("diagan_act_bwd", [P, P, F, P, P, I64, P])
@@ -98,6 +99,18 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mome
     nat.call("diagan_bn_stats", ptr(x), M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
              ptr(running_var), 1 if training else 0, ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale),
              ptr(ctx.shift), ptr(ws), st())
+    return ctx
+
+
+def bn_stats_fused(partials, tiles, M, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """Training-mode BatchNorm context from the per-tile sums emitted by the producing conv's epilogue."""
+    C = gamma.numel()
+    buf = _f32((4, C), gamma.device)
+    ctx = BNCtx()
+    ctx.mean, ctx.invstd, ctx.scale, ctx.shift, ctx.M, ctx.C = buf[0], buf[1], buf[2], buf[3], M, C
+    ctx.training = True
+    nat.call("diagan_bn_stats_fused", ptr(partials), tiles, M, C, ptr(gamma), ptr(beta), eps, momentum,
+             ptr(running_mean), ptr(running_var), ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale), ptr(ctx.shift), st())
     return ctx
 
 
