@@ -45,11 +45,14 @@ struct ConvGemmArgs {
   ConvGeom g;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
-  constexpr int BK = 32;
+  constexpr int CH = BK / 4;                           // 16-byte chunks per tile row
+  constexpr int RP = 256 / CH;                         // tile rows covered by one pass of the 256 loaders
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
-  constexpr int AJ = BM / 32, BJ = BN / 32;            // 16-byte chunks per thread per tile
+  constexpr int AJ = BM / RP, BJ = BN / RP;            // 16-byte chunks per thread per tile
+  // XOR swizzle of the chunk index: conflict-free ds_read_b128 fragments (bank row = 256 B)
+  auto swz = [](int row, int q) { return BK == 32 ? (q ^ ((row >> 1) & 7)) : (q ^ ((row >> 2) & 3)); };
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BM*32]
@@ -64,11 +67,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
   // ---- loader state -------------------------------------------------------------------------
-  const int lrow = tid >> 3, lq = tid & 7;  // row within a 32-row group, 16-byte chunk in the K-step
+  const int lrow = tid / CH, lq = tid % CH;  // row within an RP-row group, 16-byte chunk in the K-step
   int pix_base[AJ], iy0[AJ], ix0[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int m = m0 + lrow + 32 * j;
+    const int m = m0 + lrow + RP * j;
     if (m < a.M) {
       const int ox = m % g.Wo, t = m / g.Wo;
       const int oy = t % g.Ho, b = t / g.Ho;
@@ -82,13 +85,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
   }
   // K-step range of this workgroup (split-K over gridDim.y for problems with few output tiles)
-  const int nk_all = g.Kp / 32;
+  const int nk_all = g.Kp / BK;
   const int k_per = (nk_all + a.ksplit - 1) / a.ksplit;
   const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk_all);
   // (tap, c) of this thread's chunk, advanced incrementally by 32 channels per K-step
   int kc, kr, ks;
   {
-    const int kflat = k_begin * 32 + lq * 4, tap = kflat / g.Ci;
+    const int kflat = k_begin * BK + lq * 4, tap = kflat / g.Ci;
     kc = kflat - tap * g.Ci;
     kr = tap / g.S;
     ks = tap - kr * g.S;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     const unsigned kcol = (unsigned)(kk * BK + lq * 4);
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const unsigned n = (unsigned)(n0 + lrow + 32 * j);
+      const unsigned n = (unsigned)(n0 + lrow + RP * j);
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (n * g.Kp + kcol) * 4u, 0, 0));
     }
     // advance (tap, c) to the next K-step
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     float* Bd = Bs + buf * BN * BK;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int row = lrow + 32 * j;
+      const int row = lrow + RP * j;
       f32x4 v = ra[j];
       if (a.pro_mode != PRO_NONE) {
         if (affine) v = v * psc + psh;
@@ -154,12 +157,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         }
         if (affine && !((a_ok >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // padding is zero AFTER the transform
       }
-      *reinterpret_cast<f32x4*>(Ad + row * BK + ((lq ^ ((row >> 1) & 7)) << 2)) = v;
+      *reinterpret_cast<f32x4*>(Ad + row * BK + (swz(row, lq) << 2)) = v;
     }
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int row = lrow + 32 * j;
-      *reinterpret_cast<f32x4*>(Bd + row * BK + ((lq ^ ((row >> 1) & 7)) << 2)) = rb[j];
+      const int row = lrow + RP * j;
+      *reinterpret_cast<f32x4*>(Bd + row * BK + (swz(row, lq) << 2)) = rb[j];
     }
   };
 
@@ -185,18 +188,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     const float* Ac = As + cur * BM * BK;
     const float* Bc = Bs + cur * BN * BK;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < BK / 8; ++u) {
       const int q = 2 * u + fh;
       f32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * (TM * 32) + i * 32 + fi;
-        fa[i] = *reinterpret_cast<const f32x4*>(Ac + row * BK + ((q ^ ((row >> 1) & 7)) << 2));
+        fa[i] = *reinterpret_cast<const f32x4*>(Ac + row * BK + (swz(row, q) << 2));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * (TN * 32) + j * 32 + fi;
-        fb[j] = *reinterpret_cast<const f32x4*>(Bc + row * BK + ((q ^ ((row >> 1) & 7)) << 2));
+        fb[j] = *reinterpret_cast<const f32x4*>(Bc + row * BK + (swz(row, q) << 2));
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -298,11 +301,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK = 32>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN>;
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -392,6 +395,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     case 2: return launch_cfg<256, 64, 4, 1>(a, st);
     case 3: return launch_cfg<64, 64, 2, 2>(a, st);
     case 4: return launch_cfg<128, 64, 2, 2>(a, st);
+    case 5: return launch_cfg<128, 128, 2, 2, 16>(a, st);
     default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
   }
 }

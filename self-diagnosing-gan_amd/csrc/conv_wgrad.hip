@@ -401,7 +401,8 @@ DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
   const int total_steps = cdiv(M, 32);
   int splits = 512 / tiles;                      // <= 2 resident workgroups per CU: ONE round of blocks
                                                  // (540 blocks on 512 slots would cost a second, nearly empty round)
-  if (splits > total_steps / 4) splits = total_steps / 4;  // at least 4 K-steps per split
+  static const int min_steps = getenv("DIAGAN_WGRAD_MINSTEPS") ? atoi(getenv("DIAGAN_WGRAD_MINSTEPS")) : 4;
+  if (splits > total_steps / min_steps) splits = total_steps / min_steps;  // at least min_steps K-steps per split
   if (splits < 1) splits = 1;
   if (splits > 256) splits = 256;
   return splits;

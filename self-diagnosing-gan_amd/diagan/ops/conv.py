@@ -27,7 +27,8 @@ nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2>", 2: "conv_gemm_kernel<256,64,4,1>",
-              3: "conv_gemm_kernel<64,64,2,2>", 4: "conv_gemm_kernel<128,64,2,2>"}
+              3: "conv_gemm_kernel<64,64,2,2>", 4: "conv_gemm_kernel<128,64,2,2>",
+              5: "conv_gemm_kernel<128,128,2,2,16>"}
 
 
 class KernelTimer:
