@@ -124,6 +124,40 @@ def cpu_baseline(dataset, res, loss_type, batch, n_dis, budget_s=25.0):
                       f"{n_dis}*t_D + t_G = {t_step:.2f} s (warm-up D update {warm:.1f} s not counted)"}
 
 
+def scorer_leg(device, N=50000, T=50):
+    """Second half of BASELINE.json's metric: LDR-score max-abs-err of the HIP scorer against the oracle
+    on a SURVEY §8(d)-shaped record (T=50 snapshots of N=50000 logits), plus its run time."""
+    import numpy as np
+    from diagan.utils.plot import LogitRecord, ldr_scores_device
+    from oracle import scorer as osc
+    rng = np.random.default_rng(0)
+    mu, sg = rng.normal(0.0, 2.0, size=N), rng.uniform(0.05, 1.0, size=N)
+    logits = {35000 + 100 * t: (mu + sg * rng.normal(size=N)).astype(np.float32).astype(np.float64) for t in range(T)}
+    rec = LogitRecord.from_dict(logits, device=device)
+    rows = rec.window(0, 10 ** 9)
+    ldr_scores_device(rows)                                   # warm-up
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(10):
+        stats, conf, tv = ldr_scores_device(rows)
+    e.record()
+    torch.cuda.synchronize()
+    gpu_ms = s.elapsed_time(e) / 10
+    t0 = time.time()
+    ref = osc.calculate_scores_c(logits, 0, 10 ** 9)
+    cpu_ms = (time.time() - t0) * 1e3
+    err = 0.0
+    for k in ("ldr", "ldrd", "ldrv", "ldrm"):
+        err = max(err, float(np.abs(stats[k].cpu().numpy() - ref[k]).max()))
+    for j, t in enumerate(tv):
+        if f"{t:.1f}" in ("0.3", "5.0"):
+            err = max(err, float(np.abs(conf[j].cpu().numpy() - ref[f"ldr_conf_{t:.1f}_ratio_50"]).max()))
+    bytes_alg = 8.0 * T * N + 8.0 * N * (4 + len(tv))
+    return {"record": f"T={T} x N={N} float64", "max_abs_err": err, "gpu_ms_all_103_scores": round(gpu_ms, 4),
+            "cpu_oracle_ms_1_core": round(cpu_ms, 1), "algorithmic_GBps": round(bytes_alg / gpu_ms / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +260,7 @@ def main():
         }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dataset, res, args.loss_type, args.batch_size, args.n_dis)
+        line["ldr_scorer"] = scorer_leg(device)
     print(json.dumps(line))
 
 

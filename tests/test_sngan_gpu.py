@@ -248,3 +248,31 @@ def test_checkpoint_roundtrip(tmp_path):
     ck = torch.load(str(tmp_path / "netD" / "netD_7_steps.pth"), weights_only=False)
     assert ck['model_state_dict']['block1.c1.weight'].shape == (128, 3, 3, 3)
     assert ck['model_state_dict']['l5.weight'].shape == (1, 128)
+
+
+def test_gold_and_topk_train_steps_vs_oracle():
+    """GOLD re-weighted D loss (train_mimicry_phase2.py --gold) and top-k G training (--topk) through the
+    real train steps, against the oracle with the same switches."""
+    from diagan.models.predefined_models import get_gan_model
+    oG, oD, ooptG, ooptD = O.make_pair('cifar10', 'ns', seed=2)
+    oD.use_gold = True
+    torch.manual_seed(2)
+    netG, netD, optG, optD = get_gan_model('cifar10', model='sngan', loss_type='ns', gold=True, topk=True)
+    netG.load_state_dict(oG.state_dict()), netD.load_state_dict(oD.state_dict())
+    netG.to('cuda'), netD.to('cuda')
+    assert netD.use_gold and netG.use_topk
+    netG.decay_topk_rate(782 * 30, epoch_steps=782)          # rate 0.99^30 = 0.7397 -> k = 5 of 8
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1
+    zd, zg = torch.randn(8, 128, generator=g), torch.randn(8, 128, generator=g)
+    errD, _, _ = oD.train_step((x, None), oG, ooptD, noise=zd)
+    log = netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda',
+                          noise=zd.cuda())
+    assert abs(log.m['errD'].item() - errD) < 1e-3
+    gr = netD.export_grads()
+    for k, p in oD.named_parameters():
+        l2close(gr[k], p.grad, 1e-2, f"gold D grad {k}")
+    errG = oG.train_step((x, None), oD, ooptG, noise=zg, topk_rate=netG.topk_rate)
+    log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda',
+                          noise=zg.cuda())
+    assert abs(log.m['errG'].item() - errG) < 5e-3 * max(1.0, abs(errG))
