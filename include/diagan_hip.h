@@ -265,6 +265,20 @@ int diagan_loss_gen(const float* out_fake, int n, int k, int loss_type, float* d
 int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, void* stream);
 
+/* ---- StyleGAN2 native ops (the reference's only native code) -------------- */
+
+/* fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale), fused_bias_act.cpp:4-20:
+ * out[i] = act(x[i] + bias[(i / step_b) % size_b]) * scale; act 1 linear, 3 leaky ReLU; grad 1 gates by
+ * refer[i] > 0 (first derivative), grad 2 gives zeros.  bias / refer may be NULL. */
+int diagan_fused_bias_act(const float* x, const float* bias, const float* refer, float* out, int64_t n,
+                          int64_t step_b, int size_b, int act, int grad, float alpha, float scale, void* stream);
+
+/* upfirdn2d.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up, down, pads), upfirdn2d.cpp:4-22.
+ * out == NULL: size query only (writes *out_h, *out_w). */
+int diagan_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
+                     int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
+                     int pad_y0, int pad_y1, int* out_h, int* out_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+// The two native ops of the reference's StyleGAN2 path, as gfx950
+// HIP kernels behind the same operator semantics:
+//
+//   fused_bias_act  diagan-pkg/diagan/models/op/fused_bias_act.cpp:4-20, fused_bias_act_kernel.cu:18-49
+//       y = act(x + b[(i / step_b) % size_b]) * scale ;  act*10+grad in {10,11: linear, 12: 0,
+//       30: leaky ReLU, 31: its derivative gated by ref > 0, 32: 0}
+//   upfirdn2d       diagan-pkg/diagan/models/op/upfirdn2d.cpp:4-22, upfirdn2d_kernel.cu:49-207
+//       zero-insertion upsample (up), pad / crop, FIR filter with the flipped kernel, decimate (down)
+//       on a [major, H, W, minor] tensor; CPU statement of the same op: op/upfirdn2d.py:159-200.
+//
+// upfirdn2d here is ONE gather formula instead of the reference's six tile specialisations:
+//   out[oy][ox] = sum_{iy,ix} in[iy][ix] * k[kh-1-(iy*up_y+pad_y0-oy*down_y)][kw-1-(ix*up_x+pad_x0-ox*down_x)]
+// over the (iy, ix) whose kernel index is in range; the filter taps sit in LDS, lanes run along ox
+// (then minor) so global reads are coalesced.  Roofline: HBM (in read ~once through L2, out written once).
+#include "common.h"
+
+namespace diagan {
+
+__global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                                             const float* __restrict__ ref, float* __restrict__ out,
+                                                             long n, long step_b, int size_b, int mode, float alpha,
+                                                             float scale) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = x[i];
+    if (b) v += b[(i / step_b) % size_b];
+    float y;
+    switch (mode) {
+      case 12: case 32: y = 0.f; break;
+      case 30: y = v > 0.f ? v : v * alpha; break;
+      case 31: y = (ref ? ref[i] : 0.f) > 0.f ? v : v * alpha; break;
+      default: y = v; break;   // 10, 11 and anything else: linear
+    }
+    out[i] = y * scale;
+  }
+}
+
+struct UpFirDnArgs {
+  const float* in;
+  const float* k;
+  float* out;
+  int major, in_h, in_w, minor, kh, kw, out_h, out_w;
+  int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+};
+
+static __host__ __device__ __forceinline__ int floor_div_i(int a, int b) {
+  int q = a / b;
+  return (q * b > a) ? q - 1 : q;
+}
+static __host__ __device__ __forceinline__ int ceil_div_i(int a, int b) { return -floor_div_i(-a, b); }
+
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpFirDnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float taps[];
+  for (int i = threadIdx.x; i < a.kh * a.kw; i += 256) taps[i] = a.k[i];
+  __syncthreads();
+  const long per_major = (long)a.out_h * a.out_w * a.minor;
+  const long total = per_major * a.major;
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    const int mi = (int)(o % a.minor);
+    long t = o / a.minor;
+    const int ox = (int)(t % a.out_w); t /= a.out_w;
+    const int oy = (int)(t % a.out_h);
+    const int mj = (int)(t / a.out_h);
+    // valid input rows: 0 <= iy*up + pad0 - oy*down < kh
+    const int by = oy * a.down_y - a.pad_y0, bx = ox * a.down_x - a.pad_x0;
+    const int iy0 = max(ceil_div_i(by, a.up_y), 0), iy1 = min(floor_div_i(by + a.kh - 1, a.up_y), a.in_h - 1);
+    const int ix0 = max(ceil_div_i(bx, a.up_x), 0), ix1 = min(floor_div_i(bx + a.kw - 1, a.up_x), a.in_w - 1);
+    const float* src = a.in + (long)mj * a.in_h * a.in_w * a.minor + mi;
+    float v = 0.f;
+    for (int iy = iy0; iy <= iy1; ++iy) {
+      const int ky = a.kh - 1 - (iy * a.up_y - by);
+      for (int ix = ix0; ix <= ix1; ++ix) {
+        const int kx = a.kw - 1 - (ix * a.up_x - bx);
+        v = fmaf(src[((long)iy * a.in_w + ix) * a.minor], taps[ky * a.kw + kx], v);
+      }
+    }
+    a.out[o] = v;
+  }
+}
+
+}  // namespace diagan
+
+using namespace diagan;
+
+DIAGAN_API int diagan_fused_bias_act(const float* x, const float* bias, const float* refer, float* out, int64_t n,
+                                     int64_t step_b, int size_b, int act, int grad, float alpha, float scale,
+                                     void* stream) {
+  DG_REQUIRE(x && out && n >= 0, "fused_bias_act: null tensor");
+  DG_REQUIRE(!bias || (step_b > 0 && size_b > 0), "fused_bias_act: bad bias geometry");
+  if (n == 0) return DIAGAN_OK;
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fused_bias_act_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, refer, out,
+                     (long)n, (long)step_b, size_b, act * 10 + grad, alpha, scale);
+  return check_launch("fused_bias_act");
+}
+
+// out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL
+DIAGAN_API int diagan_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
+                                int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,
+                                int pad_x0, int pad_x1, int pad_y0, int pad_y1, int* out_h, int* out_w, void* stream) {
+  DG_REQUIRE(major >= 0 && in_h > 0 && in_w > 0 && minor > 0 && kernel_h > 0 && kernel_w > 0, "upfirdn2d: bad dims");
+  DG_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0, "upfirdn2d: up/down must be positive");
+  DG_REQUIRE(kernel_h * kernel_w <= 4096, "upfirdn2d: filter larger than 4096 taps");
+  const int oh = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) / down_y + 1;
+  const int ow = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) / down_x + 1;
+  if (out_h) *out_h = oh;
+  if (out_w) *out_w = ow;
+  if (!out) return DIAGAN_OK;    // size query
+  DG_REQUIRE(input && kernel, "upfirdn2d: null tensor");
+  DG_REQUIRE(oh > 0 && ow > 0, "upfirdn2d: empty output (%d x %d)", oh, ow);
+  if (major == 0) return DIAGAN_OK;
+  UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow,
+                up_x, up_y, down_x, down_y, pad_x0, pad_y0};
+  const long total = (long)major * oh * ow * minor;
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upfirdn2d_kernel, dim3((int)blocks), dim3(256), (size_t)kernel_h * kernel_w * sizeof(float),
+                     (hipStream_t)stream, a);
+  return check_launch("upfirdn2d");
+}

@@ -1,0 +1,93 @@
+"""GPU: the HIP fused_bias_act / upfirdn2d ops (reference operator API, diagan/models/op) against the
+reference-generated goldens and the oracle, including first- and second-order autograd."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stylegan_ops as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_upfirdn2d_forward_backward_vs_reference(golden_dir):
+    from diagan.models.op import upfirdn2d
+    from diagan.models.op.upfirdn2d import UpFirDn2d
+    g = np.load(os.path.join(golden_dir, "stylegan_ops.npz"))
+    for name in [str(n) for n in g["names"]]:
+        x = torch.from_numpy(g[f"{name}_x"]).cuda().requires_grad_(True)
+        k = torch.from_numpy(g[f"{name}_k"]).cuda()
+        u, d, px0, px1, py0, py1 = [int(v) for v in g[f"{name}_cfg"]]
+        y = UpFirDn2d.apply(x, k, (u, u), (d, d), (px0, px1, py0, py1))
+        assert tuple(y.shape) == g[f"{name}_y"].shape, name
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{name}_y"], atol=1e-5, err_msg=name)
+        (y * torch.from_numpy(g[f"{name}_cot"]).cuda()).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{name}_gx"], atol=1e-5, err_msg=name)
+    # the public helper (symmetric pads) = StyleGAN2's Upsample / Blur / Downsample call forms
+    x = torch.randn(2, 4, 16, 16, device="cuda")
+    k = torch.from_numpy(g["upsample2_k"]).cuda()
+    ref = S.upfirdn2d(x.cpu(), k.cpu(), 2, 2, 1, 1, 2, 1, 2, 1)
+    np.testing.assert_allclose(upfirdn2d(x, k, up=2, down=1, pad=(2, 1)).cpu().numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_upfirdn2d_double_backward():
+    """R1 / path-length regularisation differentiate the gradient: grad-of-grad vs autograd on the oracle."""
+    from diagan.models.op import upfirdn2d
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 2, 6, 6, generator=g)
+    k = torch.rand(4, 4, generator=g)
+    w = torch.randn(1, 2, 12, 12, generator=g)
+
+    def run(fn, x, k, w):
+        x = x.clone().requires_grad_(True)
+        y = fn(x, k)
+        gx, = torch.autograd.grad((y * w).sum() + (y ** 2).sum(), x, create_graph=True)
+        ggx, = torch.autograd.grad((gx ** 2).sum(), x)
+        return gx.detach().cpu(), ggx.cpu()
+
+    a = run(lambda x, k: upfirdn2d(x, k, up=2, down=1, pad=(2, 1)), x.cuda(), k.cuda(), w.cuda())
+    b = run(lambda x, k: S.upfirdn2d(x, k, 2, 2, 1, 1, 2, 1, 2, 1), x, k, w)
+    np.testing.assert_allclose(a[0].numpy(), b[0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(a[1].numpy(), b[1].numpy(), atol=1e-3)
+
+
+def test_fused_leaky_relu_vs_reference(golden_dir):
+    from diagan.models.op import FusedLeakyReLU, fused_leaky_relu
+    g = np.load(os.path.join(golden_dir, "stylegan_ops.npz"))
+    for tag in ("4d", "2d"):
+        x = torch.from_numpy(g[f"flr_{tag}_x"]).cuda().requires_grad_(True)
+        b = torch.from_numpy(g[f"flr_{tag}_b"]).cuda().requires_grad_(True)
+        y = fused_leaky_relu(x, b, 0.2, 2 ** 0.5)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"flr_{tag}_y"], atol=1e-6)
+        (y * torch.from_numpy(g[f"flr_{tag}_cot"]).cuda()).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"flr_{tag}_gx"], atol=1e-6)
+        np.testing.assert_allclose(b.grad.cpu().numpy(), g[f"flr_{tag}_gb"], atol=1e-5)
+    y = fused_leaky_relu(torch.from_numpy(g["flr_nobias_x"]).cuda(), None, 0.2, 2 ** 0.5)
+    np.testing.assert_allclose(y.cpu().numpy(), g["flr_nobias_y"], atol=1e-6)
+    m = FusedLeakyReLU(8).cuda()
+    assert m(torch.randn(2, 8, 3, 3, device="cuda")).shape == (2, 8, 3, 3)
+
+
+def test_fused_bias_act_table_and_second_order():
+    from diagan.models.op.fused_act import fused_bias_act, fused_leaky_relu
+    g = torch.Generator().manual_seed(2)
+    x, ref, b = torch.randn(3, 5, 4, 4, generator=g), torch.randn(3, 5, 4, 4, generator=g), torch.randn(5, generator=g)
+    for act, grad in ((1, 0), (1, 1), (1, 2), (3, 0), (3, 1), (3, 2)):
+        got = fused_bias_act(x.cuda(), b.cuda(), ref.cuda(), act, grad, 0.3, 1.7)
+        exp = S.fused_bias_act(x, b, ref, act, grad, 0.3, 1.7)
+        np.testing.assert_allclose(got.cpu().numpy(), exp.numpy(), atol=1e-6, err_msg=str((act, grad)))
+    with pytest.raises(RuntimeError):
+        fused_bias_act(x, b, ref, 3, 0, 0.2, 1.0)            # CPU tensor: the reference's CHECK_CUDA
+
+    def run(fn, x, b):
+        x, b = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = fn(x, b)
+        gx, = torch.autograd.grad((y ** 2).sum(), x, create_graph=True)
+        ggb, = torch.autograd.grad((gx ** 2).sum(), b)
+        return gx.detach().cpu(), ggb.cpu()
+
+    a = run(lambda x, b: fused_leaky_relu(x, b, 0.2, 2 ** 0.5), x.cuda(), b.cuda())
+    c = run(lambda x, b: S.fused_leaky_relu(x, b, 0.2, 2 ** 0.5), x, b)
+    np.testing.assert_allclose(a[0].numpy(), c[0].numpy(), atol=1e-4)
+    np.testing.assert_allclose(a[1].numpy(), c[1].numpy(), rtol=1e-3, atol=1e-3)

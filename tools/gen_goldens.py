@@ -125,10 +125,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     gen_scorer()
     gen_scheduler()
-    extra = os.path.join(HERE, "gen_goldens_models.py")
-    if os.path.exists(extra):
-        import runpy
-        runpy.run_path(extra, run_name="__main__")
+    import runpy
+    for extra in ("gen_goldens_models.py", "gen_goldens_stylegan_ops.py"):
+        if os.path.exists(os.path.join(HERE, extra)):
+            runpy.run_path(os.path.join(HERE, extra), run_name="__main__")
     print("wrote", sorted(os.listdir(OUT)))
 
 
