@@ -72,3 +72,32 @@ def test_logit_record_matches_direct_eval(tmp_path):
     # summation order may differ -> equal to rounding, placed at exactly the right indices
     assert row.dtype == np.float64
     np.testing.assert_allclose(row, direct, rtol=2e-6, atol=2e-6)
+
+
+def test_drs_generates_on_gpu():
+    """DRS wrapper (reference models/drs.py:9-68) over the HIP nets: burn-in maximum equals the max over the
+    same 50 batches evaluated directly, accepted images come from the generator's batch, count is exact."""
+    from diagan.models.drs import DRS
+    from diagan.models.predefined_models import get_gan_model
+    torch.manual_seed(5)
+    np.random.seed(5)
+    netG, netD, _, _ = get_gan_model('cifar10', model='sngan', loss_type='hinge')
+    netG.eval(); netD.eval()
+    torch.manual_seed(11)
+    drs = DRS(netG, netD, device='cuda')
+    torch.manual_seed(11)
+    mx = -100000
+    for _ in range(50):
+        with torch.no_grad():
+            mx = max(mx, netD(netG.generate_images(256, device='cuda')).max().item())
+    assert abs(float(drs.maximum) - mx) <= 2e-6 * max(1.0, abs(mx))
+    imgs, ldr = drs.get_fake_samples_and_ldr(256)
+    assert ldr.shape == (256, 1) and ldr.dtype == np.float32
+    st = np.random.get_state()
+    kept = drs.sub_rejection_sampler(imgs, ldr)
+    np.random.set_state(st)
+    mask = drs.acceptance(ldr)
+    assert 0 < kept.shape[0] < 256 and kept.shape[0] == int(mask.sum())
+    assert torch.equal(kept, imgs.cpu()[torch.from_numpy(mask)])
+    out = drs.generate_images(300)
+    assert tuple(out.shape) == (300, 3, 32, 32) and torch.isfinite(out).all()

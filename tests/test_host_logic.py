@@ -210,3 +210,29 @@ def test_topk_rate_decay():
     assert t.topk_rate == 0.99 ** 10
     t.decay_topk_rate(782 * 1000, epoch_steps=782)
     assert t.topk_rate == 0.5
+
+
+def test_drs_acceptance_matches_reference(golden_dir):
+    """DRS eval-time rejection sampling: same logits + same NumPy RNG state -> same accepted samples as the
+    reference class (golden from diagan-pkg/diagan/models/drs.py run on scripted nets)."""
+    from diagan.models.drs import DRS
+    g = np.load(os.path.join(golden_dir, "drs.npz"))
+
+    class FakeG:
+        def generate_images(self, n, device=None):
+            return torch.arange(n, dtype=torch.float32).view(n, 1)
+
+    class FakeD:
+        def __init__(self):
+            self.g = torch.Generator().manual_seed(23)
+
+        def __call__(self, imgs):
+            return torch.randn(imgs.shape[0], 1, generator=self.g) * 1.5
+
+    np.random.seed(7)
+    drs = DRS(FakeG(), FakeD(), device='cpu')
+    assert float(drs.maximum) == float(g["maximum_after_init"])
+    for i in range(3):
+        kept = drs.sub_rejection_sampler(torch.arange(256, dtype=torch.float32).view(256, 1), g[f"ldr{i}"])
+        assert np.array_equal(kept.numpy().reshape(-1), g[f"kept{i}"])
+    assert float(drs.maximum) == float(g["maximum_final"])

@@ -153,3 +153,34 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def gen_drs():
+    """DRS acceptance (diagan-pkg/diagan/models/drs.py:36-55) on scripted logits: which indices survive."""
+    from diagan.models.drs import DRS
+
+    class FakeG:
+        def generate_images(self, n, device=None):
+            return torch.arange(n, dtype=torch.float32).view(n, 1)
+
+    class FakeD:
+        def __init__(self):
+            self.g = torch.Generator().manual_seed(23)
+
+        def __call__(self, imgs):
+            return torch.randn(imgs.shape[0], 1, generator=self.g) * 1.5
+
+    np.random.seed(7)
+    drs = DRS(FakeG(), FakeD(), device='cpu')
+    out = {"maximum_after_init": np.array(drs.maximum)}
+    g = torch.Generator().manual_seed(29)
+    for i in range(3):
+        ldr = (torch.randn(256, 1, generator=g) * 2).numpy()
+        kept = drs.sub_rejection_sampler(torch.arange(256, dtype=torch.float32).view(256, 1), ldr)
+        out[f"ldr{i}"], out[f"kept{i}"] = ldr, kept.numpy().reshape(-1)
+    out["maximum_final"] = np.array(drs.maximum)
+    np.savez_compressed(os.path.join(OUT, "drs.npz"), **out)
+
+
+if __name__ == "__main__":
+    gen_drs()
