@@ -45,7 +45,7 @@ struct ConvGemmArgs {
   ConvGeom g;
 };
 
-template <int BM, int BN, int WM, int WN, int BK = 32>
+template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int CH = BK / 4;                           // 16-byte chunks per tile row
   constexpr int RP = 256 / CH;                         // tile rows covered by one pass of the 256 loaders
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   float* Bs = smem + 2 * BM * BK;    // [2][BN*32]
 
   const ConvGeom& g = a.g;
+  const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;   // compile-time in the specialised kernels: straight-line store phase
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.Co + BN - 1) / BN;
@@ -67,28 +68,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
   // ---- loader state -------------------------------------------------------------------------
+  // The gather is made separable once per workgroup: per tile row j a byte offset base[j] of the
+  // (r=0,s=0) tap and a validity mask (bit r: tap row r inside the image, bit 16+s: tap column s),
+  // per K-step one tap offset shared by all rows.  For up=2 (transposed conv) the offset is kept in
+  // half-pixel units: a VALID tap has an even numerator, so base + tapoff is exact there, and
+  // invalid taps are redirected past num_records (the hardware returns zeros).
   const int lrow = tid / CH, lq = tid % CH;  // row within an RP-row group, 16-byte chunk in the K-step
-  int pix_base[AJ], iy0[AJ], ix0[AJ];
+  const int ush = g.up >> 1, upm = g.up - 1;  // up in {1,2}
+  const int pstep = (g.Ci * 4) >> ush;        // bytes per numerator unit along x
+  int base[AJ];
+  unsigned vmask[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int m = m0 + lrow + RP * j;
+    base[j] = 0;
+    vmask[j] = 0;
     if (m < a.M) {
       const int ox = m % g.Wo, t = m / g.Wo;
       const int oy = t % g.Ho, b = t / g.Ho;
-      pix_base[j] = b * g.Hi * g.Wi;
-      iy0[j] = oy * g.sy + g.off;
-      ix0[j] = ox * g.sy + g.off;
-    } else {
-      pix_base[j] = 0;
-      iy0[j] = -(1 << 28);  // never valid
-      ix0[j] = -(1 << 28);
+      const int iy0 = oy * g.sy + g.off, ix0 = ox * g.sy + g.off;
+      base[j] = b * g.Hi * g.Wi * g.Ci * 4 + (iy0 * g.Wi + ix0) * pstep;
+      unsigned mk = 0;
+      for (int r = 0; r < g.R; ++r) {
+        const int yn = iy0 + r * g.dr;
+        if (yn >= 0 && (yn & upm) == 0 && (yn >> ush) < g.Hi) mk |= 1u << r;
+      }
+      for (int q = 0; q < g.S; ++q) {
+        const int xn = ix0 + q * g.dr;
+        if (xn >= 0 && (xn & upm) == 0 && (xn >> ush) < g.Wi) mk |= 0x10000u << q;
+      }
+      vmask[j] = mk;
     }
   }
   // K-step range of this workgroup (split-K over gridDim.y for problems with few output tiles)
   const int nk_all = g.Kp / BK;
   const int k_per = (nk_all + a.ksplit - 1) / a.ksplit;
   const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk_all);
-  // (tap, c) of this thread's chunk, advanced incrementally by 32 channels per K-step
+  // (tap, c) of this thread's chunk, advanced incrementally by BK channels per K-step
   int kc, kr, ks;
   {
     const int kflat = k_begin * BK + lq * 4, tap = kflat / g.Ci;
@@ -96,45 +112,44 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     kr = tap / g.S;
     ks = tap - kr * g.S;
   }
-  const int upm = g.up - 1, ush = g.up >> 1;  // up in {1,2}
+  const int rowstep = g.dr * g.Wi * pstep, colstep = g.dr * pstep;
 
-  // Loads are branch-free raw buffer loads: out-of-range elements (padding taps, rows past M / Co)
-  // get an offset beyond num_records and the hardware returns zeros.  The prologue transform is applied
-  // when the registers are written to LDS, i.e. AFTER the MFMAs of the current step, so the global
-  // loads stay in flight under the matrix work instead of being waited for one by one.
+  // Loads are branch-free raw buffer loads.  The prologue transform is applied when the registers are
+  // written to LDS, i.e. AFTER the MFMAs of the current step, so the global loads stay in flight under
+  // the matrix work instead of being waited for one by one.
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.w), 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
-  constexpr unsigned OOB = 0x7FFFFFF0u;
-  const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
+  const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
+  unsigned wbase[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) wbase[j] = ((unsigned)(n0 + lrow + RP * j) * g.Kp + lq * 4) * 4u;
 
   f32x4 ra[AJ], rb[BJ], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   unsigned a_ok = 0;
 
   auto load_tiles = [&](int kk) {
-    const bool tap_ok = kr < g.R;
-    const int dy = kr * g.dr, dx = ks * g.dr;
+    const int tapoff = kr * rowstep + ks * colstep + kc * 4;
+    const int krs = min(kr, 15);               // K-padding taps (kr >= R) hit a zero mask bit
     a_ok = 0;
 #pragma unroll
     for (int j = 0; j < AJ; ++j) {
-      const int yn = iy0[j] + dy, xn = ix0[j] + dx;
-      const int iy = yn >> ush, ix = xn >> ush;
-      const bool ok = tap_ok && yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi;
-      const unsigned off = ok ? (unsigned)((pix_base[j] + iy * g.Wi + ix) * g.Ci + kc) * 4u : OOB;
+      const unsigned okb = (vmask[j] >> krs) & (vmask[j] >> (16 + ks)) & 1u;
+      // invalid -> bit 31 set: beyond num_records (< 2 GiB) whatever the garbage below it
+      const unsigned off = (unsigned)(base[j] + tapoff) | ((okb ^ 1u) << 31);
       ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
-      a_ok |= (ok ? 1u : 0u) << j;
+      a_ok |= okb << j;
     }
-    if (affine && tap_ok) {
-      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
-      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
+    if (affine) {
+      const int kcs = min(kc, g.Ci - 4);       // kc < Ci always; keeps the address in range for the optimiser
+      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kcs);
+      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kcs);
     }
-    const unsigned kcol = (unsigned)(kk * BK + lq * 4);
+    const unsigned kcol = (unsigned)kk * (BK * 4u);
 #pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      const unsigned n = (unsigned)(n0 + lrow + RP * j);
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (n * g.Kp + kcol) * 4u, 0, 0));
-    }
+    for (int j = 0; j < BJ; ++j)
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wbase[j] + kcol, 0, 0));
     // advance (tap, c) to the next K-step
     kc += BK;
     while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
@@ -146,16 +161,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     for (int j = 0; j < AJ; ++j) {
       const int row = lrow + RP * j;
       f32x4 v = ra[j];
-      if (a.pro_mode != PRO_NONE) {
+      if (pro_mode != PRO_NONE) {
         if (affine) v = v * psc + psh;
-        if (a.pro_mode == PRO_LRELU) {
+        if (pro_mode == PRO_LRELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-        } else if (a.pro_mode != PRO_AFFINE) {
+        } else if (pro_mode != PRO_AFFINE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (affine && !((a_ok >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};  // padding is zero AFTER the transform
+        if (affine) {                            // padding is zero AFTER the transform
+          const float keep = (float)((a_ok >> j) & 1u);
+          v *= keep;
+        }
       }
       *reinterpret_cast<f32x4*>(Ad + row * BK + (swz(row, lq) << 2)) = v;
     }
@@ -301,11 +319,11 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK = 32>
-static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int BK, int PRO>
+static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK>;
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -318,6 +336,21 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, a);
   }
   return check_launch("conv_gemm");
+}
+
+// SPEC: one kernel per prologue mode (the two production tiles); otherwise the mode is a run-time argument
+template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false>
+static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
+  if (SPEC) {
+    switch (a.pro_mode) {
+      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1>(a, st);
+      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1>(a, st);
+      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1>(a, st);
+      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1>(a, st);
+      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1>(a, st);
+    }
+  }
+  return launch_one<BM, BN, WM, WN, BK, -1>(a, st);
 }
 
 }  // namespace diagan
@@ -367,6 +400,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
   DG_REQUIRE(up == 1 || up == 2, "conv_gemm: up=%d unsupported (1 or 2)", up);
   DG_REQUIRE(dr == 1 || dr == -1, "conv_gemm: dr must be +-1");
+  DG_REQUIRE(R <= 15 && S <= 15, "conv_gemm: filter %dx%d larger than 15x15", R, S);
   DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_gemm: Kp=%d must be a multiple of 32 and >= R*S*Ci=%d", Kp, R * S * Ci);
   DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "conv_gemm: bad pro_mode %d", pro_mode);
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift),
@@ -391,9 +425,9 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     if (ks > 1 && (int64_t)ks * a.M * Co <= splitk_ws_floats) a.ksplit = ks;
   }
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2>(a, st);
+    case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);
     case 2: return launch_cfg<256, 64, 4, 1>(a, st);
-    case 3: return launch_cfg<64, 64, 2, 2>(a, st);
+    case 3: return launch_cfg<64, 64, 2, 2, 32, true>(a, st);
     case 4: return launch_cfg<128, 64, 2, 2>(a, st);
     case 5: return launch_cfg<128, 128, 2, 2, 16>(a, st);
     default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);

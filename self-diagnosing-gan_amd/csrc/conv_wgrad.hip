@@ -53,9 +53,10 @@ struct WgradArgs {
   long bias_off;          // >= 0: column sums of dy (bias gradient) go to slab[split][bias_off + n]
   ConvGeom g;
   FastDiv dWo, dHo;
+  int adv_b, adv_y, adv_x;  // 32 pixels = adv_b images + adv_y rows + adv_x columns (pixel coordinates advance incrementally)
 };
 
-template <int BNn, int BNk>
+template <int BNn, int BNk, int PRO = -1>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   constexpr int BK = 32;                       // pixels per K-step
   constexpr int TM = BNn / 64, TN = BNk / 64;  // 2x2 waves
@@ -77,10 +78,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
   const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
 
+  const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;   // compile-time in the specialised kernels
   // A' loader (dy rows): fixed channel chunk, pixel rows ap + APR*j
   const int ac = tid % AC, ap = tid / AC;
   const int an = n0 + ac * 4;
-  const bool a_ok = an < g.Co;
+  const unsigned a_kill = an < g.Co ? 0u : 0x80000000u;   // bit 31 -> beyond num_records -> zeros
   // B' loader (gathered x): fixed (tap, c) per thread
   const int bc = tid % BC, bp = tid / BC;
   const int kf = k0 + bc * 4;
@@ -89,6 +91,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const bool b_ok = kf < g.K;
   const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
   const int upm = g.up - 1, ush = g.up >> 1;
+  const int pstep = (g.Ci * 4) >> ush;                      // bytes per numerator unit along x (see conv_gemm.hip)
+  const int img_bytes = g.Hi * g.Wi * g.Ci * 4;
+  const unsigned ylim = (unsigned)g.Hi << ush, xlim = (unsigned)g.Wi << ush;
 
   // branch-free raw buffer loads (out-of-range -> zeros); prologue applied at LDS-store time so the
   // loads stay in flight under the MFMAs (see conv_gemm.hip)
@@ -96,37 +101,53 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
-  constexpr unsigned OOB = 0x7FFFFFF0u;
-  const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
+  const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   if (affine && b_ok) {
     psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
     psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
   }
+  // pixel coordinates of this thread's BJ rows, advanced by 32 pixels per K-step without divisions
+  int pb[BJ], py[BJ], px[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int m = step0 * BK + bp + BPR * j;
+    const unsigned t = fdiv((unsigned)m, a.dWo);
+    px[j] = m - (int)t * g.Wo;
+    const unsigned b = fdiv(t, a.dHo);
+    py[j] = (int)t - (int)b * g.Ho;
+    pb[j] = (int)b;
+  }
+  unsigned aoff[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
+  const unsigned astep = (unsigned)BK * g.Co * 4u;
   f32x4 ra[AJ], rb[BJ];
   unsigned bmask = 0;
-  auto load_tiles = [&](int step) {
-    const int mb = step * BK;
+  auto load_tiles = [&]() {
 #pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const unsigned m = (unsigned)(mb + ap + APR * j);      // rows past M fall outside num_records
-      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            ysrc, a_ok ? (m * g.Co + an) * 4u : OOB, 0, 0));
+    for (int j = 0; j < AJ; ++j) {     // rows past M fall outside num_records
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[j] | a_kill, 0, 0));
+      aoff[j] += astep;
     }
     bmask = 0;
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
-      const int m = mb + bp + BPR * j;
-      const unsigned t = fdiv((unsigned)m, a.dWo);
-      const int ox = m - (int)t * g.Wo;
-      const unsigned b = fdiv(t, a.dHo);
-      const int oy = (int)t - (int)b * g.Ho;
-      const int yn = oy * g.sy + dyo, xn = ox * g.sy + dxo;
-      const int iy = yn >> ush, ix = xn >> ush;
-      const bool ok = b_ok && m < a.M && yn >= 0 && xn >= 0 && ((yn | xn) & upm) == 0 && iy < g.Hi && ix < g.Wi;
-      const unsigned off = ok ? (unsigned)(((int)b * g.Hi * g.Wi + iy * g.Wi + ix) * g.Ci + kc) * 4u : OOB;
+      const int yn = py[j] * g.sy + dyo, xn = px[j] * g.sy + dxo;
+      const bool ok = b_ok && pb[j] < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0;
+      const unsigned okb = ok ? 1u : 0u;
+      const unsigned off = (unsigned)(pb[j] * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
       rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
-      bmask |= (ok ? 1u : 0u) << j;
+      bmask |= okb << j;
+      // advance to the same row of the next K-step
+      int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
+      const int cx = x >= g.Wo ? 1 : 0;
+      x -= cx ? g.Wo : 0;
+      y += cx;
+      const int cy = y >= g.Ho ? 1 : 0;
+      y -= cy ? g.Ho : 0;
+      b += cy;
+      px[j] = x; py[j] = y; pb[j] = b;
     }
   };
   auto store_tiles = [&](int buf) {
@@ -136,16 +157,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
       f32x4 v = rb[j];
-      if (a.pro_mode != PRO_NONE) {
+      if (pro_mode != PRO_NONE) {
         if (affine) v = v * psc + psh;
-        if (a.pro_mode == PRO_LRELU) {
+        if (pro_mode == PRO_LRELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-        } else if (a.pro_mode != PRO_AFFINE) {
+        } else if (pro_mode != PRO_AFFINE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        if (affine && !((bmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (affine) v *= (float)((bmask >> j) & 1u);   // padding is zero AFTER the transform
       }
       *reinterpret_cast<f32x4*>(&Bs[buf][(bp + BPR * j) * BNk + bc * 4]) = v;
     }
@@ -163,13 +184,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const bool do_bias = a.bias_off >= 0 && k0 == 0 && tid < BNn;
   float bsum = 0.f;
   if (step0 < step1) {
-    load_tiles(step0);
+    load_tiles();
     store_tiles(0);
   }
   __syncthreads();
   for (int step = step0; step < step1; ++step) {
     const int cur = (step - step0) & 1;
-    if (step + 1 < step1) load_tiles(step + 1);
+    if (step + 1 < step1) load_tiles();
     const float* Ac = As[cur];
     const float* Bc = Bs[cur];
 #pragma unroll
@@ -362,6 +383,9 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   DG_REQUIRE(dr == 1 || dr == -1, "conv_wgrad: dr must be +-1");
   DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_wgrad: bad Kp=%d", Kp);
   DG_REQUIRE(splits >= 1, "conv_wgrad: splits=%d", splits);
+  DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "conv_wgrad: bad pro_mode %d", pro_mode);
+  DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift),
+             "conv_wgrad: affine prologue needs scale/shift");
   DG_REQUIRE(slab_stride >= (int64_t)Co * Kp && (bias_off < 0 || bias_off + Co <= slab_stride),
              "conv_wgrad: slab_stride=%ld too small for Co*Kp=%ld (+bias)", (long)slab_stride, (long)Co * Kp);
   DG_REQUIRE((long)B * Ho * Wo * Co * 4 < (1L << 31) && (long)B * Hi * Wi * Ci * 4 < (1L << 31),
@@ -372,6 +396,9 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
+  a.adv_b = 32 / (Ho * Wo);
+  a.adv_y = (32 % (Ho * Wo)) / Wo;
+  a.adv_x = (32 % (Ho * Wo)) % Wo;
   const int total_steps = cdiv(a.M, 32);
   DG_REQUIRE(segments >= 1 && splits % segments == 0, "conv_wgrad: splits=%d not a multiple of segments=%d", splits, segments);
   DG_REQUIRE(segments == 1 || (a.M % (32 * segments)) == 0, "conv_wgrad: %d pixels do not split into %d segments of whole K-steps", a.M, segments);
@@ -384,12 +411,20 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   int bn, bk;
   wgrad_tile(Co, Kp, &bn, &bk);
   const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
-  if (bn == 64 && bk == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3(tiles, splits), dim3(256), 0, st, a);
-  else if (bn == 64)
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), dim3(tiles, splits), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3(tiles, splits), dim3(256), 0, st, a);
+  const dim3 grid(tiles, splits);
+  if (bn == 64 && bk == 64) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+  } else if (bn == 64) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
+  } else {   // the production tile: one straight-line kernel per prologue mode
+    switch (pro_mode) {
+      case PRO_NONE: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_NONE>), grid, dim3(256), 0, st, a); break;
+      case PRO_RELU: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_RELU>), grid, dim3(256), 0, st, a); break;
+      case PRO_AFFINE_RELU: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_AFFINE_RELU>), grid, dim3(256), 0, st, a); break;
+      case PRO_LRELU: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_LRELU>), grid, dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_AFFINE>), grid, dim3(256), 0, st, a); break;
+    }
+  }
   return check_launch("conv_wgrad");
 }
 

@@ -26,9 +26,10 @@ nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
 nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
-TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2>", 2: "conv_gemm_kernel<256,64,4,1>",
-              3: "conv_gemm_kernel<64,64,2,2>", 4: "conv_gemm_kernel<128,64,2,2>",
-              5: "conv_gemm_kernel<128,128,2,2,16>"}
+# kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
+TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2,32,{pro}>", 2: "conv_gemm_kernel<256,64,4,1,32,-1>",
+              3: "conv_gemm_kernel<64,64,2,2,32,{pro}>", 4: "conv_gemm_kernel<128,64,2,2,32,-1>",
+              5: "conv_gemm_kernel<128,128,2,2,16,-1>"}
 
 
 class KernelTimer:
@@ -153,7 +154,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
              nat.ptr(stats[0]) if stats else None, nat.current_stream())
     if t0 is not None:
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)
-        TIMER.end(TILE_NAMES[cfg], 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
+        TIMER.end(TILE_NAMES[cfg].format(pro=mode), 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                   (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}{'+res' if residual is not None else ''}"
                                                f"{'+mask' if mask_src is not None else ''}{'+up' if up > 1 else ''}"))
     return (out, stats) if want_stats else out
@@ -230,7 +231,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp), 2.0 * M * Co * geom.R * geom.S * Ci, t0)
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode), 2.0 * M * Co * geom.R * geom.S * Ci, t0)
     if sn is None:
         nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
                  None, None, st)
@@ -262,15 +263,15 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp), 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode), 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
                   (B * Ho * Wo, Co, geom.R * geom.S * Ci, f"pro{mode}"))
 
 
-def _wgrad_kernel_name(Co, Kp):
+def _wgrad_kernel_name(Co, Kp, mode=0):
     bn, bk = (64 if Co <= 64 else 128), (64 if Kp <= 64 else 128)
     if bn == 128 and bk == 64:
         bn = 64
-    return f"conv_wgrad_kernel<{bn},{bk}>"
+    return f"conv_wgrad_kernel<{bn},{bk},{mode if bn == 128 else -1}>"
 
 
 def sn_power_iter(W, u_buffer, sigma_buffer, training=True, eps=1e-12):

@@ -82,6 +82,7 @@ def test_drs_generates_on_gpu():
     torch.manual_seed(5)
     np.random.seed(5)
     netG, netD, _, _ = get_gan_model('cifar10', model='sngan', loss_type='hinge')
+    netG, netD = netG.to('cuda'), netD.to('cuda')
     netG.eval(); netD.eval()
     torch.manual_seed(11)
     drs = DRS(netG, netD, device='cuda')
