@@ -288,8 +288,18 @@ __global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __r
     double dot = 0.0;
     if (i < L.n_elem) {
       float* sl = L.slab[c];
-      f32x4 s = *reinterpret_cast<const f32x4*>(sl + i);
-      for (int k = 1; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + i);
+      // four independent partial sums: the split loads stay in flight together (fixed order: deterministic)
+      f32x4 s = *reinterpret_cast<const f32x4*>(sl + i), s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+      int k = 1;
+      for (; k + 3 < L.splits; k += 4) {
+        const float* q = sl + (long)k * L.stride + i;
+        s += *reinterpret_cast<const f32x4*>(q);
+        s1 += *reinterpret_cast<const f32x4*>(q + L.stride);
+        s2 += *reinterpret_cast<const f32x4*>(q + 2 * L.stride);
+        s3 += *reinterpret_cast<const f32x4*>(q + 3 * L.stride);
+      }
+      for (; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + i);
+      s = (s + s1) + (s2 + s3);
       if (sn) {
         if (i < L.n_w) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + i);

@@ -36,10 +36,13 @@ class KernelTimer:
     """Optional per-launch HIP-event timing of the GEMM kernels (bench.py's roofline leg).
     Events are recorded on torch's current stream, which is the stream the kernels are launched on."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (kernel name, flop, start event, stop event)
+        self.only = only           # optional set of kernel names: launches of other kernels are not bracketed
 
-    def begin(self):
+    def begin(self, name=None):
+        if self.only is not None and name not in self.only:
+            return None
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         return ev
@@ -130,7 +133,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     stats = None
     if (mask_src is None and row_scale is None and out_scale == 1.0 and not res_relu and tile_cfg == 0
             and not want_stats and nat.fn("diagan_conv3x3_co4_supported")(Ci, Co, R, S, sy, dr, off, up)):
-        t0 = TIMER.begin() if TIMER is not None else None
+        t0 = TIMER.begin("conv3x3_co4_kernel") if TIMER is not None else None
         nat.call("diagan_conv3x3_co4", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
                  nat.ptr(scale), nat.ptr(shift), mode, B, Hi, Wi, Ci, dr, off, Kp, nat.current_stream())
         if t0 is not None:
@@ -145,7 +148,10 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
             tiles = (M + (127 if cfg == 1 else 63)) // (128 if cfg == 1 else 64)
             stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
             tile_cfg = cfg
-    t0 = TIMER.begin() if TIMER is not None else None
+    kname = None
+    if TIMER is not None:
+        kname = TILE_NAMES[tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)].format(pro=mode)
+    t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
@@ -153,8 +159,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
              nat.ptr(stats[0]) if stats else None, nat.current_stream())
     if t0 is not None:
-        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)
-        TIMER.end(TILE_NAMES[cfg].format(pro=mode), 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
+        TIMER.end(kname, 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                   (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}{'+res' if residual is not None else ''}"
                                                f"{'+mask' if mask_src is not None else ''}{'+up' if up > 1 else ''}"))
     return (out, stats) if want_stats else out
@@ -227,7 +232,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     slab = _slab(dy.device, splits * n_elem + extra)
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
-    t0 = TIMER.begin() if TIMER is not None else None
+    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode)) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
@@ -258,7 +263,7 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
     _, Hi, Wi, Ci = x.shape
     mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
     sy, dr, off, up = geom.fwd_params()
-    t0 = TIMER.begin() if TIMER is not None else None
+    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode)) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
