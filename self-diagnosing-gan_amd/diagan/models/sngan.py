@@ -55,12 +55,15 @@ class GBlock(nn.Module):
             c1_in, c1_pro = x, _bn_pro(bn1)
         k1 = self.c1.prepare(training, need_dgrad)
         h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro)
+        # shortcut: a 1x1 conv commutes with the (linear) bilinear upsampling, so c_sc runs on the LOW
+        # resolution input (4x fewer FLOP) and its output is upsampled: c_sc(up(x)) == up(c_sc(x))
         if self.learnable_sc:
-            sc_in = E.upsample2x(x) if self.upsample else x
             ksc = self.c_sc.prepare(training, need_dgrad)
-            sc = self.c_sc.fwd(ksc, sc_in)
+            sc = self.c_sc.fwd(ksc, x)
+            if self.upsample:
+                sc = E.upsample2x(sc)
         else:
-            sc_in, ksc, sc = None, None, x
+            ksc, sc = None, x
         k2 = self.c2.prepare(training, need_dgrad)
         bn_out = None
         if next_bn is not None:
@@ -68,7 +71,7 @@ class GBlock(nn.Module):
         else:
             out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc)
         if save:
-            ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, sc_in=sc_in, ksc=ksc, k2=k2)
+            ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, ksc=ksc, k2=k2)
         return out, ctx, bn_out
 
     def backward(self, ctx, gout):
@@ -80,9 +83,10 @@ class GBlock(nn.Module):
         self.c1.wgrad(ctx['k1'], g_h1, ctx['c1_in'], pro=ctx['c1_pro'])
         g_c1in = self.c1.dgrad(ctx['k1'], g_h1, ctx['c1_in'].shape[1:3])
         if self.learnable_sc:
-            self.c_sc.wgrad(ctx['ksc'], gout, ctx['sc_in'])
-            g_scin = self.c_sc.dgrad(ctx['ksc'], gout, ctx['sc_in'].shape[1:3])
-            g_x_sc = E.upsample2x_bwd(g_scin) if self.upsample else g_scin
+            # gradient of the low-resolution shortcut: adjoint of the upsampling applied to gout
+            g_sc = E.upsample2x_bwd(gout) if self.upsample else gout
+            self.c_sc.wgrad(ctx['ksc'], g_sc, x)
+            g_x_sc = self.c_sc.dgrad(ctx['ksc'], g_sc, x.shape[1:3])
         else:
             g_x_sc = gout
         g_a1 = E.upsample2x_bwd(g_c1in) if self.upsample else g_c1in
