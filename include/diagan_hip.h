@@ -97,7 +97,7 @@ int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bi
                        const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W, int Ci,
                        int dr, int off, int Kp, void* stream);
 
-int diagan_conv_gemm_pick_cfg(int M, int Co); /* tile config chosen when tile_cfg == 0 (host only) */
+int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp); /* tile config chosen when tile_cfg == 0 (host only) */
 
 /* Weight gradient, split over pixels: slab[s][n][k] = sum_{m in split s} dy[m][n]*pro(x gathered).
  * Replaces the weight half of conv2d / conv_transpose2d backward (errD.backward()/errG.backward()

@@ -19,6 +19,7 @@
 //
 // Roofline: MFMA fp32 (algorithmic FLOP = 2*M*Co*K).
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace diagan {
 
@@ -358,7 +359,10 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
 using namespace diagan;
 
 // tile selection used when tile_cfg == 0: 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 128x64
-DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
+DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
+  // short K loops (first conv of D on RGB, 1x1 shortcuts) are bound by the output stream, not the MFMAs: more,
+  // smaller workgroups in flight win (measured 52 -> 46 us at M=131072,N=128,K=36; 27 -> 19 us at K=128)
+  if (Kp <= 128) return 3;
   // measured on MI355X (tools/bench_conv.py, SWEEP=1): the 64x64 tile (5 blocks/CU) is within ~5 % of
   // the 128x128 tile everywhere and far better on small grids and narrow outputs; 128x128 wins by
   // 5-10 % once it has >= 512 tiles (2 resident blocks on every CU) and wastes no columns.
@@ -377,6 +381,8 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co) {
 // latency bound (one workgroup per CU cannot hide its own global loads); splitting K across
 // gridDim.y fills the 1280 resident slots.  Returns 1 when not worthwhile.
 DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
+  static const int forced = getenv("DIAGAN_KSPLIT") ? atoi(getenv("DIAGAN_KSPLIT")) : 0;   // tuning experiments only
+  if (forced > 0 && !(Co & 3)) return forced < Kp / 32 ? forced : Kp / 32;
   if (cfg != 3 || (Co & 3)) return 1;
   const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
   const int nk = Kp / 32;
@@ -416,7 +422,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co) : tile_cfg;
+  const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp) : tile_cfg;
   a.slab = splitk_ws;
   a.ksplit = 1;
   a.stat_partials = stat_partials;

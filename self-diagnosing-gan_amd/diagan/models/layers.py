@@ -194,15 +194,29 @@ class BatchNorm(nn.Module):
         self.register_buffer('running_mean', torch.zeros(ch))
         self.register_buffer('running_var', torch.ones(ch))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        # the counter is only ever read through state_dict(): count on the host and fold the pending
+        # increments into the buffer there (a device add per forward was 42 launches per global step)
+        self._pending_batches = 0
+        self.register_state_dict_pre_hook(BatchNorm._flush_counter)
+        self._register_load_state_dict_pre_hook(self._drop_pending)
+
+    @staticmethod
+    def _flush_counter(module, prefix, keep_vars):
+        if module._pending_batches:
+            module.num_batches_tracked += module._pending_batches
+            module._pending_batches = 0
+
+    def _drop_pending(self, *args):
+        self._pending_batches = 0
 
     def stats(self, x, training):
         if training:
-            self.num_batches_tracked += 1
+            self._pending_batches += 1
         return E.bn_stats(x, self.weight.data, self.bias.data, self.running_mean, self.running_var, training,
                           self.eps, self.momentum)
 
     def stats_fused(self, partials, tiles, M):
-        self.num_batches_tracked += 1
+        self._pending_batches += 1
         return E.bn_stats_fused(partials, tiles, M, self.weight.data, self.bias.data, self.running_mean,
                                 self.running_var, self.eps, self.momentum)
 

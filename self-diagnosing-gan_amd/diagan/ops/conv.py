@@ -12,7 +12,7 @@ from diagan import _native as nat
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
-nat.register("diagan_conv_gemm_pick_cfg", [I, I])
+nat.register("diagan_conv_gemm_pick_cfg", [I, I, I])
 nat.register("diagan_conv3x3_co4_supported", [I] * 8)
 nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P])
 nat.register("diagan_conv_wgrad", [P, P, P, I, I, I64, I64, P, P, I] + [I] * 14 + [P])
@@ -143,14 +143,14 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     ws = _splitk_ws(x.device)
     if want_stats:
         M = B * Ho * Wo
-        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co)
+        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, Kp)
         if nat.fn("diagan_conv_gemm_pick_ksplit")(M, Co, Kp, cfg) == 1:
             tiles = (M + (127 if cfg == 1 else 63)) // (128 if cfg == 1 else 64)
             stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
             tile_cfg = cfg
     kname = None
     if TIMER is not None:
-        kname = TILE_NAMES[tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co)].format(pro=mode)
+        kname = TILE_NAMES[tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp)].format(pro=mode)
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,

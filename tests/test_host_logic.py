@@ -236,3 +236,15 @@ def test_drs_acceptance_matches_reference(golden_dir):
         kept = drs.sub_rejection_sampler(torch.arange(256, dtype=torch.float32).view(256, 1), g[f"ldr{i}"])
         assert np.array_equal(kept.numpy().reshape(-1), g[f"kept{i}"])
     assert float(drs.maximum) == float(g["maximum_final"])
+
+
+def test_batchnorm_counter_is_folded_into_state_dict():
+    """num_batches_tracked is counted on the host and materialised by state_dict() (nn.BatchNorm2d semantics)."""
+    from diagan.models.layers import BatchNorm
+    bn = BatchNorm(8)
+    bn._pending_batches += 3            # what three training-mode forwards do
+    sd = bn.state_dict()
+    assert int(sd['num_batches_tracked']) == 3 and bn._pending_batches == 0
+    bn._pending_batches = 5
+    bn.load_state_dict(sd)
+    assert int(bn.state_dict()['num_batches_tracked']) == 3

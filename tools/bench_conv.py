@@ -33,6 +33,10 @@ SHAPES = [
     ("D32.b3.pair", 128, 8, 8, 128, 128, 3),
     ("D64.b5.pair", 128, 4, 4, 512, 1024, 3),
     ("D64.b4.pair", 128, 8, 8, 256, 512, 3),
+    ("D32.b1.c1.pair", 128, 32, 32, 4, 128, 3),
+    ("D64.b1.c1.pair", 128, 64, 64, 4, 64, 3),
+    ("D32.b2.sc.pair", 128, 16, 16, 128, 128, 1),
+    ("G32.b4.sc.lo", 64, 16, 16, 256, 256, 1),
 ]
 
 
