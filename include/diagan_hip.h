@@ -89,13 +89,23 @@ int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias
  * the factor that would be used (1 = none). */
 int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 
-/* 3x3 / stride 1 / pad 1 convolution (or its data-gradient) to FOUR output channels, Ci in {64,128,256}:
- * lane-parallel reduction instead of the matrix cores (generator's last conv, D's first-layer dgrad).
+/* 3x3 / stride 1 / pad 1 convolution (or its data-gradient) to FOUR output channels, Ci % 16 == 0, on the
+ * 4x4x1 matrix instruction (N is exactly 4: no wasted columns) -- the generator's last conv (mimicry
+ * SNGANGenerator32.c5 / Generator64.c6) and D's first-layer data-gradient.
  * Same prologue / bias / residual semantics as diagan_conv_gemm. */
 int diagan_conv3x3_co4_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up);
 int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bias, const float* residual,
                        const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W, int Ci,
                        int dr, int off, int Kp, void* stream);
+/* Weight (+ bias) gradient of the same layer, Ci in {64,128,256}, Kp == 9*Ci: the whole [4][Kp] gradient lives in
+ * each wave's accumulators; writes diagan_conv3x3_co4_wgrad_splits(B, H) partial slabs
+ * slab[split][slab_stride] in the packed-weight layout (bias column sums at bias_off if >= 0), to be summed by
+ * diagan_wgrad_finish_batched / diagan_wgrad_reduce like the slabs of diagan_conv_wgrad. */
+int diagan_conv3x3_co4_wgrad_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up);
+int diagan_conv3x3_co4_wgrad_splits(int B, int H);
+int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64_t slab_stride, int64_t bias_off,
+                             const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W,
+                             int Ci, int Kp, void* stream);
 
 int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp); /* tile config chosen when tile_cfg == 0 (host only) */
 

@@ -1,14 +1,22 @@
 // 3x3 convolution to FOUR output channels (RGB + pad), stride 1, pad 1 -- the generator's last conv
-// and the data-gradient of the discriminator's first conv (SURVEY §8 a2/a4 "c5/c6", a3/a5 block1).
+// and the data-gradient of the discriminator's first conv (SURVEY §8 a2/a4 "c5/c6", a3/a5 block1) --
+// and the weight gradient of the same layer (conv3x3_co4_wgrad, below).
 //
-// On the matrix cores these cost a full 32-wide (64 with the tile) N dimension for 4 useful columns
-// (measured 5.5 TFLOP/s, 218 us for M=65536, K=2304).  Here the reduction over K is spread over
-// the LANES instead: LPP = Ci/4 lanes share one pixel, each lane owns 4 input channels and keeps
-// its 9 x 4 x 4 weights LDS-resident (staged once per workgroup); a 3x3 sliding window of float4 loads (3 new 16-byte loads per
-// pixel) feeds 144 FMAs, and the four partial sums are combined across the LPP lanes with wave
-// shuffles.  Same gather formula / prologue / epilogue semantics as conv_gemm_kernel.
+// On the 32x32 matrix tiles these cost a full 32-wide (64 with the tile) N dimension for 4 useful columns
+// (measured 5.5 TFLOP/s, 218 us for M=65536, K=2304).  gfx950 has a matrix instruction whose N is exactly 4:
+// v_mfma_f32_4x4x1_16B_f32 = 16 independent 4x4 outer products per wave, D_b[i][j] += A_b[i] * B_b[j],
+// lane 4b+i supplies A_b[i], lane 4b+j supplies B_b[j] and receives column j of D_b (layout probed on the
+// hardware: tools/probe/mfma4x4.hip).  It runs at the same 256 FLOP/cycle/CU as the big fp32 tiles.
 //
-// Roofline: HBM / L2 (each input row is read ~3x); algorithmic FLOP 2*M*4*9*Ci is negligible.
+//   forward / dgrad:  i = one of 4 pixels of block b (lane = pixel), j = output channel, one k per instruction:
+//                     a wave produces 64 pixels x 4 channels; A comes from an LDS tile of the (prologue-
+//                     transformed) input with halo, B from the LDS copy of the packed weights.
+//   weight gradient:  i = input channel 4b+i of a 64-channel chunk (lane = channel: coalesced global reads, no
+//                     LDS), j = output channel, one PIXEL per instruction; the whole 4 x 9 x Ci gradient lives
+//                     in the wave's accumulators (4 VGPRs per tap per chunk).
+//
+// Same gather formula / prologue / epilogue semantics as conv_gemm_kernel.  Roofline: LDS bandwidth for the
+// forward (one 16-byte A read per lane per 4 instructions), HBM / L2 for the weight gradient.
 #include "conv_common.h"
 
 namespace diagan {
@@ -24,66 +32,69 @@ struct SmallCoArgs {
   int pro_mode;
   int B, H, W, Ci, Kp;
   int dr, off;            // tap r reads row oy + r*dr + off (conv pad 1: +1,-1; its data-gradient: -1,+1)
+  int tiles_x, tiles_y;
 };
 
-constexpr int SC_RUN = 8;  // consecutive output pixels per lane group (sliding window along x)
+constexpr int SC_TH = 4, SC_TW = 32;        // output tile of a workgroup: 4 rows x 32 columns (2 waves of 64 pixels)
+constexpr int SC_CC = 16;                   // channels per LDS stage
+constexpr int SC_PS = SC_CC + 4;            // padded pixel stride in floats: conflict-free ds_read_b128 across pixels
+constexpr int SC_TILE = (SC_TH + 2) * (SC_TW + 2) * SC_PS;
+constexpr int SC_WT = 9 * 4 * SC_CC;
+constexpr int SC_NLOAD = (SC_TH + 2) * (SC_TW + 2) * (SC_CC / 4);   // float4 loads per stage (816)
+constexpr int SC_LPT = (SC_NLOAD + 255) / 256;
 
-template <int LPP>
+// 256 threads = 4 waves: wave = (pixel group pg = rows 2pg, 2pg+1 of the tile) x (channel half kh of each stage);
+// the two channel halves are summed through LDS at the end.
 __global__ __launch_bounds__(256) void conv3x3_co4_kernel(const SmallCoArgs a) {
-  constexpr int G = 64 / LPP;  // pixel groups per wave
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cl = lane % LPP, grp = lane / LPP;
-  const int runs_per_row = (a.W + SC_RUN - 1) / SC_RUN;
-  const long total_runs = (long)a.B * a.H * runs_per_row;
-  const int c0 = cl * 4;
-
-  // weights staged once per workgroup in LDS as wl[(dy+1)*3 + (dx+1)][n][Ci] (indexed by the WINDOW
-  // offset they multiply, so conv and data-gradient share the inner loop); a lane reads its 16 bytes
-  // per (offset, n) with conflict-free ds_read_b128.  Registers stay < 128 -> 4 waves/SIMD hide the
-  // global-load latency of the sliding window.
-  extern __shared__ __attribute__((aligned(16))) float wl[];
-  for (int i = threadIdx.x; i < 9 * 4 * (a.Ci / 4); i += 256) {
-    const int c4 = i % (a.Ci / 4), n = (i / (a.Ci / 4)) % 4, tap = i / (a.Ci);   // tap = i / (4 * Ci/4)
-    const int r = tap / 3, sx = tap % 3;
-    const int slot = (r * a.dr + a.off + 1) * 3 + (sx * a.dr + a.off + 1);
-    *reinterpret_cast<f32x4*>(wl + ((long)slot * 4 + n) * a.Ci + c4 * 4) =
-        *reinterpret_cast<const f32x4*>(a.w + (long)n * a.Kp + tap * a.Ci + c4 * 4);
-  }
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) float xt[2][SC_TILE];
+  __shared__ __attribute__((aligned(16))) float wt[2][SC_WT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pg = wave & 1, kh = wave >> 1;
+  int t = blockIdx.x;
+  const int tx = t % a.tiles_x; t /= a.tiles_x;
+  const int ty = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
   const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
-  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-  if (affine) {
-    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0);
-    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0);
-  }
-  const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias) : f32x4{0.f, 0.f, 0.f, 0.f};
-  // persistent workgroups: the 36*Ci floats of LDS weights are staged once and reused for many runs;
-  // a whole lane group leaves the loop together (shuffles stay inside a group)
-  for (long run = ((long)blockIdx.x * 4 + wave) * G + grp; run < total_runs; run += (long)gridDim.x * 4 * G) {
-  const int xr = (int)(run % runs_per_row);
-  const long t = run / runs_per_row;
-  const int oy = (int)(t % a.H), b = (int)(t / a.H);
-  const int x0 = xr * SC_RUN;
-  const float* img = a.x + (long)b * a.H * a.W * a.Ci + c0;
-  bool rowok[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) rowok[d] = (oy + d - 1) >= 0 && (oy + d - 1) < a.H;
+  const int nchunk = a.Ci / SC_CC;
 
-  // raw loads are branch-free (clamped address) and issued one column AHEAD of their use; the
-  // prologue transform and the zero padding are applied when the column enters the window
-  auto issue_col = [&](int ix, f32x4 (&raw)[3]) {
-    const int ixc = min(max(ix, 0), a.W - 1);
+  // ---- stage loader: thread-fixed (tile pixel, channel quad) slots ----------------------------------
+  int goff[SC_LPT], loff[SC_LPT];
+  bool gok[SC_LPT], lok[SC_LPT];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const int iyc = min(max(oy + d - 1, 0), a.H - 1);
-      raw[d] = *reinterpret_cast<const f32x4*>(img + ((long)iyc * a.W + ixc) * a.Ci);
+  for (int i = 0; i < SC_LPT; ++i) {
+    const int s = tid + 256 * i;
+    const int q = s & 3, pix = s >> 2;
+    const int px = pix % (SC_TW + 2), py = pix / (SC_TW + 2);
+    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+    lok[i] = s < SC_NLOAD;
+    gok[i] = lok[i] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    goff[i] = gok[i] ? ((b * a.H + iy) * a.W + ix) * a.Ci + q * 4 : 0;
+    loff[i] = pix * SC_PS + q * 4;
+  }
+  const int q_own = tid & 3;   // 256 % 4 == 0: every slot of a thread has the same channel quad
+  // weights of a stage: wt[tap][j][16] <- w[j][tap*Ci + chunk*16 ...]: 144 float4
+  const bool w_ok = tid < 9 * 4 * 4;
+  const int w_q = tid & 3, w_j = (tid >> 2) & 3, w_tap = tid >> 4;
+  const int w_goff = w_j * a.Kp + w_tap * a.Ci + w_q * 4;
+  const int w_loff = (w_tap * 4 + w_j) * SC_CC + w_q * 4;
+
+  f32x4 rx[SC_LPT], rw, psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  auto load_stage = [&](int chunk) {
+    const int c0 = chunk * SC_CC;
+#pragma unroll
+    for (int i = 0; i < SC_LPT; ++i)
+      rx[i] = gok[i] ? *reinterpret_cast<const f32x4*>(a.x + goff[i] + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rw = w_ok ? *reinterpret_cast<const f32x4*>(a.w + w_goff + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + q_own * 4);
+      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + q_own * 4);
     }
   };
-  auto finish_col = [&](int ix, const f32x4 (&raw)[3], f32x4 (&col)[3]) {
-    const bool cok = ix >= 0 && ix < a.W;
+  auto store_stage = [&](int buf) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      f32x4 v = raw[d];
+    for (int i = 0; i < SC_LPT; ++i) {
+      f32x4 v = rx[i];
       if (affine) v = v * psc + psh;
       if (a.pro_mode == PRO_LRELU) {
 #pragma unroll
@@ -92,48 +103,210 @@ __global__ __launch_bounds__(256) void conv3x3_co4_kernel(const SmallCoArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      if (!(cok && rowok[d])) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      col[d] = v;
+      if (!gok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};     // padding is zero AFTER the transform
+      if (lok[i]) *reinterpret_cast<f32x4*>(&xt[buf][loff[i]]) = v;
+    }
+    if (w_ok) *reinterpret_cast<f32x4*>(&wt[buf][w_loff]) = rw;
+  };
+
+  // ---- MFMA side --------------------------------------------------------------------------------------
+  const int pr = 2 * pg + (lane >> 5), pc = lane & 31, j = lane & 3;
+  // window offset of tap (r, s) inside the haloed tile: row pr + 1 + (r*dr + off)
+  int aoff[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int r = tap / 3, s = tap % 3;
+    aoff[tap] = ((pr + 1 + r * a.dr + a.off) * (SC_TW + 2) + (pc + 1 + s * a.dr + a.off)) * SC_PS;
+  }
+  f32x4 acc[4];   // one accumulator per k of a 16-byte operand: consecutive instructions never depend on each other
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int cur = chunk & 1;
+    if (chunk + 1 < nchunk) load_stage(chunk + 1);
+    const float* xc = xt[cur];
+    const float* wc = wt[cur];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int c4 = 2 * kh + cc;
+        const f32x4 av = *reinterpret_cast<const f32x4*>(xc + aoff[tap] + c4 * 4);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(wc + (tap * 4 + j) * SC_CC + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc[e] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], bv[e], acc[e], 0, 0, 0);
+      }
+    }
+    if (chunk + 1 < nchunk) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+  f32x4 o = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  // sum the two channel halves: kh == 1 waves park their accumulators in LDS (the tiles are done with)
+  float* red = xt[0];
+  if (kh == 1) *reinterpret_cast<f32x4*>(red + (pg * 64 + lane) * 4) = o;
+  __syncthreads();
+  if (kh == 0) {
+    o += *reinterpret_cast<const f32x4*>(red + (pg * 64 + lane) * 4);
+    const float bj = a.bias ? a.bias[j] : 0.f;
+    // lane 4g+j holds out[pixel 4g+e][j], e = 0..3; pixels 4g..4g+3 are consecutive columns of one row
+    const int p0 = lane & ~3;
+    const int oy = oy0 + 2 * pg + (p0 >> 5);
+    if (oy < a.H) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ox = ox0 + (p0 & 31) + e;
+        if (ox >= a.W) continue;
+        const long m = ((long)b * a.H + oy) * a.W + ox;
+        float v = o[e] + bj;
+        if (a.residual) v += a.residual[m * 4 + j];
+        a.y[m * 4 + j] = v;
+      }
+    }
+  }
+}
+
+// ---- weight gradient of the same layer --------------------------------------------------------------
+struct SmallCoWgradArgs {
+  const float* dy;        // [B,H,W,4]
+  const float* x;         // [B,H,W,Ci]
+  float* slab;            // [gridDim.x][slab_stride]: weight partials laid out as the packed weight, [4][Kp]
+  const float* pro_scale;
+  const float* pro_shift;
+  int pro_mode;
+  int B, H, W, Ci, Kp;
+  long slab_stride;
+  long bias_off;          // >= 0: column sums of dy go to slab[blk][bias_off + j]
+  int rows_per_block;     // image rows (of B*H) per workgroup
+};
+
+// Wave w of a workgroup owns the 64-channel chunk (w % NCH) -- lane = channel, 9 taps x 4 accumulator VGPRs -- and
+// the image rows (w / NCH) mod RG of the workgroup's row range (RG = 4 / NCH).  Work item = 8 consecutive
+// pixels of one row: its 3 x 10 input values per lane and 8 dy values are loaded as ONE burst of branch-free
+// clamped loads into the register buffer that is not being consumed (two buffers, explicitly unrolled by two, so
+// the burst of item q+1 is in flight under the 72 matrix instructions of item q); padding and the prologue
+// are applied when a buffer is consumed.  Per pixel: B = dy[p][lane & 3], A = pro(x[p + tap][channel]).
+constexpr int SW_SEG = 8;    // 38 loads per item: the previous burst can be waited for with an encodable vmcnt
+
+template <int NCH>
+__global__ __launch_bounds__(256) void conv3x3_co4_wgrad_kernel(const SmallCoWgradArgs a) {
+  constexpr int RG = 4 / NCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = wave % NCH, rg = wave / NCH;
+  const int j = lane & 3;
+  const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
+  const float psc = affine ? a.pro_scale[chunk * 64 + lane] : 1.f;
+  const float psh = affine ? a.pro_shift[chunk * 64 + lane] : 0.f;
+  // branch-free prologue: v*scale+shift (1, 0 when not affine), then max(v, slope*v) with slope 1 / 0 / 0.2
+  const float slope = (a.pro_mode == PRO_RELU || a.pro_mode == PRO_AFFINE_RELU) ? 0.f : (a.pro_mode == PRO_LRELU ? 0.2f : 1.f);
+
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int total_rows = a.B * a.H;
+  const int row0 = blockIdx.x * a.rows_per_block;
+  const int row1 = min(row0 + a.rows_per_block, total_rows);
+  const int nseg = (a.W + SW_SEG - 1) / SW_SEG;
+  const int my_rows = (row1 - row0 - rg + RG - 1) / RG;          // rows row0 + rg + RG*i < row1
+  const int nitems = my_rows > 0 ? my_rows * nseg : 0;
+  const float* xc = a.x + chunk * 64 + lane;
+
+  struct Item { float x[3][SW_SEG + 2]; float d[SW_SEG]; };
+  auto issue = [&](int q, Item& it) {
+    const int qq = min(q, max(nitems - 1, 0));
+    const int ri = qq / nseg, seg = qq - ri * nseg;
+    const int row = min(row0 + rg + RG * ri, total_rows - 1);
+    const int b = row / a.H, oy = row - b * a.H;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int iy = min(max(oy + d - 1, 0), a.H - 1);
+      const float* xr = xc + ((long)b * a.H + iy) * a.W * a.Ci;
+#pragma unroll
+      for (int k = 0; k < SW_SEG + 2; ++k) it.x[d][k] = xr[(long)min(max(seg * SW_SEG - 1 + k, 0), a.W - 1) * a.Ci];
+    }
+    const float* dr = a.dy + (long)row * a.W * 4 + j;
+#pragma unroll
+    for (int k = 0; k < SW_SEG; ++k) it.d[k] = dr[min(seg * SW_SEG + k, a.W - 1) * 4];
+  };
+  auto consume = [&](int q, Item& it) {
+    const bool live = q < nitems;
+    const int qq = min(q, max(nitems - 1, 0));
+    const int ri = qq / nseg, seg = qq - ri * nseg;
+    const int row = min(row0 + rg + RG * ri, total_rows - 1);
+    const int oy = row % a.H;
+    // validity masks are wave-uniform scalars
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool rok = (oy + d - 1) >= 0 && (oy + d - 1) < a.H;
+#pragma unroll
+      for (int k = 0; k < SW_SEG + 2; ++k) {
+        const int ix = seg * SW_SEG - 1 + k;
+        float v = fmaf(it.x[d][k], psc, psh);
+        v = fmaxf(v, v * slope);
+        it.x[d][k] = (rok && ix >= 0 && ix < a.W) ? v : 0.f;     // padding is zero AFTER the transform
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SW_SEG; ++k) {
+      const float dv = (live && seg * SW_SEG + k < a.W) ? it.d[k] : 0.f;
+      bsum += dv;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int s2 = 0; s2 < 3; ++s2)
+          acc[d * 3 + s2] = __builtin_amdgcn_mfma_f32_4x4x1f32(it.x[d][k + s2], dv, acc[d * 3 + s2], 0, 0, 0);
     }
   };
 
-  f32x4 c_m[3], c_0[3], c_p[3], nxt[3];  // window columns x-1, x, x+1 and the raw column in flight
-  issue_col(x0 - 1, nxt);
-  finish_col(x0 - 1, nxt, c_m);
-  issue_col(x0, nxt);
-  finish_col(x0, nxt, c_0);
-  issue_col(x0 + 1, nxt);
-#pragma unroll 1
-  for (int i = 0; i < SC_RUN; ++i) {
-    const int ox = x0 + i;
-    if (ox >= a.W) break;
-    finish_col(ox + 1, nxt, c_p);
-    issue_col(ox + 2, nxt);          // lands while this pixel's 144 FMAs and shuffles run
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < 3; ++d)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + ((d * 3 + 0) * 4 + n) * a.Ci + c0);
-        const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + ((d * 3 + 1) * 4 + n) * a.Ci + c0);
-        const f32x4 w2 = *reinterpret_cast<const f32x4*>(wl + ((d * 3 + 2) * 4 + n) * a.Ci + c0);
-        const f32x4 p = c_m[d] * w0 + c_0[d] * w1 + c_p[d] * w2;
-        acc[n] += (p[0] + p[1]) + (p[2] + p[3]);
-      }
-#pragma unroll
-    for (int o = LPP >> 1; o > 0; o >>= 1)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], o, 64);
-    if (cl == 0) {
-      const long m = ((long)b * a.H + oy) * a.W + ox;
-      f32x4 o4 = {acc[0], acc[1], acc[2], acc[3]};
-      o4 += bv;
-      if (a.residual) o4 += reinterpret_cast<const f32x4*>(a.residual)[m];
-      reinterpret_cast<f32x4*>(a.y)[m] = o4;
+  Item bufA, bufB;
+  if (nitems > 0) {
+    issue(0, bufA);
+    // sched_barrier(0): the scheduler may not move anything across -- otherwise it sinks each load next to
+    // its first use to save registers and the burst is gone
+    for (int q = 0; q < nitems; q += 2) {
+      issue(q + 1, bufB);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(q, bufA);
+      __builtin_amdgcn_sched_barrier(0);
+      issue(q + 2, bufA);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(q + 1, bufB);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { c_m[d] = c_0[d]; c_0[d] = c_p[d]; }
   }
+
+  // lane 4g+jj, element e of acc[t] = dW[jj][t*Ci + chunk*64 + 4g + e]; row groups are summed through LDS in a
+  // fixed order, then ONE slab per workgroup
+  __shared__ __attribute__((aligned(16))) float red[RG > 1 ? RG - 1 : 1][NCH][9][64 * 4];
+  __shared__ float bred[4][4];
+  float* out = a.slab + (long)blockIdx.x * a.slab_stride;
+  if (RG > 1 && rg > 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) *reinterpret_cast<f32x4*>(&red[rg - 1][chunk][t][lane * 4]) = acc[t];
+  }
+  if (lane < 4) bred[wave][lane] = bsum;
+  __syncthreads();
+  if (rg == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      f32x4 s = acc[t];
+#pragma unroll
+      for (int r = 0; r < RG - 1; ++r) s += *reinterpret_cast<const f32x4*>(&red[r][chunk][t][lane * 4]);
+      *reinterpret_cast<f32x4*>(out + (long)j * a.Kp + t * a.Ci + chunk * 64 + (lane & ~3)) = s;
+    }
+  }
+  if (a.bias_off >= 0 && tid < 4) {
+    // every wave of chunk 0 summed the dy columns of its rows: add the RG row groups (waves 0, NCH, 2*NCH, ...)
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) t += bred[r * NCH][tid];
+    out[a.bias_off + tid] = t;
   }
 }
 
@@ -144,25 +317,55 @@ using namespace diagan;
 // 1 if diagan_conv3x3_co4 supports this geometry (host-side check, no device work)
 DIAGAN_API int diagan_conv3x3_co4_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up) {
   const bool geo = R == 3 && S == 3 && sy == 1 && up == 1 && ((dr == 1 && off == -1) || (dr == -1 && off == 1));
-  return geo && Co == 4 && (Ci == 64 || Ci == 128 || Ci == 256);
+  return geo && Co == 4 && Ci >= SC_CC && (Ci % SC_CC) == 0;
 }
 
 DIAGAN_API int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bias, const float* residual,
                                   const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W,
                                   int Ci, int dr, int off, int Kp, void* stream) {
   DG_REQUIRE(x && w && y, "conv3x3_co4: null tensor");
+  DG_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_co4: bad dims");
   DG_REQUIRE(diagan_conv3x3_co4_supported(Ci, 4, 3, 3, 1, dr, off, 1), "conv3x3_co4: unsupported geometry Ci=%d dr=%d off=%d", Ci, dr, off);
   DG_REQUIRE(Kp >= 9 * Ci && pro_mode >= 0 && pro_mode <= 4, "conv3x3_co4: bad Kp / pro_mode");
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift), "conv3x3_co4: affine prologue needs scale/shift");
-  SmallCoArgs a{x, w, y, bias, residual, pro_scale, pro_shift, pro_mode, B, H, W, Ci, Kp, dr, off};
-  const int lpp = Ci / 4, groups = 64 / lpp;
-  const long runs = (long)B * H * cdiv(W, SC_RUN);
-  int blocks = cdiv(runs, 4L * groups);
-  if (blocks > 1024) blocks = 1024;          // persistent: 4 workgroups per CU, each loops over runs
-  hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)36 * Ci * sizeof(float);
-  if (lpp == 64) hipLaunchKernelGGL(conv3x3_co4_kernel<64>, dim3(blocks), dim3(256), lds, st, a);
-  else if (lpp == 32) hipLaunchKernelGGL(conv3x3_co4_kernel<32>, dim3(blocks), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(conv3x3_co4_kernel<16>, dim3(blocks), dim3(256), lds, st, a);
+  DG_REQUIRE((long)B * H * W * Ci * 4 < (1L << 31), "conv3x3_co4: tensors must be smaller than 2 GiB");
+  SmallCoArgs a{x, w, y, bias, residual, pro_scale, pro_shift, pro_mode, B, H, W, Ci, Kp, dr, off,
+                cdiv(W, SC_TW), cdiv(H, SC_TH)};
+  const long blocks = (long)B * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL(conv3x3_co4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3x3_co4");
+}
+
+// 1 if diagan_conv3x3_co4_wgrad supports the layer (3x3, stride 1, pad 1, 4 output channels)
+DIAGAN_API int diagan_conv3x3_co4_wgrad_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up) {
+  return R == 3 && S == 3 && sy == 1 && up == 1 && dr == 1 && off == -1 && Co == 4 && (Ci == 64 || Ci == 128 || Ci == 256);
+}
+
+// number of slabs (= workgroups) diagan_conv3x3_co4_wgrad writes for this problem
+DIAGAN_API int diagan_conv3x3_co4_wgrad_splits(int B, int H) {
+  const int rows = B * H;
+  int per = cdiv(rows, 512);          // <= 512 workgroups (2 per CU): one 36*Ci-float slab each
+  if (per < 4) per = 4;
+  return cdiv(rows, per);
+}
+
+DIAGAN_API int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64_t slab_stride,
+                                        int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode,
+                                        int B, int H, int W, int Ci, int Kp, void* stream) {
+  DG_REQUIRE(dy && x && slab, "conv3x3_co4_wgrad: null tensor");
+  DG_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_co4_wgrad: bad dims");
+  DG_REQUIRE(Ci == 64 || Ci == 128 || Ci == 256, "conv3x3_co4_wgrad: Ci=%d unsupported (64, 128, 256)", Ci);
+  DG_REQUIRE(Kp >= 9 * Ci && pro_mode >= 0 && pro_mode <= 4, "conv3x3_co4_wgrad: bad Kp / pro_mode");
+  DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift), "conv3x3_co4_wgrad: affine prologue needs scale/shift");
+  DG_REQUIRE(slab_stride >= (int64_t)4 * Kp && (bias_off < 0 || bias_off + 4 <= slab_stride), "conv3x3_co4_wgrad: slab_stride too small");
+  const int splits = diagan_conv3x3_co4_wgrad_splits(B, H);
+  SmallCoWgradArgs a{dy, x, slab, pro_scale, pro_shift, pro_mode, B, H, W, Ci, Kp, (long)slab_stride, (long)bias_off,
+                     cdiv(B * H, splits)};
+  // K padding columns of the slab (k >= 9*Ci) are never written by the kernel: the packed layout has none for these Ci
+  DG_REQUIRE(Kp == 9 * Ci, "conv3x3_co4_wgrad: padded Kp=%d != 9*Ci", Kp);
+  hipStream_t st = (hipStream_t)stream;
+  if (Ci == 256) hipLaunchKernelGGL(conv3x3_co4_wgrad_kernel<4>, dim3(splits), dim3(256), 0, st, a);
+  else if (Ci == 128) hipLaunchKernelGGL(conv3x3_co4_wgrad_kernel<2>, dim3(splits), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv3x3_co4_wgrad_kernel<1>, dim3(splits), dim3(256), 0, st, a);
+  return check_launch("conv3x3_co4_wgrad");
 }

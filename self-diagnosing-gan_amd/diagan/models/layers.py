@@ -487,7 +487,7 @@ class WgradBatch:
         self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, max_elem, any_sn)
         self.flat_id = None
 
-    def _entry(self, layer, slot, M, segments=1):
+    def _entry(self, layer, slot, M, segments=1, dy_shape=None):
         if self.flat_id != id(self.net.flat_grads):          # gradient slab was re-allocated
             self.entries.clear(), self.tables.clear()
             self.flat_id = id(self.net.flat_grads)
@@ -501,6 +501,8 @@ class WgradBatch:
                 raise RuntimeError("bias gradient does not follow the weight gradient in the flat slab")
             stride = n_w + n_b
             splits = max(segments, C.wgrad_splits(M, g.Co, g.Kp) // segments * segments)
+            if segments == 1 and dy_shape is not None and C.small_co_wgrad(g):
+                splits = C.small_co_wgrad_splits(dy_shape[0], dy_shape[1])
             dev = layer.weight.device
             e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, bias_off=n_w if has_bias else -1,
                      segments=segments,
@@ -514,7 +516,7 @@ class WgradBatch:
         """sn_ctx: None (plain layer), one SN context, or a tuple of `segments` contexts (one per
         batched forward; the pixel range is cut accordingly and each part gets its own correction)."""
         M = dy.numel() // dy.shape[-1]
-        e = self._entry(layer, slot, M, segments)
+        e = self._entry(layer, slot, M, segments, tuple(dy.shape))
         e['sn_ctx'] = sn_ctx
         C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro,
                           segments=segments)

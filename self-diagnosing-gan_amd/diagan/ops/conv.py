@@ -15,6 +15,9 @@ nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I])
 nat.register("diagan_conv3x3_co4_supported", [I] * 8)
 nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P])
+nat.register("diagan_conv3x3_co4_wgrad_supported", [I] * 8)
+nat.register("diagan_conv3x3_co4_wgrad_splits", [I, I])
+nat.register("diagan_conv3x3_co4_wgrad", [P, P, P, I64, I64, P, P, I, I, I, I, I, I, P])
 nat.register("diagan_conv_wgrad", [P, P, P, I, I, I64, I64, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_pack_batched", [P, I, I, I, I, I, P])
 nat.register("diagan_wgrad_finish_batched", [P, I, I64, I, P])
@@ -256,6 +259,17 @@ def wgrad_splits(M, Co, Kp):
     return nat.fn("diagan_conv_wgrad_splits")(M, Co, Kp)
 
 
+def small_co_wgrad(geom):
+    """True if the layer's weight gradient has the dedicated 4-output-channel kernel."""
+    sy, dr, off, up = geom.fwd_params()
+    return bool(nat.fn("diagan_conv3x3_co4_wgrad_supported")(geom.Ci, geom.Co, geom.R, geom.S, sy, dr, off, up)
+                and geom.Kp == 9 * geom.Ci)
+
+
+def small_co_wgrad_splits(B, H):
+    return nat.fn("diagan_conv3x3_co4_wgrad_splits")(B, H)
+
+
 def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segments=1):
     """Split-K weight (+bias) gradient partials into a caller-owned slab [splits][stride]; the sum over
     splits is done later for all layers at once (diagan_wgrad_finish_batched)."""
@@ -263,6 +277,16 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
     _, Hi, Wi, Ci = x.shape
     mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
     sy, dr, off, up = geom.fwd_params()
+    if segments == 1 and small_co_wgrad(geom):
+        if splits != small_co_wgrad_splits(B, Ho):
+            raise RuntimeError(f"conv_wgrad_into: slab has {splits} splits, the 4-channel kernel writes "
+                               f"{small_co_wgrad_splits(B, Ho)}")
+        t0 = TIMER.begin("conv3x3_co4_wgrad_kernel") if TIMER is not None else None
+        nat.call("diagan_conv3x3_co4_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), stride, bias_off, nat.ptr(scale),
+                 nat.ptr(shift), mode, B, Hi, Wi, Ci, geom.Kp, nat.current_stream())
+        if t0 is not None:
+            TIMER.end("conv3x3_co4_wgrad_kernel", 2.0 * B * Ho * Wo * Co * 9 * Ci, t0, (B * Ho * Wo, Co, 9 * Ci, f"pro{mode}"))
+        return
     t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode)) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,

@@ -164,6 +164,33 @@ def test_small_co_kernel_fwd_and_dgrad(Ci, H, W, B, pro):
         close(nchw(dx)[:, :3], xi.grad)
 
 
+@pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
+@pytest.mark.parametrize("pro", [0, 1, 2])
+def test_small_co_kernel_wgrad(Ci, H, W, B, pro):
+    """conv3x3_co4_wgrad: weight + bias gradient of a 3x3 conv to 4 (RGB+pad) channels, partial slabs summed
+    over splits, against autograd of F.conv2d on the prologue-transformed input."""
+    from diagan.ops import conv as C
+    g = torch.Generator().manual_seed(Ci + pro)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    w = (torch.randn(4, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).requires_grad_(True)
+    bias = torch.zeros(4, requires_grad=True)
+    y = F.conv2d(ref_pro(x, pro, scale, shift), w, bias, padding=1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    geom = C.Geom("conv", Ci, 4, 3, 3, 1, 1)
+    assert C.small_co_wgrad(geom)
+    splits = C.small_co_wgrad_splits(B, H)
+    stride = 4 * geom.Kp + 4
+    slab = torch.full((splits, stride), float('nan'), device="cuda")
+    C.conv_wgrad_into(geom, nhwc(dy).cuda(), nhwc(x).cuda(), slab, splits, stride, 4 * geom.Kp,
+                      pro=(pro, scale.cuda(), shift.cuda()))
+    tot = slab.double().sum(0).float().cpu()
+    assert torch.isfinite(tot).all()
+    close(C.unpack_oihw(tot[:4 * geom.Kp].view(4, geom.Kp), 4, Ci, 3, 3), w.grad)
+    close(tot[4 * geom.Kp:], bias.grad)
+
+
 def test_full_size_sngan32_g_block4():
     """BASELINE configs[1] dominant GEMM: M=65536, N=256, K=2304 (SNGAN G-32 block4.c1)."""
     from diagan.ops import conv as C
