@@ -235,11 +235,11 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     slab = _slab(dy.device, splits * n_elem + extra)
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
-    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode)) if TIMER is not None else None
+    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo)) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode), 2.0 * M * Co * geom.R * geom.S * Ci, t0)
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo), 2.0 * M * Co * geom.R * geom.S * Ci, t0)
     if sn is None:
         nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
                  None, None, st)
@@ -287,20 +287,24 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
         if t0 is not None:
             TIMER.end("conv3x3_co4_wgrad_kernel", 2.0 * B * Ho * Wo * Co * 9 * Ci, t0, (B * Ho * Wo, Co, 9 * Ci, f"pro{mode}"))
         return
-    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode)) if TIMER is not None else None
+    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo)) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode), 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo), 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
                   (B * Ho * Wo, Co, geom.R * geom.S * Ci, f"pro{mode}"))
 
 
-def _wgrad_kernel_name(Co, Kp, mode=0):
+def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0):
+    """Kernel name as rocprofv3 prints it (template arguments BNn, BNk, PRO, P2)."""
     bn, bk = (64 if Co <= 64 else 128), (64 if Kp <= 64 else 128)
     if bn == 128 and bk == 64:
         bn = 64
-    return f"conv_wgrad_kernel<{bn},{bk},{mode if bn == 128 else -1}>"
+    if bn != 128:
+        return f"conv_wgrad_kernel<{bn},{bk},-1,false>"
+    p2 = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
+    return f"conv_wgrad_kernel<128,128,{mode},{'true' if p2 else 'false'}>"
 
 
 def sn_power_iter(W, u_buffer, sigma_buffer, training=True, eps=1e-12):
