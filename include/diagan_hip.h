@@ -232,7 +232,9 @@ int diagan_upsample2x_bwd(const float* g, float* out, int B, int H, int W, int C
                           void* stream);
 
 /* F.avg_pool2d(x, 2) (+ residual at the pooled resolution) and its adjoint (+ residual). H, W = input size. */
-int diagan_avgpool2(const float* x, float* out, int B, int H, int W, int C, const float* residual, void* stream);
+/* out = avgpool2x2(relu_in ? max(x,0) : x) + residual */
+int diagan_avgpool2(const float* x, float* out, int B, int H, int W, int C, const float* residual, int relu_in,
+                    void* stream);
 int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
                         void* stream);
 

@@ -437,26 +437,28 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   wgrad_tile(Co, Kp, &bn, &bk);
   const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
   const dim3 grid(tiles, splits);
+  // one straight-line kernel per prologue mode (x power-of-two image or not) for the two production tiles
+  const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
+  a.lgW = a.lgHW = 0;
+  while ((1 << a.lgW) < Wo) ++a.lgW;
+  while ((1 << a.lgHW) < Ho * Wo) ++a.lgHW;
+#define DG_WG(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_kernel<BN_, 128, PRO_, true>), grid, dim3(256), 0, st, a); \
+                              else hipLaunchKernelGGL((conv_wgrad_kernel<BN_, 128, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
+#define DG_WG_ALL(BN_) switch (pro_mode) { \
+      case PRO_NONE: DG_WG(BN_, PRO_NONE); break; \
+      case PRO_RELU: DG_WG(BN_, PRO_RELU); break; \
+      case PRO_AFFINE_RELU: DG_WG(BN_, PRO_AFFINE_RELU); break; \
+      case PRO_LRELU: DG_WG(BN_, PRO_LRELU); break; \
+      default: DG_WG(BN_, PRO_AFFINE); break; }
   if (bn == 64 && bk == 64) {
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
   } else if (bn == 64) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
-  } else {   // the production tile: one straight-line kernel per prologue mode (x power-of-two image or not)
-    const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
-    a.lgW = a.lgHW = 0;
-    while ((1 << a.lgW) < Wo) ++a.lgW;
-    while ((1 << a.lgHW) < Ho * Wo) ++a.lgHW;
-#define DG_WG(PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_, true>), grid, dim3(256), 0, st, a); \
-                         else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
-    switch (pro_mode) {
-      case PRO_NONE: DG_WG(PRO_NONE); break;
-      case PRO_RELU: DG_WG(PRO_RELU); break;
-      case PRO_AFFINE_RELU: DG_WG(PRO_AFFINE_RELU); break;
-      case PRO_LRELU: DG_WG(PRO_LRELU); break;
-      default: DG_WG(PRO_AFFINE); break;
-    }
-#undef DG_WG
+    DG_WG_ALL(64)
+  } else {
+    DG_WG_ALL(128)
   }
+#undef DG_WG_ALL
+#undef DG_WG
   return check_launch("conv_wgrad");
 }
 

@@ -349,7 +349,7 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ g, float* __rest
 
 // ---- 2x2 average pool and its adjoint ----------------------------------------------------------
 __global__ void avgpool2_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
-                                const float* __restrict__ residual) {
+                                const float* __restrict__ residual, int relu_in) {
   const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const long n4 = (long)B * Ho * Wo * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -359,9 +359,15 @@ __global__ void avgpool2_kernel(const float* __restrict__ x, float* __restrict__
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
     const float* base = x + (((long)b * H + 2 * oy) * W + 2 * ox) * C + c4 * 4;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + C);
-    const f32x4 a2 = *reinterpret_cast<const f32x4*>(base + (long)W * C);
-    const f32x4 a3 = *reinterpret_cast<const f32x4*>(base + (long)W * C + C);
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(base), a1 = *reinterpret_cast<const f32x4*>(base + C);
+    f32x4 a2 = *reinterpret_cast<const f32x4*>(base + (long)W * C);
+    f32x4 a3 = *reinterpret_cast<const f32x4*>(base + (long)W * C + C);
+    if (relu_in) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = fmaxf(a0[e], 0.f); a1[e] = fmaxf(a1[e], 0.f); a2[e] = fmaxf(a2[e], 0.f); a3[e] = fmaxf(a3[e], 0.f);
+      }
+    }
     f32x4 o = ((a0 + a1) + (a2 + a3)) * 0.25f;
     if (residual) o += reinterpret_cast<const f32x4*>(residual)[i];
     reinterpret_cast<f32x4*>(out)[i] = o;
@@ -673,11 +679,11 @@ DIAGAN_API int diagan_upsample2x_bwd(const float* g, float* out, int B, int H, i
 }
 
 DIAGAN_API int diagan_avgpool2(const float* x, float* out, int B, int H, int W, int C, const float* residual,
-                               void* stream) {
+                               int relu_in, void* stream) {
   DG_REQUIRE(x && out && B > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0 && C > 0 && (C & 3) == 0,
              "avgpool2: bad args (even H, W required)");
   hipLaunchKernelGGL(avgpool2_kernel, dim3(ew_blocks((long)B * H * W * C / 16)), dim3(EW_T), 0, ST, x, out, B, H, W, C,
-                     residual);
+                     residual, relu_in);
   return check_launch("avgpool2");
 }
 

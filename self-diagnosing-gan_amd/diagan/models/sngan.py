@@ -114,19 +114,31 @@ class DBlock(nn.Module):
         k1 = self.c1.prepare(training, need_dgrad, slot)
         k2 = self.c2.prepare(training, need_dgrad, slot)
         h1 = self.c1.fwd(k1, x, pro=RELU)
-        if self.learnable_sc:
+        xp = None
+        # (the batched D(real)+D(fake) weight gradient cuts the pixel range in two segments of whole 32-pixel
+        #  K-steps: keep the full-resolution shortcut when the pooled tensor is too small for that)
+        lo_ok = (x.shape[0] * (x.shape[1] // 2) * (x.shape[2] // 2)) % 64 == 0
+        if self.learnable_sc and self.downsample and lo_ok:
+            # avg_pool2d(c_sc(relu x)) == c_sc(avg_pool2d(relu x)) for the 1x1 shortcut conv: pool first (4x fewer
+            # FLOP and bytes in its forward / dgrad / wgrad), add the low-resolution shortcut in the pooling of c2
+            ksc = self.c_sc.prepare(training, need_dgrad, slot)
+            xp = E.avgpool2(x, relu_in=True)
+            sc = self.c_sc.fwd(ksc, xp)
+            out = E.avgpool2(self.c2.fwd(k2, h1, pro=RELU), residual=sc)
+        elif self.learnable_sc:
             ksc = self.c_sc.prepare(training, need_dgrad, slot)
             sc = self.c_sc.fwd(ksc, x, pro=RELU)
             h2 = self.c2.fwd(k2, h1, pro=RELU, residual=sc)
+            out = E.avgpool2(h2) if self.downsample else h2
         else:
             ksc = None
             h2 = self.c2.fwd(k2, h1, pro=RELU, residual=x, res_relu=True)
-        out = E.avgpool2(h2) if self.downsample else h2
-        ctx = dict(x=x, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=0 if slot is None else slot) if save else {}
+            out = E.avgpool2(h2) if self.downsample else h2
+        ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=0 if slot is None else slot) if save else {}
         return out, ctx
 
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
-        x, h1, slot = ctx['x'], ctx['h1'], ctx['slot']
+        x, xp, h1, slot = ctx['x'], ctx['xp'], ctx['h1'], ctx['slot']
         hw = x.shape[1:3]
         g_full = E.avgpool2_bwd(gout) if self.downsample else gout
         if need_wgrad:
@@ -134,10 +146,15 @@ class DBlock(nn.Module):
         g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
         if need_wgrad:
             self.c1.wgrad(ctx['k1'], g_h1, x, pro=RELU, slot=slot)
-            if self.learnable_sc:
+            if xp is not None:
+                self.c_sc.wgrad(ctx['ksc'], gout, xp, slot=slot)
+            elif self.learnable_sc:
                 self.c_sc.wgrad(ctx['ksc'], g_full, x, pro=RELU, slot=slot)
         if not need_gx:
             return None
+        if xp is not None:
+            tmp = E.avgpool2_bwd(self.c_sc.dgrad(ctx['ksc'], gout, xp.shape[1:3]))
+            return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=tmp, mask_src=x)
         if self.learnable_sc:
             tmp = self.c_sc.dgrad(ctx['ksc'], g_full, hw)
             return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=tmp, mask_src=x)

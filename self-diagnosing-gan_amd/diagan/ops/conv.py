@@ -301,10 +301,10 @@ def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0):
     bn, bk = (64 if Co <= 64 else 128), (64 if Kp <= 64 else 128)
     if bn == 128 and bk == 64:
         bn = 64
-    if bn != 128:
+    if bk != 128:
         return f"conv_wgrad_kernel<{bn},{bk},-1,false>"
     p2 = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
-    return f"conv_wgrad_kernel<128,128,{mode},{'true' if p2 else 'false'}>"
+    return f"conv_wgrad_kernel<{bn},128,{mode},{'true' if p2 else 'false'}>"
 
 
 def sn_power_iter(W, u_buffer, sigma_buffer, training=True, eps=1e-12):

@@ -22,7 +22,7 @@ nat.register("diagan_linear1_wgrad", [P, P, P, P, I, I, P])
 nat.register("diagan_colsum", [P, I64, I, P, I, P, P])
 nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, P])
 nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
-nat.register("diagan_avgpool2", [P, P, I, I, I, I, P, P])
+nat.register("diagan_avgpool2", [P, P, I, I, I, I, P, I, P])
 nat.register("diagan_avgpool2_bwd", [P, P, I, I, I, I, P, P])
 nat.register("diagan_head_fwd", [P, P, P, P, I, P, P, P, I, I, I, P])
 nat.register("diagan_head_bwd", [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P])
@@ -148,10 +148,10 @@ def upsample2x_bwd(g, residual=None):
     return out
 
 
-def avgpool2(x, residual=None):
+def avgpool2(x, residual=None, relu_in=False):
     B, H, W, C = x.shape
     out = _f32((B, H // 2, W // 2, C), x.device)
-    nat.call("diagan_avgpool2", ptr(x), ptr(out), B, H, W, C, ptr(residual), st())
+    nat.call("diagan_avgpool2", ptr(x), ptr(out), B, H, W, C, ptr(residual), 1 if relu_in else 0, st())
     return out
 
 
