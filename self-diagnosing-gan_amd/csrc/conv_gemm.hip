@@ -19,6 +19,7 @@
 //
 // Roofline: MFMA fp32 (algorithmic FLOP = 2*M*Co*K).
 #include "conv_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace diagan {
@@ -232,38 +233,75 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     __syncthreads();
   }
 
-  const float sc0 = a.scale0 ? a.scale0[0] : 1.f, sc1 = a.scale1 ? a.scale1[0] : 1.f;
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
+  // Straight-line per variant (residual / mask / statistics / raw split-K partials are compile-time flags of the
+  // lambda below) with raw buffer accesses: one 32-bit lane offset per accumulator tile plus a SCALAR row offset
+  // per element, rows past M and columns past Co dropped by the range check.  (The former per-element 64-bit
+  // index arithmetic and uniform branches made the epilogue ~12 us per tile -- longer than 25 K-steps.)
+  const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
+  const int split = a.scale0 ? a.scale_split : 0x7fffffff;
+  const unsigned rowbytes = (unsigned)g.Co * 4u;
+  const unsigned ybytes = (unsigned)a.M * rowbytes;
+  float* ydst = a.ksplit > 1 ? a.slab + (long)blockIdx.y * a.M * g.Co : a.y;
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(ydst, 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.residual ? a.residual : a.y), 0, a.residual ? (int)ybytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.mask_src ? a.mask_src : a.y), 0, a.mask_src ? (int)ybytes : 0, 0x00020000);
+  const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();   // max(r, rfloor): relu(r) or r
   float cs1[TN], cs2[TN];   // fused BatchNorm statistics: column sums of the stored values
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs1[j] = cs2[j] = 0.f;
-  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  auto epilogue = [&](auto has_res, auto has_mask, auto has_stats, auto raw) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (TN * 32) + j * 32 + fi;
-      if (n >= g.Co) continue;
-      const float bv = a.bias ? a.bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (TN * 32) + j * 32 + fi;
+        const bool col_ok = n < g.Co;
+        const float bv = (!decltype(raw)::value && a.bias && col_ok) ? a.bias[n] : 0.f;
+        const int mrow = m0 + wm * (TM * 32) + i * 32 + 4 * fh;
+        const unsigned vbase = col_ok ? ((unsigned)mrow * g.Co + n) * 4u : 0x80000000u;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (m >= a.M) continue;
-        const long o = (long)m * g.Co + n;
-        if (a.ksplit > 1) {
-          a.slab[(long)blockIdx.y * a.M * g.Co + o] = acc[i][j][e];
-          continue;
-        }
-        const float sc = a.scale0 ? (m < a.scale_split ? sc0 : sc1) : a.out_scale;
-        float v = acc[i][j][e] * sc + bv;
-        if (a.residual) { const float r = a.residual[o]; v += a.res_relu ? fmaxf(r, 0.f) : r; }
-        if (a.mask_src) v = a.mask_src[o] > 0.f ? v : v * a.mask_slope;
-        a.y[o] = v;
-        if (a.stat_partials) {
-          cs1[j] += v;
-          cs2[j] = fmaf(v, v, cs2[j]);
+        for (int e = 0; e < 16; ++e) {
+          const int k = (e & 3) + 8 * (e >> 2);
+          const int soff = (int)(k * rowbytes);
+          const float av = acc[i][j][e];
+          if (decltype(raw)::value) {
+            // (__float_as_uint of a scalar copy: bit_cast of the vector element was miscompiled to element 0 here)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), ysrc, vbase, soff, 0);
+            continue;
+          }
+          const int m = mrow + k;
+          float v = fmaf(av, m < split ? sc0 : sc1, bv);
+          if (decltype(has_res)::value) {
+            const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vbase, soff, 0));
+            v += fmaxf(r, rfloor);
+          }
+          if (decltype(has_mask)::value) {
+            const float ms = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msrc, vbase, soff, 0));
+            v = ms > 0.f ? v : v * a.mask_slope;
+          }
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ysrc, vbase, soff, 0);
+          if (decltype(has_stats)::value) {
+            const float vm = (m < a.M && col_ok) ? v : 0.f;
+            cs1[j] += vm;
+            cs2[j] = fmaf(vm, vm, cs2[j]);
+          }
         }
       }
     }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    const bool hr = a.residual != nullptr, hm = a.mask_src != nullptr, hs = a.stat_partials != nullptr;
+    if (a.ksplit > 1) epilogue(F{}, F{}, F{}, T{});
+    else if (hs) { if (hr) epilogue(T{}, F{}, T{}, F{}); else epilogue(F{}, F{}, T{}, F{}); }   // statistics: forward only (no mask)
+    else if (hr && hm) epilogue(T{}, T{}, F{}, F{});
+    else if (hr) epilogue(T{}, F{}, F{}, F{});
+    else if (hm) epilogue(F{}, T{}, F{}, F{});
+    else epilogue(F{}, F{}, F{}, F{});
   }
   if (a.stat_partials) {
     // combine the two half-waves (same column), then the WM wave rows through LDS (tiles are done with it)
@@ -419,6 +457,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.mask_slope = mask_slope; a.out_scale = out_scale;
   a.scale0 = scale0; a.scale1 = scale1; a.scale_split = scale_split;
   DG_REQUIRE(!scale0 || scale1, "conv_gemm: scale0 and scale1 must be given together");
+  DG_REQUIRE(!(stat_partials && mask_src), "conv_gemm: stat_partials (forward statistics) and mask_src (backward mask) are exclusive");
   a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   hipStream_t st = (hipStream_t)stream;
