@@ -52,6 +52,26 @@ __device__ __forceinline__ f32x4 apply_pro(f32x4 v, int mode, const float* __res
   return v;
 }
 
+struct FastDiv {  // unsigned division by a runtime constant: q = (n * mul) >> 32 >> shift  (n < 2^31)
+  unsigned mul, shift, d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  unsigned l = 0;
+  while ((1u << l) < d) ++l;                                   // ceil(log2 d)
+  const unsigned long long m = ((1ull << (32 + l)) + d - 1) / d;  // needs 33 bits in general
+  f.mul = (unsigned)(m - (1ull << 32));
+  f.shift = l;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  const unsigned t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
 // Bijective XCD-aware remap of a linear workgroup id (cdna guide T1): consecutive logical tiles
 // land on the same XCD (= same L2), so neighbouring tiles share halo rows and weight panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -45,6 +45,7 @@ struct ConvGemmArgs {
   int pro_mode;
   int M;                  // B*Ho*Wo
   ConvGeom g;
+  FastDiv dWo, dHo;       // pixel index -> (b, oy, ox) without integer division
 };
 
 template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1>
@@ -86,18 +87,30 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     base[j] = 0;
     vmask[j] = 0;
     if (m < a.M) {
-      const int ox = m % g.Wo, t = m / g.Wo;
-      const int oy = t % g.Ho, b = t / g.Ho;
+      const unsigned t = fdiv((unsigned)m, a.dWo);
+      const int ox = m - (int)t * g.Wo;
+      const unsigned b = fdiv(t, a.dHo);
+      const int oy = (int)t - (int)b * g.Ho;
       const int iy0 = oy * g.sy + g.off, ix0 = ox * g.sy + g.off;
-      base[j] = b * g.Hi * g.Wi * g.Ci * 4 + (iy0 * g.Wi + ix0) * pstep;
+      base[j] = (int)b * g.Hi * g.Wi * g.Ci * 4 + (iy0 * g.Wi + ix0) * pstep;
       unsigned mk = 0;
-      for (int r = 0; r < g.R; ++r) {
-        const int yn = iy0 + r * g.dr;
-        if (yn >= 0 && (yn & upm) == 0 && (yn >> ush) < g.Hi) mk |= 1u << r;
-      }
-      for (int q = 0; q < g.S; ++q) {
-        const int xn = ix0 + q * g.dr;
-        if (xn >= 0 && (xn & upm) == 0 && (xn >> ush) < g.Wi) mk |= 0x10000u << q;
+      if (g.up == 1) {
+        // closed form: taps r with 0 <= iy0 + r*dr < Hi form one interval [lo, hi]
+        const int ylo = g.dr > 0 ? max(0, -iy0) : max(0, iy0 - g.Hi + 1);
+        const int yhi = g.dr > 0 ? min(g.R - 1, g.Hi - 1 - iy0) : min(g.R - 1, iy0);
+        const int xlo = g.dr > 0 ? max(0, -ix0) : max(0, ix0 - g.Wi + 1);
+        const int xhi = g.dr > 0 ? min(g.S - 1, g.Wi - 1 - ix0) : min(g.S - 1, ix0);
+        if (yhi >= ylo) mk |= (2u << yhi) - (1u << ylo);
+        if (xhi >= xlo) mk |= ((2u << xhi) - (1u << xlo)) << 16;
+      } else {
+        for (int r = 0; r < g.R; ++r) {
+          const int yn = iy0 + r * g.dr;
+          if (yn >= 0 && (yn & upm) == 0 && (yn >> ush) < g.Hi) mk |= 1u << r;
+        }
+        for (int q = 0; q < g.S; ++q) {
+          const int xn = ix0 + q * g.dr;
+          if (xn >= 0 && (xn & upm) == 0 && (xn >> ush) < g.Wi) mk |= 0x10000u << q;
+        }
       }
       vmask[j] = mk;
     }
@@ -460,6 +473,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   DG_REQUIRE(!(stat_partials && mask_src), "conv_gemm: stat_partials (forward statistics) and mask_src (backward mask) are exclusive");
   a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
+  a.dWo = make_fastdiv((unsigned)Wo);
+  a.dHo = make_fastdiv((unsigned)Ho);
   hipStream_t st = (hipStream_t)stream;
   const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp) : tile_cfg;
   a.slab = splitk_ws;

@@ -18,26 +18,6 @@
 
 namespace diagan {
 
-struct FastDiv {  // unsigned division by a runtime constant: q = (n * mul) >> 32 >> shift  (n < 2^31)
-  unsigned mul, shift, d;
-};
-static FastDiv make_fastdiv(unsigned d) {
-  FastDiv f;
-  f.d = d;
-  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
-  unsigned l = 0;
-  while ((1u << l) < d) ++l;                                   // ceil(log2 d)
-  const unsigned long long m = ((1ull << (32 + l)) + d - 1) / d;  // needs 33 bits in general
-  f.mul = (unsigned)(m - (1ull << 32));
-  f.shift = l;
-  return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-  if (f.d == 1) return n;
-  const unsigned t = __umulhi(n, f.mul);
-  return (t + ((n - t) >> 1)) >> (f.shift - 1);
-}
-
 struct WgradArgs {
   const float* dy;        // pixel tensor [M][Co]
   const float* x;         // gathered tensor NHWC [B,Hi,Wi,Ci]
@@ -232,16 +212,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   float* out = a.slab + (long)split * a.slab_stride;
   if (do_bias && n0 + tid < g.Co) out[a.bias_off + n0 + tid] = bsum;
+  // raw buffer stores: one lane offset per accumulator tile + a scalar row offset per element; rows past Co fall
+  // outside num_records, columns past Kp get the out-of-range bit (see the epilogue of conv_gemm.hip)
+  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
+  const unsigned rowbytes = (unsigned)g.Kp * 4u;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int k = k0 + wn * (TN * 32) + j * 32 + fi;
-      if (k >= g.Kp) continue;
+      const int nrow = n0 + wm * (TM * 32) + i * 32 + 4 * fh;
+      const unsigned vbase = k < g.Kp ? ((unsigned)nrow * g.Kp + k) * 4u : 0x80000000u;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int n = n0 + wm * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (n < g.Co) out[(long)n * g.Kp + k] = acc[i][j][e];
+        const float av = acc[i][j][e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), osrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0);
       }
     }
 }
@@ -413,6 +398,7 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
              "conv_wgrad: affine prologue needs scale/shift");
   DG_REQUIRE(slab_stride >= (int64_t)Co * Kp && (bias_off < 0 || bias_off + Co <= slab_stride),
              "conv_wgrad: slab_stride=%ld too small for Co*Kp=%ld (+bias)", (long)slab_stride, (long)Co * Kp);
+  DG_REQUIRE((long)Co * Kp * 4 < (1L << 31), "conv_wgrad: weight tensor must be smaller than 2 GiB");
   DG_REQUIRE((long)B * Ho * Wo * Co * 4 < (1L << 31) && (long)B * Hi * Wi * Ci * 4 < (1L << 31),
              "conv_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
   WgradArgs a;
