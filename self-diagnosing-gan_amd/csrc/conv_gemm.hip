@@ -169,11 +169,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     kc += BK;
     while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
   };
-  auto store_tiles = [&](int buf) {
-    float* Ad = As + buf * BM * BK;
-    float* Bd = Bs + buf * BN * BK;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
+  // one 16-byte piece of the next tile: prologue on its way from the staging registers to LDS
+  auto store_piece = [&](int buf, int p) {
+    if (p < AJ) {
+      const int j = p;
       const int row = lrow + RP * j;
       f32x4 v = ra[j];
       if (pro_mode != PRO_NONE) {
@@ -190,13 +189,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
           v *= keep;
         }
       }
-      *reinterpret_cast<f32x4*>(Ad + row * BK + (swz(row, lq) << 2)) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
+      *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK + (swz(row, lq) << 2)) = v;
+    } else {
+      const int j = p - AJ;
       const int row = lrow + RP * j;
-      *reinterpret_cast<f32x4*>(Bd + row * BK + (swz(row, lq) << 2)) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK + (swz(row, lq) << 2)) = rb[j];
     }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < AJ + BJ; ++p) store_piece(buf, p);
   };
 
   f32x16 acc[TM][TN];
@@ -215,9 +217,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   }
   __syncthreads();
 
-  for (int kk = k_begin; kk < k_end; ++kk) {
+  // One K-step: the next tile's global loads are issued first; its AJ+BJ pieces are then written to the OTHER
+  // LDS buffer one per e-step during the LAST e-steps of this tile's MFMAs: an MFMA occupies the matrix pipe for
+  // 64 cycles after it issues, so the ~15 VALU / LDS-write instructions of a piece ride in its shadow instead of
+  // forming a store phase after the MFMAs during which the pipe has nothing from this workgroup.
+  constexpr int NE = (BK / 8) * 4, NP = AJ + BJ;
+  static_assert(NP <= NE, "more staging pieces than e-steps");
+  auto kstep = [&](int kk, auto has_next) {
     const int cur = (kk - k_begin) & 1;
-    if (kk + 1 < k_end) load_tiles(kk + 1);  // global loads in flight under the MFMAs below
+    if (decltype(has_next)::value) load_tiles(kk + 1);
     const float* Ac = As + cur * BM * BK;
     const float* Bc = Bs + cur * BN * BK;
 #pragma unroll
@@ -235,16 +243,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         fb[j] = *reinterpret_cast<const f32x4*>(Bc + row * BK + (swz(row, q) << 2));
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
+        const int es = u * 4 + e;
+        if (decltype(has_next)::value && es >= NE - NP) {
+          __builtin_amdgcn_sched_barrier(0);   // keep the piece HERE: hoisted to the top it would wait for its load first
+          store_piece(cur ^ 1, es - (NE - NP));
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+      }
     }
-    if (kk + 1 < k_end) store_tiles(cur ^ 1);
     __syncthreads();
-  }
+  };
+  for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+  if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
   // Straight-line per variant (residual / mask / statistics / raw split-K partials are compile-time flags of the
@@ -275,6 +291,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         const float bv = (!decltype(raw)::value && a.bias && col_ok) ? a.bias[n] : 0.f;
         const int mrow = m0 + wm * (TM * 32) + i * 32 + 4 * fh;
         const unsigned vbase = col_ok ? ((unsigned)mrow * g.Co + n) * 4u : 0x80000000u;
+        // all residual / mask loads of the tile first: issued back to back, not one round trip per element
+        float rres[16], rmsk[16];
+        if (decltype(has_res)::value) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            rres[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    rsrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0));
+        }
+        if (decltype(has_mask)::value) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            rmsk[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                    msrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0));
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int k = (e & 3) + 8 * (e >> 2);
@@ -287,14 +317,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
           }
           const int m = mrow + k;
           float v = fmaf(av, m < split ? sc0 : sc1, bv);
-          if (decltype(has_res)::value) {
-            const float r = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vbase, soff, 0));
-            v += fmaxf(r, rfloor);
-          }
-          if (decltype(has_mask)::value) {
-            const float ms = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(msrc, vbase, soff, 0));
-            v = ms > 0.f ? v : v * a.mask_slope;
-          }
+          if (decltype(has_res)::value) v += fmaxf(rres[e], rfloor);
+          if (decltype(has_mask)::value) v = rmsk[e] > 0.f ? v : v * a.mask_slope;
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ysrc, vbase, soff, 0);
           if (decltype(has_stats)::value) {
             const float vm = (m < a.M && col_ok) ? v : 0.f;
