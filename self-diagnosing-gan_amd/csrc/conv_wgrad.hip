@@ -15,6 +15,7 @@
 // Roofline: MFMA fp32 (algorithmic FLOP = 2*M*Co*K).
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace diagan {
 
@@ -35,6 +36,8 @@ struct WgradArgs {
   FastDiv dWo, dHo;
   int adv_b, adv_y, adv_x;  // 32 pixels = adv_b images + adv_y rows + adv_x columns (pixel coordinates advance incrementally)
   int lgW, lgHW;            // log2(Wo), log2(Ho*Wo) when both are powers of two (P2 kernels)
+  int tiles;                // output tiles (the grid is tiles * splits workgroups)
+  int same;                 // stride-1, un-dilated, same-size conv (Hi == Ho, Wi == Wo): linear gather offsets
 };
 
 // P2: Ho and Wo are powers of two -- pixel coordinates come from shifts and masks of the pixel index instead of
@@ -53,10 +56,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_k = (g.Kp + BNk - 1) / BNk;
-  const int nwg = gridDim.x;
-  const int tile = xcd_remap(blockIdx.x, nwg);
+  // 1-D grid of tiles x splits, XCD-aware: consecutive logical ids -- the tiles of ONE split, which share its dy
+  // rows and re-read the same x rows tap by tap -- land on the same XCD (= the same L2)
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / a.tiles, tile = logical - split * a.tiles;
   const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
-  const int split = blockIdx.y;
   const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
   const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
   const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
@@ -102,38 +106,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     pb[j] = (int)b;
   }
   int mstep = step0 * BK;
+  unsigned xoff[BJ];         // (P2 && same) linear offsets of the gathered rows
+  const unsigned xstep = (unsigned)BK * g.Ci * 4u;
+#pragma unroll
+  for (int j = 0; j < BJ; ++j)
+    xoff[j] = (unsigned)((step0 * BK + bp + BPR * j + dyo * g.Wi + dxo) * g.Ci * 4 + kc * 4);
   unsigned aoff[AJ];
 #pragma unroll
   for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
   const unsigned astep = (unsigned)BK * g.Co * 4u;
   f32x4 ra[AJ], rb[BJ];
   unsigned bmask = 0;
-  auto load_tiles = [&]() {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {     // rows past M fall outside num_records
-      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[j] | a_kill, 0, 0));
-      aoff[j] += astep;
+  // one 16-byte load of the next tile (piece p < AJ: dy rows; else gathered x rows with their coordinates)
+  auto load_piece = [&](int p) {
+    if (p < AJ) {     // rows past M fall outside num_records
+      ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[p] | a_kill, 0, 0));
+      aoff[p] += astep;
+      return;
     }
-    bmask = 0;
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-      int pbj, pyj, pxj;
-      if (P2) {
-        const int m = mstep + bp + BPR * j;
-        pxj = m & (g.Wo - 1);
-        pyj = (m >> a.lgW) & (g.Ho - 1);
-        pbj = m >> a.lgHW;
-      } else {
-        pbj = pb[j]; pyj = py[j]; pxj = px[j];
-      }
-      const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
-      const bool ok = b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0;
+    const int j = p - AJ;
+    if (j == 0) bmask = 0;
+    if (P2 && a.same) {
+      // same-size stride-1 conv on a power-of-two image: the gathered offset is LINEAR in the pixel index
+      // (m*Ci*4 + a per-thread tap constant); only the border test needs (oy, ox), from shifts and masks
+      const int m = mstep + bp + BPR * j;
+      const int yn = ((m >> a.lgW) & (g.Ho - 1)) + dyo, xn = (m & (g.Wo - 1)) + dxo;
+      const bool ok = b_ok && m < a.M && (unsigned)yn < (unsigned)g.Hi && (unsigned)xn < (unsigned)g.Wi;
       const unsigned okb = ok ? 1u : 0u;
-      const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[j] | ((okb ^ 1u) << 31), 0, 0));
+      xoff[j] += xstep;
       bmask |= okb << j;
-      if (P2) continue;
-      // advance to the same row of the next K-step
+      if (j == BJ - 1) mstep += BK;
+      return;
+    }
+    int pbj, pyj, pxj;
+    if (P2) {
+      const int m = mstep + bp + BPR * j;
+      pxj = m & (g.Wo - 1);
+      pyj = (m >> a.lgW) & (g.Ho - 1);
+      pbj = m >> a.lgHW;
+    } else {
+      pbj = pb[j]; pyj = py[j]; pxj = px[j];
+    }
+    const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
+    const bool ok = b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0;
+    const unsigned okb = ok ? 1u : 0u;
+    const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
+    rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+    bmask |= okb << j;
+    if (!P2) {      // advance to the same row of the next K-step
       int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
       const int cx = x >= g.Wo ? 1 : 0;
       x -= cx ? g.Wo : 0;
@@ -143,14 +164,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       b += cy;
       px[j] = x; py[j] = y; pb[j] = b;
     }
-    mstep += BK;
+    if (j == BJ - 1) mstep += BK;
   };
-  auto store_tiles = [&](int buf) {
+  auto load_tiles = [&]() {
 #pragma unroll
-    for (int j = 0; j < AJ; ++j)
-      *reinterpret_cast<f32x4*>(&As[buf][(ap + APR * j) * BNn + ac * 4]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
+    for (int p = 0; p < AJ + BJ; ++p) load_piece(p);
+  };
+  // one 16-byte piece of the next tile (prologue applied on the way from the staging registers to LDS)
+  auto store_piece = [&](int buf, int p) {
+    if (p < AJ) {
+      *reinterpret_cast<f32x4*>(&As[buf][(ap + APR * p) * BNn + ac * 4]) = ra[p];
+    } else {
+      const int j = p - AJ;
       f32x4 v = rb[j];
       if (pro_mode != PRO_NONE) {
         if (affine) v = v * psc + psh;
@@ -165,6 +190,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       }
       *reinterpret_cast<f32x4*>(&Bs[buf][(bp + BPR * j) * BNk + bc * 4]) = v;
     }
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < AJ + BJ; ++p) store_piece(buf, p);
   };
 
   f32x16 acc[TM][TN];
@@ -183,32 +212,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     store_tiles(0);
   }
   __syncthreads();
-  for (int step = step0; step < step1; ++step) {
+  // One K-step (32 pixels): next tile's loads first; its AJ+BJ staging pieces are written to the other LDS buffer
+  // one per s-step during the LAST s-steps, in the shadow of the MFMAs (see conv_gemm.hip); the bias column sums
+  // are spread over the s-steps the same way.
+  constexpr int NS = BK / 2, NP = AJ + BJ;
+  static_assert(2 * NP <= NS, "load and store pieces of a tile must not share an s-step");
+  auto kstep = [&](int step, auto has_next) {
     const int cur = (step - step0) & 1;
-    if (step + 1 < step1) load_tiles();
     const float* Ac = As[cur];
     const float* Bc = Bs[cur];
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
+    // MFMA fragments are read one s-step AHEAD (two register sets): the LDS latency of step s+1 is covered by the
+    // 4 x 64 cycles of step s instead of opening a bubble in the matrix pipe every s-step
+    float fa[2][TM], fb[2][TN];
+    auto read_frag = [&](int s, int set) {
       const int p = 2 * s + fh;
-      float fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = Ac[p * BNn + wm * (TM * 32) + i * 32 + fi];
+      for (int i = 0; i < TM; ++i) fa[set][i] = Ac[p * BNn + wm * (TM * 32) + i * 32 + fi];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = Bc[p * BNk + wn * (TN * 32) + j * 32 + fi];
+      for (int j = 0; j < TN; ++j) fb[set][j] = Bc[p * BNk + wn * (TN * 32) + j * 32 + fi];
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) read_frag(s + 1, (s + 1) & 1);
+      if (decltype(has_next)::value && s < NP) {            // next tile's loads: one per s-step, first NP s-steps
+        __builtin_amdgcn_sched_barrier(0);
+        load_piece(s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (decltype(has_next)::value && s >= NS - NP) {      // ... and its LDS stores in the last NP s-steps
+        __builtin_amdgcn_sched_barrier(0);
+        store_piece(cur ^ 1, s - (NS - NP));
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+      if (do_bias) bsum += Ac[(2 * s) * BNn + tid] + Ac[(2 * s + 1) * BNn + tid];   // k0 == 0 tile column only
     }
-    if (do_bias) {  // bias gradient: column sums of this step's dy tile (only the k0 == 0 tile column)
-#pragma unroll 8
-      for (int p = 0; p < BK; ++p) bsum += Ac[p * BNn + tid];
-    }
-    if (step + 1 < step1) store_tiles(cur ^ 1);
     __syncthreads();
-  }
+  };
+  for (int step = step0; step + 1 < step1; ++step) kstep(step, std::true_type{});
+  if (step0 < step1) kstep(step1 - 1, std::false_type{});
 
   float* out = a.slab + (long)split * a.slab_stride;
   if (do_bias && n0 + tid < g.Co) out[a.bias_off + n0 + tid] = bsum;
@@ -422,7 +469,9 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   int bn, bk;
   wgrad_tile(Co, Kp, &bn, &bk);
   const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
-  const dim3 grid(tiles, splits);
+  a.tiles = tiles;
+  a.same = (Hi == Ho && Wi == Wo && sy == 1 && up == 1) ? 1 : 0;
+  const dim3 grid(tiles * splits);
   // one straight-line kernel per prologue mode (x power-of-two image or not) for the two production tiles
   const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
   a.lgW = a.lgHW = 0;
