@@ -70,7 +70,7 @@ int diagan_logit_scatter(const float* logit, const int64_t* idx, int64_t n, void
  *   epi: + bias[n], + residual (or max(residual,0) if res_relu), then (mask_src > 0 ? v : mask_slope*v).
  * Replaces F.conv2d / nn.ConvTranspose2d forward and their input gradient
  * (SNGAN blocks: SURVEY §8 a2-a7; DCGAN: diagan-pkg/diagan/models/mnist.py:55-71,163-190).
- * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto.
+ * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto, 1 = 128x128, 3 = 64x64.
  * scale0/scale1 (device scalars, optional): pixel rows m < scale_split are scaled by *scale0, the rest
  * by *scale1 instead of out_scale -- two forwards of one spectral-norm layer (different sigma) batched
  * into one GEMM on the un-normalised weight. */

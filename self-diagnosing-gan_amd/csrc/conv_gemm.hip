@@ -144,30 +144,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   f32x4 ra[AJ], rb[BJ], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   unsigned a_ok = 0;
 
-  auto load_tiles = [&](int kk) {
-    const int tapoff = kr * rowstep + ks * colstep + kc * 4;
-    const int krs = min(kr, 15);               // K-padding taps (kr >= R) hit a zero mask bit
-    a_ok = 0;
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) {
-      const unsigned okb = (vmask[j] >> krs) & (vmask[j] >> (16 + ks)) & 1u;
+  // one 16-byte global load of the next tile (p < AJ: gathered activation rows; else weight rows)
+  int tapoff = 0, krs = 0, kss = 0;
+  auto load_piece = [&](int kk, int p) {
+    if (p == 0) {
+      tapoff = kr * rowstep + ks * colstep + kc * 4;
+      krs = min(kr, 15);               // K-padding taps (kr >= R) hit a zero mask bit
+      kss = 16 + ks;
+      a_ok = 0;
+      if (affine) {
+        const int kcs = min(kc, g.Ci - 4);       // kc < Ci always; keeps the address in range for the optimiser
+        psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kcs);
+        psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kcs);
+      }
+    }
+    if (p < AJ) {
+      const int j = p;
+      const unsigned okb = (vmask[j] >> krs) & (vmask[j] >> kss) & 1u;
       // invalid -> bit 31 set: beyond num_records (< 2 GiB) whatever the garbage below it
       const unsigned off = (unsigned)(base[j] + tapoff) | ((okb ^ 1u) << 31);
       ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
       a_ok |= okb << j;
+    } else {
+      const int j = p - AJ;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wbase[j] + (unsigned)kk * (BK * 4u), 0, 0));
     }
-    if (affine) {
-      const int kcs = min(kc, g.Ci - 4);       // kc < Ci always; keeps the address in range for the optimiser
-      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kcs);
-      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kcs);
+    if (p == AJ + BJ - 1) {            // advance (tap, c) to the next K-step
+      kc += BK;
+      while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
     }
-    const unsigned kcol = (unsigned)kk * (BK * 4u);
+  };
+  auto load_tiles = [&](int kk) {
 #pragma unroll
-    for (int j = 0; j < BJ; ++j)
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wbase[j] + kcol, 0, 0));
-    // advance (tap, c) to the next K-step
-    kc += BK;
-    while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
+    for (int p = 0; p < AJ + BJ; ++p) load_piece(kk, p);
   };
   // one 16-byte piece of the next tile: prologue on its way from the staging registers to LDS
   auto store_piece = [&](int buf, int p) {
@@ -222,10 +231,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   // 64 cycles after it issues, so the ~15 VALU / LDS-write instructions of a piece ride in its shadow instead of
   // forming a store phase after the MFMAs during which the pipe has nothing from this workgroup.
   constexpr int NE = (BK / 8) * 4, NP = AJ + BJ;
-  static_assert(NP <= NE, "more staging pieces than e-steps");
+  static_assert(2 * NP <= NE, "load and store pieces of a tile must not share an e-step");
   auto kstep = [&](int kk, auto has_next) {
     const int cur = (kk - k_begin) & 1;
-    if (decltype(has_next)::value) load_tiles(kk + 1);
     const float* Ac = As + cur * BM * BK;
     const float* Bc = Bs + cur * BN * BK;
 #pragma unroll
@@ -245,6 +253,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int es = u * 4 + e;
+        if (decltype(has_next)::value && es < NP) {           // next tile's global loads: first NP e-steps
+          __builtin_amdgcn_sched_barrier(0);
+          load_piece(kk + 1, es);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (decltype(has_next)::value && es >= NE - NP) {
           __builtin_amdgcn_sched_barrier(0);   // keep the piece HERE: hoisted to the top it would wait for its load first
           store_piece(cur ^ 1, es - (NE - NP));
@@ -433,7 +446,7 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
 
 using namespace diagan;
 
-// tile selection used when tile_cfg == 0: 1 = 128x128, 2 = 256x64, 3 = 64x64, 4 = 128x64
+// tile selection used when tile_cfg == 0: 1 = 128x128, 3 = 64x64 (2, 4, 5 were sweep-only shapes, retired)
 DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
   // short K loops (first conv of D on RGB, 1x1 shortcuts) are bound by the output stream, not the MFMAs: more,
   // smaller workgroups in flight win (measured 52 -> 46 us at M=131072,N=128,K=36; 27 -> 19 us at K=128)
@@ -510,10 +523,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);
-    case 2: return launch_cfg<256, 64, 4, 1>(a, st);
     case 3: return launch_cfg<64, 64, 2, 2, 32, true>(a, st);
-    case 4: return launch_cfg<128, 64, 2, 2>(a, st);
-    case 5: return launch_cfg<128, 128, 2, 2, 16>(a, st);
-    default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
+    default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64)", tile_cfg);
   }
 }

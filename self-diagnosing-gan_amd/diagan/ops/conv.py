@@ -30,9 +30,7 @@ nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
-TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2,32,{pro}>", 2: "conv_gemm_kernel<256,64,4,1,32,-1>",
-              3: "conv_gemm_kernel<64,64,2,2,32,{pro}>", 4: "conv_gemm_kernel<128,64,2,2,32,-1>",
-              5: "conv_gemm_kernel<128,128,2,2,16,-1>"}
+TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2,32,{pro}>", 3: "conv_gemm_kernel<64,64,2,2,32,{pro}>"}
 
 
 class KernelTimer:

@@ -84,7 +84,7 @@ def test_fwd(case, pro):
     close(nchw(y), ref + res)
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile_cfg", [1, 3])
 def test_fwd_all_tile_configs(tile_cfg):
     from diagan.ops import conv as C
     case = ("conv", 3, 9, 11, 64, 96, 3, 1, 1)

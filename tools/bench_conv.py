@@ -57,7 +57,7 @@ def main():
     only = sys.argv[1:] or None
     cfgs = [0]
     if os.environ.get("SWEEP"):
-        cfgs = [1, 3, 5]
+        cfgs = [1, 3]
     for name, B, H, W, Ci, Co, R in SHAPES:
         if only and name not in only:
             continue
