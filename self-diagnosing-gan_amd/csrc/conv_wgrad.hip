@@ -335,17 +335,23 @@ __global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __r
     double dot = 0.0;
     if (i < L.n_elem) {
       float* sl = L.slab[c];
-      // four independent partial sums: the split loads stay in flight together (fixed order: deterministic)
-      f32x4 s = *reinterpret_cast<const f32x4*>(sl + i), s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+      // eight independent partial sums: the split loads stay in flight together (fixed order: deterministic)
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 s = *reinterpret_cast<const f32x4*>(sl + i), s1 = z4, s2 = z4, s3 = z4, s4 = z4, s5 = z4, s6 = z4, s7 = z4;
       int k = 1;
-      for (; k + 3 < L.splits; k += 4) {
+      for (; k + 7 < L.splits; k += 8) {
         const float* q = sl + (long)k * L.stride + i;
         s += *reinterpret_cast<const f32x4*>(q);
         s1 += *reinterpret_cast<const f32x4*>(q + L.stride);
         s2 += *reinterpret_cast<const f32x4*>(q + 2 * L.stride);
         s3 += *reinterpret_cast<const f32x4*>(q + 3 * L.stride);
+        s4 += *reinterpret_cast<const f32x4*>(q + 4 * L.stride);
+        s5 += *reinterpret_cast<const f32x4*>(q + 5 * L.stride);
+        s6 += *reinterpret_cast<const f32x4*>(q + 6 * L.stride);
+        s7 += *reinterpret_cast<const f32x4*>(q + 7 * L.stride);
       }
       for (; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + i);
+      s2 += s6; s3 += s7; s += s4; s1 += s5;
       s = (s + s1) + (s2 + s3);
       if (sn) {
         if (i < L.n_w) {

@@ -462,7 +462,8 @@ __global__ __launch_bounds__(EW_T) void head_wgrad_kernel(const float* __restric
   double d = 0.0;
   for (int c = threadIdx.x; c < C; c += EW_T) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s = fmaf(dlogit[b], pooled[(long)b * C + c], s);
+#pragma unroll 16
+    for (int b = 0; b < B; ++b) s = fmaf(dlogit[b], pooled[(long)b * C + c], s);   // unrolled: 16 loads in flight
     G[c] = s;
     d += (double)s * w[c];
   }
