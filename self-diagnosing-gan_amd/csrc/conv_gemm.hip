@@ -253,15 +253,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int es = u * 4 + e;
-        if (decltype(has_next)::value && es < NP) {           // next tile's global loads: first NP e-steps
-          __builtin_amdgcn_sched_barrier(0);
-          load_piece(kk + 1, es);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        if (decltype(has_next)::value && es < NP) load_piece(kk + 1, es);   // next tile's global loads: first NP e-steps
         if (decltype(has_next)::value && es >= NE - NP) {
           __builtin_amdgcn_sched_barrier(0);   // keep the piece HERE: hoisted to the top it would wait for its load first
           store_piece(cur ^ 1, es - (NE - NP));
-          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)

@@ -117,6 +117,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const unsigned astep = (unsigned)BK * g.Co * 4u;
   f32x4 ra[AJ], rb[BJ];
   unsigned bmask = 0;
+  // bias gradient = column sums of dy, taken by the k0 == 0 tile column from the staging REGISTERS of the dy
+  // loader (every thread adds its own 16-byte pieces; one LDS reduction over the APR pixel-row groups at the end).
+  // (Summing from the LDS tile cost those workgroups an LDS round trip per s-step -- and a launch is one round
+  // of workgroups, so its slowest workgroups set the kernel time.)
+  const bool bias_tile = a.bias_off >= 0 && k0 == 0;
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
   // one 16-byte load of the next tile (piece p < AJ: dy rows; else gathered x rows with their coordinates)
   auto load_piece = [&](int p) {
     if (p < AJ) {     // rows past M fall outside num_records
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   auto store_piece = [&](int buf, int p) {
     if (p < AJ) {
       *reinterpret_cast<f32x4*>(&As[buf][(ap + APR * p) * BNn + ac * 4]) = ra[p];
+      if (bias_tile) bacc += ra[p];
     } else {
       const int j = p - AJ;
       f32x4 v = rb[j];
@@ -205,8 +212,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int fi = lane & 31, fh = lane >> 5;
-  const bool do_bias = a.bias_off >= 0 && k0 == 0 && tid < BNn;
-  float bsum = 0.f;
   if (step0 < step1) {
     load_tiles();
     store_tiles(0);
@@ -221,9 +226,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int cur = (step - step0) & 1;
     const float* Ac = As[cur];
     const float* Bc = Bs[cur];
-    // MFMA fragments are read one s-step AHEAD (two register sets): the LDS latency of step s+1 is covered by the
+    // MFMA fragments are read PF s-steps AHEAD (PF + 1 register sets): the LDS latency of step s+1 is covered by the
     // 4 x 64 cycles of step s instead of opening a bubble in the matrix pipe every s-step
-    float fa[2][TM], fb[2][TN];
+    constexpr int PF = 1;          // s-steps of read-ahead (2 measured the same)
+    float fa[PF + 1][TM], fb[PF + 1][TN];
     auto read_frag = [&](int s, int set) {
       const int p = 2 * s + fh;
 #pragma unroll
@@ -231,26 +237,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[set][j] = Bc[p * BNk + wn * (TN * 32) + j * 32 + fi];
     };
-    read_frag(0, 0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) read_frag(s, s);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (s + 1 < NS) read_frag(s + 1, (s + 1) & 1);
-      if (decltype(has_next)::value && s < NP) {            // next tile's loads: one per s-step, first NP s-steps
-        __builtin_amdgcn_sched_barrier(0);
-        load_piece(s);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (decltype(has_next)::value && s >= NS - NP) {      // ... and its LDS stores in the last NP s-steps
+      if (s + PF < NS) read_frag(s + PF, (s + PF) % (PF + 1));
+      // (the scheduler is free to spread a piece's instructions between the MFMAs that follow it; the barrier
+      //  BEFORE a store piece keeps it from being hoisted to where its load has not landed yet)
+      if (decltype(has_next)::value && s < NP) load_piece(s);       // next tile's loads: first NP s-steps
+      if (decltype(has_next)::value && s >= NS - NP) {               // ... and its LDS stores in the last NP s-steps
         __builtin_amdgcn_sched_barrier(0);
         store_piece(cur ^ 1, s - (NS - NP));
-        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
-      if (do_bias) bsum += Ac[(2 * s) * BNn + tid] + Ac[(2 * s + 1) * BNn + tid];   // k0 == 0 tile column only
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % (PF + 1)][i], fb[s % (PF + 1)][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   };
@@ -258,7 +261,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   if (step0 < step1) kstep(step1 - 1, std::false_type{});
 
   float* out = a.slab + (long)split * a.slab_stride;
-  if (do_bias && n0 + tid < g.Co) out[a.bias_off + n0 + tid] = bsum;
+  if (bias_tile) {     // (block-uniform) tiles are done with: reuse As for the APR partial rows
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(&As[0][ap * BNn + ac * 4]) = bacc;
+    __syncthreads();
+    if (tid < BNn && n0 + tid < g.Co) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < APR; ++r) t += As[0][r * BNn + tid];
+      out[a.bias_off + n0 + tid] = t;
+    }
+  }
   // raw buffer stores: one lane offset per accumulator tile + a scalar row offset per element; rows past Co fall
   // outside num_records, columns past Kp get the out-of-range bit (see the epilogue of conv_gemm.hip)
   const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
