@@ -460,20 +460,30 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
   return 1.08 * q128 * waste128 > q64 * waste64 ? 1 : 3;
 }
 
-// Split-K factor for the 64x64 tile: problems with fewer than ~2 tiles per CU and a long K loop are
-// latency bound (one workgroup per CU cannot hide its own global loads); splitting K across
-// gridDim.y fills the 1280 resident slots.  Returns 1 when not worthwhile.
+// Split-K factor for the 64x64 tile (1 = none), re-measured with the overlapped K-step schedule
+// (tools/bench_split.py):
+//  * at most ~1 tile per CU: a workgroup alone on its CU runs a K-step in ~0.9 us, so splitting only pays for
+//    long K loops (M=4096,N=256,K=2304: 60 -> 54 us with 3 splits; M=8192,N=128,K=1152: 31.6 us unsplit, 36 split);
+//  * up to 2 tiles per CU: fill the 1280 resident slots, at least 8 K-steps per split;
+//  * more tiles: no split.  (Splitting 1024-tile problems to even out the last round of workgroups makes the
+//    GEMM itself 5-8 % faster -- 91 -> 85 us -- but the second-stage launches and slab traffic cost more than that
+//    over a whole training step: 2350 -> 2323 images/s.)
 DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   static const int forced = getenv("DIAGAN_KSPLIT") ? atoi(getenv("DIAGAN_KSPLIT")) : 0;   // tuning experiments only
   if (forced > 0 && !(Co & 3)) return forced < Kp / 32 ? forced : Kp / 32;
   if (cfg != 3 || (Co & 3)) return 1;
   const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
   const int nk = Kp / 32;
-  if (tiles > 512 || nk < 16) return 1;
-  long s = 1280 / tiles;
-  if (s > nk / 8) s = nk / 8;       // at least 8 K-steps per split
-  if (s > 16) s = 16;
-  return s < 2 ? 1 : (int)s;
+  if (nk < 16) return 1;
+  if (tiles <= 320) {
+    if (nk < 64) return 1;
+    int s = nk / 24;
+    return s > 4 ? 4 : s;
+  }
+  if (tiles > 512) return 1;
+  long sp = 1280 / tiles;
+  if (sp > nk / 8) sp = nk / 8;       // at least 8 K-steps per split
+  return sp < 2 ? 1 : (int)sp;
 }
 
 // see include/diagan_hip.h
