@@ -291,6 +291,21 @@ int diagan_upfirdn2d(const float* input, const float* kernel, float* out, int ma
                      int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1,
                      int pad_y0, int pad_y1, int* out_h, int* out_w, void* stream);
 
+/* ---- precision / recall in feature space (diagan-pkg/diagan/trainer/compute_pr.py:11-124) --------------------
+ * The pairwise matrix T[r][c] = |b_c|^2 - 2 a_r.b_c is produced by diagan_conv_gemm (1x1 geometry, out_scale -2,
+ * bias = squared norms of b); the consumers add the row term |a_r|^2 (row_add) on the fly.
+ * row_sqnorm: out[r] = sum_c x[r][c]^2 (torch.sum(torch.square(x), dim=1), compute_pr.py:26-27).
+ * kth_smallest_rows: out[r] = k-th smallest of T[r][:] (+ row_add[r]), k in [1,16] (get_kth_value, :34-50).
+ * any_lt_rows / any_lt_cols: out = 1.0 where ANY element of the row / column satisfies
+ *   T[r][c] + row_add[r] < thr, thr = thr_col[c] or thr_row[r] (exactly one given)   ((dist < radii).any(axis), :85-93). */
+int diagan_row_sqnorm(const float* x, float* out, int N, int D, int ld, void* stream);
+int diagan_kth_smallest_rows(const float* T, const float* row_add, int rows, int cols, int ld, int k, float* out,
+                             void* stream);
+int diagan_any_lt_rows(const float* T, const float* row_add, const float* thr_col, const float* thr_row, int rows,
+                       int cols, int ld, float* out, void* stream);
+int diagan_any_lt_cols(const float* T, const float* row_add, const float* thr_col, const float* thr_row, int rows,
+                       int cols, int ld, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

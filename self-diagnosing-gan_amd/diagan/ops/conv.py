@@ -180,7 +180,7 @@ def _splitk_ws(dev):
 
 
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False):
+             want_stats=False, out_scale=1.0):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
@@ -188,7 +188,7 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
     Ho, Wo = geom.out_hw(Hi, Wi)
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
-    return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, 1.0,
+    return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
                  tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats)
 
 

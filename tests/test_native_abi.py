@@ -33,6 +33,7 @@ def test_library_loads_and_exports_all_symbols():
 def test_binding_table_matches_header():
     from diagan import _native as nat
     import diagan.ops  # noqa: F401  (registers the op signatures)
+    import diagan.trainer.compute_pr  # noqa: F401  (registers the precision/recall entry points)
     declared = set(_declared()) - {"diagan_last_error", "diagan_target_arch"}
     assert declared == set(nat._SIGS), declared ^ set(nat._SIGS)
 

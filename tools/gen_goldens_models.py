@@ -184,3 +184,25 @@ def gen_drs():
 
 if __name__ == "__main__":
     gen_drs()
+
+
+def gen_pr():
+    """Precision / recall (diagan-pkg/diagan/trainer/compute_pr.py) on seeded feature sets, device='cpu'."""
+    import contextlib
+    import io
+    from diagan.trainer import compute_pr as ref
+    rng = np.random.default_rng(11)
+    real = rng.normal(size=(384, 64)).astype(np.float32)
+    fake = (rng.normal(size=(320, 64)) * 1.1 + 0.25).astype(np.float32)
+    with contextlib.redirect_stdout(io.StringIO()):
+        pr = ref.compute_pr(real, fake, nearest_k=5, device='cpu')
+        part = ref.compute_partial_recall(real[:100], fake, nearest_k=5, device='cpu')
+    np.savez_compressed(os.path.join(OUT, "pr.npz"), real=real, fake=fake, nearest_k=5,
+                        dist=ref.compute_pairwise_distance(real[:64], fake[:48], device='cpu'),
+                        radii=ref.compute_nearest_neighbour_distances(real, 5, device='cpu'),
+                        kth=ref.get_kth_value(np.abs(real[:32]), 3, device='cpu'),
+                        precision=pr['precision'], recall=pr['recall'], partial_recall=part['recall'])
+
+
+if __name__ == "__main__":
+    gen_pr()
