@@ -1,63 +1,71 @@
-"""Discriminator Rejection Sampling at evaluation time (reference: diagan-pkg/diagan/models/drs.py:9-68).
+"""Discriminator Rejection Sampling at evaluation time.
 
-Wraps a generator and the D_drs discriminator trained in phase 2: images come from the HIP generator, the
-log-density-ratio from the HIP discriminator; the acceptance arithmetic (running maximum, percentile
-gamma, sigmoid, np.random.rand draw) is the reference's host-side NumPy, so that for the same logits and
-NumPy RNG state the same samples are accepted."""
+Public surface of the reference wrapper (diagan-pkg/diagan/models/drs.py:9-68): `DRS(netG, netD, device, gamma=None,
+percentile=80)` behaves like a generator -- `generate_images(n)` -- whose samples have passed the D_drs acceptance
+test.  Images come from the HIP generator and logits from the HIP discriminator; the acceptance arithmetic is host
+NumPy on 256 values per round, deliberately: the draw from NumPy's global generator is part of the observable
+behaviour (same logits + same `np.random` state => same accepted samples, pinned by tests/golden/drs.npz).
+
+Acceptance of a sample with log-density-ratio l, given the running maximum M of all logits seen so far:
+    F = (l - M) - log(1 - exp(l - M - eps));   accept iff sigmoid(F - gamma) > u,  u ~ U[0, 1)
+where gamma is fixed or the `percentile`-th percentile of F over the current round."""
 import numpy as np
 import torch
 import torch.nn as nn
 
+ROUND = 256          # samples per round of generation (the reference's batch_size)
+BURN_IN_ROUNDS = 50  # rounds used to estimate the maximum logit before sampling starts
 
-def sigmoid(x):
-    return 1 / (1 + np.exp(-x))
+
+def acceptance_probability(ldr, running_max, gamma=None, percentile=80, eps=1e-6):
+    """NumPy array of acceptance probabilities for one round of logits (drs.py:41-49 of the reference)."""
+    shifted = ldr - running_max
+    F = shifted - np.log(1 - np.exp(shifted - eps))
+    if gamma is None:
+        gamma = np.percentile(F, percentile)
+    return 1 / (1 + np.exp(-(F - gamma)))
 
 
 class DRS(nn.Module):
     def __init__(self, netG, netD, device, gamma=None, percentile=80):
         super().__init__()
-        self.netG, self.netD = netG, netD
+        self.netG, self.netD, self.device = netG, netD, device
+        self.gamma, self.percentile = gamma, percentile
+        self.batch_size = ROUND
         self.maximum = -100000
-        self.device = device
-        self.batch_size = 256
-        self.percentile = percentile
-        self.gamma = gamma
         self.init_drs()
 
+    # -- generator + discriminator round -------------------------------------------------------------------
     def get_fake_samples_and_ldr(self, num_data):
         with torch.no_grad():
-            imgs = self.netG.generate_images(num_data, device=self.device)
-            netD_out = self.netD(imgs)
-            if type(netD_out) is tuple:
-                netD_out = netD_out[0]
-            ldr = netD_out.detach().cpu().numpy()
-        return imgs, ldr
+            fake = self.netG.generate_images(num_data, device=self.device)
+            logit = self.netD(fake)
+            logit = logit[0] if type(logit) is tuple else logit        # D may return (logit, features)
+        return fake, logit.detach().cpu().numpy()
+
+    def _observe(self, ldr):
+        self.maximum = max(self.maximum, ldr.max())
 
     def init_drs(self):
-        for _ in range(50):                       # burn-in estimate of the maximum logit (drs.py:29-34)
-            _, ldr = self.get_fake_samples_and_ldr(self.batch_size)
-            self.maximum = max(self.maximum, ldr.max())
+        for _ in range(BURN_IN_ROUNDS):
+            self._observe(self.get_fake_samples_and_ldr(self.batch_size)[1])
 
+    # -- acceptance ------------------------------------------------------------------------------------------
     def acceptance(self, ldr, eps=1e-6):
-        """Boolean accept mask for one batch of logits (drs.py:36-55)."""
-        self.maximum = max(self.maximum, ldr.max())
-        ldr_max = ldr - self.maximum
-        F = ldr_max - np.log(1 - np.exp(ldr_max - eps))
-        gamma = np.percentile(F, self.percentile) if self.gamma is None else self.gamma
-        sigF = sigmoid(F - gamma)
-        psi = np.random.rand(len(sigF))
-        return np.array([bool(sigF[i] > psi[i]) for i in range(len(sigF))])
+        """Boolean mask of the accepted samples of one round; consumes len(ldr) draws of np.random."""
+        self._observe(ldr)
+        prob = acceptance_probability(ldr, self.maximum, self.gamma, self.percentile, eps)
+        draw = np.random.rand(len(prob))
+        return np.fromiter((bool(p > u) for p, u in zip(prob, draw)), dtype=bool, count=len(prob))
 
     def sub_rejection_sampler(self, fake_samples, ldr, eps=1e-6):
-        keep = self.acceptance(ldr, eps)
-        idx = torch.from_numpy(np.nonzero(keep)[0]).to(fake_samples.device)
-        return fake_samples.detach().index_select(0, idx).cpu()
+        kept = torch.from_numpy(np.flatnonzero(self.acceptance(ldr, eps))).to(fake_samples.device)
+        return fake_samples.detach().index_select(0, kept).cpu()
 
     def generate_images(self, num_images, device=None):
-        out, n = [], 0
-        while n < num_images:
-            fake_samples, ldrs = self.get_fake_samples_and_ldr(self.batch_size)
-            acc = self.sub_rejection_sampler(fake_samples, ldrs)
-            out.append(acc)
-            n += acc.size(0)
-        return torch.cat(out, dim=0)[:num_images]
+        rounds, have = [], 0
+        while have < num_images:
+            accepted = self.sub_rejection_sampler(*self.get_fake_samples_and_ldr(self.batch_size))
+            rounds.append(accepted)
+            have += accepted.size(0)
+        return torch.cat(rounds, dim=0)[:num_images]

@@ -32,43 +32,51 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     return out.to(input.dtype)
 
 
-class FusedLeakyReLUFunctionBackward(Function):
-    @staticmethod
-    def forward(ctx, grad_output, out, bias, negative_slope, scale):
-        ctx.save_for_backward(out)
-        ctx.negative_slope, ctx.scale = negative_slope, scale
-        empty = grad_output.new_empty(0)
-        grad_input = fused_bias_act(grad_output, empty, out, 3, 1, negative_slope, scale)
-        dim = [0] + list(range(2, grad_input.ndim))
-        grad_bias = grad_input.sum(dim).detach() if bias else empty
-        return grad_input, grad_bias
+class _LeakyGate(Function):
+    """g -> g * scale * (1 where ref > 0 else slope): the derivative of the fused activation with respect to its
+    pre-activation, as ONE launch of the native op (act 3, grad 1, gated by `ref`).  The map is linear in g, so its own
+    backward is the same map: the class differentiates itself to any order (the reference needs second order for
+    the R1 / path-length penalties, stylegan2/train_ffhq.py:74-102)."""
 
     @staticmethod
-    def backward(ctx, gradgrad_input, gradgrad_bias):
-        out, = ctx.saved_tensors
-        gradgrad_out = fused_bias_act(gradgrad_input, gradgrad_bias, out, 3, 1, ctx.negative_slope, ctx.scale)
-        return gradgrad_out, None, None, None, None
-
-
-class FusedLeakyReLUFunction(Function):
-    @staticmethod
-    def forward(ctx, input, bias, negative_slope, scale):
-        empty = input.new_empty(0)
-        ctx.bias = bias is not None
-        out = fused_bias_act(input, bias if bias is not None else empty, empty, 3, 0, negative_slope, scale)
-        ctx.save_for_backward(out)
-        ctx.negative_slope, ctx.scale = negative_slope, scale
-        return out
+    def forward(ctx, g, ref, slope, scale):
+        ctx.save_for_backward(ref)
+        ctx.hyper = (slope, scale)
+        return fused_bias_act(g, None, ref, 3, 1, slope, scale)
 
     @staticmethod
-    def backward(ctx, grad_output):
-        out, = ctx.saved_tensors
-        grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, ctx.bias, ctx.negative_slope,
-                                                                     ctx.scale)
-        return grad_input, (grad_bias if ctx.bias else None), None, None
+    def backward(ctx, gg):
+        ref, = ctx.saved_tensors
+        return _LeakyGate.apply(gg, ref, *ctx.hyper), None, None, None
+
+
+class _BiasLeakyReLU(Function):
+    """y = leaky_relu(x + bias[channel]) * scale in one launch; sign(y) == sign(x + bias), so y itself gates the
+    backward and the input is not kept."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope, scale):
+        y = fused_bias_act(x, bias, None, 3, 0, slope, scale)
+        ctx.save_for_backward(y)
+        ctx.hyper = (slope, scale)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        gx = _LeakyGate.apply(gy, y, *ctx.hyper)
+        gb = gx.sum([d for d in range(gx.dim()) if d != 1]) if ctx.has_bias else None
+        return gx, gb, None, None
+
+
+def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    return _BiasLeakyReLU.apply(input, bias, negative_slope, scale)
 
 
 class FusedLeakyReLU(nn.Module):
+    """Module form (reference fused_act.py:90-103): owns the per-channel bias."""
+
     def __init__(self, channel, bias=True, negative_slope=0.2, scale=2 ** 0.5):
         super().__init__()
         self.bias = nn.Parameter(torch.zeros(channel)) if bias else None
@@ -76,7 +84,3 @@ class FusedLeakyReLU(nn.Module):
 
     def forward(self, input):
         return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)
-
-
-def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
-    return FusedLeakyReLUFunction.apply(input, bias, negative_slope, scale)

@@ -1,9 +1,12 @@
 """upsample / FIR filter / downsample (reference: diagan-pkg/diagan/models/op/upfirdn2d.py:19-156).
 
 `upfirdn2d_op(input[major,H,W,minor], kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)`
-is the reference's pybind entry (upfirdn2d.cpp:4-22) on HIP; the autograd wrapper mirrors the
-reference's: backward = the same op with the flipped kernel and up <-> down swapped, and it is itself
-differentiable (R1 / path-length regularisation need the second order)."""
+is the reference's pybind entry (upfirdn2d.cpp:4-22) on HIP.
+
+Autograd: upfirdn2d is a LINEAR map of its input, and its adjoint is again an upfirdn2d -- flipped kernel, up and
+down exchanged, pads (kw - px0 - 1, in_w*up - out_w*down + px0 - up + 1, same in y).  So one autograd Function
+parameterised by a `_Plan` serves every order of differentiation: its backward applies the Function with the dual
+plan (R1 / path-length regularisation of the reference need the second order)."""
 import ctypes
 
 import torch
@@ -30,55 +33,52 @@ def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_
     return out.to(input.dtype)
 
 
-class UpFirDn2dBackward(Function):
+class _Plan:
+    """Geometry of one upfirdn2d application on [batch, channel, in_h, in_w] images, linked to its adjoint."""
+
+    def __init__(self, kernel, up, down, pad, in_hw, out_hw, dual=None):
+        self.kernel, self.up, self.down, self.pad = kernel, tuple(up), tuple(down), tuple(pad)
+        self.in_hw, self.out_hw = tuple(in_hw), tuple(out_hw)
+        self.dual = dual
+
+    @classmethod
+    def forward_plan(cls, kernel, up, down, pad, in_hw):
+        (ux, uy), (dx, dy), (px0, px1, py0, py1) = up, down, pad
+        kh, kw = kernel.shape
+        in_h, in_w = in_hw
+        out_h = (in_h * uy + py0 + py1 - kh) // dy + 1
+        out_w = (in_w * ux + px0 + px1 - kw) // dx + 1
+        plan = cls(kernel, up, down, pad, in_hw, (out_h, out_w))
+        adjoint_pad = (kw - px0 - 1, in_w * ux - out_w * dx + px0 - ux + 1,
+                       kh - py0 - 1, in_h * uy - out_h * dy + py0 - uy + 1)
+        plan.dual = cls(torch.flip(kernel, [0, 1]), down, up, adjoint_pad, (out_h, out_w), in_hw, dual=plan)
+        return plan
+
+    def run(self, images):
+        b, c = images.shape[:2]
+        flat = images.reshape(-1, self.in_hw[0], self.in_hw[1], 1)
+        out = upfirdn2d_op(flat, self.kernel, self.up[0], self.up[1], self.down[0], self.down[1], *self.pad)
+        return out.view(b, c, self.out_hw[0], self.out_hw[1])
+
+
+class _LinearFIR(Function):
     @staticmethod
-    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
-        up_x, up_y = up
-        down_x, down_y = down
-        g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1 = g_pad
-        grad_output = grad_output.reshape(-1, out_size[0], out_size[1], 1)
-        grad_input = upfirdn2d_op(grad_output, grad_kernel, down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1, g_pad_y0,
-                                  g_pad_y1)
-        grad_input = grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
-        ctx.save_for_backward(kernel)
-        ctx.up, ctx.down, ctx.pad, ctx.in_size, ctx.out_size = up, down, pad, in_size, out_size
-        return grad_input
+    def forward(ctx, images, plan):
+        ctx.plan = plan
+        return plan.run(images)
 
     @staticmethod
-    def backward(ctx, gradgrad_input):
-        kernel, = ctx.saved_tensors
-        gradgrad_input = gradgrad_input.reshape(-1, ctx.in_size[2], ctx.in_size[3], 1)
-        out = upfirdn2d_op(gradgrad_input, kernel, ctx.up[0], ctx.up[1], ctx.down[0], ctx.down[1], *ctx.pad)
-        out = out.view(ctx.in_size[0], ctx.in_size[1], ctx.out_size[0], ctx.out_size[1])
-        return out, None, None, None, None, None, None, None, None
+    def backward(ctx, grad):
+        return _LinearFIR.apply(grad.contiguous(), ctx.plan.dual), None
 
 
-class UpFirDn2d(Function):
-    @staticmethod
-    def forward(ctx, input, kernel, up, down, pad):
-        up_x, up_y = up
-        down_x, down_y = down
-        pad_x0, pad_x1, pad_y0, pad_y1 = pad
-        kernel_h, kernel_w = kernel.shape
-        batch, channel, in_h, in_w = input.shape
-        ctx.in_size = input.shape
-        input = input.reshape(-1, in_h, in_w, 1)
-        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
-        out_h = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) // down_y + 1
-        out_w = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) // down_x + 1
-        ctx.out_size = (out_h, out_w)
-        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1)
-        ctx.g_pad = (kernel_w - pad_x0 - 1, in_w * up_x - out_w * down_x + pad_x0 - up_x + 1,
-                     kernel_h - pad_y0 - 1, in_h * up_y - out_h * down_y + pad_y0 - up_y + 1)
-        out = upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
-        return out.view(-1, channel, out_h, out_w)
+class UpFirDn2d:
+    """Call-compatible with the reference's autograd Function: `UpFirDn2d.apply(input, kernel, up, down, pad)` with
+    up = (up_x, up_y), down = (down_x, down_y), pad = (pad_x0, pad_x1, pad_y0, pad_y1)."""
 
     @staticmethod
-    def backward(ctx, grad_output):
-        kernel, grad_kernel = ctx.saved_tensors
-        grad_input = UpFirDn2dBackward.apply(grad_output, kernel, grad_kernel, ctx.up, ctx.down, ctx.pad, ctx.g_pad,
-                                             ctx.in_size, ctx.out_size)
-        return grad_input, None, None, None, None
+    def apply(input, kernel, up, down, pad):
+        return _LinearFIR.apply(input, _Plan.forward_plan(kernel, up, down, pad, input.shape[2:]))
 
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):

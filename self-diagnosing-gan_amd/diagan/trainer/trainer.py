@@ -24,61 +24,68 @@ from diagan.trainer.scheduler import DRS_LRScheduler
 from diagan.utils.plot import LogitRecord
 
 
+class _Clock:
+    """Wall time per printed step (the reference prints the mean over `print_steps`)."""
+
+    def __init__(self):
+        self.t = time.time()
+
+    def lap(self, steps):
+        now = time.time()
+        dt, self.t = (now - self.t) / steps, now
+        return dt
+
+
 class LogTrainer:
+    """Keyword-compatible with the reference's LogTrainer (trainer.py:16-49); extra: `compat_fetch_quirk`."""
+
+    _AT_LEAST_ONE = ('num_steps', 'n_dis', 'print_steps', 'vis_steps', 'log_steps', 'save_steps', 'flush_secs')
+
     def __init__(self, output_path, netD, netG, optD, optG, dataloader, num_steps, netD_drs=None, optD_drs=None,
                  dataloader_drs=None, netD_drs_ckpt_file=None, log_dir='./log', n_dis=1, lr_decay=None, device=None,
                  netG_ckpt_file=None, netD_ckpt_file=None, print_steps=1, vis_steps=500, log_steps=50,
                  save_steps=5000, flush_secs=30, logit_save_steps=500, amp=False, save_logits=True, topk=False,
                  gold=False, gold_step=None, save_logit_after=0, stop_save_logit_after=100000,
                  save_eval_logits=True, compat_fetch_quirk=False):
-        self.output_path = output_path
-        self.logit_save_steps = logit_save_steps
-        self.netD, self.netG, self.optD, self.optG = netD, netG, optD, optG
-        self.n_dis, self.lr_decay = n_dis, lr_decay
-        self.dataloader, self.num_steps, self.device, self.log_dir = dataloader, num_steps, device, log_dir
-        self.netG_ckpt_file, self.netD_ckpt_file = netG_ckpt_file, netD_ckpt_file
-        self.print_steps, self.vis_steps, self.log_steps, self.save_steps = print_steps, vis_steps, log_steps, save_steps
-        self.amp, self.save_logits = amp, save_logits
-        self.save_logit_after, self.stop_save_logit_after = save_logit_after, stop_save_logit_after
-        self.save_eval_logits = save_eval_logits
-        self.netD_drs, self.dataloader_drs, self.optD_drs = netD_drs, dataloader_drs, optD_drs
-        self.netD_drs_ckpt_file = netD_drs_ckpt_file
-        self.topk, self.gold, self.gold_step = topk, gold, gold_step
-        self.compat_fetch_quirk = compat_fetch_quirk
-        if self.amp:
+        given = dict(locals())
+        given.pop('self')
+        for name in self._AT_LEAST_ONE:
+            if given[name] < 1:
+                raise ValueError('{} must be at least 1 but got {}.'.format(name, given[name]))
+        if amp:
             raise NotImplementedError("amp is not part of the fp32 MI355X path")
-        if self.gold:
-            assert self.gold_step is not None
-        if self.netD_drs is not None:
-            assert self.dataloader_drs is not None and self.optD_drs is not None
-            self.train_drs = True
-        else:
-            self.train_drs = False
-        for name, var in dict(num_steps=num_steps, n_dis=n_dis, print_steps=print_steps, vis_steps=vis_steps,
-                              log_steps=log_steps, save_steps=save_steps, flush_secs=flush_secs).items():
-            if var < 1:
-                raise ValueError('{} must be at least 1 but got {}.'.format(name, var))
+        if gold and gold_step is None:
+            raise AssertionError("gold re-weighting needs gold_step")
+        self.train_drs = netD_drs is not None
+        if self.train_drs and (dataloader_drs is None or optD_drs is None):
+            raise AssertionError("netD_drs needs dataloader_drs and optD_drs")
+        given.pop('flush_secs')
+        for name, value in given.items():            # every constructor keyword is an attribute of the same name
+            setattr(self, name, value)
+
         os.makedirs(self.log_dir, exist_ok=True)
+        self.device = self._resolve_device(device)
         self.logger = Logger(log_dir=self.log_dir, num_steps=self.num_steps, dataset_size=len(self.dataloader),
                              flush_secs=flush_secs, device=self.device)
-        # base learning rates are cached here, i.e. before any checkpoint restore (scheduler.py:38)
-        self.scheduler = DRS_LRScheduler(lr_decay=self.lr_decay,
-                                         optimizers=[o for o in [self.optD, self.optD_drs, self.optG] if o is not None],
-                                         num_steps=self.num_steps)
-        self.netG_ckpt_dir = os.path.join(self.log_dir, 'checkpoints', 'netG')
-        self.netD_ckpt_dir = os.path.join(self.log_dir, 'checkpoints', 'netD')
-        self.netD_drs_ckpt_dir = os.path.join(self.log_dir, 'checkpoints', 'netD_drs') if self.train_drs else None
-        if not self.device:
-            self.device = torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
-        self.device = torch.device(self.device)
-        if self.device.type == 'cuda' and self.device.index is None:
-            self.device = torch.device('cuda', torch.cuda.current_device())
-        for net in [self.netD, self.netG, self.netD_drs]:
+        # the scheduler caches the base learning rates NOW, i.e. before any checkpoint restore (scheduler.py:38)
+        live = [opt for opt in (self.optD, self.optD_drs, self.optG) if opt is not None]
+        self.scheduler = DRS_LRScheduler(lr_decay=self.lr_decay, optimizers=live, num_steps=self.num_steps)
+        ckpt_root = os.path.join(self.log_dir, 'checkpoints')
+        self.netG_ckpt_dir, self.netD_ckpt_dir = os.path.join(ckpt_root, 'netG'), os.path.join(ckpt_root, 'netD')
+        self.netD_drs_ckpt_dir = os.path.join(ckpt_root, 'netD_drs') if self.train_drs else None
+        for net in (self.netD, self.netG, self.netD_drs):
             if net is not None and net.device != self.device:
                 net.to(self.device)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.logit_records = {}
         self.events = []          # (global_step, event) trace used by the control-flow tests
+
+    @staticmethod
+    def _resolve_device(device):
+        dev = torch.device(device if device else ('cuda:0' if torch.cuda.is_available() else 'cpu'))
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        return dev
 
     # ---- logit record -------------------------------------------------------------------------
     @property
@@ -176,86 +183,85 @@ class LogTrainer:
         return iter_dataloader, real_batch
 
     # ---- the loop -----------------------------------------------------------------------------
-    def train(self):
-        global_step = self._restore_models_and_step()
-        if self.gold and global_step >= self.gold_step:
-            self.netD.use_gold = True
-        print("INFO: Starting training from global step {}...".format(global_step))
-        try:
-            start_time = time.time()
-            scaler = None
-            iter_dataloader = iter(self.dataloader)
+    # Order of one global step (trainer.py:238-299): [top-k decay] [GOLD switch] n_dis x (D update [, D_drs update]),
+    # the G update on the LAST D batch, step += 1, LR schedule, then the periodic duties in the order
+    # summaries, console line, sample grid, logit snapshot, checkpoint (+ pickle of the record).
+    def _updates(self, step, streams, log):
+        for i in range(self.n_dis):
+            streams['main'], batch = self._fetch_data(iter_dataloader=streams['main'])
+            log = self.netD.train_step(real_batch=batch, netG=self.netG, optD=self.optD, log_data=log,
+                                       global_step=step, device=self.device, scaler=None)
+            self.events.append((step, 'D'))
             if self.train_drs:
-                iter_dataloader_drs = iter(self.dataloader_drs)
-            while global_step < self.num_steps:
-                log_data = MetricLog()
+                streams['drs'], batch_drs = self._fetch_data(iter_dataloader=streams['drs'],
+                                                             dataloader=self.dataloader_drs)
+                log = self.netD_drs.train_step(real_batch=batch_drs, netG=self.netG, optD=self.optD_drs,
+                                               log_data=log, global_step=step, device=self.device, scaler=None)
+                self.events.append((step, 'D_drs'))
+        log = self.netG.train_step(real_batch=batch, netD=self.netD, optG=self.optG, global_step=step, log_data=log,
+                                   device=self.device, scaler=None)
+        self.events.append((step, 'G'))
+        return log
+
+    def _report(self, step, log, clock):
+        if step % self.log_steps == 0 and self.rank == 0:
+            self.logger.write_summaries(log_data=log, global_step=step)
+        if step % self.print_steps == 0:
+            log.add_metric('topk_rate', getattr(self.netG, 'topk_rate', 1), group='topk_rate', precision=6)
+            per_step = clock.lap(self.print_steps)
+            if self.rank == 0:
+                self.logger.print_log(global_step=step, log_data=log, time_taken=per_step)
+        if step % self.vis_steps == 0 and self.rank == 0:
+            self.logger.vis_images(netG=self.netG, global_step=step)
+
+    def _snapshot_due(self, step):
+        """Bounds are inclusive on both sides (trainer.py:328)."""
+        return (self.save_logits and step % self.logit_save_steps == 0
+                and self.save_logit_after <= step <= self.stop_save_logit_after)
+
+    def _snapshot(self, step):
+        net, name = (self.netD_drs, 'netD_drs') if self.train_drs else (self.netD, 'netD')
+        mode = 'eval' if self.save_eval_logits else 'train'
+        print(f"INFO: logit saving {mode} netD: {name}...")
+        key = f'{name}_{mode}'
+        if key not in self.logit_records:
+            self.logit_records[key] = LogitRecord(len(self.dataloader.dataset), capacity=64, device=self.device)
+        self._get_logit(netD=net, eval_mode=(mode == 'eval'), record=self.logit_records[key], step=step)
+        self.events.append((step, 'logit'))
+
+    def _persist(self, step, banner):
+        print(banner)
+        self._save_model_checkpoints(step)
+        if self.save_logits and step >= self.save_logit_after:
+            self._save_logit()
+
+    def train(self):
+        step = self._restore_models_and_step()
+        if self.gold and step >= self.gold_step:
+            self.netD.use_gold = True
+        print("INFO: Starting training from global step {}...".format(step))
+        streams = {'main': iter(self.dataloader)}
+        if self.train_drs:
+            streams['drs'] = iter(self.dataloader_drs)
+        clock = _Clock()
+        try:
+            while step < self.num_steps:
                 if self.topk:
-                    self.netG.decay_topk_rate(global_step, epoch_steps=len(self.dataloader))
-                if self.gold and global_step == self.gold_step:
+                    self.netG.decay_topk_rate(step, epoch_steps=len(self.dataloader))
+                if self.gold and step == self.gold_step:
                     self.netD.use_gold = True
-                for i in range(self.n_dis):
-                    iter_dataloader, real_batch = self._fetch_data(iter_dataloader=iter_dataloader)
-                    log_data = self.netD.train_step(real_batch=real_batch, netG=self.netG, optD=self.optD,
-                                                    log_data=log_data, global_step=global_step, device=self.device,
-                                                    scaler=scaler)
-                    self.events.append((global_step, 'D'))
-                    if self.train_drs:
-                        iter_dataloader_drs, real_batch_drs = self._fetch_data(iter_dataloader=iter_dataloader_drs,
-                                                                               dataloader=self.dataloader_drs)
-                        log_data = self.netD_drs.train_step(real_batch=real_batch_drs, netG=self.netG,
-                                                            optD=self.optD_drs, log_data=log_data,
-                                                            global_step=global_step, device=self.device, scaler=scaler)
-                        self.events.append((global_step, 'D_drs'))
-                    if i == (self.n_dis - 1):       # G once per global step, on the last D batch
-                        log_data = self.netG.train_step(real_batch=real_batch, netD=self.netD, optG=self.optG,
-                                                        global_step=global_step, log_data=log_data,
-                                                        device=self.device, scaler=scaler)
-                        self.events.append((global_step, 'G'))
-                global_step += 1
-                log_data = self.scheduler.step(log_data=log_data, global_step=global_step)
-
-                if global_step % self.log_steps == 0 and self.rank == 0:
-                    self.logger.write_summaries(log_data=log_data, global_step=global_step)
-                if global_step % self.print_steps == 0:
-                    curr_time = time.time()
-                    topk_rate = self.netG.topk_rate if hasattr(self.netG, 'topk_rate') else 1
-                    log_data.add_metric('topk_rate', topk_rate, group='topk_rate', precision=6)
-                    if self.rank == 0:
-                        self.logger.print_log(global_step=global_step, log_data=log_data,
-                                              time_taken=(curr_time - start_time) / self.print_steps)
-                    start_time = curr_time
-                if global_step % self.vis_steps == 0 and self.rank == 0:
-                    self.logger.vis_images(netG=self.netG, global_step=global_step)
-
-                if (self.save_logits and global_step % self.logit_save_steps == 0
-                        and global_step >= self.save_logit_after and global_step <= self.stop_save_logit_after):
-                    netD, netD_name = (self.netD_drs, 'netD_drs') if self.train_drs else (self.netD, 'netD')
-                    mode = 'eval' if self.save_eval_logits else 'train'
-                    print(f"INFO: logit saving {mode} netD: {netD_name}...")
-                    key = f'{netD_name}_{mode}'
-                    if key not in self.logit_records:
-                        self.logit_records[key] = LogitRecord(len(self.dataloader.dataset), capacity=64,
-                                                              device=self.device)
-                    self._get_logit(netD=netD, eval_mode=(mode == 'eval'), record=self.logit_records[key],
-                                    step=global_step)
-                    self.events.append((global_step, 'logit'))
-
-                if global_step % self.save_steps == 0:
-                    print("INFO: Saving checkpoints...")
-                    self._save_model_checkpoints(global_step)
-                    self.events.append((global_step, 'ckpt'))
-                    if self.save_logits and global_step >= self.save_logit_after:
-                        self._save_logit()
-
-            print("INFO: Saving final checkpoints...")
-            self._save_model_checkpoints(global_step)
-            if self.save_logits and global_step >= self.save_logit_after:
-                self._save_logit()
+                log = self._updates(step, streams, MetricLog())
+                step += 1                                  # the schedule and all periodic duties see the NEW step
+                log = self.scheduler.step(log_data=log, global_step=step)
+                self._report(step, log, clock)
+                if self._snapshot_due(step):
+                    self._snapshot(step)
+                if step % self.save_steps == 0:
+                    self._persist(step, "INFO: Saving checkpoints...")
+                    self.events.append((step, 'ckpt'))
+            self._persist(step, "INFO: Saving final checkpoints...")
         except KeyboardInterrupt:
-            print("INFO: Saving checkpoints from keyboard interrupt...")
-            self._save_model_checkpoints(global_step)
-            if self.save_logits and global_step >= self.save_logit_after:
-                self._save_logit()
+            self._persist(step, "INFO: Saving checkpoints from keyboard interrupt...")
         finally:
             self.logger.close_writers()
         print("INFO: Training Ended.")

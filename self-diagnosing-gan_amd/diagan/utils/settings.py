@@ -1,18 +1,33 @@
-"""Seed contract of the reference (diagan-pkg/diagan/utils/settings.py:8-18)."""
+"""Seeding (API of diagan-pkg/diagan/utils/settings.py:8-18: `set_seed(seed=3)`, `None` = leave every generator alone).
+
+One seed feeds, in this order, Python's `random`, the hash seed exported to child processes, NumPy's legacy global
+generator and torch's CPU and device generators -- the same generators the reference seeds, so host-side draws
+(sampler order, DRS acceptance, NumPy noise) repeat for a given seed.  There is no cuDNN to configure here: the HIP
+kernels of this engine are deterministic by construction (fixed-order reductions, no float atomics)."""
 import os
 import random
 
-import numpy as np
+import numpy
 import torch
+
+_BANNER = '=======> Using Fixed Random Seed: {} <========'      # printed by the reference; log scrapers rely on it
+
+
+def _device_generators(seed):
+    if not torch.cuda.is_available():
+        return
+    torch.cuda.manual_seed(seed)            # current device, then all of them, as the reference calls both
+    torch.cuda.manual_seed_all(seed)
 
 
 def set_seed(seed=3):
-    if seed is not None:
-        print(f'=======> Using Fixed Random Seed: {seed} <========')
-        random.seed(seed)
-        os.environ['PYTHONHASHSEED'] = str(seed)
-        np.random.seed(seed)
-        torch.manual_seed(seed)
-        if torch.cuda.is_available():
-            torch.cuda.manual_seed(seed)
-            torch.cuda.manual_seed_all(seed)
+    if seed is None:
+        return
+    print(_BANNER.format(seed))
+    seeders = (random.seed,
+               lambda s: os.environ.__setitem__('PYTHONHASHSEED', str(s)),
+               numpy.random.seed,
+               torch.manual_seed,
+               _device_generators)
+    for apply in seeders:
+        apply(seed)
