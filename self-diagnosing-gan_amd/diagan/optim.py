@@ -41,26 +41,84 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.net.zero_grad()
 
-    # checkpoint: flat moments + step (optimizer_state_dict entry of mimicry's checkpoint dict)
+    # ---- checkpoint boundary: the wire format is torch.optim.Adam's ---------------------------------------
+    # mimicry checkpoints hold `optimizer.state_dict()` of a torch.optim.Adam over `net.parameters()`
+    # (diagan-pkg/diagan/trainer/trainer.py:158-204 restores it): per-parameter `exp_avg` / `exp_avg_sq` in the
+    # parameter's own (reference) shape, keyed by position.  The flat moment slabs are converted with the same
+    # state-dict hooks that convert the parameters themselves (OIHW <-> packed Wp[Co][Kp], latent-linear row order,
+    # channel padding), so a FusedAdam resumes from a genuine Adam state and vice versa (SURVEY §8(f) rank 3;
+    # verified against the oracle's torch.optim.Adam, not against a real mimicry install).
+    def _views(self, flat):
+        base = self.net.flat_params
+        out = {}
+        for name, p in self.net.named_parameters():
+            off = (p.data_ptr() - base.data_ptr()) // base.element_size()
+            out[name] = flat[off: off + p.numel()].view(p.shape)
+        return out
+
+    def _layout_hooks(self):
+        for prefix, mod in self.net.named_modules():
+            if hasattr(mod, '_sd_hook') and hasattr(mod, '_load_hook'):
+                yield (prefix + '.' if prefix else ''), mod
+
+    def _export(self, flat):
+        """flat moment slab -> {parameter name: tensor in the reference's shape} (CPU)."""
+        sd = {name: v.detach().clone() for name, v in self._views(flat).items()}
+        for prefix, mod in self._layout_hooks():
+            mod._sd_hook(mod, sd, prefix, None)
+        return {k: v.cpu() for k, v in sd.items()}
+
+    def _import(self, by_name, flat):
+        sd = {k: v.to(device=flat.device, dtype=flat.dtype) for k, v in by_name.items()}
+        for prefix, mod in self._layout_hooks():
+            mod._load_hook(sd, prefix)
+        flat.zero_()
+        for name, view in self._views(flat).items():
+            view.copy_(sd[name].view(view.shape))
+
     def state_dict(self):
         self._ensure_state()
-        return {
-            'fused_adam': True,
-            'step': self._step,
-            'exp_avg': self._m.detach().cpu(),
-            'exp_avg_sq': self._v.detach().cpu(),
-            'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups],
-        }
+        names = [n for n, _ in self.net.named_parameters()]
+        state = {}
+        if self._step > 0:
+            m, v = self._export(self._m), self._export(self._v)
+            state = {i: {'step': torch.tensor(float(self._step)), 'exp_avg': m[n], 'exp_avg_sq': v[n]}
+                     for i, n in enumerate(names)}
+        group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        for key, default in (('weight_decay', 0), ('amsgrad', False), ('maximize', False), ('foreach', None),
+                             ('capturable', False), ('differentiable', False), ('fused', None)):
+            group.setdefault(key, default)
+        group['params'] = list(range(len(names)))
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
-        if not sd.get('fused_adam'):
-            raise RuntimeError("optimizer state is not a FusedAdam state (loading torch.optim.Adam state of a "
-                               "genuine mimicry checkpoint is listed as 'next' in SURVEY §8(f) rank 3)")
         self._ensure_state()
-        if sd['exp_avg'].numel() != self._m.numel():
-            raise RuntimeError("optimizer state size mismatch")
-        self._m.copy_(sd['exp_avg'])
-        self._v.copy_(sd['exp_avg_sq'])
-        self._step = int(sd['step'])
-        for g, saved in zip(self.param_groups, sd['param_groups']):
-            g.update(saved)
+        if sd.get('fused_adam'):                     # flat format written by earlier builds of this engine
+            if sd['exp_avg'].numel() != self._m.numel():
+                raise RuntimeError("optimizer state size mismatch")
+            self._m.copy_(sd['exp_avg'])
+            self._v.copy_(sd['exp_avg_sq'])
+            self._step = int(sd['step'])
+        else:
+            names = [n for n, _ in self.net.named_parameters()]
+            order = sd['param_groups'][0]['params']
+            if len(order) != len(names):
+                raise RuntimeError(f"optimizer state has {len(order)} parameters, the network has {len(names)}")
+            state = sd['state']
+            if not state:
+                self._m.zero_(), self._v.zero_()
+                self._step = 0
+            else:
+                missing = [names[i] for i, key in enumerate(order) if key not in state]
+                if missing:
+                    raise RuntimeError(f"optimizer state lacks entries for {missing[:3]}...")
+                self._import({names[i]: state[key]['exp_avg'] for i, key in enumerate(order)}, self._m)
+                self._import({names[i]: state[key]['exp_avg_sq'] for i, key in enumerate(order)}, self._v)
+                steps = {int(float(state[key]['step'])) for key in order}
+                if len(steps) != 1:
+                    raise RuntimeError(f"per-parameter step counts differ: {sorted(steps)}")
+                self._step = steps.pop()
+        saved = {k: v for k, v in sd['param_groups'][0].items() if k in ('lr', 'betas', 'eps')}
+        if 'betas' in saved:
+            saved['betas'] = tuple(saved['betas'])
+        self.param_groups[0].update(saved)

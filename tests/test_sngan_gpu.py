@@ -276,3 +276,49 @@ def test_gold_and_topk_train_steps_vs_oracle():
     log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda',
                           noise=zg.cuda())
     assert abs(log.m['errG'].item() - errG) < 5e-3 * max(1.0, abs(errG))
+
+
+def test_resume_from_torch_adam_state(tmp_path):
+    """Checkpoint wire format: a FusedAdam resumes from a torch.optim.Adam state_dict taken
+    over the reference-shaped parameters (what a mimicry checkpoint's 'optimizer_state_dict' holds), and writes one
+    a torch.optim.Adam accepts.  The oracle (plain torch.optim.Adam, lr 2e-4, betas (0, 0.9)) warms up alone for
+    two D and one G update; both sides then continue from its model + optimizer state and must stay together."""
+    (oG, oD, ooptG, ooptD), (netG, netD, optG, optD) = build('cifar10', 'hinge')
+    assert [n for n, _ in netD.named_parameters()] == [n for n, _ in oD.named_parameters()]
+    assert [n for n, _ in netG.named_parameters()] == [n for n, _ in oG.named_parameters()]
+    g = torch.Generator().manual_seed(9)
+    B = 8
+    batch = lambda: (torch.rand(B, 3, 32, 32, generator=g) * 2 - 1, torch.randn(B, 128, generator=g))
+    for _ in range(2):
+        x, z = batch()
+        oD.train_step((x, None), oG, ooptD, noise=z)
+    x, z = batch()
+    oG.train_step((x, None), oD, ooptG, noise=z)
+    # genuine-format checkpoint files written by torch, restored through the engine's own restore_checkpoint
+    for net, opt, name in ((oD, ooptD, 'netD'), (oG, ooptG, 'netG')):
+        torch.save({'model_state_dict': net.state_dict(), 'optimizer_state_dict': opt.state_dict(), 'global_step': 3},
+                   tmp_path / f'{name}_3_steps.pth')
+    assert netD.restore_checkpoint(ckpt_file=str(tmp_path / 'netD_3_steps.pth'), optimizer=optD) == 3
+    assert netG.restore_checkpoint(ckpt_file=str(tmp_path / 'netG_3_steps.pth'), optimizer=optG) == 3
+    assert optD._step == 2 and optG._step == 1
+    # moments round-trip exactly through the packed device layout
+    back = optD.state_dict()
+    ref = ooptD.state_dict()
+    for i in ref['state']:
+        assert torch.equal(back['state'][i]['exp_avg_sq'], ref['state'][i]['exp_avg_sq'].cpu()), i
+    torch.optim.Adam(list(copy.deepcopy(oD).parameters()), lr=2e-4, betas=(0.0, 0.9)).load_state_dict(back)
+    # continue on both sides from the restored state
+    x, z = batch()
+    errD, _, _ = oD.train_step((x, None), oG, ooptD, noise=z)
+    log = netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=z.cuda())
+    assert abs(log.m['errD'].item() - errD) < 1e-3
+    x, z = batch()
+    errG = oG.train_step((x, None), oD, ooptG, noise=z)
+    log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda', noise=z.cuda())
+    assert abs(log.m['errG'].item() - errG) < 5e-3 * max(1.0, abs(errG))
+    sD, sG = netD.state_dict(), netG.state_dict()
+    for k, v in oD.state_dict().items():
+        assert (sD[k].cpu() - v).abs().max() < 2e-3, k
+    for k, v in oG.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert (sG[k].cpu() - v).abs().max() < 2e-3, k
