@@ -227,6 +227,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+    # two more UN-timed steps on EVERY rank (each step contains the gradient all-reduces): every GEMM launch is
+    # bracketed for the per-kernel table rank 0 prints
+    summ_all = None
+    if timer is not None:
+        C.TIMER = full = C.KernelTimer()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        C.TIMER = None
+        summ_all = full.summary()
+        dist.synchronize()
     if rank != 0:
         return
 
@@ -253,12 +264,6 @@ def main():
         summ = timer.summary()
         dom = max(summ.items(), key=lambda kv: kv[1]['seconds'])
         name, d = dom
-        C.TIMER = full = C.KernelTimer()          # un-timed: every GEMM kernel bracketed, for the table below
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        C.TIMER = None
-        summ_all = full.summary()
         achieved = d['flop'] / d['seconds'] / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
