@@ -84,3 +84,24 @@ def test_two_rank_step_equals_microbatch_emulation(tmp_path):
     netD.flat_grads.copy_((grads[0] + grads[1]) / 2)
     optD.step()
     assert (netD.flat_params.cpu() - r[0]['D']).abs().max().item() < 2e-6
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_prints_one_json_line():
+    """The driver's N > 1 launch of bench.py (torch.distributed.run, one process per rank) end to end, with both
+    ranks on this box's single GPU over gloo: every rank must take part in every collective of every step,
+    including the un-timed steps after the timed region; exactly one JSON line, from rank 0."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DIAGAN_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no_cpu_baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 128
+    assert rec["scaling"] == "weak" and rec["value"] > 0 and "roofline" in rec and "cpu_baseline" not in rec
