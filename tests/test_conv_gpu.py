@@ -200,6 +200,63 @@ def test_full_size_sngan32_g_block4():
     close(nchw(y), ref_fwd("conv", x, w, None, 1, 1))
 
 
+@pytest.mark.parametrize("B,H,Ci,Co,pro", [(128, 32, 128, 128, 1), (64, 32, 256, 256, 2)])
+def test_full_size_backward_sampled(B, H, Ci, Co, pro):
+    """BASELINE-size data- and weight-gradients (D-32 block1.c2 as the batched real+fake pass, G-32 block4.c2)
+    checked on SAMPLED output elements against float64 sums taken straight from the definition, plus two
+    size-independent properties: linearity of the weight gradient in dy, and <dy, conv(x)> == <dW, W>."""
+    from diagan.ops import conv as C
+    g = torch.Generator().manual_seed(B + Ci)
+    x = torch.randn(B, H, H, Ci, generator=g)
+    dy = torch.randn(B, H, H, Co, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+    wp = C.pack_oihw(w, geom.Kp).cuda()
+    xa = ref_pro(x.permute(0, 3, 1, 2), pro, scale, shift).permute(0, 2, 3, 1).contiguous()      # activated input, NHWC
+    xd, dyd = x.cuda(), dy.cuda()
+    pro_t = (pro, scale.cuda(), shift.cuda())
+    # weight gradient through the slab path the networks use
+    splits = C.wgrad_splits(B * H * H, Co, geom.Kp)
+    stride = Co * geom.Kp + Co
+    slab = torch.empty(splits * stride, device="cuda")
+    C.conv_wgrad_into(geom, dyd, xd, slab, splits, stride, Co * geom.Kp, pro=pro_t)
+    tot = slab.view(splits, stride).double().sum(0)
+    dW = tot[: Co * geom.Kp].view(Co, 3, 3, Ci)                     # packed k = (r*3+s)*Ci + c
+    db = tot[Co * geom.Kp:]
+    idx = torch.randint(0, Co * 9 * Ci, (48,), generator=g)
+    xa64, dy64 = xa.double(), dy.double()
+    xpad = torch.nn.functional.pad(xa64, (0, 0, 1, 1, 1, 1))        # zero padding AFTER the prologue
+    for i in idx.tolist():
+        n, r, s_, c = i // (9 * Ci), (i // (3 * Ci)) % 3, (i // Ci) % 3, i % Ci
+        ref = (dy64[:, :, :, n] * xpad[:, r:r + H, s_:s_ + H, c]).sum().item()
+        got = dW[n, r, s_, c].item()
+        assert abs(got - ref) <= 2e-4 * (abs(ref) + 30.0), (n, r, s_, c, got, ref)
+    np_db = dy64.sum(dim=(0, 1, 2))
+    assert (db.cpu() - np_db).abs().max() <= 1e-3 * np_db.abs().max() + 1e-2
+    # data gradient (a full GEMM launch), sampled
+    wd = torch.zeros((Ci, geom.Kd), device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    dx = C.conv_dgrad(geom, dyd, wd, (H, H)).cpu().double()
+    dypad = torch.nn.functional.pad(dy64, (0, 0, 1, 1, 1, 1))
+    w64 = w.double()
+    for i in torch.randint(0, B * H * H * Ci, (48,), generator=g).tolist():
+        c, ix, iy, b = i % Ci, (i // Ci) % H, (i // (Ci * H)) % H, i // (Ci * H * H)
+        # dx[b,iy,ix,c] = sum_{n,r,s} dy[b, iy-r+1, ix-s+1, n] * w[n,c,r,s]
+        patch = dypad[b, iy:iy + 3, ix:ix + 3, :].flip(0, 1)        # [r, s, n] -> dy[b, iy+1-r, ix+1-s, n]
+        ref = (patch * w64[:, c].permute(1, 2, 0)).sum().item()
+        assert abs(dx[b, iy, ix, c].item() - ref) <= 2e-4 * (abs(ref) + 1.0), (b, iy, ix, c)
+    # properties at full size: linearity in dy, and the adjoint identity <dy, conv(a)> == <dW, W>
+    slab2 = torch.empty_like(slab)
+    C.conv_wgrad_into(geom, (2.5 * dyd).contiguous(), xd, slab2, splits, stride, Co * geom.Kp, pro=pro_t)
+    tot2 = slab2.view(splits, stride).double().sum(0)
+    assert (tot2 - 2.5 * tot).abs().max() <= 1e-4 * tot.abs().max()
+    y = C.conv_fwd(geom, xd, wp, pro=pro_t).double()
+    lhs = (y * dyd.double()).sum().item()
+    rhs = (dW.cuda() * wp.double().view(Co, 3, 3, Ci)).sum().item()
+    assert abs(lhs - rhs) <= 2e-5 * (abs(lhs) + abs(rhs) + 1e3), (lhs, rhs)
+
+
 def test_spectral_norm_forward_backward():
     """torch_mimicry SpectralNorm semantics: one power iteration, sigma = u W v^T, W/sigma used by
     the conv, gradient through sigma with u, v constant."""
