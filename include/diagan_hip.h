@@ -135,9 +135,10 @@ typedef struct {
   const float* W;        /* master weight for SN layers, NULL otherwise */
   int64_t stride;
   int splits, n_elem, n_w, Kp;  /* splits per context */
-  int nctx, pad;         /* 1, or 2 when the backward covered two batched forwards */
+  int nctx, first_block; /* nctx: 1, or 2 when the backward covered two batched forwards; first_block: index of the
+                            layer's first workgroup in the finish kernels' 1-D grid (prefix sum of ceil(n_elem/1024)) */
 } diagan_wgrad_layer;
-int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t max_elem, int any_sn, void* stream);
+int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t total_blocks, int any_sn, void* stream);
 
 /* out (+)= sum_s slab[s]; if w: dot_partials[block] = partial <sum, w> (fp64, for the SN backward);
  * ceil(n_elem/1024) partials. */

@@ -332,16 +332,25 @@ struct WgFinish {          // mirrored by diagan_wgrad_layer in include/diagan_h
   const float* W;          // master weight (SN layers) or NULL
   long stride;
   int splits, n_elem, n_w, Kp;   // splits per context; n_elem = Co*Kp (+ Co if bias), n_w = Co*Kp
-  int nctx, pad;
+  int nctx, first_block; // first_block: index of the layer's first workgroup in the 1-D grid of the finish kernels
 };
+
+// The finish kernels run on a 1-D grid with exactly ceil(n_elem / 1024) workgroups per layer (a [blocks of the largest
+// layer] x [layers] grid launched 69 000 mostly empty workgroups for SNGAN-64 and spent its time dispatching them).
+__device__ __forceinline__ int find_layer(const WgFinish* __restrict__ tab, int n_layers, int bid) {
+  int l = 0;
+  while (l + 1 < n_layers && tab[l + 1].first_block <= bid) ++l;
+  return l;
+}
 
 // phase A: G_c = sum over the splits of context c (fixed order).  plain layers: grad += sum_c G_c.
 // SN layers: G_c kept in slab[c][0..] and the block's partial of <G_c, W> is written.
-__global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab) {
-  const WgFinish L = tab[blockIdx.z];
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+__global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab, int n_layers) {
+  const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
+  const int lb = blockIdx.x - L.first_block;          // workgroup index inside the layer
+  const long i = ((long)lb * 256 + threadIdx.x) * 4;
   const bool sn = L.W != nullptr;
-  if ((long)blockIdx.x * 1024 >= L.n_elem) return;
+  if ((long)lb * 1024 >= L.n_elem) return;
   __shared__ double red[4];
   f32x4 total = {0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < L.nctx; ++c) {
@@ -381,18 +390,17 @@ __global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __r
       __syncthreads();
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
       __syncthreads();
-      if (threadIdx.x == 0) L.partials[c][blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (threadIdx.x == 0) L.partials[c][lb] = (red[0] + red[1]) + (red[2] + red[3]);
     }
   }
   if (!sn && i < L.n_elem) *reinterpret_cast<f32x4*>(L.grad + i) += total;
 }
 
-// phase B (SN layers): grad += sum_c (G_c - <G_c,W>/sigma_c * u_c^T v_c) / sigma_c ; bias part: += G_c
-__global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab) {
-  const WgFinish L = tab[blockIdx.z];
-  if (L.W == nullptr || (long)blockIdx.x * 1024 >= L.n_elem) return;
-  // <G_c, W> = sum of the phase-A partials, reduced by the whole block in a fixed pattern (deterministic)
-  __shared__ double sdot[2];
+// between A and B: <G_c, W> of every SN layer = sum of its phase-A partials, ONCE per layer (one workgroup each,
+// fixed reduction pattern: deterministic); stored behind the partials, at index nparts
+__global__ __launch_bounds__(256) void wgrad_finish_dot_kernel(const WgFinish* __restrict__ tab) {
+  const WgFinish L = tab[blockIdx.x];
+  if (L.W == nullptr) return;
   __shared__ double red[256];
   const int nparts = (L.n_elem + 1023) / 1024;
   for (int c = 0; c < L.nctx; ++c) {
@@ -404,10 +412,20 @@ __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __r
       if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
       __syncthreads();
     }
-    if (threadIdx.x == 0) sdot[c] = red[0];
+    if (threadIdx.x == 0) L.partials[c][nparts] = red[0];
     __syncthreads();
   }
-  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+}
+
+// phase B (SN layers): grad += sum_c (G_c - <G_c,W>/sigma_c * u_c^T v_c) / sigma_c ; bias part: += G_c
+__global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab, int n_layers) {
+  const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
+  const int lb = blockIdx.x - L.first_block;
+  if (L.W == nullptr || (long)lb * 1024 >= L.n_elem) return;
+  const int nparts = (L.n_elem + 1023) / 1024;
+  double sdot[2];
+  for (int c = 0; c < L.nctx; ++c) sdot[c] = L.partials[c][nparts];
+  const long i = ((long)lb * 256 + threadIdx.x) * 4;
   if (i >= L.n_elem) return;
   f32x4 o = {0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < L.nctx; ++c) {
@@ -429,15 +447,17 @@ __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __r
 
 using namespace diagan;
 
-DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t max_elem, int any_sn,
+DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t total_blocks, int any_sn,
                                            void* stream) {
-  DG_REQUIRE(table_dev && n_layers > 0 && max_elem > 0, "wgrad_finish_batched: bad args");
+  DG_REQUIRE(table_dev && n_layers > 0 && total_blocks > 0 && total_blocks < (1L << 31), "wgrad_finish_batched: bad args");
   static_assert(sizeof(WgFinish) == 128, "descriptor layout");
   const WgFinish* tab = (const WgFinish*)table_dev;
-  const int blocks = cdiv(max_elem, 1024);
-  hipLaunchKernelGGL(wgrad_finish_a_kernel, dim3(blocks, 1, n_layers), dim3(256), 0, (hipStream_t)stream, tab);
-  if (any_sn)
-    hipLaunchKernelGGL(wgrad_finish_b_kernel, dim3(blocks, 1, n_layers), dim3(256), 0, (hipStream_t)stream, tab);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wgrad_finish_a_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, tab, n_layers);
+  if (any_sn) {
+    hipLaunchKernelGGL(wgrad_finish_dot_kernel, dim3(n_layers), dim3(256), 0, st, tab);
+    hipLaunchKernelGGL(wgrad_finish_b_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, tab, n_layers);
+  }
   return check_launch("wgrad_finish_batched");
 }
 

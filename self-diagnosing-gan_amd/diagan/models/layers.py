@@ -484,7 +484,7 @@ class WgradBatch:
         self.net = net
         self.entries = {}        # (layer, slot) -> dict
         self.launched = {}       # slot -> list of layers launched in the current pass
-        self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, max_elem, any_sn)
+        self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, total_blocks, any_sn)
         self.flat_id = None
 
     def _entry(self, layer, slot, M, segments=1, dy_shape=None):
@@ -507,7 +507,7 @@ class WgradBatch:
             e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, bias_off=n_w if has_bias else -1,
                      segments=segments,
                      slab=torch.empty(splits * stride, dtype=torch.float32, device=dev),
-                     partials=torch.empty((segments, (stride + 1023) // 1024), dtype=torch.float64, device=dev))
+                     partials=torch.empty((segments, (stride + 1023) // 1024 + 1), dtype=torch.float64, device=dev))
             self.entries[(layer, slot)] = e
             self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
         return e
@@ -533,11 +533,10 @@ class WgradBatch:
         if t is None:
             desc = np.dtype([('p', np.uint64, 12), ('stride', np.int64), ('i', np.int32, 6)])
             tab = np.zeros(len(layers), dtype=desc)
-            any_sn, max_elem = 0, 0
+            any_sn, total_blocks = 0, 0
             for li, layer in enumerate(layers):
                 e = self.entries[(layer, slot)]
                 c = e['sn_ctx']
-                max_elem = max(max_elem, e['n_elem'])
                 ctxs = list(c) if isinstance(c, tuple) else [c]
                 nctx = len(ctxs)
                 per = e['splits'] // nctx                  # splits of each batched forward
@@ -554,8 +553,9 @@ class WgradBatch:
                 pp[10] = layer.weight.grad.data_ptr()
                 pp[11] = layer.weight.data.data_ptr() if sn else 0
                 tab[li]['p'], tab[li]['stride'] = pp, e['stride']
-                tab[li]['i'] = [per, e['n_elem'], e['n_w'], layer.geom.Kp, nctx, 0]
-            t = (torch.from_numpy(tab.view(np.uint8).copy()).to(layers[0].weight.device), len(layers), max_elem, any_sn)
+                tab[li]['i'] = [per, e['n_elem'], e['n_w'], layer.geom.Kp, nctx, total_blocks]
+                total_blocks += (e['n_elem'] + 1023) // 1024
+            t = (torch.from_numpy(tab.view(np.uint8).copy()).to(layers[0].weight.device), len(layers), total_blocks, any_sn)
             self.tables[key] = t
         nat.call("diagan_wgrad_finish_batched", t[0].data_ptr(), t[1], t[2], t[3], nat.current_stream())
 
