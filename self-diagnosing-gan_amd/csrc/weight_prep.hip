@@ -196,23 +196,32 @@ struct SnLayer {          // mirrored by diagan_sn_layer in include/diagan_hip.h
 constexpr int SN_RSPLIT = 8;
 constexpr int SN_MAX_KP = 9216;
 
-// vpart[r][k] = sum_{n in row chunk r} u[n] W[n][k]
+// vpart[r][k] = sum_{n in row chunk r} u[n] W[n][k].  A workgroup covers 64 columns x one row chunk with 4 row lanes
+// (then an LDS reduction): 4x the workgroups of a one-thread-per-column mapping -- the large SNGAN-64 weights
+// (1024 x 4608) had 144 workgroups for 19 MB.
 __global__ __launch_bounds__(256) void sn_cols_batched_kernel(const SnLayer* __restrict__ tab) {
+  __shared__ float red[4][64];
   const SnLayer L = tab[blockIdx.z];
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= L.Kp) return;
+  const int kl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kl;
+  if (blockIdx.x * 64 >= L.Kp) return;
   const int per = (L.Co + SN_RSPLIT - 1) / SN_RSPLIT;
   const int n0 = blockIdx.y * per, n1 = min(n0 + per, L.Co);
   float s = 0.f;
-  for (int n = n0; n < n1; ++n) s = fmaf(L.u_buf[n], L.W[(long)n * L.Kp + k], s);
-  L.work[(long)blockIdx.y * L.Kp + k] = s;
+  if (k < L.Kp) {
+#pragma unroll 4
+    for (int n = n0 + rl; n < n1; n += 4) s = fmaf(L.u_buf[n], L.W[(long)n * L.Kp + k], s);
+  }
+  red[rl][kl] = s;
+  __syncthreads();
+  if (rl == 0 && k < L.Kp) L.work[(long)blockIdx.y * L.Kp + k] = (red[0][kl] + red[1][kl]) + (red[2][kl] + red[3][kl]);
 }
 
-// v_raw = sum_r vpart[r] (into LDS; block 0 also stores it to v_out); t_raw[n] = W[n] . v_raw, 16 rows/block
+// v_raw = sum_r vpart[r] (into LDS; block 0 also stores it to v_out); t_raw[n] = W[n] . v_raw, 8 rows/block
 __global__ __launch_bounds__(256) void sn_rows_batched_kernel(const SnLayer* __restrict__ tab) {
   __shared__ float vs[SN_MAX_KP];
   const SnLayer L = tab[blockIdx.z];
-  const int row0 = blockIdx.x * 16;
+  const int row0 = blockIdx.x * 8;
   if (row0 >= L.Co) return;
   for (int k = threadIdx.x; k < L.Kp; k += 256) {
     float s = 0.f;
@@ -224,8 +233,8 @@ __global__ __launch_bounds__(256) void sn_rows_batched_kernel(const SnLayer* __r
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* t_raw = L.work + (long)SN_RSPLIT * L.Kp;
-  for (int i = 0; i < 4; ++i) {
-    const int n = row0 + wave * 4 + i;
+  for (int i = 0; i < 2; ++i) {
+    const int n = row0 + wave * 2 + i;
     if (n >= L.Co) break;
     float s = 0.f;
     for (int k = lane * 4; k < L.Kp; k += 256) {
@@ -301,8 +310,8 @@ DIAGAN_API int diagan_sn_prepare_batched(const void* table_dev, int n_layers, in
   static_assert(sizeof(SnLayer) == 96, "descriptor layout");
   hipStream_t st = (hipStream_t)stream;
   const SnLayer* tab = (const SnLayer*)table_dev;
-  hipLaunchKernelGGL(sn_cols_batched_kernel, dim3(cdiv(max_Kp, 256), SN_RSPLIT, n_layers), dim3(256), 0, st, tab);
-  hipLaunchKernelGGL(sn_rows_batched_kernel, dim3(cdiv(max_Co, 16), 1, n_layers), dim3(256), 0, st, tab);
+  hipLaunchKernelGGL(sn_cols_batched_kernel, dim3(cdiv(max_Kp, 64), SN_RSPLIT, n_layers), dim3(256), 0, st, tab);
+  hipLaunchKernelGGL(sn_rows_batched_kernel, dim3(cdiv(max_Co, 8), 1, n_layers), dim3(256), 0, st, tab);
   hipLaunchKernelGGL(sn_finalize_batched_kernel, dim3(1, 1, n_layers), dim3(256), 0, st, tab, eps, update_buffers);
   if (write_wd >= 0)      // write_wd < 0: power iteration only (operands are packed elsewhere)
     hipLaunchKernelGGL(pack_batched_kernel, dim3(cdiv(max_Ci, 32), cdiv(max_Co, 32), n_layers * max_RS), dim3(256), 0,
