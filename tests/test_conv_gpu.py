@@ -128,6 +128,52 @@ def test_dgrad_and_wgrad(case):
         assert torch.all(grad[:, R * R * Ci:] == 0.5)
 
 
+def test_random_geometries():
+    """Seeded fuzz over geometry (odd sizes, channel counts that are not tile multiples, 1x1 / 3x3 / 4x4 filters,
+    stride 1 and 2, conv and transposed conv), prologue mode and epilogue options: forward, data gradient and
+    weight gradient against torch CPU autograd.  Catches gather / padding / tile-edge mistakes the fixed cases miss."""
+    from diagan.ops import conv as C
+    rng = torch.Generator().manual_seed(20240)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=rng))
+    for trial in range(36):
+        kind = "convT" if trial % 4 == 3 else "conv"
+        R = (1, 3, 3, 4)[ri(0, 3)] if kind == "conv" else 4
+        stride = ri(1, 2) if R > 1 else 1
+        pad = {1: 0, 3: 1, 4: 1}[R] if not (kind == "convT" and stride == 1) else 0
+        B, H, W = ri(1, 5), ri(R, 19), ri(R, 21)
+        if kind == "conv" and stride == 2:
+            H, W = H + (H + 2 * pad - R) % 2 * 0, W          # any size: output is floor((H + 2p - R)/2) + 1
+        Ci, Co = 4 * ri(1, 24), 4 * ri(1, 40)
+        pro = ri(0, 4)
+        case = (kind, B, H, W, Ci, Co, R, stride, pad)
+        geom, x, w, wp = make(*case, seed=100 + trial)
+        scale = torch.rand(Ci, generator=rng) + 0.5
+        shift = torch.randn(Ci, generator=rng) * 0.3
+        bias = torch.randn(Co, generator=rng)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        a = ref_pro(xr, pro, scale, shift)
+        a.retain_grad()
+        y = ref_fwd(kind, a, wr, bias, stride, pad)
+        res = torch.randn(y.shape, generator=rng)
+        dy = torch.randn(y.shape, generator=rng)
+        y.backward(dy)
+        tag = f"trial {trial}: {case} pro={pro}"
+        pro_t = (pro, scale.cuda(), shift.cuda())
+        try:
+            got = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(), pro=pro_t)
+            close(nchw(got), y.detach() + res)
+            wd = torch.zeros((Ci, geom.Kd), device="cuda")
+            C.pack_weights(wp, Co, Ci, R * R, geom.Kp, geom.Kd, Wd=wd)
+            da = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W))
+            close(nchw(da), a.grad)
+            grad = torch.zeros((Co, geom.Kp), device="cuda")
+            C.conv_wgrad(geom, nhwc(dy).cuda(), nhwc(x).cuda(), grad, accumulate=False, pro=pro_t)
+            gw = C.unpack_oihw(grad, Co, Ci, R, R) if kind == "conv" else C.unpack_iohw(grad, Ci, Co, R, R)
+            close(gw, wr.grad, tol=5e-4)
+        except AssertionError as e:
+            raise AssertionError(f"{tag}: {e}") from None
+
+
 @pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
 @pytest.mark.parametrize("pro", [0, 2])
 def test_small_co_kernel_fwd_and_dgrad(Ci, H, W, B, pro):
