@@ -73,6 +73,7 @@ def make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, n_dis,
         return (b, None)
 
     def step():
+        netG.prefetch_fakes(n_dis * (2 if netD_drs is not None else 1), batches[0].shape[0], device=device)   # as LogTrainer._updates
         for i in range(n_dis):
             real = fetch()
             netD.train_step(real_batch=real, netG=netG, optD=optD, log_data=log, global_step=state['step'],

@@ -80,7 +80,10 @@ int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias
                      const float* scale0, const float* scale1, int scale_split,
                      int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                      int dr, int off, int up, int Kp, int tile_cfg, float* splitk_ws, int64_t splitk_ws_floats,
-                     float* stat_partials, void* stream);
+                     float* stat_partials, int pro_group_rows, void* stream);
+/* pro_group_rows > 0: the rows (pixels) form M / pro_group_rows groups and group g reads its affine prologue from
+ * pro_scale / pro_shift + g*Ci -- several independently batch-normalised batches (the n_dis generator forwards of one
+ * global step) as ONE GEMM.  Must be a multiple of the tile's row count and divide M. */
 /* stat_partials (optional, [ceil(M/BM)][2][Co] floats, BM = 128 for tile_cfg 1 else 64): the epilogue also
  * writes per-tile column sums of y and y^2 -- the BatchNorm statistics of the layer that consumes y
  * (diagan_bn_stats_fused), so the activation is not re-read; disables split-K. */
@@ -96,7 +99,8 @@ int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 int diagan_conv3x3_co4_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up);
 int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bias, const float* residual,
                        const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W, int Ci,
-                       int dr, int off, int Kp, void* stream);
+                       int dr, int off, int Kp, int group_imgs, void* stream);
+/* group_imgs > 0: image b reads the affine prologue of group b / group_imgs (see diagan_conv_gemm pro_group_rows). */
 /* Weight (+ bias) gradient of the same layer, Ci in {64,128,256}, Kp == 9*Ci: the whole [4][Kp] gradient lives in
  * each wave's accumulators; writes diagan_conv3x3_co4_wgrad_splits(B, H) partial slabs
  * slab[split][slab_stride] in the packed-weight layout (bias column sums at bias_off if >= 0), to be summed by
@@ -228,7 +232,7 @@ int diagan_colsum(const float* x, int64_t M, int C, float* out, int accumulate, 
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) with the conv prologue
  * modes applied to the source pixels, and its adjoint (+ residual). x [B,H,W,C] -> [B,2H,2W,C]. */
 int diagan_upsample2x(const float* x, float* out, int B, int H, int W, int C, int pro_mode,
-                      const float* scale, const float* shift, void* stream);
+                      const float* scale, const float* shift, int group_imgs, void* stream);
 int diagan_upsample2x_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
                           void* stream);
 

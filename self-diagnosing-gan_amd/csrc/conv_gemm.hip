@@ -33,6 +33,8 @@ struct ConvGemmArgs {
   const float* mask_src;  // same shape as y or null: y = mask_src > 0 ? y : lrelu_slope*y
   const float* pro_scale; // [Ci] for PRO_AFFINE*
   const float* pro_shift;
+  int pro_group_rows;     // > 0: rows [g*pro_group_rows, (g+1)*pro_group_rows) use pro_scale/shift + g*Ci (several
+                          // independently normalised batches -- BatchNorm statistics per group -- in ONE GEMM)
   float mask_slope;       // 0 for ReLU backward, 0.2 for LeakyReLU backward
   float out_scale;        // multiplies the accumulator before bias/residual (1.0 normally)
   const float* scale0;    // optional device scalars: rows m < scale_split use *scale0, the others *scale1
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.w), 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
   const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
+  const int pro_group_off = a.pro_group_rows > 0 ? (m0 / a.pro_group_rows) * g.Ci : 0;   // a tile never straddles groups
   unsigned wbase[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) wbase[j] = ((unsigned)(n0 + lrow + RP * j) * g.Kp + lq * 4) * 4u;
@@ -154,8 +157,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       a_ok = 0;
       if (affine) {
         const int kcs = min(kc, g.Ci - 4);       // kc < Ci always; keeps the address in range for the optimiser
-        psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kcs);
-        psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kcs);
+        psc = *reinterpret_cast<const f32x4*>(a.pro_scale + pro_group_off + kcs);
+        psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + kcs);
       }
     }
     if (p < AJ) {
@@ -493,7 +496,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                                 float out_scale, const float* scale0, const float* scale1, int scale_split,
                                 int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co,
                                 int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
-                                float* splitk_ws, int64_t splitk_ws_floats, float* stat_partials, void* stream) {
+                                float* splitk_ws, int64_t splitk_ws_floats, float* stat_partials, int pro_group_rows,
+                                void* stream) {
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
@@ -519,6 +523,9 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.dHo = make_fastdiv((unsigned)Ho);
   hipStream_t st = (hipStream_t)stream;
   const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp) : tile_cfg;
+  a.pro_group_rows = pro_group_rows;
+  DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % (cfg == 1 ? 128 : 64) == 0 && a.M % pro_group_rows == 0)),
+             "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, cfg == 1 ? 128 : 64, a.M);
   a.slab = splitk_ws;
   a.ksplit = 1;
   a.stat_partials = stat_partials;

@@ -33,6 +33,7 @@ struct SmallCoArgs {
   int B, H, W, Ci, Kp;
   int dr, off;            // tap r reads row oy + r*dr + off (conv pad 1: +1,-1; its data-gradient: -1,+1)
   int tiles_x, tiles_y;
+  int group_imgs;         // > 0: image b reads its affine prologue from pro_scale / pro_shift + (b / group_imgs)*Ci
 };
 
 constexpr int SC_TH = 4, SC_TW = 32;        // output tile of a workgroup: 4 rows x 32 columns (2 waves of 64 pixels)
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void conv3x3_co4_kernel(const SmallCoArgs a) {
   const int oy0 = ty * SC_TH, ox0 = tx * SC_TW;
   const bool affine = a.pro_mode == PRO_AFFINE_RELU || a.pro_mode == PRO_AFFINE;
   const int nchunk = a.Ci / SC_CC;
+  const int pgo = a.group_imgs > 0 ? (b / a.group_imgs) * a.Ci : 0;
 
   // ---- stage loader: thread-fixed (tile pixel, channel quad) slots ----------------------------------
   int goff[SC_LPT], loff[SC_LPT];
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(256) void conv3x3_co4_kernel(const SmallCoArgs a) {
       rx[i] = gok[i] ? *reinterpret_cast<const f32x4*>(a.x + goff[i] + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
     rw = w_ok ? *reinterpret_cast<const f32x4*>(a.w + w_goff + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
     if (affine) {
-      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + q_own * 4);
-      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + q_own * 4);
+      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + pgo + c0 + q_own * 4);
+      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pgo + c0 + q_own * 4);
     }
   };
   auto store_stage = [&](int buf) {
@@ -322,15 +324,16 @@ DIAGAN_API int diagan_conv3x3_co4_supported(int Ci, int Co, int R, int S, int sy
 
 DIAGAN_API int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bias, const float* residual,
                                   const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W,
-                                  int Ci, int dr, int off, int Kp, void* stream) {
+                                  int Ci, int dr, int off, int Kp, int group_imgs, void* stream) {
   DG_REQUIRE(x && w && y, "conv3x3_co4: null tensor");
+  DG_REQUIRE(group_imgs >= 0 && (group_imgs == 0 || B % group_imgs == 0), "conv3x3_co4: group_imgs=%d must divide B=%d", group_imgs, B);
   DG_REQUIRE(B > 0 && H > 0 && W > 0, "conv3x3_co4: bad dims");
   DG_REQUIRE(diagan_conv3x3_co4_supported(Ci, 4, 3, 3, 1, dr, off, 1), "conv3x3_co4: unsupported geometry Ci=%d dr=%d off=%d", Ci, dr, off);
   DG_REQUIRE(Kp >= 9 * Ci && pro_mode >= 0 && pro_mode <= 4, "conv3x3_co4: bad Kp / pro_mode");
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift), "conv3x3_co4: affine prologue needs scale/shift");
   DG_REQUIRE((long)B * H * W * Ci * 4 < (1L << 31), "conv3x3_co4: tensors must be smaller than 2 GiB");
   SmallCoArgs a{x, w, y, bias, residual, pro_scale, pro_shift, pro_mode, B, H, W, Ci, Kp, dr, off,
-                cdiv(W, SC_TW), cdiv(H, SC_TH)};
+                cdiv(W, SC_TW), cdiv(H, SC_TH), group_imgs};
   const long blocks = (long)B * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL(conv3x3_co4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3x3_co4");

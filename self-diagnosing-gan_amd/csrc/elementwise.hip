@@ -291,7 +291,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 // ---- bilinear 2x upsample (align_corners=False) and its adjoint ---------------------------------
 // out[2j]   = 0.25*x[max(j-1,0)] + 0.75*x[j] ; out[2j+1] = 0.75*x[j] + 0.25*x[min(j+1,H-1)]
 __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
-                                  int pro_mode, const float* __restrict__ scale, const float* __restrict__ shift) {
+                                  int pro_mode, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  int group_imgs) {
   const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
   const long n4 = (long)B * Ho * Wo * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -306,9 +307,10 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict
     const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
     const float wy1 = 1.f - wy0, wx1 = 1.f - wx0;
     const float* base = x + (long)b * H * W * C + c4 * 4;
+    const int pc = (group_imgs > 0 ? (b / group_imgs) * C : 0) + c4 * 4;     // per-group BatchNorm scale / shift
     auto ld = [&](int yy, int xx) {
       f32x4 v = *reinterpret_cast<const f32x4*>(base + ((long)yy * W + xx) * C);
-      return apply_pro(v, pro_mode, scale, shift, c4 * 4);
+      return apply_pro(v, pro_mode, scale, shift, pc);
     };
     // PyTorch evaluates (w0*a + w1*b) along x inside the y blend; same grouping here
     const f32x4 top = wx0 * ld(y0, x0) + wx1 * ld(y0, x1);
@@ -662,12 +664,13 @@ DIAGAN_API int diagan_colsum(const float* x, int64_t M, int C, float* out, int a
 }
 
 DIAGAN_API int diagan_upsample2x(const float* x, float* out, int B, int H, int W, int C, int pro_mode,
-                                 const float* scale, const float* shift, void* stream) {
+                                 const float* scale, const float* shift, int group_imgs, void* stream) {
+  DG_REQUIRE(group_imgs >= 0 && (group_imgs == 0 || B % group_imgs == 0), "upsample2x: group_imgs=%d must divide B=%d", group_imgs, B);
   DG_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "upsample2x: bad args");
   DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "upsample2x: bad pro_mode");
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (scale && shift), "upsample2x: affine needs scale/shift");
   hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(EW_T), 0, ST, x, out, B, H, W, C,
-                     pro_mode, scale, shift);
+                     pro_mode, scale, shift, group_imgs);
   return check_launch("upsample2x");
 }
 

@@ -14,6 +14,9 @@ from diagan.models.layers import FlatNet
 from diagan.ops import eltwise as E
 
 
+PREFETCH_FAKES = os.environ.get("DIAGAN_PREFETCH_FAKES", "1") != "0"
+
+
 class BaseModel(FlatNet):
     """Checkpoint I/O with mimicry's file layout: {model_state_dict, optimizer_state_dict,
     global_step} at <directory>/<basename(directory)>_<step>_steps.pth (consumers:
@@ -75,9 +78,42 @@ class BaseGenerator(BaseModel):
     def generate_images_nhwc(self, num_images, device=None, noise=None, save=False, out=None):
         if device is None:
             device = self.device
+        if noise is None and not save:
+            ready = self._take_prefetched(num_images)
+            if ready is not None:
+                if out is not None:
+                    out.copy_(ready)
+                    ready = out
+                return ready, None
         if noise is None:
             noise = torch.randn((num_images, self.nz), device=device)
         return self.forward_nhwc(noise, self.training, save=save, out=out)
+
+    # ---- fake batches of a whole global step in ONE forward --------------------------------------------------
+    # The n_dis discriminator updates of a global step (trainer.py:250-277) each start with G(z) under no_grad, and G
+    # does not change until its own update at the end of the step: the forwards are independent.  `prefetch_fakes`
+    # draws the noise batches in the order the updates would (same generator state afterwards) and runs them as one
+    # stacked forward with per-batch BatchNorm statistics; `generate_images_nhwc` then hands the batches out in order.
+    supports_stacked_forward = False
+
+    def prefetch_fakes(self, count, batch_size, device=None):
+        self._fake_pool = []
+        if not (self.supports_stacked_forward and self.training and count > 1 and PREFETCH_FAKES):
+            return
+        device = self.device if device is None else device
+        noise = torch.cat([torch.randn((batch_size, self.nz), device=device) for _ in range(count)])
+        imgs, _ = self.forward_nhwc(noise, True, save=False, groups=count)
+        self._fake_pool = list(imgs.split(batch_size))
+        self._fake_pool_version = self.param_version
+
+    def _take_prefetched(self, num_images):
+        pool = getattr(self, '_fake_pool', None)
+        if not pool:
+            return None
+        if pool[0].shape[0] != num_images or self._fake_pool_version != self.param_version or not self.training:
+            self._fake_pool = []        # ragged last batch, changed parameters or eval mode: fall back
+            return None
+        return pool.pop(0)
 
     def compute_gan_loss(self, output):
         k = None

@@ -150,17 +150,19 @@ class ConvLayer(nn.Module):
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale)
 
-    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None):
+    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1):
         """Forward + the BatchNorm statistics of the layer that consumes the output, taken from the GEMM
-        epilogue's per-tile sums (no second pass over the activation).  Returns (y, bn context)."""
+        epilogue's per-tile sums (no second pass over the activation).  Returns (y, bn context).
+        groups > 1: the batch is `groups` stacked batches with separate statistics (tiles never straddle groups)."""
         if not training:
             y = self.fwd(ctx, x, pro=pro, residual=residual)
             return y, bn.stats(y, False)
         y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                               residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True)
-        if stats is None:
-            return y, bn.stats(y, True)
-        return y, bn.stats_fused(stats[0], stats[1], y.numel() // y.shape[-1])
+        M = y.numel() // y.shape[-1]
+        if stats is None or stats[1] % groups or (M // groups) % (M // stats[1]):
+            return y, bn.stats(y, True, groups=groups)
+        return y, bn.stats_fused(stats[0], stats[1], M, groups=groups, group_imgs=y.shape[0] // groups)
 
     def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
@@ -209,16 +211,17 @@ class BatchNorm(nn.Module):
     def _drop_pending(self, *args):
         self._pending_batches = 0
 
-    def stats(self, x, training):
+    def stats(self, x, training, groups=1):
+        """groups > 1: `groups` batches stacked along dim 0, each normalised by its own statistics (forward only)."""
         if training:
-            self._pending_batches += 1
+            self._pending_batches += groups
         return E.bn_stats(x, self.weight.data, self.bias.data, self.running_mean, self.running_var, training,
-                          self.eps, self.momentum)
+                          self.eps, self.momentum, groups=groups if training else 1)
 
-    def stats_fused(self, partials, tiles, M):
-        self._pending_batches += 1
+    def stats_fused(self, partials, tiles, M, groups=1, group_imgs=0):
+        self._pending_batches += groups
         return E.bn_stats_fused(partials, tiles, M, self.weight.data, self.bias.data, self.running_mean,
-                                self.running_var, self.eps, self.momentum)
+                                self.running_var, self.eps, self.momentum, groups=groups, group_imgs=group_imgs)
 
     def bwd(self, g, x, ctx, relu, residual=None, slope=0.0, drop=None):
         return E.bn_bwd(g, x, ctx, relu, self.weight.grad, self.bias.grad, True, residual=residual, slope=slope,

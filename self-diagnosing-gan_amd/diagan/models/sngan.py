@@ -24,7 +24,7 @@ RELU = (C.PRO_RELU, None, None)
 
 
 def _bn_pro(bn):
-    return (C.PRO_AFFINE_RELU, bn.scale, bn.shift)
+    return (C.PRO_AFFINE_RELU, bn.scale, bn.shift, bn.group_imgs)
 
 
 class GBlock(nn.Module):
@@ -43,18 +43,21 @@ class GBlock(nn.Module):
             self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0)
             self.c_sc.xavier_(1.0)
 
-    def forward(self, x, training, save=True, need_dgrad=True, bn1=None, next_bn=None):
+    def forward(self, x, training, save=True, need_dgrad=True, bn1=None, next_bn=None, groups=1):
         """bn1: statistics of x if the producer already reduced them; next_bn: the BatchNorm module that will
-        consume this block's output (its statistics are then taken from the last conv's epilogue)."""
+        consume this block's output (its statistics are then taken from the last conv's epilogue).
+        groups > 1 (forward only): x stacks `groups` batches that are batch-normalised independently."""
         ctx = {}
+        if groups > 1 and save:
+            raise RuntimeError("GBlock: stacked batches are a forward-only path")
         if bn1 is None:
-            bn1 = self.b1.stats(x, training)
+            bn1 = self.b1.stats(x, training, groups=groups)
         if self.upsample:
             c1_in, c1_pro = E.upsample2x(x, pro=_bn_pro(bn1)), None
         else:
             c1_in, c1_pro = x, _bn_pro(bn1)
         k1 = self.c1.prepare(training, need_dgrad)
-        h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro)
+        h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro, groups=groups)
         # shortcut: a 1x1 conv commutes with the (linear) bilinear upsampling, so c_sc runs on the LOW
         # resolution input (4x fewer FLOP) and its output is upsampled: c_sc(up(x)) == up(c_sc(x))
         if self.learnable_sc:
@@ -67,7 +70,7 @@ class GBlock(nn.Module):
         k2 = self.c2.prepare(training, need_dgrad)
         bn_out = None
         if next_bn is not None:
-            out, bn_out = self.c2.fwd_bn(k2, h1, next_bn, training, pro=_bn_pro(bn2), residual=sc)
+            out, bn_out = self.c2.fwd_bn(k2, h1, next_bn, training, pro=_bn_pro(bn2), residual=sc, groups=groups)
         else:
             out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc)
         if save:
@@ -202,11 +205,15 @@ class DBlockOptimized(nn.Module):
 
 class SNGANBaseGenerator(BaseGenerator):
     out_channels = 3
+    supports_stacked_forward = True
 
     def _blocks(self):
         raise NotImplementedError
 
-    def forward_nhwc(self, z, training, save=True, out=None):
+    def forward_nhwc(self, z, training, save=True, out=None, groups=1):
+        """groups > 1 (forward only, save=False): z stacks `groups` noise batches; the result equals `groups`
+        successive forwards (BatchNorm statistics and running-statistics updates per batch, in order) at the GEMM
+        efficiency of the large batch."""
         z = z.to(dtype=self.l1.weight.dtype)
         x0, h = self.l1.fwd(z)
         bctx = []
@@ -214,7 +221,7 @@ class SNGANBaseGenerator(BaseGenerator):
         bn = None
         for i, blk in enumerate(blocks):
             nxt = blocks[i + 1].b1 if i + 1 < len(blocks) else self._last_bn
-            h, c, bn = blk.forward(h, training, save=save, need_dgrad=save, bn1=bn, next_bn=nxt)
+            h, c, bn = blk.forward(h, training, save=save, need_dgrad=save, bn1=bn, next_bn=nxt, groups=groups)
             bctx.append(c)
         k = self._last_conv.prepare(training, need_dgrad=save)
         y_pre = self._last_conv.fwd(k, h, pro=_bn_pro(bn))

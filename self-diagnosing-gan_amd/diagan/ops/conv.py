@@ -10,11 +10,11 @@ import torch
 from diagan import _native as nat
 
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
-nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, P])
+nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, I, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I])
 nat.register("diagan_conv3x3_co4_supported", [I] * 8)
-nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P])
+nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
 nat.register("diagan_conv3x3_co4_wgrad_supported", [I] * 8)
 nat.register("diagan_conv3x3_co4_wgrad_splits", [I, I])
 nat.register("diagan_conv3x3_co4_wgrad", [P, P, P, I64, I64, P, P, I, I, I, I, I, I, P])
@@ -107,6 +107,15 @@ class Geom:
         return (1, -1, self.pad, self.stride) if self.kind == 'conv' else (self.stride, 1, -self.pad, 1)
 
 
+def _pro3(pro):
+    """(mode, scale, shift) of a prologue tuple for the kernels that take ONE batch (weight gradients)."""
+    if pro is None:
+        return PRO_NONE, None, None
+    if len(pro) > 3 and pro[3]:
+        raise RuntimeError("grouped BatchNorm prologues exist for the forward kernels only")
+    return tuple(pro)[:3]
+
+
 def _chk(t, name):
     if t is None:
         return
@@ -121,7 +130,8 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
-    mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
+    # pro = (mode, scale, shift[, group_imgs]): group_imgs > 0 -> scale / shift are [G, Ci], one row per group of images
+    mode, scale, shift, group_imgs = (tuple(pro) + (0,))[:4] if pro is not None else (PRO_NONE, None, None, 0)
     for t, n in ((x, 'x'), (w, 'w'), (out, 'out'), (bias, 'bias'), (residual, 'residual'),
                  (mask_src, 'mask_src'), (scale, 'pro_scale'), (shift, 'pro_shift')):
         _chk(t, n)
@@ -136,7 +146,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
             and not want_stats and nat.fn("diagan_conv3x3_co4_supported")(Ci, Co, R, S, sy, dr, off, up)):
         t0 = TIMER.begin("conv3x3_co4_kernel") if TIMER is not None else None
         nat.call("diagan_conv3x3_co4", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
-                 nat.ptr(scale), nat.ptr(shift), mode, B, Hi, Wi, Ci, dr, off, Kp, nat.current_stream())
+                 nat.ptr(scale), nat.ptr(shift), mode, B, Hi, Wi, Ci, dr, off, Kp, group_imgs, nat.current_stream())
         if t0 is not None:
             TIMER.end("conv3x3_co4_kernel", 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                       (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}"))
@@ -159,7 +169,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
              (B // 2) * Ho * Wo if row_scale else 0,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
-             nat.ptr(stats[0]) if stats else None, nat.current_stream())
+             nat.ptr(stats[0]) if stats else None, group_imgs * Ho * Wo, nat.current_stream())
     if t0 is not None:
         TIMER.end(kname, 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                   (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}{'+res' if residual is not None else ''}"
@@ -224,7 +234,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     sn = (W_master, u, v, state): backward through W/sigma (diagan_sn_grad_fix)."""
     B, Ho, Wo, Co = dy.shape
     _, Hi, Wi, Ci = x.shape
-    mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
+    mode, scale, shift = _pro3(pro)
     for t, n in ((dy, 'dy'), (x, 'x'), (grad, 'grad'), (scale, 'pro_scale'), (shift, 'pro_shift')):
         _chk(t, n)
     M = B * Ho * Wo
@@ -274,7 +284,7 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
     splits is done later for all layers at once (diagan_wgrad_finish_batched)."""
     B, Ho, Wo, Co = dy.shape
     _, Hi, Wi, Ci = x.shape
-    mode, scale, shift = pro if pro is not None else (PRO_NONE, None, None)
+    mode, scale, shift = _pro3(pro)
     sy, dr, off, up = geom.fwd_params()
     if segments == 1 and small_co_wgrad(geom):
         if splits != small_co_wgrad_splits(B, Ho):

@@ -20,7 +20,7 @@ nat.register("diagan_linear1_bwd_input", [P, P, P, I, I, P])
 nat.register("diagan_linear1_fwd", [P, P, P, P, I, I, P])
 nat.register("diagan_linear1_wgrad", [P, P, P, P, I, I, P])
 nat.register("diagan_colsum", [P, I64, I, P, I, P, P])
-nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, P])
+nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, I, P])
 nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
 nat.register("diagan_avgpool2", [P, P, I, I, I, I, P, I, P])
 nat.register("diagan_avgpool2_bwd", [P, P, I, I, I, I, P, P])
@@ -85,32 +85,51 @@ def tanh_bwd(y, g):
 
 
 class BNCtx:
-    __slots__ = ("mean", "invstd", "scale", "shift", "M", "C", "training")
+    """mean / invstd / scale / shift of one BatchNorm application: [C], or [G, C] when the batch consists of G groups
+    that are normalised independently (`group_imgs` images each, 0 = one group)."""
+    __slots__ = ("mean", "invstd", "scale", "shift", "M", "C", "training", "group_imgs")
 
 
-def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1):
-    C = x.shape[-1]
-    M = x.numel() // C
-    buf = _f32((4, C), x.device)
+def _bn_ctx(C, M, training, groups, group_imgs, dev):
+    buf = _f32((4, groups, C) if groups > 1 else (4, C), dev)
     ctx = BNCtx()
     ctx.mean, ctx.invstd, ctx.scale, ctx.shift, ctx.M, ctx.C = buf[0], buf[1], buf[2], buf[3], M, C
-    ctx.training = bool(training)
-    ws = _colred_ws(x.device, M, C) if training else None
-    nat.call("diagan_bn_stats", ptr(x), M, C, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
-             ptr(running_var), 1 if training else 0, ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale),
-             ptr(ctx.shift), ptr(ws), st())
+    ctx.training, ctx.group_imgs = bool(training), (group_imgs if groups > 1 else 0)
     return ctx
 
 
-def bn_stats_fused(partials, tiles, M, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
-    """Training-mode BatchNorm context from the per-tile sums emitted by the producing conv's epilogue."""
+def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, groups=1):
+    """groups > 1: x holds `groups` equally sized batches along dim 0, each normalised with its OWN statistics; the
+    running statistics take the momentum updates in group order (as `groups` successive forwards would)."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    if x.shape[0] % groups:
+        raise RuntimeError(f"bn_stats: batch of {x.shape[0]} does not split into {groups} groups")
+    Mg, bg = M // groups, x.shape[0] // groups
+    ctx = _bn_ctx(C, Mg, training, groups, bg, x.device)
+    ws = _colred_ws(x.device, Mg, C) if training else None
+    for g in range(groups):
+        o = g * C * 4
+        nat.call("diagan_bn_stats", ptr(x) + g * Mg * C * 4, Mg, C, ptr(gamma), ptr(beta), eps, momentum,
+                 ptr(running_mean), ptr(running_var), 1 if training else 0, ptr(ctx.mean) + o, ptr(ctx.invstd) + o,
+                 ptr(ctx.scale) + o, ptr(ctx.shift) + o, ptr(ws), st())
+    return ctx
+
+
+def bn_stats_fused(partials, tiles, M, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, groups=1,
+                   group_imgs=0):
+    """Training-mode BatchNorm context from the per-tile sums emitted by the producing conv's epilogue
+    (groups > 1: the tiles of a group are contiguous; one finalize per group, in order)."""
     C = gamma.numel()
-    buf = _f32((4, C), gamma.device)
-    ctx = BNCtx()
-    ctx.mean, ctx.invstd, ctx.scale, ctx.shift, ctx.M, ctx.C = buf[0], buf[1], buf[2], buf[3], M, C
-    ctx.training = True
-    nat.call("diagan_bn_stats_fused", ptr(partials), tiles, M, C, ptr(gamma), ptr(beta), eps, momentum,
-             ptr(running_mean), ptr(running_var), ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale), ptr(ctx.shift), st())
+    if tiles % groups or M % groups:
+        raise RuntimeError(f"bn_stats_fused: {tiles} tiles / {M} rows do not split into {groups} groups")
+    tg, Mg = tiles // groups, M // groups
+    ctx = _bn_ctx(C, Mg, True, groups, group_imgs, gamma.device)
+    for g in range(groups):
+        o = g * C * 4
+        nat.call("diagan_bn_stats_fused", ptr(partials) + g * tg * 2 * C * 4, tg, Mg, C, ptr(gamma), ptr(beta), eps,
+                 momentum, ptr(running_mean), ptr(running_var), ptr(ctx.mean) + o, ptr(ctx.invstd) + o,
+                 ptr(ctx.scale) + o, ptr(ctx.shift) + o, st())
     return ctx
 
 
@@ -135,9 +154,9 @@ def colsum(x, out, accumulate):
 
 def upsample2x(x, pro=None):
     B, H, W, C = x.shape
-    mode, scale, shift = pro if pro is not None else (0, None, None)
+    mode, scale, shift, group_imgs = (tuple(pro) + (0,))[:4] if pro is not None else (0, None, None, 0)
     out = _f32((B, 2 * H, 2 * W, C), x.device)
-    nat.call("diagan_upsample2x", ptr(x), ptr(out), B, H, W, C, mode, ptr(scale), ptr(shift), st())
+    nat.call("diagan_upsample2x", ptr(x), ptr(out), B, H, W, C, mode, ptr(scale), ptr(shift), group_imgs, st())
     return out
 
 

@@ -187,6 +187,10 @@ class LogTrainer:
     # the G update on the LAST D batch, step += 1, LR schedule, then the periodic duties in the order
     # summaries, console line, sample grid, logit snapshot, checkpoint (+ pickle of the record).
     def _updates(self, step, streams, log):
+        # the fake batches of all the D (and D_drs) updates of this step in one stacked generator forward
+        prefetch = getattr(self.netG, 'prefetch_fakes', None)       # optional part of the generator protocol
+        if prefetch is not None:
+            prefetch(self.n_dis * (2 if self.train_drs else 1), self.dataloader.batch_size, device=self.device)
         for i in range(self.n_dis):
             streams['main'], batch = self._fetch_data(iter_dataloader=streams['main'])
             log = self.netD.train_step(real_batch=batch, netG=self.netG, optD=self.optD, log_data=log,

@@ -322,3 +322,51 @@ def test_resume_from_torch_adam_state(tmp_path):
     for k, v in oG.state_dict().items():
         if v.dtype.is_floating_point:
             assert (sG[k].cpu() - v).abs().max() < 2e-3, k
+
+
+@pytest.mark.parametrize("dataset", ["cifar10", "celeba"])
+def test_stacked_generator_forward_equals_successive_forwards(dataset):
+    """prefetch_fakes: the n_dis generator forwards of a global step as ONE stacked forward with per-batch BatchNorm
+    statistics -- same images, same running statistics (momentum chain in order), same RNG state afterwards."""
+    from diagan.models import base as MB
+    (_, _, _, _), (netG, _, _, _) = build(dataset, 'ns')
+    ref = copy.deepcopy(netG)
+    B, n = 8, 3
+    torch.manual_seed(21)
+    netG.prefetch_fakes(n, B, device='cuda')
+    got = [netG.generate_images_nhwc(B)[0] for _ in range(n)]
+    after = torch.randn(4, device='cuda')
+    assert netG._fake_pool == []                                   # pool exhausted: the next call is an ordinary forward
+    torch.manual_seed(21)
+    want = [ref.generate_images_nhwc(B)[0] for _ in range(n)]      # ref never prefetched: n ordinary forwards
+    assert torch.equal(after, torch.randn(4, device='cuda'))       # the generator consumed the same random numbers
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() < 2e-6
+    sa, sb = netG.state_dict(), ref.state_dict()
+    for k in sb:
+        if 'running' in k:
+            assert (sa[k] - sb[k]).abs().max().item() < 1e-6, k
+    # ragged request / changed parameters / eval mode invalidate the pool instead of serving stale images
+    netG.prefetch_fakes(n, B, device='cuda')
+    assert netG.generate_images_nhwc(B - 1)[0].shape[0] == B - 1 and not netG._fake_pool
+    netG.prefetch_fakes(n, B, device='cuda')
+    netG.param_version += 1
+    netG.generate_images_nhwc(B)
+    assert not netG._fake_pool
+
+
+def test_d_updates_with_prefetched_fakes_match(monkeypatch):
+    """Two D updates fed from the pool equal two D updates that run their own generator forward."""
+    (_, _, _, _), (netG, netD, optG, optD) = build('cifar10', 'hinge')
+    (_, _, _, _), (netG2, netD2, _, optD2) = build('cifar10', 'hinge')          # same seed: identical twins
+    g = torch.Generator().manual_seed(4)
+    xs = [(torch.rand(8, 3, 32, 32, generator=g) * 2 - 1).cuda() for _ in range(2)]
+    torch.manual_seed(33)
+    netG.prefetch_fakes(2, 8, device='cuda')
+    logs = [netD.train_step(real_batch=(x, None), netG=netG, optD=optD, log_data=Log(), device='cuda') for x in xs]
+    torch.manual_seed(33)
+    logs2 = [netD2.train_step(real_batch=(x, None), netG=netG2, optD=optD2, log_data=Log(), device='cuda') for x in xs]
+    for a, b in zip(logs, logs2):
+        assert abs(a.m['errD'].item() - b.m['errD'].item()) < 1e-5
+    assert (netD.flat_params - netD2.flat_params).abs().max().item() < 1e-6
