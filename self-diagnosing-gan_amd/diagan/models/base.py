@@ -95,15 +95,22 @@ class BaseGenerator(BaseModel):
     # draws the noise batches in the order the updates would (same generator state afterwards) and runs them as one
     # stacked forward with per-batch BatchNorm statistics; `generate_images_nhwc` then hands the batches out in order.
     supports_stacked_forward = False
+    max_stacked_images = 0        # largest stacked batch whose activations stay below 2 GiB
 
     def prefetch_fakes(self, count, batch_size, device=None):
         self._fake_pool = []
         if not (self.supports_stacked_forward and self.training and count > 1 and PREFETCH_FAKES):
             return
         device = self.device if device is None else device
-        noise = torch.cat([torch.randn((batch_size, self.nz), device=device) for _ in range(count)])
-        imgs, _ = self.forward_nhwc(noise, True, save=False, groups=count)
-        self._fake_pool = list(imgs.split(batch_size))
+        # every activation of the stacked forward must stay below 2 GiB (32-bit buffer offsets in the kernels)
+        per_chunk = min(count, self.max_stacked_images // max(batch_size, 1))
+        if per_chunk < 2:
+            return
+        noise = [torch.randn((batch_size, self.nz), device=device) for _ in range(count)]   # in update order
+        for lo in range(0, count, per_chunk):
+            part = noise[lo: lo + per_chunk]
+            imgs, _ = self.forward_nhwc(torch.cat(part), True, save=False, groups=len(part))
+            self._fake_pool.extend(imgs.split(batch_size))
         self._fake_pool_version = self.param_version
 
     def _take_prefetched(self, num_images):

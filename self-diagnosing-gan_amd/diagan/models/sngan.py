@@ -242,6 +242,8 @@ class SNGANBaseGenerator(BaseGenerator):
 
 
 class SNGANGenerator32(SNGANBaseGenerator):
+    max_stacked_images = 1536     # largest activation [N,32,32,256] fp32
+
     def __init__(self, nz=128, ngf=256, bottom_width=4, loss_type='hinge', **kwargs):
         super().__init__(nz=nz, ngf=ngf, bottom_width=bottom_width, loss_type=loss_type, **kwargs)
         self.l1 = LatentLinear(nz, ngf, bottom_width)
@@ -267,6 +269,8 @@ class SNGANGenerator32(SNGANBaseGenerator):
 
 
 class SNGANGenerator64(SNGANBaseGenerator):
+    max_stacked_images = 768      # largest activation [N,64,64,128] fp32 (upsampled input of block5)
+
     def __init__(self, nz=128, ngf=1024, bottom_width=4, loss_type='hinge', **kwargs):
         super().__init__(nz=nz, ngf=ngf, bottom_width=bottom_width, loss_type=loss_type, **kwargs)
         self.l1 = LatentLinear(nz, ngf, bottom_width)

@@ -347,6 +347,17 @@ def test_stacked_generator_forward_equals_successive_forwards(dataset):
     for k in sb:
         if 'running' in k:
             assert (sa[k] - sb[k]).abs().max().item() < 1e-6, k
+    # a stack that would not fit the 2 GiB tensor limit is cut into several stacked forwards: same images again
+    netG.load_state_dict(ref.state_dict())                      # same running statistics as before the chunked run ...
+    ref2 = copy.deepcopy(ref)
+    netG.max_stacked_images = 2 * B
+    torch.manual_seed(22)
+    netG.prefetch_fakes(n, B, device='cuda')
+    assert len(netG._fake_pool) == n
+    chunked = [netG.generate_images_nhwc(B)[0] for _ in range(n)]
+    torch.manual_seed(22)
+    for a in chunked:
+        assert (a - ref2.generate_images_nhwc(B)[0]).abs().max().item() < 2e-6
     # ragged request / changed parameters / eval mode invalidate the pool instead of serving stale images
     netG.prefetch_fakes(n, B, device='cuda')
     assert netG.generate_images_nhwc(B - 1)[0].shape[0] == B - 1 and not netG._fake_pool
