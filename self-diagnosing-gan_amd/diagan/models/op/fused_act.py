@@ -14,8 +14,9 @@ P, I, F32, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_fused_bias_act", [P, P, P, P, I64, I64, I, I, I, F32, F32, P])
 
 
-def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
-    """The reference's native entry point, on HIP.  Empty `bias` / `refer` tensors mean "absent"."""
+def fused_bias_act(input, bias, refer, act, grad, alpha, scale, bias_dim=1):
+    """The reference's native entry point, on HIP.  Empty `bias` / `refer` tensors mean "absent".
+    `bias_dim` (extension): the dimension the bias runs along; the reference fixes 1, channels-last callers pass -1."""
     if not input.is_cuda:
         raise RuntimeError("fused_bias_act: input must be a CUDA tensor")        # CHECK_CUDA of the reference
     x = input.contiguous().float()
@@ -24,7 +25,7 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     if b is not None and not b.is_cuda:
         raise RuntimeError("fused_bias_act: bias must be a CUDA tensor")
     step_b = 1
-    for i in range(2, x.dim()):
+    for i in range(bias_dim % x.dim() + 1, x.dim()):
         step_b *= x.size(i)
     out = torch.empty_like(x)
     nat.call("diagan_fused_bias_act", nat.ptr(x), nat.ptr(b), nat.ptr(r), nat.ptr(out), x.numel(), step_b,
@@ -55,23 +56,23 @@ class _BiasLeakyReLU(Function):
     backward and the input is not kept."""
 
     @staticmethod
-    def forward(ctx, x, bias, slope, scale):
-        y = fused_bias_act(x, bias, None, 3, 0, slope, scale)
+    def forward(ctx, x, bias, slope, scale, bias_dim=1):
+        y = fused_bias_act(x, bias, None, 3, 0, slope, scale, bias_dim)
         ctx.save_for_backward(y)
         ctx.hyper = (slope, scale)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.bias_dim = bias is not None, bias_dim % x.dim()
         return y
 
     @staticmethod
     def backward(ctx, gy):
         y, = ctx.saved_tensors
         gx = _LeakyGate.apply(gy, y, *ctx.hyper)
-        gb = gx.sum([d for d in range(gx.dim()) if d != 1]) if ctx.has_bias else None
-        return gx, gb, None, None
+        gb = gx.sum([d for d in range(gx.dim()) if d != ctx.bias_dim]) if ctx.has_bias else None
+        return gx, gb, None, None, None
 
 
-def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
-    return _BiasLeakyReLU.apply(input, bias, negative_slope, scale)
+def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5, bias_dim=1):
+    return _BiasLeakyReLU.apply(input, bias, negative_slope, scale, bias_dim)
 
 
 class FusedLeakyReLU(nn.Module):

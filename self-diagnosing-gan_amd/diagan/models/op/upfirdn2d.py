@@ -36,25 +36,29 @@ def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_
 class _Plan:
     """Geometry of one upfirdn2d application on [batch, channel, in_h, in_w] images, linked to its adjoint."""
 
-    def __init__(self, kernel, up, down, pad, in_hw, out_hw, dual=None):
+    def __init__(self, kernel, up, down, pad, in_hw, out_hw, dual=None, channels_last=False):
         self.kernel, self.up, self.down, self.pad = kernel, tuple(up), tuple(down), tuple(pad)
         self.in_hw, self.out_hw = tuple(in_hw), tuple(out_hw)
         self.dual = dual
+        self.channels_last = channels_last      # images are [batch, in_h, in_w, channel]: the native op's own layout
 
     @classmethod
-    def forward_plan(cls, kernel, up, down, pad, in_hw):
+    def forward_plan(cls, kernel, up, down, pad, in_hw, channels_last=False):
         (ux, uy), (dx, dy), (px0, px1, py0, py1) = up, down, pad
         kh, kw = kernel.shape
         in_h, in_w = in_hw
         out_h = (in_h * uy + py0 + py1 - kh) // dy + 1
         out_w = (in_w * ux + px0 + px1 - kw) // dx + 1
-        plan = cls(kernel, up, down, pad, in_hw, (out_h, out_w))
+        plan = cls(kernel, up, down, pad, in_hw, (out_h, out_w), channels_last=channels_last)
         adjoint_pad = (kw - px0 - 1, in_w * ux - out_w * dx + px0 - ux + 1,
                        kh - py0 - 1, in_h * uy - out_h * dy + py0 - uy + 1)
-        plan.dual = cls(torch.flip(kernel, [0, 1]), down, up, adjoint_pad, (out_h, out_w), in_hw, dual=plan)
+        plan.dual = cls(torch.flip(kernel, [0, 1]), down, up, adjoint_pad, (out_h, out_w), in_hw, dual=plan,
+                        channels_last=channels_last)
         return plan
 
     def run(self, images):
+        if self.channels_last:
+            return upfirdn2d_op(images, self.kernel, self.up[0], self.up[1], self.down[0], self.down[1], *self.pad)
         b, c = images.shape[:2]
         flat = images.reshape(-1, self.in_hw[0], self.in_hw[1], 1)
         out = upfirdn2d_op(flat, self.kernel, self.up[0], self.up[1], self.down[0], self.down[1], *self.pad)
@@ -83,3 +87,10 @@ class UpFirDn2d:
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+def upfirdn2d_nhwc(input, kernel, up=1, down=1, pad=(0, 0)):
+    """Same filter on [batch, H, W, channel] activations (the layout of this engine's convolutions)."""
+    plan = _Plan.forward_plan(kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]), input.shape[1:3],
+                              channels_last=True)
+    return _LinearFIR.apply(input, plan)

@@ -1,0 +1,199 @@
+"""GPU: the StyleGAN2 row -- the any-order-differentiable convolution ops over the HIP GEMM
+kernels, and StyleGANGenerator / StyleGANDiscriminator with the trainer's losses and second-order regularisers,
+against the reference-generated vectors (tests/golden/stylegan2.npz) and the pinned oracle (oracle/stylegan2.py).
+Tolerance: 1e-3 relative (fp32; the engine sums in MFMA tile order and evaluates the modulated convolution
+activation-side)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import stylegan2 as O
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "stylegan2.npz"))
+SIZE = int(GOLD["size"])
+T = lambda k: torch.from_numpy(GOLD[k]).cuda()
+
+
+def close(a, b, rtol=1e-3, what=""):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(np.abs(b).max(), 1e-30), err_msg=what)
+
+
+# ---- ops ---------------------------------------------------------------------------------------------------------
+CASES = [  # kind, B, H, W, Ci, Co, k, stride, pad
+    ("conv", 2, 8, 8, 32, 64, 3, 1, 1),
+    ("conv", 3, 11, 9, 16, 32, 3, 2, 0),        # blurred odd-sized map into the stride-2 convolution
+    ("conv", 2, 9, 9, 32, 16, 1, 2, 0),         # the residual skip
+    ("conv", 4, 4, 4, 32, 8, 4, 1, 0),          # flatten + linear as a 4x4 convolution
+    ("conv", 2, 6, 6, 4, 32, 1, 1, 0),          # from RGB (3 planes + 1 zero plane)
+    ("convT", 2, 4, 4, 32, 64, 3, 2, 0),
+    ("convT", 3, 8, 8, 64, 32, 3, 2, 0),
+]
+
+
+def _ref_op(kind, x, w, stride, pad):
+    if kind == "conv":
+        return F.conv2d(x, w, stride=stride, padding=pad)
+    return F.conv_transpose2d(x, w.transpose(0, 1), stride=stride, padding=pad)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(map(str, c)))
+def test_diffconv_first_and_second_order(case):
+    """y, dy/dx, dy/dw and the gradients OF a function of the input gradient (R1's structure) and of the weight
+    gradient, against torch autograd over F.conv2d / F.conv_transpose2d on the CPU in float64."""
+    from diagan.ops import diffconv as dc
+    kind, B, H, W, Ci, Co, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x0 = torch.randn(B, Ci, H, W, generator=g, dtype=torch.float64)
+    w0 = torch.randn(Co, Ci, k, k, generator=g, dtype=torch.float64) / (Ci * k * k) ** 0.5
+
+    def run(x, w, op, nhwc):
+        x = x.clone().requires_grad_(True)
+        w = w.clone().requires_grad_(True)
+        y = op(x.permute(0, 2, 3, 1).contiguous() if nhwc else x, w)
+        if nhwc:
+            y = y.permute(0, 3, 1, 2)
+        cot = torch.cos(torch.arange(y.numel(), dtype=torch.float64).view(y.shape)).to(y)
+        gx, gw = torch.autograd.grad((y * cot).sum() + 0.5 * (y ** 2).sum(), (x, w), create_graph=True)
+        penalty = (gx ** 2).sum() + (gw ** 2).sum()
+        ggx, ggw = torch.autograd.grad(penalty, (x, w))
+        return [t.detach().cpu().double() for t in (y, gx, gw, ggx, ggw)]
+
+    ours = run(x0.float().cuda(), w0.float().cuda(),
+               (lambda x, w: dc.conv2d(x, w, stride, pad)) if kind == "conv" else
+               (lambda x, w: dc.conv_transpose2d(x, w, stride, pad)), True)
+    ref = run(x0, w0, lambda x, w: _ref_op(kind, x, w, stride, pad), False)
+    for name, a, b in zip(("y", "dx", "dw", "d(penalty)/dx", "d(penalty)/dw"), ours, ref):
+        close(a, b, what=f"{case} {name}")
+
+
+def test_linear_matches_torch():
+    from diagan.ops import diffconv as dc
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 512, generator=g)
+    w = torch.randn(7, 512, generator=g)
+    close(dc.linear(x.cuda(), w.cuda()), F.linear(x.double(), w.double()))
+    x = torch.randn(3, 10, generator=g)
+    w = torch.randn(6, 10, generator=g)
+    close(dc.linear(x.cuda(), w.cuda()), F.linear(x.double(), w.double()))
+
+
+# ---- model -------------------------------------------------------------------------------------------------------
+def build(kind, seed):
+    from diagan.models import stylegan2 as M
+    net = (M.StyleGANGenerator if kind == "g" else M.StyleGANDiscriminator)(size=SIZE)
+    shapes = O.generator_shapes(SIZE) if kind == "g" else O.discriminator_shapes(SIZE)
+    # names and shapes are the reference's: the oracle's inventory loads strictly (FIR kernels are buffers the
+    # module builds itself, exactly as in the reference)
+    missing, unexpected = net.load_state_dict(O.seeded_state(shapes, seed), strict=False)
+    assert not unexpected and all(k.endswith("kernel") for k in missing), (missing, unexpected)
+    return net.cuda()
+
+
+def grad_norms(net):
+    return {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}
+
+
+def check_norms(tag, net, rtol=2e-3):
+    ours = grad_norms(net)
+    keys = [str(k) for k in GOLD[f"{tag}_keys"]]
+    assert sorted(ours) == keys
+    got, want = np.array([ours[k] for k in keys]), GOLD[f"{tag}_norms"]
+    # a NoiseInjection strength is ONE scalar whose gradient sums B*H*W*C products of either sign (524 288 terms
+    # here, result ~1e-2): its value depends on the fp32 summation order at the 1e-3..1e-2 level on any device
+    tol = lambda k: 1e-2 if k.endswith("noise.weight") else rtol
+    bad = [(k, a, b) for k, a, b in zip(keys, got, want) if abs(a - b) > tol(k) * abs(b) + 1e-6]
+    assert not bad, f"{tag}: gradient norms off: {bad}"
+
+
+def test_generator_forward_vs_reference():
+    G = build("g", int(GOLD["seed_g"]))
+    with torch.no_grad():
+        img, lat = G([T("z1")], return_latents=True, randomize_noise=False)
+        mix, none = G([T("z1"), T("z2")], inject_index=3, randomize_noise=False)
+    assert none is None and img.shape == (4, 3, SIZE, SIZE) and img.is_contiguous()
+    close(lat, GOLD["g_latent"], what="latent")
+    close(img, GOLD["g_image"], what="image")
+    close(mix, GOLD["g_image_mix"], what="style mixing")
+    # random noise path: draws fresh noise every call
+    with torch.no_grad():
+        a, _ = G([T("z1")])
+        b, _ = G([T("z1")])
+    assert not torch.equal(a, b)
+
+
+def test_discriminator_loss_and_gradients_vs_reference():
+    from diagan.trainer import stylegan2 as TR
+    D = build("d", int(GOLD["seed_d"]))
+    D.zero_grad()
+    rp, fp = D(T("d_real")), D(T("d_fake"))
+    close(rp, GOLD["d_real_pred"], what="real logits")
+    close(fp, GOLD["d_fake_pred"], what="fake logits")
+    loss = TR.d_logistic_loss(rp, fp)
+    close(loss, GOLD["d_loss"])
+    loss.backward()
+    check_norms("d_loss_grad", D)
+    close(D.final_linear[1].weight.grad, GOLD["d_loss_grad_last"])
+    # the gradients live in the flat slab the fused Adam steps over
+    assert D.final_linear[1].weight.grad.data_ptr() >= D.flat_grads.data_ptr()
+    assert float(D.flat_grads.double().norm()) > 0
+
+
+def test_r1_second_order_vs_reference():
+    from diagan.trainer import stylegan2 as TR
+    D = build("d", int(GOLD["seed_d"]))
+    D.zero_grad()
+    x = T("d_real").clone().requires_grad_(True)
+    rp = D(x)
+    r1 = TR.d_r1_loss(rp, x)
+    close(r1, GOLD["r1"])
+    (10.0 / 2 * r1 * 16 + 0 * rp[0]).backward()
+    check_norms("r1_grad", D)
+    close(D.convs[0][0].weight.grad, GOLD["r1_grad_first"])
+
+
+def test_generator_loss_and_path_length_vs_reference():
+    from diagan.trainer import stylegan2 as TR
+    G, D = build("g", int(GOLD["seed_g"])), build("d", int(GOLD["seed_d"]))
+    TR.requires_grad(D, False)
+    G.zero_grad()
+    fake, _ = G([T("z1")], randomize_noise=False)
+    loss = TR.g_nonsaturating_loss(D(fake))
+    close(loss, GOLD["g_loss"])
+    loss.backward()
+    check_norms("g_loss_grad", G)
+    close(G.to_rgbs[-1].bias.grad, GOLD["g_loss_grad_rgb_bias"])
+
+    G.zero_grad()
+    fake, lat = G([T("zp")], return_latents=True, randomize_noise=False)
+    pl, mean_path, lengths = TR.g_path_regularize(fake, lat, 0.3, noise=T("pl_noise"))
+    close(lengths, GOLD["path_lengths"])
+    close(pl, GOLD["path_loss"])
+    close(mean_path, GOLD["mean_path"])
+    (2.0 * 4 * pl + 0 * fake[0, 0, 0, 0]).backward()
+    check_norms("path_grad", G)
+    close(G.input.input.grad, GOLD["path_grad_input"])
+
+
+def test_other_resolutions_vs_oracle():
+    """size 8 and 32 (different pyramid depths; batch 5 = a ragged minibatch-stddev group of 1... the reference
+    requires batch % group == 0, so 6 with group 4 is invalid there too: use 4 and 8)"""
+    from diagan.models import stylegan2 as M
+    for size, batch in ((8, 4), (32, 8)):
+        G, D = M.StyleGANGenerator(size=size), M.StyleGANDiscriminator(size=size)
+        sg = O.seeded_state(O.generator_shapes(size), 21)
+        sd_ = O.seeded_state(O.discriminator_shapes(size), 22)
+        G.load_state_dict(sg, strict=False), D.load_state_dict(sd_, strict=False)
+        G.cuda(), D.cuda()
+        z = torch.randn(batch, 512, generator=torch.Generator().manual_seed(size))
+        with torch.no_grad():
+            img, _ = G([z.cuda()], randomize_noise=False)
+            ref, _ = O.generator(sg, size, [z])
+            close(img, ref, what=f"G size {size}")
+            close(D(img), O.discriminator(sd_, size, ref), what=f"D size {size}")
