@@ -30,6 +30,7 @@ CASES = [  # kind, B, H, W, Ci, Co, k, stride, pad
     ("conv", 2, 8, 8, 32, 64, 3, 1, 1),
     ("conv", 3, 11, 9, 16, 32, 3, 2, 0),        # blurred odd-sized map into the stride-2 convolution
     ("conv", 2, 9, 9, 32, 16, 1, 2, 0),         # the residual skip
+    ("conv", 2, 10, 12, 16, 16, 3, 2, 0),       # last input row / column never read: zero data gradient there
     ("conv", 4, 4, 4, 32, 8, 4, 1, 0),          # flatten + linear as a 4x4 convolution
     ("conv", 2, 6, 6, 4, 32, 1, 1, 0),          # from RGB (3 planes + 1 zero plane)
     ("convT", 2, 4, 4, 32, 64, 3, 2, 0),
