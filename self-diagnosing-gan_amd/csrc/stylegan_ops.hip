@@ -16,6 +16,39 @@
 
 namespace diagan {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// channels-last fast path: bias runs along the innermost dimension (step_b == 1), 4 channels per lane
+__global__ __launch_bounds__(256) void fused_bias_act_cl4_kernel(const f32x4* __restrict__ x, const float* __restrict__ b,
+                                                                 const f32x4* __restrict__ ref, f32x4* __restrict__ out,
+                                                                 long n4, int size_b, int mode, float alpha, float scale) {
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  // size_b % 4 == 0: a lane's channel quad advances by (stride * 4) % size_b per trip
+  int c = (int)((i * 4) % size_b);
+  const int dc = (int)((stride * 4) % size_b);
+  for (; i < n4; i += stride) {
+    f32x4 v = x[i];
+    if (b) v += *reinterpret_cast<const f32x4*>(b + c);
+    f32x4 y;
+    if (mode == 30) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = v[e] > 0.f ? v[e] : v[e] * alpha;
+    } else if (mode == 31) {
+      const f32x4 r = ref[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = r[e] > 0.f ? v[e] : v[e] * alpha;
+    } else if (mode == 12 || mode == 32) {
+      y = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      y = v;
+    }
+    out[i] = y * scale;
+    c += dc;
+    if (c >= size_b) c -= size_b;
+  }
+}
+
 __global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
                                                              const float* __restrict__ ref, float* __restrict__ out,
                                                              long n, long step_b, int size_b, int mode, float alpha,
@@ -47,6 +80,54 @@ static __host__ __device__ __forceinline__ int floor_div_i(int a, int b) {
   return (q * b > a) ? q - 1 : q;
 }
 static __host__ __device__ __forceinline__ int ceil_div_i(int a, int b) { return -floor_div_i(-a, b); }
+
+// FIR without resampling (up = down = 1: StyleGAN2's Blur and its adjoint) on channels-last data with minor % 4 == 0:
+// a lane owns 4 channels x OXT consecutive output columns and slides a (KW + OXT - 1)-wide register window down the
+// kh filter rows, so that every input element is fetched (KW + OXT - 1) / OXT times instead of KW times and as 16-byte
+// loads; lanes run along the channel quads, then along the column groups (coalesced 512 B+ segments).
+template <int KW, int OXT>
+__global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
+  __shared__ float taps[64];
+  if (threadIdx.x < a.kh * KW) taps[threadIdx.x] = a.k[threadIdx.x];
+  __syncthreads();
+  const int q = a.minor >> 2, gx = (a.out_w + OXT - 1) / OXT;
+  const long total = (long)a.major * a.out_h * gx * q;
+  const f32x4* __restrict__ in4 = reinterpret_cast<const f32x4*>(a.in);
+  f32x4* __restrict__ out4 = reinterpret_cast<f32x4*>(a.out);
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    const int c4 = (int)(o % q);
+    long t = o / q;
+    const int ox0 = (int)(t % gx) * OXT; t /= gx;
+    const int oy = (int)(t % a.out_h);
+    const int mj = (int)(t / a.out_h);
+    f32x4 acc[OXT];
+#pragma unroll
+    for (int j = 0; j < OXT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bx = ox0 - a.pad_x0;
+    for (int dy = 0; dy < a.kh; ++dy) {
+      const int iy = oy - a.pad_y0 + dy;
+      if (iy < 0 || iy >= a.in_h) continue;
+      const f32x4* row = in4 + ((long)mj * a.in_h + iy) * a.in_w * q + c4;
+      f32x4 win[KW + OXT - 1];
+#pragma unroll
+      for (int u = 0; u < KW + OXT - 1; ++u) {
+        const int ix = bx + u;
+        win[u] = (ix >= 0 && ix < a.in_w) ? row[(long)ix * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const float* kr = taps + (a.kh - 1 - dy) * KW;
+#pragma unroll
+      for (int dx = 0; dx < KW; ++dx) {
+        const float w = kr[KW - 1 - dx];
+#pragma unroll
+        for (int j = 0; j < OXT; ++j) acc[j] += win[j + dx] * w;
+      }
+    }
+    f32x4* dst = out4 + (((long)mj * a.out_h + oy) * a.out_w + ox0) * q + c4;
+#pragma unroll
+    for (int j = 0; j < OXT; ++j)
+      if (ox0 + j < a.out_w) dst[(long)j * q] = acc[j];
+  }
+}
 
 __global__ __launch_bounds__(256) void upfirdn2d_kernel(const UpFirDnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float taps[];
@@ -87,6 +168,16 @@ DIAGAN_API int diagan_fused_bias_act(const float* x, const float* bias, const fl
   DG_REQUIRE(x && out && n >= 0, "fused_bias_act: null tensor");
   DG_REQUIRE(!bias || (step_b > 0 && size_b > 0), "fused_bias_act: bad bias geometry");
   if (n == 0) return DIAGAN_OK;
+  if (step_b == 1 && (!bias || (size_b & 3) == 0) && (n & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)refer |
+                                                                      (uintptr_t)bias) & 15) == 0) {
+    const long n4 = n / 4;
+    long blocks4 = (n4 + 255) / 256;
+    if (blocks4 > 8192) blocks4 = 8192;
+    hipLaunchKernelGGL(fused_bias_act_cl4_kernel, dim3((int)blocks4), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)x, bias, (const f32x4*)refer, (f32x4*)out, n4, bias ? size_b : 4, act * 10 + grad,
+                       alpha, scale);
+    return check_launch("fused_bias_act");
+  }
   long blocks = (n + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(fused_bias_act_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, refer, out,
@@ -111,6 +202,14 @@ DIAGAN_API int diagan_upfirdn2d(const float* input, const float* kernel, float* 
   if (major == 0) return DIAGAN_OK;
   UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow,
                 up_x, up_y, down_x, down_y, pad_x0, pad_y0};
+  if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kernel_w == 4 && kernel_h <= 16 && (minor & 3) == 0 &&
+      (((uintptr_t)input | (uintptr_t)out) & 15) == 0) {
+    const long work = (long)major * oh * ((ow + 3) / 4) * (minor / 4);
+    long fb = (work + 255) / 256;
+    if (fb > 32768) fb = 32768;
+    hipLaunchKernelGGL((fir_cl4_kernel<4, 4>), dim3((int)fb), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("upfirdn2d");
+  }
   const long total = (long)major * oh * ow * minor;
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;

@@ -91,3 +91,49 @@ def test_fused_bias_act_table_and_second_order():
     c = run(lambda x, b: S.fused_leaky_relu(x, b, 0.2, 2 ** 0.5), x, b)
     np.testing.assert_allclose(a[0].numpy(), c[0].numpy(), atol=1e-4)
     np.testing.assert_allclose(a[1].numpy(), c[1].numpy(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape,kshape,pad", [
+    ((2, 9, 11, 8), (4, 4), (2, 1)),        # StyleGAN2 blur, ragged width (11 + 3 - 4 + 1 = 11 columns: 2 full groups + 3)
+    ((1, 6, 6, 128), (4, 4), (1, 1)),
+    ((3, 7, 5, 4), (3, 4), (2, 2)),         # rectangular filter
+    ((2, 10, 10, 12), (4, 4), (-1, 2)),     # cropping pad
+    ((1, 1, 1, 4), (4, 4), (3, 3)),         # single pixel: every tap out of range somewhere
+])
+def test_channels_last_fir_fast_path_vs_oracle(shape, kshape, pad):
+    """the 4-channel x 4-column register-window kernel that serves up = down = 1 on [B, H, W, C] activations"""
+    from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g)
+    k = torch.randn(*kshape, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    y = upfirdn2d_nhwc(xg, k.cuda(), pad=pad)
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = S.upfirdn2d(xr, k, 1, 1, 1, 1, pad[0], pad[1], pad[0], pad[1])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().permute(0, 2, 3, 1).numpy(), atol=1e-5)
+    cot = torch.randn(ref.shape, generator=g)
+    (ref * cot).sum().backward()
+    (y * cot.permute(0, 2, 3, 1).cuda()).sum().backward()          # adjoint: the same fast path, flipped filter
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.permute(0, 2, 3, 1).numpy(), atol=1e-5)
+
+
+def test_channels_last_bias_act_fast_path_vs_oracle():
+    from diagan.models.op.fused_act import fused_bias_act, fused_leaky_relu
+    g = torch.Generator().manual_seed(9)
+    for shape in ((2, 5, 5, 8), (3, 12), (1, 3, 3, 516)):
+        x = torch.randn(*shape, generator=g)
+        b = torch.randn(shape[-1], generator=g)
+        r = torch.randn(*shape, generator=g)
+        to_cf = (lambda t: t.permute(0, 3, 1, 2)) if len(shape) == 4 else (lambda t: t)
+        back = (lambda t: t.permute(0, 2, 3, 1)) if len(shape) == 4 else (lambda t: t)
+        for act, grad, ref_t in ((3, 0, None), (3, 1, r), (1, 0, None), (3, 2, r)):
+            want = S.fused_bias_act(to_cf(x), b, to_cf(ref_t) if ref_t is not None else None, act, grad, 0.2, 1.5)
+            got = fused_bias_act(x.cuda(), b.cuda(), ref_t.cuda() if ref_t is not None else None, act, grad, 0.2, 1.5,
+                                 bias_dim=-1)
+            np.testing.assert_allclose(got.cpu().numpy(), back(want).numpy(), atol=1e-6, err_msg=f"{shape} {act}{grad}")
+        xg, bg = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        (fused_leaky_relu(xg, bg, bias_dim=-1) ** 2).sum().backward()
+        (S.fused_leaky_relu(to_cf(xr), br) ** 2).sum().backward()
+        np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), atol=1e-5)
+        np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
