@@ -168,7 +168,7 @@ DIAGAN_API int diagan_fused_bias_act(const float* x, const float* bias, const fl
   DG_REQUIRE(x && out && n >= 0, "fused_bias_act: null tensor");
   DG_REQUIRE(!bias || (step_b > 0 && size_b > 0), "fused_bias_act: bad bias geometry");
   if (n == 0) return DIAGAN_OK;
-  if (step_b == 1 && (!bias || (size_b & 3) == 0) && (n & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)refer |
+  if ((!bias || (step_b == 1 && (size_b & 3) == 0)) && (n & 3) == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)refer |
                                                                       (uintptr_t)bias) & 15) == 0) {
     const long n4 = n / 4;
     long blocks4 = (n4 + 255) / 256;

@@ -249,8 +249,8 @@ class StyleGAN2Trainer:
         zero = torch.tensor(0.0, device=self.device)
         self.r1_loss, self.path_loss, self.path_lengths = zero, zero, zero
         sample_z = torch.randn(a.n_sample, a.latent, device=self.device)
-        for idx in range(a.iter):
-            i = idx + a.start_iter
+        for idx in range(a.iter):                     # the reference's `pbar = range(args.iter)`: i stops at iter - 1
+            i = idx + a.start_iter                    # for a fresh run and at iter for a resumed one
             if i > a.iter:
                 print("Done!")
                 break
@@ -265,7 +265,7 @@ class StyleGAN2Trainer:
             if i % self.log_every == 0 or i == a.iter:
                 reduced = reduce_loss_dict(losses)
                 if get_rank() == 0:
-                    vals = {k: float(v.mean()) for k, v in reduced.items()}
+                    vals = {k: float(v.detach().mean()) for k, v in reduced.items()}
                     vals['step'] = i
                     self.history.append(vals)
                     print("; ".join(f"{k}: {vals[k]:.4f}" for k in ('d', 'drs_d', 'g', 'r1', 'path') if k in vals)
