@@ -4,8 +4,9 @@
 `drs=True` `(netG, netD, netD_drs, optG, optD, optD_drs)` where D_drs is a second discriminator of the same
 architecture trained with the 'ns' loss.  Architectures and Adam settings per dataset are the reference's; they are
 declared as data below, and the per-dataset helpers of the reference (`get_cifar10_gen`, ...) are generated from the
-table.  Optimisers are `FusedAdam` (one launch per step over the network's flat parameter slab).  Model families
-outside the accelerated hot path (infomax_gan, ssgan, toy, stylegan, inclusive) raise NotImplementedError."""
+table.  Optimisers are `FusedAdam` (one launch per step over the network's flat parameter slab).  'ffhq' builds the StyleGAN2 pair at 256^2
+(reference :153-163; extra keywords -- loss_type, gold, ... -- are swallowed by the classes' **kwargs as there).  Model
+families outside the accelerated path (infomax_gan, ssgan, toy, inclusive) raise NotImplementedError."""
 from diagan.optim import FusedAdam
 
 
@@ -40,8 +41,11 @@ RECIPES = {
     'mnist_fmnist': dict(family='mnist_dcgan', adam=(1e-4, (0.5, 0.9)), fixed=dict(nc=1),
                          gen=_named('diagan.models.mnist', 'MNIST_DCGAN_Generator'),
                          disc=_named('diagan.models.mnist', 'MNIST_DCGAN_Discriminator')),
+    'ffhq': dict(family='stylegan', adam=(2e-4, (0.0, 0.9)), fixed=dict(size=256),
+                 gen=_named('diagan.models.stylegan2', 'StyleGANGenerator'),
+                 disc=_named('diagan.models.stylegan2', 'StyleGANDiscriminator')),
 }
-NOT_ACCELERATED = ('25gaussian', 'ffhq')     # toy MLPs, StyleGAN2: SURVEY §8(f) ranks StyleGAN2 as the 'next' row
+NOT_ACCELERATED = ('25gaussian',)            # toy MLPs
 
 
 def _optimizer(net, recipe):
@@ -51,8 +55,7 @@ def _optimizer(net, recipe):
 
 def _recipe(dataset_name, model):
     if dataset_name in NOT_ACCELERATED:
-        raise NotImplementedError(f"dataset '{dataset_name}' uses a model family outside the accelerated hot path "
-                                  "(SURVEY §8(f): StyleGAN2 is the ranked 'next' row)")
+        raise NotImplementedError(f"dataset '{dataset_name}' uses a model family outside the accelerated hot path")
     recipe = RECIPES[dataset_name]
     if recipe['family'] == 'sngan' and model != 'sngan':
         raise NotImplementedError(f"model '{model}' is outside the accelerated hot path (SURVEY §8: sngan and "
@@ -63,7 +66,9 @@ def _recipe(dataset_name, model):
 def build_generator(dataset_name, model='sngan', loss_type='hinge', gold=False, topk=False, num_pack=1,
                     reweight=False, **kwargs):
     recipe = _recipe(dataset_name, model)
-    if recipe['family'] == 'sngan':
+    if recipe['family'] == 'stylegan':
+        netG = recipe['gen']()(**recipe['fixed'], **kwargs)
+    elif recipe['family'] == 'sngan':
         netG = recipe['gen_topk']()(loss_type=loss_type, topk=topk, **kwargs) if topk else \
             recipe['gen']()(loss_type=loss_type, **kwargs)
     else:
@@ -75,7 +80,9 @@ def build_generator(dataset_name, model='sngan', loss_type='hinge', gold=False, 
 
 def build_discriminator(dataset_name, model='sngan', loss_type='hinge', gold=False, topk=False, num_pack=1, **kwargs):
     recipe = _recipe(dataset_name, model)
-    if recipe['family'] == 'sngan':
+    if recipe['family'] == 'stylegan':
+        netD = recipe['disc']()(**recipe['fixed'], **kwargs)
+    elif recipe['family'] == 'sngan':
         netD = recipe['disc_gold' if gold else 'disc']()(loss_type=loss_type, **kwargs)
     else:
         netD = recipe['disc']()(use_gold=gold, loss_type=loss_type, num_pack=num_pack, **recipe['fixed'], **kwargs)

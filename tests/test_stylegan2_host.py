@@ -52,3 +52,26 @@ def test_trainer_helpers():
     r, f = torch.tensor([[1.0], [-2.0]]), torch.tensor([[0.5], [3.0]])
     assert abs(TR.d_logistic_loss(r, f).item() - O.d_logistic_loss(r, f).item()) < 1e-7
     assert abs(TR.g_nonsaturating_loss(f).item() - O.g_nonsaturating_loss(f).item()) < 1e-7
+
+
+def test_factory_builds_stylegan_for_ffhq():
+    from diagan.models import stylegan2 as M
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.optim import FusedAdam
+    netG, netD, netD_drs, optG, optD, optD_drs = get_gan_model('ffhq', model='stylegan', drs=True)
+    assert isinstance(netG, M.StyleGANGenerator) and netG.size == 256
+    assert isinstance(netD, M.StyleGANDiscriminator) and isinstance(netD_drs, M.StyleGANDiscriminator)
+    assert netD is not netD_drs and all(isinstance(o, FusedAdam) for o in (optG, optD, optD_drs))
+    assert optG.param_groups[0]['lr'] == 2e-4 and tuple(optG.param_groups[0]['betas']) == (0.0, 0.9)
+
+
+def test_command_line_defaults_follow_the_reference():
+    from diagan.stylegan2_cli import SIZES, build_parser
+    p1, p2 = build_parser(1).parse_args([]), build_parser(2).parse_args([])
+    assert (p1.r1, p2.r1) == (0.1, 10) and (p1.save_logit_after, p1.stop_save_logit_after) == (195000, 200000)
+    assert p2.save_logit_after == 1000000 and p2.p1_step == 200000 and not hasattr(p2, 'stop_save_logit_after')
+    for a in (p1, p2):
+        assert (a.iter, a.batch, a.n_sample, a.size, a.path_regularize, a.path_batch_shrink) == (800000, 16, 64, 32, 2, 2)
+        assert (a.d_reg_every, a.g_reg_every, a.mixing, a.lr, a.channel_multiplier) == (16, 4, 0.9, 0.002, 2)
+        assert (a.work_dir, a.exp_name, a.seed, a.logit_save_steps, a.dataset) == ("./exp_results", "test", 1, 100, "cifar10")
+    assert SIZES == {'cifar10': 32, 'celeba': 64, 'utk_faces': 64, 'imagenet': 128, 'ffhq': 256}
