@@ -198,3 +198,84 @@ def test_other_resolutions_vs_oracle():
             ref, _ = O.generator(sg, size, [z])
             close(img, ref, what=f"G size {size}")
             close(D(img), O.discriminator(sd_, size, ref), what=f"D size {size}")
+
+
+def test_training_trajectory_vs_oracle():
+    """Three full iterations (D step, R1 step, G step, path-length step; Adam with the reference's lazy-regularisation
+    hyper-parameters) on the HIP engine with FusedAdam over the flat slabs, against the same iterations on the oracle
+    with torch.optim.Adam: per-iteration losses and the final parameters."""
+    from diagan.models import stylegan2 as M
+    from diagan.trainer import stylegan2 as TR
+    size, batch, iters = 8, 4, 3
+    gen = torch.Generator().manual_seed(77)
+    sg = O.seeded_state(O.generator_shapes(size), 31)
+    sd_ = O.seeded_state(O.discriminator_shapes(size), 32)
+    G, D = M.StyleGANGenerator(size=size), M.StyleGANDiscriminator(size=size)
+    G.load_state_dict(sg, strict=False), D.load_state_dict(sd_, strict=False)
+    G.cuda(), D.cuda()
+    g_optim, d_optim = TR.make_optimizers(G, D, lr=0.002, g_reg_every=4, d_reg_every=16)
+
+    pg = {k: v.clone().requires_grad_(not k.startswith("noises.")) for k, v in sg.items()}
+    pd = {k: v.clone().requires_grad_(True) for k, v in sd_.items()}
+    gr, dr = 4 / 5, 16 / 17
+    og = torch.optim.Adam([v for v in pg.values() if v.requires_grad], lr=0.002 * gr, betas=(0 ** gr, 0.99 ** gr))
+    od = torch.optim.Adam(list(pd.values()), lr=0.002 * dr, betas=(0 ** dr, 0.99 ** dr))
+
+    def step_ref(opt, loss):
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    mean_path, mean_path_ref = 0, 0
+    for it in range(iters):
+        real = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+        z = [torch.randn(batch, 512, generator=gen) for _ in range(4)]
+        pl_noise = torch.randn(2, 3, size, size, generator=gen)
+        # ---- engine ----
+        TR.requires_grad(G, False), TR.requires_grad(D, True)
+        with torch.no_grad():
+            fake, _ = G([z[0].cuda()], randomize_noise=False)
+        d_loss = TR.d_logistic_loss(D(real.cuda()), D(fake))
+        TR.StyleGAN2Trainer._step(D, d_optim, d_loss)
+        x = real.cuda().requires_grad_(True)
+        rp = D(x)
+        r1 = TR.d_r1_loss(rp, x)
+        TR.StyleGAN2Trainer._step(D, d_optim, 10.0 / 2 * r1 * 16 + 0 * rp[0])
+        TR.requires_grad(G, True), TR.requires_grad(D, False)
+        fake, _ = G([z[1].cuda(), z[2].cuda()], inject_index=2, randomize_noise=False)
+        g_loss = TR.g_nonsaturating_loss(D(fake))
+        TR.StyleGAN2Trainer._step(G, g_optim, g_loss)
+        fake, lat = G([z[3][:2].cuda()], return_latents=True, randomize_noise=False)
+        pl, mean_path, _ = TR.g_path_regularize(fake, lat, mean_path, noise=pl_noise.cuda())
+        TR.StyleGAN2Trainer._step(G, g_optim, 2.0 * 4 * pl + 0 * fake[0, 0, 0, 0])
+        # ---- oracle ----
+        with torch.no_grad():
+            fake_r, _ = O.generator(pg, size, [z[0]])
+        d_loss_r = O.d_logistic_loss(O.discriminator(pd, size, real), O.discriminator(pd, size, fake_r))
+        step_ref(od, d_loss_r)
+        xr = real.clone().requires_grad_(True)
+        rpr = O.discriminator(pd, size, xr)
+        r1_r = O.d_r1_loss(rpr, xr)
+        step_ref(od, 10.0 / 2 * r1_r * 16 + 0 * rpr[0])
+        fake_r, _ = O.generator(pg, size, [z[1], z[2]], inject_index=2)
+        frozen = {k: v.detach() for k, v in pd.items()}
+        g_loss_r = O.g_nonsaturating_loss(O.discriminator(frozen, size, fake_r))
+        step_ref(og, g_loss_r)
+        fake_r, lat_r = O.generator(pg, size, [z[3][:2]])
+        pl_r, mean_path_ref, _ = O.g_path_regularize(fake_r, lat_r, mean_path_ref, pl_noise)
+        step_ref(og, 2.0 * 4 * pl_r + 0 * fake_r[0, 0, 0, 0])
+        for name, a, b in (("d", d_loss, d_loss_r), ("r1", r1, r1_r), ("g", g_loss, g_loss_r), ("path", pl, pl_r)):
+            assert abs(float(a) - float(b)) <= 5e-3 * max(1.0, abs(float(b))), (it, name, float(a), float(b))
+    assert abs(float(mean_path) - float(mean_path_ref)) < 1e-3 * abs(float(mean_path_ref))
+
+    def rel_err(net, ref):
+        num = den = 0.0
+        for k, v in net.state_dict().items():
+            if k in ref:
+                num += float((v.cpu().double() - ref[k].detach().double()).pow(2).sum())
+                den += float(ref[k].detach().double().pow(2).sum())
+        return (num / den) ** 0.5
+    # Adam's first steps move every weight by ~lr * sign(gradient): elements whose gradient is within rounding of
+    # zero may step the other way, so the comparison is a global relative L2 error, not element-wise
+    assert rel_err(D, pd) < 1e-3 and rel_err(G, pg) < 1e-3
+    assert float((D.state_dict()["final_linear.1.weight"].cpu() - sd_["final_linear.1.weight"]).abs().max()) > 1e-3
