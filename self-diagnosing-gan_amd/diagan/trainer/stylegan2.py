@@ -24,17 +24,21 @@ import torch.nn.functional as F
 from torch import autograd
 from torch.utils import data
 
+from diagan.datasets.sampler import ShardedSampler
 from diagan.optim import FusedAdam
 from diagan.trainer import distributed as dist
 from diagan.trainer.distributed import get_rank, get_world_size, reduce_loss_dict, reduce_sum
 
 
 def data_sampler(dataset, shuffle, distributed, weights=None):
-    """train_ffhq.py:34-45 / train_ffhq_phase2.py:35-46 (a distributed run ignores `weights`, as there)"""
+    """train_ffhq.py:34-45 / train_ffhq_phase2.py:35-46.  One deliberate difference: the reference tests
+    `distributed` first, so a multi-GPU phase 2 silently trains on UNweighted data; here the weights
+    stay in force -- every rank draws the same weighted order (shared CPU seed) and keeps every W-th index."""
+    if weights is not None:
+        weighted = data.WeightedRandomSampler(weights, len(weights), replacement=True)
+        return ShardedSampler(weighted, get_rank(), get_world_size()) if distributed else weighted
     if distributed:
         return data.distributed.DistributedSampler(dataset, shuffle=shuffle)
-    if weights is not None:
-        return data.WeightedRandomSampler(weights, len(weights), replacement=True)
     return data.RandomSampler(dataset) if shuffle else data.SequentialSampler(dataset)
 
 

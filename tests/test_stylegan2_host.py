@@ -40,6 +40,10 @@ def test_trainer_helpers():
     assert isinstance(TR.data_sampler(ds, False, False), torch.utils.data.SequentialSampler)
     w = TR.data_sampler(ds, True, False, weights=np.linspace(0, 1, 10))
     assert isinstance(w, torch.utils.data.WeightedRandomSampler) and w.num_samples == 10 and w.replacement
+    # under data parallelism the weights stay in force (the reference drops them): same order on every rank, strided
+    from diagan.datasets.sampler import ShardedSampler
+    sh = TR.data_sampler(ds, True, True, weights=np.array([0.0] * 9 + [1.0]))
+    assert isinstance(sh, ShardedSampler) and set(iter(sh)) == {9}
     random.seed(0)
     kinds = {len(TR.mixing_noise(2, 8, 0.9, "cpu")) for _ in range(50)}
     assert kinds == {1, 2}

@@ -40,8 +40,12 @@ def main():
     a = ap.parse_args()
     from diagan.models.stylegan2 import StyleGANDiscriminator, StyleGANGenerator
     from diagan.ops import conv as K
+    from diagan.trainer import distributed as dist
     from diagan.trainer import stylegan2 as TR
-    dev = torch.device("cuda:0")
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N tools/stylegan2_step_time.py`
+    rank, local_rank, world = dist.init_from_env()
+    dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
     torch.manual_seed(0)
     G, D = StyleGANGenerator(size=a.size).to(dev), StyleGANDiscriminator(size=a.size).to(dev)
     g_ema = StyleGANGenerator(size=a.size).to(dev).eval()
@@ -60,10 +64,12 @@ def main():
     tr = TR.StyleGAN2Trainer(args, mk(), G, D, g_optim, d_optim, g_ema, dev, "/tmp/sg2_time", **extra)
     zero = torch.tensor(0.0, device=dev)
     tr.r1_loss, tr.path_loss, tr.path_lengths = zero, zero, zero
-    print(f"params: G {sum(p.numel() for p in G.parameters()) / 1e6:.1f} M, D "
-          f"{sum(p.numel() for p in D.parameters()) / 1e6:.1f} M", flush=True)
+    if rank == 0:
+        print(f"params: G {sum(p.numel() for p in G.parameters()) / 1e6:.1f} M, D "
+              f"{sum(p.numel() for p in D.parameters()) / 1e6:.1f} M; {world} rank(s)", flush=True)
     for i in range(1, a.warmup + 1):          # iteration numbers that do not trigger the regularisers... except 4
         tr.train_step(i)
+    dist.synchronize()
     torch.cuda.synchronize()
     per = {}
     if a.kernels:
@@ -75,12 +81,19 @@ def main():
         torch.cuda.synchronize()
         kind = ("r1+" if i % 16 == 0 else "") + ("path" if i % 4 == 0 else "") or "plain"
         per.setdefault(kind, []).append(time.perf_counter() - t0)
+    dist.synchronize()
     total = time.perf_counter() - t_all
-    print({k: float(v) for k, v in losses.items()})
+    if world > 1:
+        t = torch.tensor([total], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        total = float(t)
+    if rank != 0:
+        return
+    print({k: float(v.detach()) for k, v in losses.items()})
     for k, v in per.items():
         print(f"{k:8s}: {1e3 * sum(v) / len(v):8.1f} ms  (n={len(v)})")
-    print(f"mean iteration {1e3 * total / a.iters:.1f} ms = {a.batch * a.iters / total:.1f} images/s "
-          f"(size {a.size}, batch {a.batch}, phase {'2' if a.phase2 else '1'}); "
+    print(f"mean iteration {1e3 * total / a.iters:.1f} ms = {world * a.batch * a.iters / total:.1f} images/s "
+          f"(size {a.size}, batch {a.batch} per GPU x {world} GPU(s), phase {'2' if a.phase2 else '1'}); "
           f"peak memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
     if a.kernels:
         rows = sorted(K.TIMER.by_shape().items(), key=lambda kv: -kv[1]['seconds'])
