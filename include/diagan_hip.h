@@ -290,6 +290,14 @@ int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
 int diagan_fused_bias_act(const float* x, const float* bias, const float* refer, float* out, int64_t n,
                           int64_t step_b, int size_b, int act, int grad, float alpha, float scale, void* stream);
 
+/* The tail of StyledConv.forward (diagan-pkg/diagan/models/stylegan2.py:323-329) in one pass over a channels-last
+ * activation x[B][P][C]:  out = leaky_relu(x * demod[b][c] + strength[0] * noise[b or 0][p] + bias[c], alpha) * scale.
+ * demod (the demodulation factor of :231-233 applied activation-side), noise and bias may each be NULL;
+ * noise_per_image: noise is [B][P] (1) or one [P] map shared by the batch (0).  C % 4 == 0. */
+int diagan_styled_bias_act(const float* x, const float* demod, const float* noise, const float* strength,
+                           const float* bias, float* out, int B, int P, int C, int noise_per_image, float alpha,
+                           float scale, void* stream);
+
 /* upfirdn2d.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up, down, pads), upfirdn2d.cpp:4-22.
  * out == NULL: size query only (writes *out_h, *out_w). */
 int diagan_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor,

@@ -49,6 +49,30 @@ __global__ __launch_bounds__(256) void fused_bias_act_cl4_kernel(const f32x4* __
   }
 }
 
+// StyledConv tail in one pass (stylegan2.py:323-329 after the activation-side modulated convolution):
+//   out[b,p,c] = lrelu( x[b,p,c] * demod[b,c] + strength * noise[b or 0, p] + bias[c] ) * scale
+// x [B, P, C] channels-last, 4 channels per lane; demod / noise / bias optional.
+__global__ __launch_bounds__(256) void styled_act_cl4_kernel(const f32x4* __restrict__ x, const float* __restrict__ demod,
+                                                             const float* __restrict__ noise, const float* __restrict__ strength,
+                                                             const float* __restrict__ bias, f32x4* __restrict__ out,
+                                                             long n4, int P, int C, int noise_per_image, float alpha,
+                                                             float scale) {
+  const int q = C >> 2;
+  const float w = (noise && strength) ? strength[0] : 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long pix = i / q;                 // b * P + p
+    const int c = (int)(i - pix * q) << 2;
+    const int b = (int)(pix / P);
+    f32x4 v = x[i];
+    if (demod) v *= *reinterpret_cast<const f32x4*>(demod + (long)b * C + c);
+    if (noise) v += w * noise[noise_per_image ? pix : pix - (long)b * P];
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * alpha) * scale;
+    out[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
                                                              const float* __restrict__ ref, float* __restrict__ out,
                                                              long n, long step_b, int size_b, int mode, float alpha,
@@ -183,6 +207,21 @@ DIAGAN_API int diagan_fused_bias_act(const float* x, const float* bias, const fl
   hipLaunchKernelGGL(fused_bias_act_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, refer, out,
                      (long)n, (long)step_b, size_b, act * 10 + grad, alpha, scale);
   return check_launch("fused_bias_act");
+}
+
+DIAGAN_API int diagan_styled_bias_act(const float* x, const float* demod, const float* noise, const float* strength,
+                                      const float* bias, float* out, int B, int P, int C, int noise_per_image,
+                                      float alpha, float scale, void* stream) {
+  DG_REQUIRE(x && out && B > 0 && P > 0 && C > 0 && (C & 3) == 0, "styled_bias_act: bad dims (C must be a multiple of 4)");
+  DG_REQUIRE(!noise || strength, "styled_bias_act: noise needs its strength");
+  DG_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)demod | (uintptr_t)bias) & 15) == 0,
+             "styled_bias_act: pointers must be 16-byte aligned");
+  const long n4 = (long)B * P * (C / 4);
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(styled_act_cl4_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, demod,
+                     noise, strength, bias, (f32x4*)out, n4, P, C, noise_per_image, alpha, scale);
+  return check_launch("styled_bias_act");
 }
 
 // out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL

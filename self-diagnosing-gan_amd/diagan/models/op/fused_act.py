@@ -12,6 +12,7 @@ from diagan import _native as nat
 
 P, I, F32, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_fused_bias_act", [P, P, P, P, I64, I64, I, I, I, F32, F32, P])
+nat.register("diagan_styled_bias_act", [P, P, P, P, P, P, I, I, I, I, F32, F32, P])
 
 
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale, bias_dim=1):
@@ -69,6 +70,43 @@ class _BiasLeakyReLU(Function):
         gx = _LeakyGate.apply(gy, y, *ctx.hyper)
         gb = gx.sum([d for d in range(gx.dim()) if d != ctx.bias_dim]) if ctx.has_bias else None
         return gx, gb, None, None, None
+
+
+class _StyledAct(Function):
+    """y = leaky_relu(x * demod[b, c] + strength * noise[b, h, w] + bias[c]) * scale on [B, H, W, C] in ONE launch
+    (the reference spends three passes: weight demodulation aside, NoiseInjection and FusedLeakyReLU,
+    stylegan2.py:268-329).  sign(y) = sign(pre-activation), so y gates the backward.  The backward is written with
+    differentiable pieces (the self-differentiating gate + torch products / sums), which gives every higher order."""
+
+    @staticmethod
+    def forward(ctx, x, demod, noise, strength, bias, slope, scale):
+        b, h, w, c = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        per_image = noise is not None and noise.shape[0] == b and b > 1
+        nat.call("diagan_styled_bias_act", nat.ptr(x), nat.ptr(demod.contiguous()) if demod is not None else None,
+                 nat.ptr(noise.contiguous()) if noise is not None else None,
+                 nat.ptr(strength) if noise is not None else None, nat.ptr(bias) if bias is not None else None,
+                 nat.ptr(y), b, h * w, c, 1 if per_image else 0, float(slope), float(scale), nat.current_stream())
+        ctx.save_for_backward(x, demod, noise, y)
+        ctx.hyper = (slope, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, demod, noise, y = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gpre = _LeakyGate.apply(gy, y, *ctx.hyper)
+        gx = (gpre * demod[:, None, None, :] if demod is not None else gpre) if need[0] else None
+        gd = (gpre * x).sum((1, 2)) if demod is not None and need[1] else None
+        gs = (gpre * noise).sum().reshape(1) if noise is not None and need[3] else None
+        gb = gpre.sum((0, 1, 2)) if need[4] else None
+        return gx, gd, None, gs, gb, None, None
+
+
+def styled_bias_act(x, demod=None, noise=None, strength=None, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    """x [B,H,W,C]; demod [B,C]; noise [B or 1, H, W, 1] with its scalar `strength` [1]; bias [C]"""
+    return _StyledAct.apply(x, demod, noise, strength, bias, negative_slope, scale)
 
 
 def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5, bias_dim=1):

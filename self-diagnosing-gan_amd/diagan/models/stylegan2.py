@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from diagan.models.layers import FlatNet
-from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu
+from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, styled_bias_act
 from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
 
@@ -186,6 +186,12 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
 
     def forward(self, x, style):
+        y, d = self.forward_parts(x, style)
+        return y * d[:, None, None, :] if d is not None else y
+
+    def forward_parts(self, x, style):
+        """(convolution of the modulated input, demodulation factors [B, Co] or None): the caller applies d -- StyledConv
+        does it inside its fused noise + bias + activation pass"""
         s = self.modulation(style)                                   # [B, Ci]
         w = self.weight[0] * self.scale
         if self.downsample:
@@ -197,10 +203,8 @@ class ModulatedConv2d(nn.Module):
             y = dc.conv2d(x, w, stride=2, padding=0)
         else:
             y = dc.conv2d(x, w, stride=1, padding=self.padding)
-        if self.demodulate:
-            d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3))) + self.eps)      # [B, Co]
-            y = y * d[:, None, None, :]
-        return y
+        d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3))) + self.eps) if self.demodulate else None
+        return y, d
 
     def __repr__(self):
         return (f"{type(self).__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, "
@@ -212,13 +216,17 @@ class NoiseInjection(nn.Module):
         super().__init__()
         self.weight = nn.Parameter(torch.zeros(1))
 
-    def forward(self, image, noise=None):
+    @staticmethod
+    def draw(image, noise=None):
+        """the noise map as [B or 1, H, W, 1]: fresh N(0,1) (same draw count and order as the reference's
+        [B,1,H,W]) or the given [B or 1, 1, H, W] tensor"""
         b, h, w, _ = image.shape
-        if noise is None:                               # same draw count and order as the reference's [B,1,H,W]
-            noise = image.new_empty(b, h, w, 1).normal_()
-        else:                                           # given as [B or 1, 1, H, W]
-            noise = noise.reshape(noise.shape[0], h, w, 1)
-        return image + self.weight * noise
+        if noise is None:
+            return image.new_empty(b, h, w, 1).normal_()
+        return noise.reshape(noise.shape[0], h, w, 1)
+
+    def forward(self, image, noise=None):
+        return image + self.weight * self.draw(image, noise)
 
 
 class ConstantInput(nn.Module):
@@ -240,7 +248,10 @@ class StyledConv(nn.Module):
         self.activate = _ChannelsLastLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
-        return self.activate(self.noise(self.conv(input, style), noise=noise))
+        # conv -> * demod -> + strength * noise -> + bias -> leaky ReLU * sqrt(2): the last four in one launch
+        y, d = self.conv.forward_parts(input, style)
+        return styled_bias_act(y, d, self.noise.draw(y, noise), self.noise.weight, self.activate.bias,
+                               self.activate.negative_slope, self.activate.scale)
 
 
 class ToRGB(nn.Module):

@@ -46,8 +46,13 @@ def _splits_stride2(geom, transposed_gather):
     return transposed_gather and geom.stride == 2 and geom.pad == 0
 
 
-def _pad_hw(x, py, px):
-    return F.pad(x, (0, 0, px, px, py, py)) if (py or px) else x
+def _sub_problem(C, n_out, ny, nx):
+    """dense stride-1 sub-convolution of one parity class.  The class needs the 'full' correlation (ny-1 / nx-1 zeros
+    on each side); the kernels take ONE symmetric padding, so the larger of the two is used and the surplus border
+    rows / columns of the result (products with padding only) are trimmed when the class is interleaved -- no padded
+    copy of the input is ever made."""
+    p = max(ny, nx) - 1
+    return K.Geom('conv', C, n_out, ny, nx, 1, p), p - (ny - 1), p - (nx - 1)
 
 
 def _up2_gather(x, w, n_out, R, S, C, out_hw):
@@ -61,12 +66,12 @@ def _up2_gather(x, w, n_out, R, S, C, out_hw):
     for cy, ry in _parity_taps(R):
         for cx, sx in _parity_taps(S):
             ny, nx = len(ry), len(sx)
-            sub = K.Geom('conv', C, n_out, ny, nx, 1, 0)
+            sub, ty, tx = _sub_problem(C, n_out, ny, nx)
             ws = w4[:, ry][:, :, sx].reshape(n_out, ny * nx * C)
             if ws.shape[1] != sub.Kp:
                 ws = F.pad(ws, (0, sub.Kp - ws.shape[1]))
-            y = K.conv_fwd(sub, _pad_hw(x, ny - 1, nx - 1), ws.contiguous())
-            out[:, cy:full_h:2, cx:full_w:2] = y
+            y = K.conv_fwd(sub, x, ws.contiguous())
+            out[:, cy:full_h:2, cx:full_w:2] = y[:, ty: ty + H + ny - 1, tx: tx + W + nx - 1]
     return out
 
 
@@ -77,9 +82,10 @@ def _up2_wgrad(g, x, geom):
     for cy, ry in _parity_taps(R):
         for cx, sx in _parity_taps(S):
             ny, nx = len(ry), len(sx)
-            sub = K.Geom('conv', Ci, Co, ny, nx, 1, 0)
+            sub, ty, tx = _sub_problem(Ci, Co, ny, nx)
             part = torch.empty((Co, sub.Kp), dtype=torch.float32, device=g.device)
-            K.conv_wgrad(sub, g[:, cy::2, cx::2].contiguous(), _pad_hw(x, ny - 1, nx - 1), part, accumulate=False)
+            gc = F.pad(g[:, cy::2, cx::2], (0, 0, tx, tx, ty, ty)) if (ty or tx) else g[:, cy::2, cx::2].contiguous()
+            K.conv_wgrad(sub, gc, x, part, accumulate=False)
             part = part[:, : ny * nx * Ci].view(Co, ny, nx, Ci)
             for u, r in enumerate(ry):
                 for v, s in enumerate(sx):

@@ -137,3 +137,33 @@ def test_channels_last_bias_act_fast_path_vs_oracle():
         (S.fused_leaky_relu(to_cf(xr), br) ** 2).sum().backward()
         np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), atol=1e-5)
         np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_styled_bias_act_first_and_second_order():
+    """the one-launch StyledConv tail against its three-pass composition, values and gradients to second order"""
+    from diagan.models.op.fused_act import styled_bias_act
+    g = torch.Generator().manual_seed(4)
+    B, H, W, C = 3, 5, 6, 8
+    vals = dict(x=torch.randn(B, H, W, C, generator=g), d=torch.rand(B, C, generator=g) + 0.5,
+                s=torch.randn(1, generator=g), b=torch.randn(C, generator=g))
+    for noise in (torch.randn(B, H, W, 1, generator=g), torch.randn(1, H, W, 1, generator=g)):
+        def run(fused, dev):
+            t = {k: v.to(dev).double().requires_grad_(True) if not fused else v.to(dev).requires_grad_(True)
+                 for k, v in vals.items()}
+            n = noise.to(dev) if fused else noise.to(dev).double()
+            if fused:
+                y = styled_bias_act(t['x'], t['d'], n, t['s'], t['b'])
+            else:
+                pre = t['x'] * t['d'][:, None, None, :] + t['s'] * n + t['b']
+                y = torch.nn.functional.leaky_relu(pre, 0.2) * 2 ** 0.5
+            cot = torch.sin(torch.arange(y.numel(), device=dev, dtype=y.dtype).view(y.shape))
+            first = torch.autograd.grad((y * cot).sum(), list(t.values()), create_graph=True)
+            second = torch.autograd.grad(sum((f ** 2).sum() for f in first), [t['x'], t['d']])
+            return [v.detach().cpu().double() for v in (y, *first, *second)]
+        ours, ref = run(True, "cuda"), run(False, "cpu")
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-4, atol=2e-4, err_msg=f"output {i}")
+    # optional operands
+    x = vals['x'].cuda()
+    np.testing.assert_allclose(styled_bias_act(x).cpu().numpy(),
+                               (torch.nn.functional.leaky_relu(vals['x'], 0.2) * 2 ** 0.5).numpy(), atol=1e-6)
