@@ -298,6 +298,13 @@ int diagan_styled_bias_act(const float* x, const float* demod, const float* nois
                            const float* bias, float* out, int B, int P, int C, int noise_per_image, float alpha,
                            float scale, void* stream);
 
+/* out[b][c] = sum_p a[b][p][c] * b[b][p][c] over channels-last [B][P][C] tensors: the gradient of a per-(image, channel)
+ * scale -- `style` in `weight = scale * W * style` (stylegan2.py:227-228) and `demod` (:231-233) when the modulated
+ * convolution is evaluated activation-side.  C a power of two in [4, 1024]; workspace: B * diagan_rowdot_chunks(B, P)
+ * * C floats.  Deterministic (fixed-order partial sums, combined in double). */
+int diagan_rowdot_chunks(int B, int P);
+int diagan_rowdot(const float* a, const float* b, float* out, float* workspace, int B, int P, int C, void* stream);
+
 /* upfirdn2d.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up, down, pads), upfirdn2d.cpp:4-22.
  * out == NULL: size query only (writes *out_h, *out_w). */
 int diagan_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor,

@@ -73,6 +73,45 @@ __global__ __launch_bounds__(256) void styled_act_cl4_kernel(const f32x4* __rest
   }
 }
 
+// Per-image channel dot products over the pixels: out[b][c] = sum_p a[b][p][c] * b_[b][p][c]  (the gradient of a
+// per-(image, channel) scale: style modulation and demodulation of the activation-side modulated convolution).
+// Stage 1: one block per (image, pixel chunk); 256 threads = (C/4 channel quads) x (256/(C/4) pixel lanes);
+// fp32 partial sums, combined across pixel lanes through LDS in a fixed order.  Stage 2 sums the chunks in double.
+__global__ __launch_bounds__(256) void rowdot_partial_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b_,
+                                                             float* __restrict__ partial, int P, int C, int chunks) {
+  __shared__ f32x4 red[256];
+  const int q = C >> 2, lanes = 256 / q;
+  const int cq = threadIdx.x % q, pl = threadIdx.x / q;
+  const int img = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int per = (P + chunks - 1) / chunks;
+  const int p0 = ch * per, p1 = min(p0 + per, P);
+  const long base = (long)img * P * q + cq;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  int p = p0 + pl;
+  for (; p + lanes < p1; p += 2 * lanes) {
+    acc0 += a[base + (long)p * q] * b_[base + (long)p * q];
+    acc1 += a[base + (long)(p + lanes) * q] * b_[base + (long)(p + lanes) * q];
+  }
+  if (p < p1) acc0 += a[base + (long)p * q] * b_[base + (long)p * q];
+  red[threadIdx.x] = acc0 + acc1;
+  __syncthreads();
+  if (pl == 0) {
+    f32x4 s = red[cq];
+    for (int l = 1; l < lanes; ++l) s += red[l * q + cq];
+    *reinterpret_cast<f32x4*>(partial + ((long)blockIdx.x * C) + cq * 4) = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void rowdot_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                            int BC, int C, int chunks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;       // b * C + c
+  if (i >= BC) return;
+  const int img = i / C, c = i - img * C;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += (double)partial[((long)img * chunks + k) * C + c];
+  out[i] = (float)s;
+}
+
 __global__ __launch_bounds__(256) void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
                                                              const float* __restrict__ ref, float* __restrict__ out,
                                                              long n, long step_b, int size_b, int mode, float alpha,
@@ -222,6 +261,25 @@ DIAGAN_API int diagan_styled_bias_act(const float* x, const float* demod, const 
   hipLaunchKernelGGL(styled_act_cl4_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, demod,
                      noise, strength, bias, (f32x4*)out, n4, P, C, noise_per_image, alpha, scale);
   return check_launch("styled_bias_act");
+}
+
+DIAGAN_API int diagan_rowdot_chunks(int B, int P) {
+  int chunks = 2048 / (B > 0 ? B : 1);                 // ~2048 blocks: 8 per CU
+  if (chunks > P / 64) chunks = P / 64;
+  return chunks < 1 ? 1 : chunks;
+}
+
+DIAGAN_API int diagan_rowdot(const float* a, const float* b, float* out, float* workspace, int B, int P, int C,
+                             void* stream) {
+  DG_REQUIRE(a && b && out && workspace && B > 0 && P > 0, "rowdot: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "rowdot: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)workspace) & 15) == 0, "rowdot: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  hipLaunchKernelGGL(rowdot_partial_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)a,
+                     (const f32x4*)b, workspace, P, C, chunks);
+  hipLaunchKernelGGL(rowdot_finish_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, workspace, out,
+                     B * C, C, chunks);
+  return check_launch("rowdot");
 }
 
 // out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL

@@ -12,6 +12,8 @@ from diagan import _native as nat
 
 P, I, F32, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_fused_bias_act", [P, P, P, P, I64, I64, I, I, I, F32, F32, P])
+nat.register("diagan_rowdot_chunks", [I, I])
+nat.register("diagan_rowdot", [P, P, P, P, I, I, I, P])
 nat.register("diagan_styled_bias_act", [P, P, P, P, P, P, I, I, I, I, F32, F32, P])
 
 
@@ -72,6 +74,51 @@ class _BiasLeakyReLU(Function):
         return gx, gb, None, None, None
 
 
+class _RowDot(Function):
+    """R(a, b)[n, c] = sum over pixels of a[n, h, w, c] * b[n, h, w, c]: one pass over both tensors.  Together with
+    S(x, s) = x * s[:, None, None, :] it is closed under differentiation (dR/da = S(b, g), dS/ds = R(g, x))."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        n, h, w, c = a.shape
+        if c < 4 or c > 1024 or c & (c - 1):
+            return (a * b).sum((1, 2))
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty((n, c), dtype=torch.float32, device=a.device)
+        work = torch.empty(n * nat.fn("diagan_rowdot_chunks")(n, h * w) * c, dtype=torch.float32, device=a.device)
+        nat.call("diagan_rowdot", nat.ptr(a), nat.ptr(b), nat.ptr(out), nat.ptr(work), n, h * w, c, nat.current_stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (scale_rows(b, g) if ctx.needs_input_grad[0] else None,
+                scale_rows(a, g) if ctx.needs_input_grad[1] else None)
+
+
+class _ScaleRows(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.save_for_backward(x, s)
+        return x * s[:, None, None, :]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, s = ctx.saved_tensors
+        return (scale_rows(g, s) if ctx.needs_input_grad[0] else None,
+                rowdot(g, x) if ctx.needs_input_grad[1] else None)
+
+
+def rowdot(a, b):
+    return _RowDot.apply(a, b)
+
+
+def scale_rows(x, s):
+    """x[n, h, w, c] * s[n, c] whose gradient with respect to s is the one-pass `rowdot`"""
+    return _ScaleRows.apply(x, s)
+
+
 class _StyledAct(Function):
     """y = leaky_relu(x * demod[b, c] + strength * noise[b, h, w] + bias[c]) * scale on [B, H, W, C] in ONE launch
     (the reference spends three passes: weight demodulation aside, NoiseInjection and FusedLeakyReLU,
@@ -97,8 +144,8 @@ class _StyledAct(Function):
         x, demod, noise, y = ctx.saved_tensors
         need = ctx.needs_input_grad
         gpre = _LeakyGate.apply(gy, y, *ctx.hyper)
-        gx = (gpre * demod[:, None, None, :] if demod is not None else gpre) if need[0] else None
-        gd = (gpre * x).sum((1, 2)) if demod is not None and need[1] else None
+        gx = (scale_rows(gpre, demod) if demod is not None else gpre) if need[0] else None
+        gd = rowdot(gpre, x) if demod is not None and need[1] else None
         gs = (gpre * noise).sum().reshape(1) if noise is not None and need[3] else None
         gb = gpre.sum((0, 1, 2)) if need[4] else None
         return gx, gd, None, gs, gb, None, None

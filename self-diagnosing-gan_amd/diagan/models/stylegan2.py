@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from diagan.models.layers import FlatNet
-from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, styled_bias_act
+from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, scale_rows, styled_bias_act
 from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
 
@@ -187,7 +187,7 @@ class ModulatedConv2d(nn.Module):
 
     def forward(self, x, style):
         y, d = self.forward_parts(x, style)
-        return y * d[:, None, None, :] if d is not None else y
+        return scale_rows(y, d) if d is not None else y
 
     def forward_parts(self, x, style):
         """(convolution of the modulated input, demodulation factors [B, Co] or None): the caller applies d -- StyledConv
@@ -196,7 +196,7 @@ class ModulatedConv2d(nn.Module):
         w = self.weight[0] * self.scale
         if self.downsample:
             x = self.blur(x)
-        x = x * s[:, None, None, :]
+        x = scale_rows(x, s)
         if self.upsample:
             y = self.blur(dc.conv_transpose2d(x, w, stride=2, padding=0))
         elif self.downsample:

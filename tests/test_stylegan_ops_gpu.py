@@ -167,3 +167,25 @@ def test_styled_bias_act_first_and_second_order():
     x = vals['x'].cuda()
     np.testing.assert_allclose(styled_bias_act(x).cpu().numpy(),
                                (torch.nn.functional.leaky_relu(vals['x'], 0.2) * 2 ** 0.5).numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 4, 4), (3, 9, 7, 64), (2, 33, 31, 128), (1, 5, 5, 512), (2, 3, 3, 12)])
+def test_rowdot_and_scale_rows_closed_pair(shape):
+    """S(x, s) = x * s[n, c] and R(a, b) = sum_pixels a * b (one-pass HIP kernel; torch fallback for channel counts
+    that are not a power of two): values and gradients to second order against plain torch in float64"""
+    from diagan.models.op.fused_act import rowdot, scale_rows
+    g = torch.Generator().manual_seed(sum(shape))
+    x0, a0 = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+    s0 = torch.randn(shape[0], shape[3], generator=g)
+
+    def run(fused, dev, dt):
+        x, a, s = (t.to(dev, dt).requires_grad_(True) for t in (x0, a0, s0))
+        y = scale_rows(x, s) if fused else x * s[:, None, None, :]
+        r = rowdot(y, a) if fused else (y * a).sum((1, 2))
+        first = torch.autograd.grad((r ** 2).sum() + (y ** 3).sum(), (x, a, s), create_graph=True)
+        second = torch.autograd.grad(sum((f ** 2).sum() for f in first), (x, a, s))
+        return [t.detach().cpu().double() for t in (y, r, *first, *second)]
+
+    ours, ref = run(True, "cuda", torch.float32), run(False, "cpu", torch.float64)
+    for i, (p, q) in enumerate(zip(ours, ref)):
+        np.testing.assert_allclose(p.numpy(), q.numpy(), rtol=1e-3, atol=1e-3 * float(q.abs().max()), err_msg=f"output {i}")
