@@ -163,7 +163,7 @@ class StyleGAN2Trainer:
         self.history = []
         self._iters = {}
         if get_world_size() > 1:
-            for net in (generator, discriminator, drs_discriminator):
+            for net in (generator, discriminator, drs_discriminator, g_ema):
                 if net is not None:
                     dist.broadcast_module_(net)
 
