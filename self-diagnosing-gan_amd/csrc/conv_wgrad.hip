@@ -542,10 +542,22 @@ DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
   wgrad_tile(Co, Kp, &bn, &bk);
   const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
   const int total_steps = cdiv(M, 32);
-  int splits = 512 / tiles;                      // <= 2 resident workgroups per CU: ONE round of blocks
-                                                 // (540 blocks on 512 slots would cost a second, nearly empty round)
+  // 512 resident workgroups (2 per CU).  Blocks run their whole K range, so the launch takes
+  //   rounds(s) * (steps / s + c)   K-step times,   rounds(s) = ceil(tiles * s / 512),
+  // c = fixed cost of a block (prologue, slab write-out) in K-steps.  One round of blocks is best whenever tiles
+  // divides the 512 slots well (9, 18, 36, 72 tiles: 504 blocks); tile counts that do not (144 tiles: 3 splits fill
+  // only 432 slots) are better served by a few FULL rounds -- 7 splits, 1008 blocks, 2 rounds: measured
+  // 5.8 -> 5.0 ms at M=131072, Co=512, K=4608.  (A second, nearly empty round is what this model prices out.)
   static const int min_steps = getenv("DIAGAN_WGRAD_MINSTEPS") ? atoi(getenv("DIAGAN_WGRAD_MINSTEPS")) : 4;
-  if (splits > total_steps / min_steps) splits = total_steps / min_steps;  // at least min_steps K-steps per split
+  static const double fixed = getenv("DIAGAN_WGRAD_FIXED") ? atof(getenv("DIAGAN_WGRAD_FIXED")) : 6.0;
+  int smax = total_steps / min_steps;               // at least min_steps K-steps per split
+  if (smax > 256) smax = 256;
+  int splits = 1;
+  double best = 1e30;
+  for (int s = 1; s <= smax; ++s) {
+    const double t = (double)cdiv(tiles * s, 512) * ((double)total_steps / s + fixed);
+    if (t < best * 0.995) { best = t; splits = s; }   // ties (and near-ties) go to fewer splits: less slab traffic
+  }
   if (splits < 1) splits = 1;
   if (splits > 256) splits = 256;
   return splits;

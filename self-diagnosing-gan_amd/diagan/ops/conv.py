@@ -248,7 +248,8 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo), 2.0 * M * Co * geom.R * geom.S * Ci, t0)
+        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo), 2.0 * M * Co * geom.R * geom.S * Ci, t0,
+                  (M, Co, geom.R * geom.S * Ci, f"pro{mode} x{splits}"))
     if sn is None:
         nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
                  None, None, st)
