@@ -37,6 +37,7 @@ WORKLOADS = {
     # name: (dataset key, resolution, description)
     'sngan32': ('cifar10', 32, "CIFAR-10 SNGAN phase-1 ns-loss bs=64, synthetic 32x32"),
     'sngan64': ('celeba', 64, "CelebA-64 SNGAN phase-1 ns-loss bs=64, synthetic 64x64"),
+    'dcgan': ('color_mnist', 32, "Colored-MNIST mnist_dcgan phase-1 bs=64, synthetic 32x32 (BASELINE configs[0] shape)"),
 }
 
 
@@ -72,7 +73,7 @@ def make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, n_dis,
         state['cursor'] += 1
         return (b, None)
 
-    def step():
+    def device_part():
         netG.prefetch_fakes(n_dis * (2 if netD_drs is not None else 1), batches[0].shape[0], device=device)   # as LogTrainer._updates
         for i in range(n_dis):
             real = fetch()
@@ -84,9 +85,16 @@ def make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, n_dis,
             if i == n_dis - 1:
                 netG.train_step(real_batch=real, netD=netD, optG=optG, log_data=log, global_step=state['step'],
                                 device=device)
+
+    def host_part():
         state['step'] += 1
         sched.step(log, state['step'])
 
+    def step():
+        device_part()
+        host_part()
+
+    step.device_part, step.host_part = device_part, host_part      # --graph replays the first, runs the second
     return step
 
 
@@ -173,6 +181,8 @@ def main():
     ap.add_argument("--n_dis", type=int, default=5)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the global step as one hipGraph (launch-bound workloads: dcgan); single GPU only")
     args = ap.parse_args()
 
     from diagan.trainer import distributed as dist
@@ -214,6 +224,15 @@ def main():
         C.TIMER = None
     if not args.no_kernel_timer:
         timer = C.KernelTimer(only={dominant} if dominant else None)
+    eager_step = step
+    if args.graph:
+        # the captured launches read the n_dis real batches from fixed tensors; every replay gets fresh data copied in
+        from diagan.utils.graph import GraphedStep
+        graphed = GraphedStep(eager_step.device_part, (netG, netD, netD_drs), (optG, optD, optD_drs), warmup=2,
+                              after=eager_step.host_part)
+        graphed.capture()
+        step = graphed
+        timer = None            # launches inside a graph carry no events; the kernel table comes from eager steps below
     dist.synchronize()
     torch.cuda.synchronize()
     C.TIMER = timer
@@ -231,10 +250,17 @@ def main():
     # two more UN-timed steps on EVERY rank (each step contains the gradient all-reduces): every GEMM launch is
     # bracketed for the per-kernel table rank 0 prints
     summ_all = None
+    if args.graph and not args.no_kernel_timer:
+        timer = C.KernelTimer(only={dominant} if dominant else None)      # roofline leg of a graph run: eager steps
+        C.TIMER = timer
+        for _ in range(2):
+            eager_step()
+        torch.cuda.synchronize()
+        C.TIMER = None
     if timer is not None:
         C.TIMER = full = C.KernelTimer()
         for _ in range(2):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         C.TIMER = None
         summ_all = full.summary()
@@ -258,7 +284,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": desc + (" + D_drs (phase 2)" if args.phase == 2 else ""),
                    "global_batch": args.batch_size * world, "n_dis": args.n_dis, "loss_type": args.loss_type,
-                   "parallelism": f"dp{world}", "steps_per_s": round(args.steps / elapsed, 3),
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager",
+                   "steps_per_s": round(args.steps / elapsed, 3),
                    "D_updates_per_s": round(args.steps * args.n_dis / elapsed, 3)},
     }
     if timer is not None:

@@ -281,6 +281,9 @@ int diagan_loss_gen(const float* out_fake, int n, int k, int loss_type, float* d
 /* torch.optim.Adam.step on one flat buffer (predefined_models.py:32,51,70,89,114,123). */
 int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, void* stream);
+/* The same step with {lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt} read from a DEVICE row of six
+ * floats: the launch can be captured in a hipGraph and replayed with values the host writes before each replay. */
+int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper6, void* stream);
 
 /* ---- StyleGAN2 native ops (the reference's only native code) -------------- */
 

@@ -122,6 +122,30 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// the same update with the hyper-parameters read from device memory: a captured hipGraph replays this launch with
+// whatever {lr, beta1, beta2, eps, bias corrections} the host wrote into the row before the replay
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long n4,
+                                                       const AdamHyper* __restrict__ hp) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const AdamHyper h = *hp;
+  const float step_size = h.lr / h.bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mv[e] = mv[e] + (gv[e] - mv[e]) * (1.f - h.beta1);
+      vv[e] = vv[e] * h.beta2 + (1.f - h.beta2) * gv[e] * gv[e];
+      const float denom = sqrtf(vv[e]) / h.bc2_sqrt + h.eps;
+      pv[e] = pv[e] - step_size * (mv[e] / denom);
+    }
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+
 }  // namespace diagan
 
 using namespace diagan;
@@ -156,4 +180,15 @@ DIAGAN_API int diagan_adam_step(float* p, const float* g, float* m, float* v, in
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, h);
   return check_launch("adam_step");
+}
+
+DIAGAN_API int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper6,
+                                    void* stream) {
+  DG_REQUIRE(p && g && m && v && hyper6 && n > 0 && (n & 3) == 0, "adam_step_dev: bad args (n must be a multiple of 4)");
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
+                     reinterpret_cast<const AdamHyper*>(hyper6));
+  return check_launch("adam_step_dev");
 }

@@ -30,6 +30,7 @@ nat.register("diagan_add", [P, P, P, I64, P])
 nat.register("diagan_loss_dis", [P, I, P, I, I, I, P, P, P, P])
 nat.register("diagan_loss_gen", [P, I, I, I, P, P, P])
 nat.register("diagan_adam_step", [P, P, P, P, I64, F, F, F, F, F, F, P])
+nat.register("diagan_adam_step_dev", [P, P, P, P, I64, P, P])
 
 LOSS_TYPES = {'gan': 0, 'ns': 1, 'hinge': 2, 'wasserstein': 3}
 ptr, st = nat.ptr, nat.current_stream
@@ -264,3 +265,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
     nat.call("diagan_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, st())
+
+
+def adam_hyper_row(lr, beta1, beta2, eps, step):
+    """the six floats diagan_adam_step_dev reads: same host arithmetic as adam_step"""
+    return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, (1.0 - beta2 ** step) ** 0.5]
+
+
+def adam_step_dev(p, g, m, v, hyper_row):
+    nat.call("diagan_adam_step_dev", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(hyper_row), st())

@@ -18,6 +18,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = None
         self._v = None
         self._step = 0
+        self._hyper_dev = None        # hipGraph replay: one device row of hyper-parameters per captured update
+        self._capturing = False
+        self._cursor = 0
+        self._updates_per_replay = 0
 
     def _ensure_state(self):
         flat = self.net.flat_params
@@ -33,10 +37,39 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         self._ensure_state()
         g = self.param_groups[0]
-        self._step += 1
-        E.adam_step(self.net.flat_params, self.net.flat_grads, self._m, self._v, g['lr'], g['betas'][0],
-                    g['betas'][1], g['eps'], self._step)
+        if self._capturing:
+            # stream capture: the launch reads its hyper-parameters from device row `cursor`, which
+            # `before_replay` fills with the values of the update it will stand for
+            if self._cursor >= self._hyper_dev.shape[0]:
+                raise RuntimeError("FusedAdam: more optimiser steps in one captured region than rows were reserved")
+            E.adam_step_dev(self.net.flat_params, self.net.flat_grads, self._m, self._v, self._hyper_dev[self._cursor])
+            self._cursor += 1
+        else:
+            self._step += 1
+            E.adam_step(self.net.flat_params, self.net.flat_grads, self._m, self._v, g['lr'], g['betas'][0],
+                        g['betas'][1], g['eps'], self._step)
         self.net.param_version += 1
+
+    # ---- hipGraph support (diagan/utils/graph.py) -------------------------------------------------------------
+    def capture_begin(self, max_updates=64):
+        self._ensure_state()
+        self._hyper_dev = torch.zeros((max_updates, 6), dtype=torch.float32, device=self.net.flat_params.device)
+        self._capturing, self._cursor = True, 0
+
+    def capture_end(self):
+        self._capturing = False
+        self._updates_per_replay = self._cursor
+
+    def before_replay(self):
+        """write the hyper-parameter rows of the next `updates_per_replay` updates (current lr; bias corrections
+        of steps step+1 ..) and advance the step counter -- the host side of what the replayed launches will do"""
+        g = self.param_groups[0]
+        k = self._updates_per_replay
+        if k == 0:
+            return
+        rows = [E.adam_hyper_row(g['lr'], g['betas'][0], g['betas'][1], g['eps'], self._step + 1 + i) for i in range(k)]
+        self._hyper_dev[:k].copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=False)
+        self._step += k
 
     def zero_grad(self, set_to_none=False):
         self.net.zero_grad()
