@@ -47,14 +47,12 @@ class MNIST_DCGAN_Generator(BaseGenerator, TopKGenerator):
         z = z.to(dtype=torch.float32)
         x0, h = self.fc.fwd(z)                                   # [B,1,1,384]
         k1 = t['0'].prepare(training, save)
-        y1 = t['0'].fwd(k1, h)                                   # [B,4,4,192]
-        bn1 = t['1'].stats(y1, training)
+        # BatchNorm statistics come out of the producing GEMM's epilogue (no second pass over y)
+        y1, bn1 = t['0'].fwd_bn(k1, h, t['1'], training)         # [B,4,4,192]
         k2 = t['3'].prepare(training, save)
-        y2 = t['3'].fwd(k2, y1, pro=_bn_pro(bn1))                # [B,8,8,96]
-        bn2 = t['4'].stats(y2, training)
+        y2, bn2 = t['3'].fwd_bn(k2, y1, t['4'], training, pro=_bn_pro(bn1))      # [B,8,8,96]
         k3 = t['6'].prepare(training, save)
-        y3 = t['6'].fwd(k3, y2, pro=_bn_pro(bn2))                # [B,16,16,48]
-        bn3 = t['7'].stats(y3, training)
+        y3, bn3 = t['6'].fwd_bn(k3, y2, t['7'], training, pro=_bn_pro(bn2))      # [B,16,16,48]
         k4 = t['9'].prepare(training, save)
         y4 = t['9'].fwd(k4, y3, pro=_bn_pro(bn3))                # [B,32,32,4]
         img = E.tanh_fwd(y4, out=out)
@@ -151,12 +149,14 @@ class MNIST_DCGAN_Discriminator(BaseDiscriminator):
         for i, (ci, bi) in enumerate(self._idx):
             conv = self.conv[ci]
             k = conv.prepare(training, need_dgrad and (i > 0 or need_in_dgrad))
-            y = conv.fwd(k, h)
-            bn = self.conv[bi].stats(y, training) if bi is not None else None
+            if bi is not None:
+                y, bn = conv.fwd_bn(k, h, self.conv[bi], training)      # statistics from the GEMM epilogue
+            else:
+                y, bn = conv.fwd(k, h), None
             drop = None
-            if training:      # Dropout(0.5): mask scaled by 1/(1-p); RNG is torch's (device generator)
+            if training:      # Dropout(0.5): keep-mask scaled by 1/(1-p); RNG is torch's (device generator)
                 drop = drop_masks[i] if drop_masks is not None else \
-                    (torch.rand(y.shape, device=y.device) >= 0.5).to(torch.float32) * 2.0
+                    torch.empty(y.shape, dtype=torch.float32, device=y.device).bernoulli_(0.5).mul_(2.0)
             a = E.act_fwd(y, 0.2, bn.scale if bn else None, bn.shift if bn else None, drop)
             saved.append((h, k, y, bn, drop))
             h = a
