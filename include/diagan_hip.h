@@ -101,6 +101,12 @@ int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bi
                        const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W, int Ci,
                        int dr, int off, int Kp, int group_imgs, void* stream);
 /* group_imgs > 0: image b reads the affine prologue of group b / group_imgs (see diagan_conv_gemm pro_group_rows). */
+/* Arithmetic of diagan_conv_gemm: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, the default, what every parity claim is
+ * made with); 1 = "bf16x6", experimental: every fp32 operand split exactly into three bf16 pieces, six exact piece
+ * products per element accumulated in fp32 on the bf16 matrix pipe (error at or below the fp32 MFMA's).  Also
+ * selectable with DIAGAN_MFMA=bf16x6 in the environment.  (No reference counterpart: cuDNN's math-mode switch.) */
+int diagan_set_mfma_mode(int mode);
+
 /* Weight (+ bias) gradient of the same layer, Ci in {64,128,256}, Kp == 9*Ci: the whole [4][Kp] gradient lives in
  * each wave's accumulators; writes diagan_conv3x3_co4_wgrad_splits(B, H) partial slabs
  * slab[split][slab_stride] in the packed-weight layout (bias column sums at bias_off if >= 0), to be summed by

@@ -21,6 +21,7 @@
 #include "conv_common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace diagan {
 
@@ -50,7 +51,16 @@ struct ConvGemmArgs {
   FastDiv dWo, dHo;       // pixel index -> (b, oy, ox) without integer division
 };
 
-template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// X6 ("bf16x6", opt-in): the same kernel on the bf16 matrix pipe with fp32 accuracy.  Every fp32 operand is
+// split EXACTLY into three bf16 pieces (8 + 8 + 8 significant bits) on its way into LDS; a product is the sum of the six
+// piece products that are not below 2^-24 relative (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0), each exact in fp32, accumulated
+// in fp32: six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles) per
+// 32x32x16 block.  Measured error against double is at or below the fp32 MFMA's (tools/probe/bf16x6.hip).
+template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool X6 = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int CH = BK / 4;                           // 16-byte chunks per tile row
   constexpr int RP = 256 / CH;                         // tile rows covered by one pass of the 256 loaders
@@ -62,6 +72,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BM*32]
   float* Bs = smem + 2 * BM * BK;    // [2][BN*32]
+  // X6: per buffer three bf16 planes per operand, rows of BK bf16 (64 B), 16-byte slots swizzled by (row >> 2) & 3
+  __bf16* Ax = reinterpret_cast<__bf16*>(smem);       // [2][3][BM][BK]
+  __bf16* Bx = Ax + 2 * 3 * BM * BK;                  // [2][3][BN][BK]
+  static_assert(!X6 || BK == 32 || BK == 16, "the bf16x6 variant is written for 16- or 32-wide K-steps");
+  // conflict-free ds_read_b128 of a lane's 8 k: rows are BK bf16 = 64 (32) bytes, 4 (2) slots of 16 B
+  auto xslot = [](int row, int q) { return BK == 32 ? (q ^ ((row >> 2) & 3)) : (q ^ ((row >> 3) & 1)); };
+  auto store_x6 = [&](__bf16* tile, int rows, int row, int lq_, f32x4 v) {
+    bf16x4 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h0 = (__bf16)v[e];
+      const float r1 = v[e] - (float)h0;          // exact
+      const __bf16 h1 = (__bf16)r1;
+      const float r2 = r1 - (float)h1;            // exact
+      p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)r2;
+    }
+    const int off = row * BK + (xslot(row, lq_ >> 1) << 3) + ((lq_ & 1) << 2);
+    *reinterpret_cast<u32x2*>(tile + off) = __builtin_bit_cast(u32x2, p0);
+    *reinterpret_cast<u32x2*>(tile + rows * BK + off) = __builtin_bit_cast(u32x2, p1);
+    *reinterpret_cast<u32x2*>(tile + 2 * rows * BK + off) = __builtin_bit_cast(u32x2, p2);
+  };
 
   const ConvGeom& g = a.g;
   const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;   // compile-time in the specialised kernels: straight-line store phase
@@ -201,11 +232,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
           v *= keep;
         }
       }
-      *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK + (swz(row, lq) << 2)) = v;
+      if constexpr (X6) store_x6(Ax + buf * 3 * BM * BK, BM, row, lq, v);
+      else *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK + (swz(row, lq) << 2)) = v;
     } else {
       const int j = p - AJ;
       const int row = lrow + RP * j;
-      *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK + (swz(row, lq) << 2)) = rb[j];
+      if constexpr (X6) store_x6(Bx + buf * 3 * BN * BK, BN, row, lq, rb[j]);
+      else *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK + (swz(row, lq) << 2)) = rb[j];
     }
   };
   auto store_tiles = [&](int buf) {
@@ -270,8 +303,58 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
     __syncthreads();
   };
-  for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
-  if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+  auto kstep_x6 = [&](int kk, auto has_next) {
+    const int cur = (kk - k_begin) & 1;
+    const __bf16* Ac = Ax + cur * 3 * BM * BK;
+    const __bf16* Bc = Bx + cur * 3 * BN * BK;
+    constexpr int NS = (BK / 16) * 6;            // (16-wide K chunks) x (six piece products)
+    static_assert(2 * NP <= 3 * NS, "piece schedule of the bf16x6 step");
+#pragma unroll
+    for (int u = 0; u < BK / 16; ++u) {
+      const int q = 2 * u + fh;                  // lane half h takes k = 8h .. 8h+7 of the chunk
+      bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * (TM * 32) + i * 32 + fi;
+        const int off = row * BK + (xslot(row, q) << 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const bf16x8*>(Ac + p * BM * BK + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * (TN * 32) + j * 32 + fi;
+        const int off = row * BK + (xslot(row, q) << 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) fb[j][p] = *reinterpret_cast<const bf16x8*>(Bc + p * BN * BK + off);
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 6; ++sidx) {
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
+        const int es = u * 6 + sidx;
+        if (decltype(has_next)::value && 2 * es < NP) {        // next tile's global loads: two per slot, first slots
+          load_piece(kk + 1, 2 * es);
+          if (2 * es + 1 < NP) load_piece(kk + 1, 2 * es + 1);
+        }
+        if (decltype(has_next)::value && es >= NS - NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          store_piece(cur ^ 1, es - (NS - NP));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[sidx]], fb[j][PB[sidx]], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  };
+  if constexpr (X6) {
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep_x6(kk, std::true_type{});
+    if (k_begin < k_end) kstep_x6(k_end - 1, std::false_type{});
+  } else {
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+    if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+  }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
   // Straight-line per variant (residual / mask / statistics / raw split-K partials are compile-time flags of the
@@ -406,11 +489,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
   }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int PRO>
+static int g_mfma_x6 = -1;       // -1: read DIAGAN_MFMA on first use; 0: fp32 MFMA (default); 1: bf16x6
+
+template <int BM, int BN, int WM, int WN, int BK, int PRO, bool X6 = false>
 static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO>;
+  const size_t lds = X6 ? (size_t)2 * 3 * (BM + BN) * BK * 2 : (size_t)2 * (BM + BN) * BK * sizeof(float);
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, X6>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -428,6 +513,14 @@ static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
 // SPEC: one kernel per prologue mode (the two production tiles); otherwise the mode is a run-time argument
 template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
+  if (g_mfma_x6 < 0) {
+    const char* m = getenv("DIAGAN_MFMA");
+    g_mfma_x6 = (m && !strcmp(m, "bf16x6")) ? 1 : 0;
+  }
+  if (g_mfma_x6 == 1) {                     // experimental: run-time prologue mode
+    static const int xbk = getenv("DIAGAN_X6_BK") ? atoi(getenv("DIAGAN_X6_BK")) : 16;
+    return xbk == 32 ? launch_one<BM, BN, WM, WN, 32, -1, true>(a, st) : launch_one<BM, BN, WM, WN, 16, -1, true>(a, st);
+  }
   if (SPEC) {
     switch (a.pro_mode) {
       case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1>(a, st);
@@ -443,6 +536,13 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
 }  // namespace diagan
 
 using namespace diagan;
+
+// 0: exact fp32 MFMA (default); 1: bf16x6 (fp32-accurate on the bf16 matrix pipe, experimental)
+DIAGAN_API int diagan_set_mfma_mode(int mode) {
+  DG_REQUIRE(mode == 0 || mode == 1, "set_mfma_mode: 0 (fp32 MFMA) or 1 (bf16x6)");
+  g_mfma_x6 = mode;
+  return DIAGAN_OK;
+}
 
 // tile selection used when tile_cfg == 0: 1 = 128x128, 3 = 64x64 (2, 4, 5 were sweep-only shapes, retired)
 DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
