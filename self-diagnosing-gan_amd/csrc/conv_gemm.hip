@@ -517,9 +517,18 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
     const char* m = getenv("DIAGAN_MFMA");
     g_mfma_x6 = (m && !strcmp(m, "bf16x6")) ? 1 : 0;
   }
-  if (g_mfma_x6 == 1) {                     // experimental: run-time prologue mode
+  if (g_mfma_x6 == 1) {                     // bf16x6: 16-wide K-steps (48 KB of LDS: two workgroups per CU)
     static const int xbk = getenv("DIAGAN_X6_BK") ? atoi(getenv("DIAGAN_X6_BK")) : 16;
-    return xbk == 32 ? launch_one<BM, BN, WM, WN, 32, -1, true>(a, st) : launch_one<BM, BN, WM, WN, 16, -1, true>(a, st);
+    if (xbk == 32) return launch_one<BM, BN, WM, WN, 32, -1, true>(a, st);
+    if (SPEC) {
+      switch (a.pro_mode) {
+        case PRO_NONE: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_NONE : -1, true>(a, st);
+        case PRO_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_RELU : -1, true>(a, st);
+        case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_AFFINE_RELU : -1, true>(a, st);
+        default: break;
+      }
+    }
+    return launch_one<BM, BN, WM, WN, 16, -1, true>(a, st);
   }
   if (SPEC) {
     switch (a.pro_mode) {
