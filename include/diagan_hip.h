@@ -106,6 +106,7 @@ int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bi
  * products per element accumulated in fp32 on the bf16 matrix pipe (error at or below the fp32 MFMA's).  Also
  * selectable with DIAGAN_MFMA=bf16x6 in the environment.  (No reference counterpart: cuDNN's math-mode switch.) */
 int diagan_set_mfma_mode(int mode);
+int diagan_get_mfma_mode(void);
 
 /* Weight (+ bias) gradient of the same layer, Ci in {64,128,256}, Kp == 9*Ci: the whole [4][Kp] gradient lives in
  * each wave's accumulators; writes diagan_conv3x3_co4_wgrad_splits(B, H) partial slabs

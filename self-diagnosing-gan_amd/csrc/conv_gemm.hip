@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+extern "C" int diagan_get_mfma_mode(void);
+
 namespace diagan {
 
 struct ConvGemmArgs {
@@ -513,11 +515,7 @@ static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
 // SPEC: one kernel per prologue mode (the two production tiles); otherwise the mode is a run-time argument
 template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
-  if (g_mfma_x6 < 0) {
-    const char* m = getenv("DIAGAN_MFMA");
-    g_mfma_x6 = (m && !strcmp(m, "bf16x6")) ? 1 : 0;
-  }
-  if (g_mfma_x6 == 1) {                     // bf16x6: 16-wide K-steps (48 KB of LDS: two workgroups per CU)
+  if (diagan_get_mfma_mode() == 1) {        // bf16x6: 16-wide K-steps (48 KB of LDS: two workgroups per CU)
     static const int xbk = getenv("DIAGAN_X6_BK") ? atoi(getenv("DIAGAN_X6_BK")) : 16;
     if (xbk == 32) return launch_one<BM, BN, WM, WN, 32, -1, true>(a, st);
     if (SPEC) {
@@ -551,6 +549,14 @@ DIAGAN_API int diagan_set_mfma_mode(int mode) {
   DG_REQUIRE(mode == 0 || mode == 1, "set_mfma_mode: 0 (fp32 MFMA) or 1 (bf16x6)");
   g_mfma_x6 = mode;
   return DIAGAN_OK;
+}
+
+DIAGAN_API int diagan_get_mfma_mode(void) {
+  if (g_mfma_x6 < 0) {
+    const char* m = getenv("DIAGAN_MFMA");
+    g_mfma_x6 = (m && !strcmp(m, "bf16x6")) ? 1 : 0;
+  }
+  return g_mfma_x6;
 }
 
 // tile selection used when tile_cfg == 0: 1 = 128x128, 3 = 64x64 (2, 4, 5 were sweep-only shapes, retired)

@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <type_traits>
 
+extern "C" int diagan_get_mfma_mode(void);
+
 namespace diagan {
 
 struct WgradArgs {
@@ -291,6 +293,268 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ---- bf16x6 variant (opt-in, see conv_gemm.hip): the same weight gradient on the bf16 matrix pipe, fp32-accurate ----
+// Both operand tiles stay PIXEL-major in LDS, as three bf16 planes each ([16 pixels][128 columns], 8-byte chunks
+// XOR-swizzled by the pixel row so that every access is bank-conflict free); the MFMA operands need 8 consecutive
+// PIXELS of one column per lane, which gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-row x 16-column block of
+// 16-bit elements per 16 lanes, delivered column-major) supplies without any shuffle.  A 32-pixel K-step is processed
+// as two 16-pixel halves with the LDS double buffer at half-step granularity (48 KB: two workgroups per CU); the
+// staging registers of one half are stored while the other half's MFMAs run and re-loaded two half-steps ahead.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
+
+template <int PRO = -1, bool P2 = false>
+__global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
+  constexpr int BNn = 128, BNk = 128, BK = 32, HK = 16;
+  constexpr int TM = 2, TN = 2, AC = 32, BC = 32, AJ = 4, BJ = 4, APR = 8, BPR = 8;
+  __shared__ __attribute__((aligned(16))) __bf16 Ax[2][3][HK * BNn];
+  __shared__ __attribute__((aligned(16))) __bf16 Bx[2][3][HK * BNk];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_k = (g.Kp + BNk - 1) / BNk;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / a.tiles, tile = logical - split * a.tiles;
+  const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
+  const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
+  const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
+  const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
+
+  const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;
+  const int ac = tid % AC, ap = tid / AC;
+  const int an = n0 + ac * 4;
+  const unsigned a_kill = an < g.Co ? 0u : 0x80000000u;
+  const int bc = tid % BC, bp = tid / BC;
+  const int kf = k0 + bc * 4;
+  const int tap = kf / g.Ci, kc = kf - tap * g.Ci;
+  const int kr = tap / g.S, ks = tap - kr * g.S;
+  const bool b_ok = kf < g.K;
+  const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
+  const int upm = g.up - 1, ush = g.up >> 1;
+  const int pstep = (g.Ci * 4) >> ush;
+  const int img_bytes = g.Hi * g.Wi * g.Ci * 4;
+  const unsigned ylim = (unsigned)g.Hi << ush, xlim = (unsigned)g.Wi << ush;
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (affine && b_ok) {
+    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
+    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
+  }
+  // every piece j advances on its own (pieces 0,1 and 2,3 of a K-step are loaded at different times)
+  int pb[BJ], py[BJ], px[BJ], mst[BJ];
+  unsigned xoff[BJ], aoff[AJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int m = step0 * BK + bp + BPR * j;
+    const unsigned t = fdiv((unsigned)m, a.dWo);
+    px[j] = m - (int)t * g.Wo;
+    const unsigned b = fdiv(t, a.dHo);
+    py[j] = (int)t - (int)b * g.Ho;
+    pb[j] = (int)b;
+    mst[j] = step0 * BK;
+    xoff[j] = (unsigned)((m + dyo * g.Wi + dxo) * g.Ci * 4 + kc * 4);
+  }
+  const unsigned xstep = (unsigned)BK * g.Ci * 4u, astep = (unsigned)BK * g.Co * 4u;
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
+  f32x4 ra[AJ], rb[BJ];
+  unsigned bmask = 0;
+  const bool bias_tile = a.bias_off >= 0 && k0 == 0;
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_a = [&](int j) {
+    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[j] | a_kill, 0, 0));
+    aoff[j] += astep;
+  };
+  auto load_b = [&](int j) {
+    unsigned okb;
+    if (P2 && a.same) {
+      const int m = mst[j] + bp + BPR * j;
+      const int yn = ((m >> a.lgW) & (g.Ho - 1)) + dyo, xn = (m & (g.Wo - 1)) + dxo;
+      okb = (b_ok && m < a.M && (unsigned)yn < (unsigned)g.Hi && (unsigned)xn < (unsigned)g.Wi) ? 1u : 0u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[j] | ((okb ^ 1u) << 31), 0, 0));
+      xoff[j] += xstep;
+    } else {
+      int pbj, pyj, pxj;
+      if (P2) {
+        const int m = mst[j] + bp + BPR * j;
+        pxj = m & (g.Wo - 1);
+        pyj = (m >> a.lgW) & (g.Ho - 1);
+        pbj = m >> a.lgHW;
+      } else {
+        pbj = pb[j]; pyj = py[j]; pxj = px[j];
+      }
+      const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
+      okb = (b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0) ? 1u : 0u;
+      const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      if (!P2) {
+        int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
+        const int cx = x >= g.Wo ? 1 : 0;
+        x -= cx ? g.Wo : 0;
+        y += cx;
+        const int cy = y >= g.Ho ? 1 : 0;
+        y -= cy ? g.Ho : 0;
+        b += cy;
+        px[j] = x; py[j] = y; pb[j] = b;
+      }
+    }
+    bmask = (bmask & ~(1u << j)) | (okb << j);
+    mst[j] += BK;
+  };
+  // exact 3-way bf16 split of four values into the three planes of an LDS tile
+  auto store3 = [&](__bf16 (*tile)[HK * 128], int prow, int chunk, f32x4 v) {
+    wbf16x4 p0, p1, p2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 h0 = (__bf16)v[e];
+      const float r1 = v[e] - (float)h0;
+      const __bf16 h1 = (__bf16)r1;
+      p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)(r1 - (float)h1);
+    }
+    const int ph = prow & (HK - 1);
+    const int off = ph * 128 + ((chunk ^ ((ph & 3) << 3)) << 2);
+    *reinterpret_cast<wu32x2*>(&tile[0][off]) = __builtin_bit_cast(wu32x2, p0);
+    *reinterpret_cast<wu32x2*>(&tile[1][off]) = __builtin_bit_cast(wu32x2, p1);
+    *reinterpret_cast<wu32x2*>(&tile[2][off]) = __builtin_bit_cast(wu32x2, p2);
+  };
+  auto store_a = [&](int buf, int j) {
+    store3(Ax[buf], ap + APR * j, ac, ra[j]);
+    if (bias_tile) bacc += ra[j];
+  };
+  auto store_b = [&](int buf, int j) {
+    f32x4 v = rb[j];
+    if (pro_mode != PRO_NONE) {
+      if (affine) v = v * psc + psh;
+      if (pro_mode == PRO_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+      } else if (pro_mode != PRO_AFFINE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (affine) v *= (float)((bmask >> j) & 1u);
+    }
+    store3(Bx[buf], bp + BPR * j, bc, v);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fi = lane & 31, fh = lane >> 5;
+  const int li = lane & 15, g1 = (lane >> 4) & 1;
+  // transposing read of one operand block: lane (4q+p) of a 16-lane group supplies row q (a pixel), columns 4p..4p+3;
+  // two reads give the lane's 8 pixels k = 8*fh .. 8*fh+7 of column (lane & 31)
+  auto read_frag = [&](const __bf16* plane, int col0) {
+    const int q = li >> 2, chunk = (col0 >> 2) + 4 * g1 + (li & 3);
+    const int off = (8 * fh + q) * 128 + ((chunk ^ (q << 3)) << 2);
+    typedef __attribute__((address_space(3))) ws16x4* lds_p;
+    const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off));
+    const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off + 4 * 128));
+    ws16x4 both[2] = {lo, hi};
+    return __builtin_bit_cast(wbf16x8, both);
+  };
+  auto mfma_half = [&](int buf, auto&& slot_work) {
+    wbf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[i][p] = read_frag(Ax[buf][p], wm * 64 + i * 32);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[j][p] = read_frag(Bx[buf][p], wn * 64 + j * 32);
+#pragma unroll
+    for (int sidx = 0; sidx < 6; ++sidx) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+      slot_work(sidx);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[sidx]], fb[j][PB[sidx]], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // prologue: the whole first K-step is loaded; its first half goes to buffer 0, and the registers of that half are
+  // re-loaded for the next K-step right away
+  if (step0 < step1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { load_a(j); load_b(j); }
+    store_a(0, 0); store_a(0, 1); store_b(0, 0); store_b(0, 1);
+    if (step0 + 1 < step1) { load_a(0); load_a(1); load_b(0); load_b(1); }
+  }
+  __syncthreads();
+  for (int step = step0; step < step1; ++step) {
+    const bool next1 = step + 1 < step1, next2 = step + 2 < step1;
+    // first half (pixels 0..15, buffer 0): the second half's pieces go to buffer 1; then their registers are re-loaded
+    mfma_half(0, [&](int sidx) {
+      if (sidx < 4) __builtin_amdgcn_sched_barrier(0);
+      if (sidx == 0) store_a(1, 2);
+      if (sidx == 1) store_a(1, 3);
+      if (sidx == 2) store_b(1, 2);
+      if (sidx == 3) store_b(1, 3);
+      if (next1 && sidx == 4) { load_a(2); load_a(3); }
+      if (next1 && sidx == 5) { load_b(2); load_b(3); }
+    });
+    __syncthreads();
+    // second half (buffer 1): the next K-step's first half goes to buffer 0
+    mfma_half(1, [&](int sidx) {
+      if (next1) {
+        if (sidx < 4) __builtin_amdgcn_sched_barrier(0);
+        if (sidx == 0) store_a(0, 0);
+        if (sidx == 1) store_a(0, 1);
+        if (sidx == 2) store_b(0, 0);
+        if (sidx == 3) store_b(0, 1);
+      }
+      if (next2 && sidx == 4) { load_a(0); load_a(1); }
+      if (next2 && sidx == 5) { load_b(0); load_b(1); }
+    });
+    __syncthreads();
+  }
+
+  float* out = a.slab + (long)split * a.slab_stride;
+  if (bias_tile) {
+    float* red = reinterpret_cast<float*>(&Ax[0][0][0]);      // tiles are done with: [APR][BNn] partial rows
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + ap * BNn + ac * 4) = bacc;
+    __syncthreads();
+    if (tid < BNn && n0 + tid < g.Co) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < APR; ++r) t += red[r * BNn + tid];
+      out[a.bias_off + n0 + tid] = t;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
+  const unsigned rowbytes = (unsigned)g.Kp * 4u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int k = k0 + wn * (TN * 32) + j * 32 + fi;
+      const int nrow = n0 + wm * (TM * 32) + i * 32 + 4 * fh;
+      const unsigned vbase = k < g.Kp ? ((unsigned)nrow * g.Kp + k) * 4u : 0x80000000u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float av = acc[i][j][e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), osrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0);
+      }
+    }
+}
+
 // out[i] (+)= sum_s slab[s][i]; optionally per-block partial of <G, W> for the SN backward
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
                                                            long n4, float* __restrict__ out, int accumulate,
@@ -524,13 +788,23 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
       case PRO_AFFINE_RELU: DG_WG(BN_, PRO_AFFINE_RELU); break; \
       case PRO_LRELU: DG_WG(BN_, PRO_LRELU); break; \
       default: DG_WG(BN_, PRO_AFFINE); break; }
-  if (bn == 64 && bk == 64) {
+#define DG_WGX(PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_x6_kernel<PRO_, true>), grid, dim3(256), 0, st, a); \
+                          else hipLaunchKernelGGL((conv_wgrad_x6_kernel<PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
+  if (bn == 128 && bk == 128 && diagan_get_mfma_mode() == 1) {      // bf16x6 (opt-in): the 128x128 tile only
+    switch (pro_mode) {
+      case PRO_NONE: DG_WGX(PRO_NONE); break;
+      case PRO_RELU: DG_WGX(PRO_RELU); break;
+      case PRO_AFFINE_RELU: DG_WGX(PRO_AFFINE_RELU); break;
+      default: DG_WGX(-1); break;
+    }
+  } else if (bn == 64 && bk == 64) {
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
   } else if (bn == 64) {
     DG_WG_ALL(64)
   } else {
     DG_WG_ALL(128)
   }
+#undef DG_WGX
 #undef DG_WG_ALL
 #undef DG_WG
   return check_launch("conv_wgrad");

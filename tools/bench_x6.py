@@ -70,3 +70,39 @@ for (B, H, Ci, Co, k) in ((64, 32, 256, 256, 3), (320, 32, 256, 256, 3), (128, 3
         res.append((t, flop / t / 1e12))
     print(f"M={B*H*H:8d} N={Co:4d} K={k*k*Ci:5d}: fp32 MFMA {res[0][0]*1e6:8.1f} us {res[0][1]:6.1f} TF | bf16x6 {res[1][0]*1e6:8.1f} us {res[1][1]:6.1f} TF  ({res[0][0]/res[1][0]:.2f}x)")
 mode(0)
+
+# ---- weight gradient ------------------------------------------------------------------------------------------
+print("weight gradient:")
+for (B, H, Ci, Co, k, pro) in ((4, 16, 128, 128, 3, None), (2, 8, 256, 256, 3, 'bn'), (3, 12, 128, 256, 3, None), (4, 16, 128, 128, 1, None)):
+    x = torch.randn(B, H, H, Ci)
+    dy = torch.randn(B, H, H, Co)
+    geom = C.Geom('conv', Ci, Co, k, k, 1, k // 2)
+    prot, xa = None, x
+    if pro == 'bn':
+        sc, sh = torch.rand(Ci) + 0.5, torch.randn(Ci) * 0.1
+        prot, xa = (C.PRO_AFFINE_RELU, sc.to(dev), sh.to(dev)), torch.relu(x * sc + sh)
+    xr = xa.permute(0, 3, 1, 2).double().requires_grad_(False)
+    wref = torch.zeros(Co, Ci, k, k, dtype=torch.float64, requires_grad=True)
+    yy = F.conv2d(xr, wref, padding=k // 2)
+    (yy * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    ref = C.pack_oihw(wref.grad, geom.Kp)
+    errs = []
+    for m in (0, 1):
+        mode(m)
+        grad = torch.zeros(Co, geom.Kp, device=dev)
+        C.conv_wgrad(geom, dy.to(dev), x.to(dev), grad, accumulate=False, pro=prot)
+        errs.append(float((grad.cpu().double() - ref).abs().mean() / ref.abs().mean()))
+    print(f"B={B} H={H} Ci={Ci} Co={Co} k={k} pro={pro}: mean|err|/mean|g|  fp32 MFMA {errs[0]:.2e}   bf16x6 {errs[1]:.2e}")
+for (B, H, Ci, Co, k) in ((128, 32, 128, 128, 3), (64, 32, 256, 256, 3), (64, 16, 256, 256, 3), (32, 256, 128, 128, 3), (32, 64, 512, 512, 3)):
+    geom = C.Geom('conv', Ci, Co, k, k, 1, k // 2)
+    x = torch.randn(B, H, H, Ci, device=dev)
+    dy = torch.randn(B, H, H, Co, device=dev)
+    grad = torch.zeros(Co, geom.Kp, device=dev)
+    flop = 2.0 * B * H * H * Co * k * k * Ci
+    res = []
+    for m in (0, 1):
+        mode(m)
+        t = timeit(lambda: C.conv_wgrad(geom, dy, x, grad, accumulate=False), n=10)
+        res.append((t, flop / t / 1e12))
+    print(f"M={B*H*H:8d} N={Co:4d} K={k*k*Ci:5d}: fp32 MFMA {res[0][0]*1e6:8.1f} us {res[0][1]:6.1f} TF | bf16x6 {res[1][0]*1e6:8.1f} us {res[1][1]:6.1f} TF  ({res[0][0]/res[1][0]:.2f}x)")
+mode(0)
