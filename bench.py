@@ -272,9 +272,7 @@ def main():
     # accumulated in fp32 on the bf16 matrix pipe; error against float64 at or below the fp32 MFMA's).
     x6 = None
     if world == 1 and not args.no_x6_leg and not args.graph:
-        from diagan import _native as nat
-        nat.register("diagan_set_mfma_mode", [nat.c_int])
-        nat.call("diagan_set_mfma_mode", 1)
+        C.set_mfma_mode('bf16x6')
         try:
             for _ in range(max(args.warmup, 2)):
                 eager_step()
@@ -285,7 +283,7 @@ def main():
             torch.cuda.synchronize()
             x6 = time.perf_counter() - t1
         finally:
-            nat.call("diagan_set_mfma_mode", 0)
+            C.set_mfma_mode(0)
     if rank != 0:
         return
 

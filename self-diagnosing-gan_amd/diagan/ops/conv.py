@@ -27,6 +27,8 @@ nat.register("diagan_sn_power_iter", [P, P, P, P, P, P, P, I, I, F, I, P])
 nat.register("diagan_sn_prepare_batched", [P, I, I, I, I, I, F, I, I, P])
 nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
 nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
+nat.register("diagan_set_mfma_mode", [I])
+nat.register("diagan_get_mfma_mode", [])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
@@ -75,6 +77,16 @@ class KernelTimer:
 
 
 TIMER = None      # set to a KernelTimer by bench.py
+
+
+def set_mfma_mode(mode):
+    """0: exact fp32 MFMA (default); 1 or 'bf16x6': experimental fp32-accurate mode on the bf16 matrix pipe (every
+    operand split exactly into three bf16 pieces, six piece products accumulated in fp32)"""
+    nat.call("diagan_set_mfma_mode", 1 if mode in (1, 'bf16x6') else 0)
+
+
+def get_mfma_mode():
+    return nat.fn("diagan_get_mfma_mode")()
 
 
 def round_up(x, m):

@@ -12,12 +12,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def modes():
-    from diagan import _native as nat
-    nat.register("diagan_set_mfma_mode", [nat.c_int])
-    nat.register("diagan_get_mfma_mode", [])
-    start = nat.fn("diagan_get_mfma_mode")()
-    yield lambda m: nat.call("diagan_set_mfma_mode", m)
-    nat.call("diagan_set_mfma_mode", start)
+    from diagan.ops import conv as C
+    start = C.get_mfma_mode()
+    yield C.set_mfma_mode
+    C.set_mfma_mode(start)
 
 
 def rel(a, ref):

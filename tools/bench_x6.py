@@ -9,11 +9,8 @@ import torch.nn.functional as F
 from diagan import _native as nat
 from diagan.ops import conv as C
 
-nat.register("diagan_set_mfma_mode", [nat.c_int])
-
-
 def mode(m):
-    nat.call("diagan_set_mfma_mode", m)
+    C.set_mfma_mode(m)
 
 
 def run(geom, x, w, pro=None, cfg=0):
