@@ -175,6 +175,10 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     kname = None
     if TIMER is not None:
         kname = TILE_NAMES[tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp)].format(pro=mode)
+        if get_mfma_mode() == 1:       # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised, X6 = true
+            kname = kname.replace(",32,", ",16,").replace(">", ",true>")
+            if mode > 2:
+                kname = kname.replace(f",{mode},true>", ",-1,true>")
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
@@ -325,6 +329,9 @@ def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0):
         bn = 64
     if bk != 128:
         return f"conv_wgrad_kernel<{bn},{bk},-1,false>"
+    if bn == 128 and get_mfma_mode() == 1:
+        p2x = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
+        return f"conv_wgrad_x6_kernel<{mode if mode <= 2 else -1},{'true' if p2x else 'false'}>"
     p2 = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
     return f"conv_wgrad_kernel<{bn},128,{mode},{'true' if p2 else 'false'}>"
 
