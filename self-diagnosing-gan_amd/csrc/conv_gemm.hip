@@ -261,6 +261,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   if (k_begin < k_end) {
     load_tiles(k_begin);
     store_tiles(0);
+    if constexpr (X6) {
+      if (k_begin + 1 < k_end) load_tiles(k_begin + 1);     // bf16x6 keeps one tile in flight in the staging registers
+    }
   }
   __syncthreads();
 
@@ -305,12 +308,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
     __syncthreads();
   };
-  auto kstep_x6 = [&](int kk, auto has_next) {
+  // bf16x6 K-step: its MFMA phase is 2.67x shorter than the fp32 one, so a tile's global loads get a WHOLE K-step to
+  // land: during step kk the pieces of tile kk+1 (loaded during step kk-1) are written to the other LDS buffer in the
+  // first slots, and the freed staging registers are re-loaded with tile kk+2 in the last slots.
+  auto kstep_x6 = [&](int kk, auto has1, auto has2) {
     const int cur = (kk - k_begin) & 1;
     const __bf16* Ac = Ax + cur * 3 * BM * BK;
     const __bf16* Bc = Bx + cur * 3 * BN * BK;
     constexpr int NS = (BK / 16) * 6;            // (16-wide K chunks) x (six piece products)
-    static_assert(2 * NP <= 3 * NS, "piece schedule of the bf16x6 step");
+    constexpr int LS = (NP + 1) / 2;             // slots that carry two loads each
+    static_assert(NP + LS <= NS, "piece schedule of the bf16x6 step");
 #pragma unroll
     for (int u = 0; u < BK / 16; ++u) {
       const int q = 2 * u + fh;                  // lane half h takes k = 8h .. 8h+7 of the chunk
@@ -333,13 +340,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       for (int sidx = 0; sidx < 6; ++sidx) {
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
         const int es = u * 6 + sidx;
-        if (decltype(has_next)::value && 2 * es < NP) {        // next tile's global loads: two per slot, first slots
-          load_piece(kk + 1, 2 * es);
-          if (2 * es + 1 < NP) load_piece(kk + 1, 2 * es + 1);
-        }
-        if (decltype(has_next)::value && es >= NS - NP) {
+        if (decltype(has1)::value && es < NP) {
           __builtin_amdgcn_sched_barrier(0);
-          store_piece(cur ^ 1, es - (NS - NP));
+          store_piece(cur ^ 1, es);
+        }
+        if (decltype(has2)::value && es >= NS - LS) {
+          const int p0 = 2 * (es - (NS - LS));
+          load_piece(kk + 2, p0);
+          if (p0 + 1 < NP) load_piece(kk + 2, p0 + 1);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -351,8 +359,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     __syncthreads();
   };
   if constexpr (X6) {
-    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep_x6(kk, std::true_type{});
-    if (k_begin < k_end) kstep_x6(k_end - 1, std::false_type{});
+    using T = std::true_type;
+    using F = std::false_type;
+    int kk = k_begin;
+    for (; kk + 2 < k_end; ++kk) kstep_x6(kk, T{}, T{});
+    if (kk + 1 < k_end) { kstep_x6(kk, T{}, F{}); ++kk; }
+    if (kk < k_end) kstep_x6(kk, F{}, F{});
   } else {
     for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
     if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
