@@ -5,7 +5,6 @@ The sampler stays on the host on purpose: `WeightedRandomSampler` draws
 the very same call with bit-identical float64 weights (the exact-f64 HIP scorer) gives bit-exact
 sample-index assignments.
 """
-import torch
 from torch.utils import data
 
 

@@ -6,7 +6,6 @@ layouts (packed weights Wp[Co][Kp], NHWC activations) inside ONE flat fp32 buffe
 all-reduce is one RCCL call per network.  state_dict()/load_state_dict() present the reference's
 tensor shapes (OIHW conv weights, [out,in] linear weights, mimicry's sn_u / sn_sigma buffers).
 """
-import math
 
 import torch
 import torch.nn as nn

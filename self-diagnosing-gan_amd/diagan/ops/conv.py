@@ -3,8 +3,6 @@ spectral-norm power iteration and GEMM operand packing.
 
 All tensors are torch CUDA fp32.  Activations are NHWC ([B,H,W,C], C % 4 == 0); weights live in
 the packed layout Wp[Co][Kp], k = (r*S+s)*Ci + c, Kp = roundup(R*S*Ci, 32)."""
-import ctypes
-
 import torch
 
 from diagan import _native as nat

@@ -5,7 +5,6 @@ Metric values may be 0-dim device tensors; they are only converted to Python flo
 is actually printed / written, so logging never forces a host sync inside the hot loop."""
 import math
 import os
-import time
 
 
 class Metric:

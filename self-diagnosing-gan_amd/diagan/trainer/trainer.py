@@ -15,7 +15,6 @@ import os
 import pickle
 import time
 
-import numpy as np
 import torch
 
 from diagan.trainer import distributed as dist

@@ -17,7 +17,7 @@ What is not a kernel argument baked into the graph is handled around the replay:
 Single process only: under data parallelism the step contains RCCL collectives and runs eagerly."""
 import torch
 
-from diagan.models.layers import BatchNorm, FlatNet
+from diagan.models.layers import BatchNorm
 from diagan.ops import conv as C
 from diagan.trainer import distributed as dist
 

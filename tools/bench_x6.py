@@ -6,7 +6,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "self-diagnosing-gan_amd"))
 import torch
 import torch.nn.functional as F
-from diagan import _native as nat
 from diagan.ops import conv as C
 
 def mode(m):
