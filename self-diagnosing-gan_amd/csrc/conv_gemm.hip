@@ -587,7 +587,10 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
   const double q64 = (double)t64 / (double)(cdiv(t64, s64) * s64);
   const double waste128 = (double)M * Co / ((double)t128 * 128 * 128);
   const double waste64 = (double)M * Co / ((double)t64 * 64 * 64);
-  return 1.08 * q128 * waste128 > q64 * waste64 ? 1 : 3;
+  // (bf16x6 mode: the 128x128 variant gains 1.4-1.6x over its fp32 twin, the latency-bound 64x64 one 1.2x)
+  static const double x6_bias = getenv("DIAGAN_X6_TILE_BIAS") ? atof(getenv("DIAGAN_X6_TILE_BIAS")) : 1.3;
+  const double bias = diagan_get_mfma_mode() == 1 ? x6_bias : 1.08;
+  return bias * q128 * waste128 > q64 * waste64 ? 1 : 3;
 }
 
 // Split-K factor for the 64x64 tile (1 = none), re-measured with the overlapped K-step schedule
