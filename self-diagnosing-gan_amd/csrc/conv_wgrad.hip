@@ -305,10 +305,12 @@ typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
 typedef short ws16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
 
-template <int PRO = -1, bool P2 = false>
+template <int BNn = 128, int PRO = -1, bool P2 = false>
 __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
-  constexpr int BNn = 128, BNk = 128, BK = 32, HK = 16;
-  constexpr int TM = 2, TN = 2, AC = 32, BC = 32, AJ = 4, BJ = 4, APR = 8, BPR = 8;
+  constexpr int BNk = 128, BK = 32, HK = 16;
+  constexpr int TM = BNn / 64, TN = 2, AC = BNn / 4, BC = 32, APR = 256 / AC, BPR = 8, AJ = BK / APR, BJ = 4;
+  constexpr int AH = AJ / 2;      // dy pieces per 16-pixel half (2 for 128 columns, 1 for 64)
+  static_assert(BNn == 128 || BNn == 64, "dy tile of 128 or 64 columns");
   __shared__ __attribute__((aligned(16))) __bf16 Ax[2][3][HK * BNn];
   __shared__ __attribute__((aligned(16))) __bf16 Bx[2][3][HK * BNk];
 
@@ -410,7 +412,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
     mst[j] += BK;
   };
   // exact 3-way bf16 split of four values into the three planes of an LDS tile
-  auto store3 = [&](__bf16 (*tile)[HK * 128], int prow, int chunk, f32x4 v) {
+  // 8-byte chunk swizzle by the pixel row: 256-byte rows (128 columns) take the two low pixel bits into chunk bits
+  // 3-4, 128-byte rows (64 columns; two pixel rows share a 256-byte bank row) take pixel bit 1 into chunk bit 3
+  auto swz = [](int pitch, int ph, int chunk) { return pitch == 128 ? (chunk ^ ((ph & 3) << 3)) : (chunk ^ (((ph >> 1) & 1) << 3)); };
+  auto store3 = [&](__bf16* t0, __bf16* t1, __bf16* t2, int pitch, int prow, int chunk, f32x4 v) {
     wbf16x4 p0, p1, p2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -420,13 +425,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
       p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)(r1 - (float)h1);
     }
     const int ph = prow & (HK - 1);
-    const int off = ph * 128 + ((chunk ^ ((ph & 3) << 3)) << 2);
-    *reinterpret_cast<wu32x2*>(&tile[0][off]) = __builtin_bit_cast(wu32x2, p0);
-    *reinterpret_cast<wu32x2*>(&tile[1][off]) = __builtin_bit_cast(wu32x2, p1);
-    *reinterpret_cast<wu32x2*>(&tile[2][off]) = __builtin_bit_cast(wu32x2, p2);
+    const int off = ph * pitch + (swz(pitch, ph, chunk) << 2);
+    *reinterpret_cast<wu32x2*>(t0 + off) = __builtin_bit_cast(wu32x2, p0);
+    *reinterpret_cast<wu32x2*>(t1 + off) = __builtin_bit_cast(wu32x2, p1);
+    *reinterpret_cast<wu32x2*>(t2 + off) = __builtin_bit_cast(wu32x2, p2);
   };
   auto store_a = [&](int buf, int j) {
-    store3(Ax[buf], ap + APR * j, ac, ra[j]);
+    store3(Ax[buf][0], Ax[buf][1], Ax[buf][2], BNn, ap + APR * j, ac, ra[j]);
     if (bias_tile) bacc += ra[j];
   };
   auto store_b = [&](int buf, int j) {
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
       }
       if (affine) v *= (float)((bmask >> j) & 1u);
     }
-    store3(Bx[buf], bp + BPR * j, bc, v);
+    store3(Bx[buf][0], Bx[buf][1], Bx[buf][2], BNk, bp + BPR * j, bc, v);
   };
 
   f32x16 acc[TM][TN];
@@ -457,12 +462,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
   const int li = lane & 15, g1 = (lane >> 4) & 1;
   // transposing read of one operand block: lane (4q+p) of a 16-lane group supplies row q (a pixel), columns 4p..4p+3;
   // two reads give the lane's 8 pixels k = 8*fh .. 8*fh+7 of column (lane & 31)
-  auto read_frag = [&](const __bf16* plane, int col0) {
+  auto read_frag = [&](const __bf16* plane, int pitch, int col0) {
     const int q = li >> 2, chunk = (col0 >> 2) + 4 * g1 + (li & 3);
-    const int off = (8 * fh + q) * 128 + ((chunk ^ (q << 3)) << 2);
+    // rows 8*fh + q and 8*fh + 4 + q have the same low pixel bits, hence the same swizzle
+    const int off = (8 * fh + q) * pitch + (swz(pitch, q, chunk) << 2);
     typedef __attribute__((address_space(3))) ws16x4* lds_p;
     const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off));
-    const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off + 4 * 128));
+    const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off + 4 * pitch));
     ws16x4 both[2] = {lo, hi};
     return __builtin_bit_cast(wbf16x8, both);
   };
@@ -471,11 +477,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[i][p] = read_frag(Ax[buf][p], wm * 64 + i * 32);
+      for (int p = 0; p < 3; ++p) fa[i][p] = read_frag(Ax[buf][p], BNn, wm * (TM * 32) + i * 32);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fb[j][p] = read_frag(Bx[buf][p], wn * 64 + j * 32);
+      for (int p = 0; p < 3; ++p) fb[j][p] = read_frag(Bx[buf][p], BNk, wn * 64 + j * 32);
 #pragma unroll
     for (int sidx = 0; sidx < 6; ++sidx) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -492,34 +498,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
   // re-loaded for the next K-step right away
   if (step0 < step1) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { load_a(j); load_b(j); }
-    store_a(0, 0); store_a(0, 1); store_b(0, 0); store_b(0, 1);
-    if (step0 + 1 < step1) { load_a(0); load_a(1); load_b(0); load_b(1); }
+    for (int j = 0; j < AJ; ++j) load_a(j);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) load_b(j);
+#pragma unroll
+    for (int t = 0; t < AH; ++t) store_a(0, t);
+    store_b(0, 0); store_b(0, 1);
+    if (step0 + 1 < step1) {
+#pragma unroll
+      for (int t = 0; t < AH; ++t) load_a(t);
+      load_b(0); load_b(1);
+    }
   }
   __syncthreads();
+  // slots 0 .. AH+1 of a half-step carry the stores of the OTHER half's pieces (AH dy pieces, 2 gathered pieces), slots
+  // 4 and 5 the re-loads of the registers just freed
   for (int step = step0; step < step1; ++step) {
     const bool next1 = step + 1 < step1, next2 = step + 2 < step1;
-    // first half (pixels 0..15, buffer 0): the second half's pieces go to buffer 1; then their registers are re-loaded
     mfma_half(0, [&](int sidx) {
-      if (sidx < 4) __builtin_amdgcn_sched_barrier(0);
-      if (sidx == 0) store_a(1, 2);
-      if (sidx == 1) store_a(1, 3);
-      if (sidx == 2) store_b(1, 2);
-      if (sidx == 3) store_b(1, 3);
-      if (next1 && sidx == 4) { load_a(2); load_a(3); }
+      if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
+      if (sidx < AH) store_a(1, AH + sidx);
+      if (sidx == AH) store_b(1, 2);
+      if (sidx == AH + 1) store_b(1, 3);
+      if (next1 && sidx == 4) {
+#pragma unroll
+        for (int t = 0; t < AH; ++t) load_a(AH + t);
+      }
       if (next1 && sidx == 5) { load_b(2); load_b(3); }
     });
     __syncthreads();
-    // second half (buffer 1): the next K-step's first half goes to buffer 0
     mfma_half(1, [&](int sidx) {
       if (next1) {
-        if (sidx < 4) __builtin_amdgcn_sched_barrier(0);
-        if (sidx == 0) store_a(0, 0);
-        if (sidx == 1) store_a(0, 1);
-        if (sidx == 2) store_b(0, 0);
-        if (sidx == 3) store_b(0, 1);
+        if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
+        if (sidx < AH) store_a(0, sidx);
+        if (sidx == AH) store_b(0, 0);
+        if (sidx == AH + 1) store_b(0, 1);
       }
-      if (next2 && sidx == 4) { load_a(0); load_a(1); }
+      if (next2 && sidx == 4) {
+#pragma unroll
+        for (int t = 0; t < AH; ++t) load_a(t);
+      }
       if (next2 && sidx == 5) { load_b(0); load_b(1); }
     });
     __syncthreads();
@@ -788,15 +806,15 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
       case PRO_AFFINE_RELU: DG_WG(BN_, PRO_AFFINE_RELU); break; \
       case PRO_LRELU: DG_WG(BN_, PRO_LRELU); break; \
       default: DG_WG(BN_, PRO_AFFINE); break; }
-#define DG_WGX(PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_x6_kernel<PRO_, true>), grid, dim3(256), 0, st, a); \
-                          else hipLaunchKernelGGL((conv_wgrad_x6_kernel<PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
-  if (bn == 128 && bk == 128 && diagan_get_mfma_mode() == 1) {      // bf16x6 (opt-in): the 128x128 tile only
-    switch (pro_mode) {
-      case PRO_NONE: DG_WGX(PRO_NONE); break;
-      case PRO_RELU: DG_WGX(PRO_RELU); break;
-      case PRO_AFFINE_RELU: DG_WGX(PRO_AFFINE_RELU); break;
-      default: DG_WGX(-1); break;
-    }
+#define DG_WGX(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_x6_kernel<BN_, PRO_, true>), grid, dim3(256), 0, st, a); \
+                               else hipLaunchKernelGGL((conv_wgrad_x6_kernel<BN_, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
+#define DG_WGX_ALL(BN_) switch (pro_mode) { \
+      case PRO_NONE: DG_WGX(BN_, PRO_NONE); break; \
+      case PRO_RELU: DG_WGX(BN_, PRO_RELU); break; \
+      case PRO_AFFINE_RELU: DG_WGX(BN_, PRO_AFFINE_RELU); break; \
+      default: DG_WGX(BN_, -1); break; }
+  if (bk == 128 && diagan_get_mfma_mode() == 1) {      // bf16x6 (opt-in): dy tiles of 128 or 64 columns x 128 packed k
+    if (bn == 128) { DG_WGX_ALL(128) } else { DG_WGX_ALL(64) }
   } else if (bn == 64 && bk == 64) {
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
   } else if (bn == 64) {
@@ -804,6 +822,7 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   } else {
     DG_WG_ALL(128)
   }
+#undef DG_WGX_ALL
 #undef DG_WGX
 #undef DG_WG_ALL
 #undef DG_WG

@@ -327,9 +327,9 @@ def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0):
         bn = 64
     if bk != 128:
         return f"conv_wgrad_kernel<{bn},{bk},-1,false>"
-    if bn == 128 and get_mfma_mode() == 1:
+    if get_mfma_mode() == 1:
         p2x = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
-        return f"conv_wgrad_x6_kernel<{mode if mode <= 2 else -1},{'true' if p2x else 'false'}>"
+        return f"conv_wgrad_x6_kernel<{bn},{mode if mode <= 2 else -1},{'true' if p2x else 'false'}>"
     p2 = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
     return f"conv_wgrad_kernel<{bn},128,{mode},{'true' if p2 else 'false'}>"
 

@@ -49,9 +49,11 @@ def test_forward_gemm_error_at_fp32_level(modes, case):
 
 
 @pytest.mark.parametrize("case", [(4, 16, 128, 128, 3, None), (2, 8, 256, 256, 3, 'bn_relu'), (3, 12, 128, 256, 3, None),
-                                  (4, 16, 128, 128, 1, 'relu'), (2, 11, 128, 160, 3, None)])
+                                  (4, 16, 128, 128, 1, 'relu'), (2, 11, 128, 160, 3, None),
+                                  (4, 16, 64, 64, 3, 'bn_relu'), (2, 8, 128, 48, 3, None), (3, 10, 32, 64, 3, 'relu')])
 def test_weight_gradient_error_at_fp32_level(modes, case):
-    """the transposing-LDS-read kernel (128x128 tile); 11x11 images take the non-power-of-two coordinate path"""
+    """the transposing-LDS-read kernels (dy tiles of 128 and of 64 columns); 11x11 / 10x10 images take the
+    non-power-of-two coordinate path; 48 output channels leave dy columns past Co masked"""
     from diagan.ops import conv as C
     B, H, Ci, Co, k, pro = case
     g = torch.Generator().manual_seed(H + Co)
