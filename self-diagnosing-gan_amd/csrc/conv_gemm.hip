@@ -609,6 +609,12 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   const int nk = Kp / 32;
   if (nk < 16) return 1;
   if (tiles <= 320) {
+    // bf16x6: the MFMA phases are 2.67x shorter, so a lone workgroup per CU is even more latency-bound: split sooner
+    static const int x6_div = getenv("DIAGAN_X6_SPLIT_DIV") ? atoi(getenv("DIAGAN_X6_SPLIT_DIV")) : 8;
+    if (x6_div > 0 && diagan_get_mfma_mode() == 1) {
+      const int s6 = nk / x6_div;
+      return s6 < 2 ? 1 : (s6 > 4 ? 4 : s6);
+    }
     if (nk < 64) return 1;
     int s = nk / 24;
     return s > 4 ? 4 : s;
