@@ -213,3 +213,121 @@ def phase2(argv=None):
                          save_steps=args.save_steps, save_logits=False)
     trainer.train()
     return trainer
+
+
+# ---- Colored-MNIST / mnist_dcgan front ends (BASELINE configs[0]) ----------------------------------------------------
+# train_mimicry_color_mnist_phase1.py (flags :48-67, trainer wiring :106-124) and train_mimicry_color_mnist_phase2.py
+# (flags :41-61, scorer call :93-97, trainer wiring :128-151).  What differs from the CIFAR/CelebA scripts: ns / hinge
+# default losses, n_dis = 1, no LR decay, 20 000 steps, logits recorded in TRAIN mode (`save_eval_logits=False`) and
+# only when the discriminator is not packed, checkpoints every 1000 and sample grids every 100 steps, `--topk` an int.
+COLOR_MNIST_SHARED = [
+    (("--dataset", "-d"), "color_mnist", str, None),
+    (("--root", "-r"), "./dataset/colour_mnist", str, "dataset dir"),
+    (("--work_dir",), "./exp_results", str, "output dir"),
+    (("--exp_name",), "colour_mnist", str, "exp name"),
+    (("--model",), "mnistgan", str, "network model"),
+    (("--gpu",), "0", str, "id(s) for CUDA_VISIBLE_DEVICES (single process only)"),
+    (("--num_pack",), 1, int, None),
+    (("--batch_size",), 64, int, None),
+    (("--seed",), 1, int, None),
+    (("--num_steps",), 20000, int, None),
+    (("--logit_save_steps",), 100, int, None),
+    (("--decay",), "None", str, None),
+    (("--n_dis",), 1, int, None),
+    (("--major_ratio",), 0.99, float, None),
+    (("--num_data",), 10000, int, None),
+    (("--resample_score",), None, str, None),
+    (("--num_workers",), 0, int, None),             # not in the reference
+]
+COLOR_MNIST_PHASE1 = [
+    (("--loss_type",), "ns", str, "loss type"),
+    (("--use_clipping",), False, _FLAG, None),
+    (("--topk",), 0, int, None),
+]
+COLOR_MNIST_PHASE2 = [
+    (("--loss_type",), "hinge", str, "loss type"),
+    (("--baseline_exp_name",), "colour_mnist", str, "exp name"),
+    (("--p1_step",), 10000, int, None),
+    (("--use_eval_logits",), None, int, None),
+]
+
+
+def color_mnist_phase1_parser():
+    return make_parser(COLOR_MNIST_SHARED, COLOR_MNIST_PHASE1)
+
+
+def color_mnist_phase2_parser():
+    return make_parser(COLOR_MNIST_SHARED, COLOR_MNIST_PHASE2)
+
+
+def floor_or_clip_weights(weights, clip=False, eps=1e-1):
+    """train_mimicry_color_mnist_phase1.py:22-32: weights floored at `eps`, or clipped to
+    [max(mean - 2 var, eps), mean + 2 var] (sic: the variance, not the standard deviation)"""
+    import numpy as np
+    weights = np.asarray(weights, dtype=np.float64)
+    if not clip:
+        return np.maximum(weights, eps)
+    mean, var = weights.mean(), weights.var()
+    return np.clip(weights, max(mean - 2 * var, eps), mean + 2 * var)
+
+
+def _plain_weighted_loader(dataset, batch_size, num_workers, weights=None):
+    """the colour-MNIST scripts hand the weights to WeightedRandomSampler as they are (phase 2 :24-37)"""
+    sampler = None if weights is None else data.WeightedRandomSampler(weights, len(weights), replacement=True)
+    world = dist.get_world_size()
+    if world > 1:
+        sampler = ShardedSampler(sampler if sampler is not None else data.RandomSampler(dataset), dist.get_rank(), world)
+    return data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=sampler is None, sampler=sampler,
+                           num_workers=num_workers, pin_memory=num_workers > 0)
+
+
+def color_mnist_phase1(argv=None, dataset=None):
+    args = color_mnist_phase1_parser().parse_args(argv)
+    run = _Run(args)
+    netG, netD, optG, optD = get_gan_model(dataset_name=args.dataset, model=args.model, num_pack=args.num_pack,
+                                           loss_type=args.loss_type, topk=args.topk == 1)
+    print_num_params(netG, netD)
+    train_set = get_predefined_dataset(dataset_name=args.dataset, root=args.root, weights=None,
+                                       major_ratio=args.major_ratio, num_data=args.num_data, dataset=dataset)
+    loader = _plain_weighted_loader(train_set, args.batch_size, args.num_workers)
+    print(args)
+    run.replicate(netG, netD)
+    trainer = LogTrainer(output_path=run.save_path, logit_save_steps=args.logit_save_steps, netD=netD, netG=netG,
+                         optD=optD, optG=optG, n_dis=args.n_dis, num_steps=args.num_steps, save_steps=1000,
+                         vis_steps=100, lr_decay=args.decay, dataloader=loader, log_dir=run.out_dir, print_steps=10,
+                         device=run.device, topk=args.topk, save_logits=args.num_pack == 1, save_eval_logits=False)
+    trainer.train()
+    return trainer
+
+
+def color_mnist_phase2(argv=None, dataset=None):
+    args = color_mnist_phase2_parser().parse_args(argv)
+    run = _Run(args)
+    baseline = Path(f'{args.work_dir}/{args.baseline_exp_name}')
+    netG, netD, netD_drs, optG, optD, optD_drs = get_gan_model(dataset_name=args.dataset, model=args.model, drs=True,
+                                                               loss_type=args.loss_type)
+    start = {net: str(_checkpoint(baseline, net, args.p1_step)) for net in ('netG', 'netD')}
+    record = baseline / ('logits_netD_eval.pkl' if args.use_eval_logits == 1 else 'logits_netD_train.pkl')
+    print(f'Use logit from: {record}')
+    with open(record, "rb") as f:
+        logits = pickle.load(f)
+    scores = calculate_scores(logits, start_epoch=args.p1_step - 5000, end_epoch=args.p1_step, device=run.device)
+    weights = scores[args.resample_score] if args.resample_score is not None else None
+    if weights is not None:
+        print(f'sample_weights mean: {weights.mean()}, var: {weights.var()}, max: {weights.max()}, min: {weights.min()}')
+    print_num_params(netG, netD)
+
+    def fresh_set():
+        return get_predefined_dataset(dataset_name=args.dataset, root=args.root, weights=None,
+                                      major_ratio=args.major_ratio, num_data=args.num_data, dataset=dataset)
+    loader = _plain_weighted_loader(fresh_set(), args.batch_size, args.num_workers, weights=weights)
+    loader_drs = _plain_weighted_loader(fresh_set(), args.batch_size, args.num_workers)
+    print(args, start['netG'], start['netD'], start['netD'])
+    trainer = LogTrainer(output_path=run.save_path, logit_save_steps=args.logit_save_steps, netD=netD, netG=netG,
+                         optD=optD, optG=optG, netG_ckpt_file=start['netG'], netD_ckpt_file=start['netD'],
+                         netD_drs_ckpt_file=start['netD'], netD_drs=netD_drs, optD_drs=optD_drs,
+                         dataloader_drs=loader_drs, n_dis=args.n_dis, num_steps=args.num_steps, save_steps=1000,
+                         vis_steps=100, lr_decay=args.decay, dataloader=loader, log_dir=run.out_dir, print_steps=10,
+                         device=run.device, save_logits=False)
+    trainer.train()
+    return trainer

@@ -102,3 +102,23 @@ def test_drs_generates_on_gpu():
     assert torch.equal(kept, imgs.cpu()[torch.from_numpy(mask)])
     out = drs.generate_images(300)
     assert tuple(out.shape) == (300, 3, 32, 32) and torch.isfinite(out).all()
+
+
+def test_color_mnist_front_ends(tmp_path):
+    """BASELINE configs[0] plumbing on the GPU engine: train_mimicry_color_mnist_phase1.py records TRAIN-mode logits
+    and checkpoints; train_mimicry_color_mnist_phase2.py scores the window [p1_step - 5000, p1_step), resamples and
+    trains D_drs from the phase-1 discriminator."""
+    sys.path.insert(0, ROOT)
+    import train_mimicry_color_mnist_phase1 as P1
+    import train_mimicry_color_mnist_phase2 as P2
+    common = ["--work_dir", str(tmp_path), "--num_data", "256", "--batch_size", "32", "--logit_save_steps", "5"]
+    tr = P1.main(common + ["--exp_name", "cm", "--num_steps", "20"])
+    assert tr.n_dis == 1 and tr.lr_decay == 'None' and not tr.save_eval_logits
+    rec = pickle.load(open(tmp_path / "cm" / "logits_netD_train.pkl", "rb"))
+    assert sorted(rec) == [5, 10, 15, 20]
+    assert all(v.shape == (256,) and np.isfinite(v).all() for v in rec.values())
+    assert (tmp_path / "cm" / "checkpoints" / "netD" / "netD_20_steps.pth").exists()
+    tr2 = P2.main(common + ["--exp_name", "cm2", "--baseline_exp_name", "cm", "--p1_step", "20", "--num_steps", "26",
+                            "--resample_score", "ldrv"])     # a non-negative score: the weights go to the sampler as they are
+    assert tr2.train_drs and isinstance(tr2.dataloader.sampler, torch.utils.data.WeightedRandomSampler)
+    assert (tmp_path / "cm2" / "checkpoints" / "netD_drs" / "netD_drs_26_steps.pth").exists()

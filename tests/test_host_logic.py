@@ -248,3 +248,22 @@ def test_batchnorm_counter_is_folded_into_state_dict():
     bn._pending_batches = 5
     bn.load_state_dict(sd)
     assert int(bn.state_dict()['num_batches_tracked']) == 3
+
+
+def test_color_mnist_front_ends_keep_the_reference_flags():
+    """train_mimicry_color_mnist_phase{1,2}.py: flag names and defaults (reference :48-67 / :41-61)"""
+    from diagan import cli
+    p1, p2 = cli.color_mnist_phase1_parser().parse_args([]), cli.color_mnist_phase2_parser().parse_args([])
+    for a in (p1, p2):
+        assert (a.dataset, a.root, a.work_dir, a.exp_name, a.model) == \
+            ("color_mnist", "./dataset/colour_mnist", "./exp_results", "colour_mnist", "mnistgan")
+        assert (a.gpu, a.num_pack, a.batch_size, a.seed, a.num_steps, a.logit_save_steps) == ('0', 1, 64, 1, 20000, 100)
+        assert (a.decay, a.n_dis, a.major_ratio, a.num_data, a.resample_score) == ('None', 1, 0.99, 10000, None)
+    assert (p1.loss_type, p1.use_clipping, p1.topk) == ("ns", False, 0)
+    assert (p2.loss_type, p2.baseline_exp_name, p2.p1_step, p2.use_eval_logits) == ("hinge", "colour_mnist", 10000, None)
+    # the weight conditioning of the phase-1 script (:22-32): floor at 0.1, or clip to mean -/+ 2 var
+    w = np.array([0.0, 0.05, 0.2, 0.5, 3.0])
+    np.testing.assert_array_equal(cli.floor_or_clip_weights(w), [0.1, 0.1, 0.2, 0.5, 3.0])
+    mean, var = w.mean(), w.var()
+    expect = np.clip(w, max(mean - 2 * var, 0.1), mean + 2 * var)
+    np.testing.assert_allclose(cli.floor_or_clip_weights(w, clip=True), expect)
