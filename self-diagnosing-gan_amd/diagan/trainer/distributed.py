@@ -65,6 +65,29 @@ def reduce_sum(tensor):
     return tensor
 
 
+def gather_grad(params):
+    """mean of every parameter's gradient over the ranks (reference distributed.py:55-64); the engine's own networks
+    use ONE all-reduce of their flat gradient slab instead (`all_reduce_mean_`)"""
+    world = get_world_size()
+    if world == 1:
+        return
+    for p in params:
+        if p.grad is not None:
+            dist.all_reduce(p.grad.data, op=dist.ReduceOp.SUM)
+            p.grad.data.div_(world)
+
+
+def all_gather(data):
+    """list of one picklable object per rank, rank order (reference distributed.py:67-101 pads pickled byte tensors by
+    hand; torch.distributed's object collective does the same exchange)"""
+    world = get_world_size()
+    if world == 1:
+        return [data]
+    out = [None] * world
+    dist.all_gather_object(out, data)
+    return out
+
+
 def all_gather_cat(tensor):
     """Rank-major concatenation of equally shaped per-rank tensors."""
     world = get_world_size()

@@ -72,6 +72,12 @@ def _worker(rank, world, port, out_dir):
         lin.weight.fill_(float(rank + 1))
     dist.broadcast_module_(lin)
     res['bcast'] = lin.weight.clone()
+    # 8. the reference's helper names: per-parameter gradient mean and the pickled-object gather
+    lin2 = torch.nn.Linear(2, 1)
+    lin2.weight.grad = torch.full((1, 2), float(rank + 1))
+    dist.gather_grad(lin2.parameters())                 # bias has no gradient: skipped
+    res['gather_grad'] = lin2.weight.grad.clone()
+    res['objects'] = dist.all_gather({'rank': rank, 'payload': 'x' * (rank + 1)})
     dist.synchronize()
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     torch.distributed.destroy_process_group()
@@ -91,6 +97,8 @@ def test_world_size_2_gloo(tmp_path):
         assert torch.allclose(r[k]['dp_grad'], (r[0]['local_grad'] + r[1]['local_grad']) / 2, rtol=0, atol=1e-7)
         assert r[k]['sum'].item() == 3.0
         assert torch.equal(r[k]['bcast'], torch.ones(2, 3))
+        assert torch.equal(r[k]['gather_grad'], torch.full((1, 2), 1.5))
+        assert r[k]['objects'] == [{'rank': 0, 'payload': 'x'}, {'rank': 1, 'payload': 'xx'}]
     assert r[0]['range'] == (0, 6, 6) and r[1]['range'] == (6, 11, 6)
     assert r[0]['loss']['d'].item() == 0.5 and r[0]['loss']['g'].item() == 1.0
     # strided shards of the same multinomial draw
