@@ -416,14 +416,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
   // 3-4, 128-byte rows (64 columns; two pixel rows share a 256-byte bank row) take pixel bit 1 into chunk bit 3
   auto swz = [](int pitch, int ph, int chunk) { return pitch == 128 ? (chunk ^ ((ph & 3) << 3)) : (chunk ^ (((ph >> 1) & 1) << 3)); };
   auto store3 = [&](__bf16* t0, __bf16* t1, __bf16* t2, int pitch, int prow, int chunk, f32x4 v) {
-    wbf16x4 p0, p1, p2;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const __bf16 h0 = (__bf16)v[e];
-      const float r1 = v[e] - (float)h0;
-      const __bf16 h1 = (__bf16)r1;
-      p0[e] = h0; p1[e] = h1; p2[e] = (__bf16)(r1 - (float)h1);
-    }
+    const wbf16x4 p0 = __builtin_convertvector(v, wbf16x4);           // one v_cvt_pk_bf16_f32 per pair of elements
+    const f32x4 r1 = v - __builtin_convertvector(p0, f32x4);          // exact
+    const wbf16x4 p1 = __builtin_convertvector(r1, wbf16x4);
+    const f32x4 r2 = r1 - __builtin_convertvector(p1, f32x4);         // exact
+    const wbf16x4 p2 = __builtin_convertvector(r2, wbf16x4);
     const int ph = prow & (HK - 1);
     const int off = ph * pitch + (swz(pitch, ph, chunk) << 2);
     *reinterpret_cast<wu32x2*>(t0 + off) = __builtin_bit_cast(wu32x2, p0);
