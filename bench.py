@@ -39,7 +39,42 @@ WORKLOADS = {
     'sngan32': ('cifar10', 32, "CIFAR-10 SNGAN phase-1 ns-loss bs=64, synthetic 32x32"),
     'sngan64': ('celeba', 64, "CelebA-64 SNGAN phase-1 ns-loss bs=64, synthetic 64x64"),
     'dcgan': ('color_mnist', 32, "Colored-MNIST mnist_dcgan phase-1 bs=64, synthetic 32x32 (BASELINE configs[0] shape)"),
+    # BASELINE configs[4] shape; one "step" = one iteration of stylegan2/train_ffhq.py (D step, G step, EMA, R1 every
+    # 16th and path-length every 4th iteration; --phase 2 adds D_drs); --batch_size defaults to 32 for this workload
+    'stylegan2': ('ffhq', 256, "FFHQ-256 StyleGAN2 (stylegan2/train_ffhq.py iteration) bs=32, synthetic 256x256"),
 }
+
+
+def make_stylegan2_step(size, batch, phase, device):
+    """the iteration of diagan/trainer/stylegan2.py on synthetic (image, index) pairs; returns (step, nets, optimizers)"""
+    import types
+    from diagan.models.stylegan2 import StyleGANDiscriminator, StyleGANGenerator
+    from diagan.trainer import stylegan2 as TR
+    from diagan.utils.settings import set_seed
+    set_seed(1)
+    G, D = StyleGANGenerator(size=size).to(device), StyleGANDiscriminator(size=size).to(device)
+    g_ema = StyleGANGenerator(size=size).to(device).eval()
+    TR.accumulate(g_ema, G, 0)
+    g_optim, d_optim = TR.make_optimizers(G, D)
+    a = types.SimpleNamespace(iter=10 ** 9, start_iter=0, batch=batch, latent=512, mixing=0.9, r1=10.0, d_reg_every=16,
+                              g_reg_every=4, path_regularize=2.0, path_batch_shrink=2, logit_save_steps=10 ** 9,
+                              save_logit_after=10 ** 9, stop_save_logit_after=0, n_sample=16, augment=False)
+    images = (torch.rand(4 * batch, 3, size, size, generator=torch.Generator().manual_seed(1234)) * 2 - 1).to(device)
+    ds = torch.utils.data.TensorDataset(images, torch.arange(len(images), device=device))     # resident in HBM
+    mk = lambda: torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=True, drop_last=True)
+    extra = {}
+    if phase == 2:
+        D2 = StyleGANDiscriminator(size=size).to(device)
+        extra = dict(drs_loader=mk(), drs_discriminator=D2, drs_d_optim=TR.make_optimizers(G, D2)[1])
+    tr = TR.StyleGAN2Trainer(a, mk(), G, D, g_optim, d_optim, g_ema, device, "/tmp/diagan_bench_sg2", **extra)
+    zero = torch.tensor(0.0, device=device)
+    tr.r1_loss, tr.path_loss, tr.path_lengths = zero, zero, zero
+    state = dict(i=0)
+
+    def step():
+        tr.train_step(state['i'])
+        state['i'] += 1
+    return step
 
 
 class NullLog:
@@ -200,16 +235,25 @@ def main():
     device = torch.device("cuda", dev_index)
     dataset, res, desc = WORKLOADS[args.workload]
 
-    netG, netD, netD_drs, optG, optD, optD_drs = build_models(dataset, args.loss_type, args.phase, device)
-    if world > 1:
-        for n in (netG, netD, netD_drs):
-            if n is not None:
-                dist.broadcast_module_(n)
-    gen = torch.Generator().manual_seed(1234 + rank)          # SURVEY §8(d) synthetic inputs
-    pool = 2 * args.n_dis
-    batches = [(torch.rand(args.batch_size, 3, res, res, generator=gen) * 2 - 1).to(device) for _ in range(pool)]
-    step = make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, args.n_dis,
-                            num_steps=50000 if dataset == 'cifar10' else 75000, device=device)
+    if args.workload == 'stylegan2':
+        if args.graph:
+            raise SystemExit("--graph is for the SNGAN / DCGAN steps")
+        if args.batch_size == 64:
+            args.batch_size = 32              # the reference's per-GPU batch for this configuration
+        args.n_dis, args.no_cpu_baseline = 1, True      # one D update per iteration; no CPU restatement is timed
+        args.loss_type = 'logistic (non-saturating) + lazy R1 / path-length'
+        step = make_stylegan2_step(res, args.batch_size, args.phase, device)
+    else:
+        netG, netD, netD_drs, optG, optD, optD_drs = build_models(dataset, args.loss_type, args.phase, device)
+        if world > 1:
+            for n in (netG, netD, netD_drs):
+                if n is not None:
+                    dist.broadcast_module_(n)
+        gen = torch.Generator().manual_seed(1234 + rank)          # SURVEY §8(d) synthetic inputs
+        pool = 2 * args.n_dis
+        batches = [(torch.rand(args.batch_size, 3, res, res, generator=gen) * 2 - 1).to(device) for _ in range(pool)]
+        step = make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, args.n_dis,
+                                num_steps=50000 if dataset == 'cifar10' else 75000, device=device)
 
     from diagan.ops import conv as C
     # Roofline instrumentation: the last warm-up step is bracketed launch by launch to find the dominant
