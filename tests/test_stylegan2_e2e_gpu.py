@@ -75,3 +75,17 @@ def test_two_ranks_stay_in_lock_step(tmp_path):
     assert sorted(logits) == [2, 4] and all(np.abs(v).min() > 0 for v in logits.values())     # every index was filled
     a, b = (torch.load(tmp_path / f"rank{r}_final.pt") for r in (0, 1))
     assert torch.equal(a["g"], b["g"]) and torch.equal(a["d"], b["d"])
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_for_the_stylegan2_workload():
+    """bench.py --workload stylegan2: one JSON line with the contract's keys (iteration = the trainer's train_step)"""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stylegan2", "--steps", "2",
+                          "--warmup", "1", "--batch_size", "4"], capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["metric"] == "images/sec (G+D step)" and line["value"] > 0 and line["n_gpus"] == 1
+    assert "StyleGAN2" in line["config"]["workload"] and line["config"]["global_batch"] == 4
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    assert line["bf16x6_mode"]["value"] > 0 and "cpu_baseline" not in line
