@@ -219,10 +219,12 @@ int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const 
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                     void* workspace, void* stream);
 
-/* BatchNorm (training mode) from the per-tile sums written by diagan_conv_gemm(stat_partials). */
+/* BatchNorm (training mode) from the per-tile sums written by diagan_conv_gemm(stat_partials).  groups > 1: `groups`
+ * independently normalised batches of M rows / `tiles` tiles each, contiguous in `partials`; finalised in order in one
+ * launch (the running statistics take `groups` momentum updates); the four outputs are [groups][C]. */
 int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M, int C, const float* gamma, const float* beta,
                           float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
-                          float* invstd_out, float* scale_out, float* shift_out, void* stream);
+                          float* invstd_out, float* scale_out, float* shift_out, int groups, void* stream);
 
 /* Backward of [BatchNorm -> optional (Leaky)ReLU -> optional dropout]: dx (+ residual), dgamma/dbeta (+)=.
  * relu != 0: g' = g * drop * (y > 0 ? 1 : slope), y = scale*x+shift (slope 0 = ReLU).  coef: 2*C floats.

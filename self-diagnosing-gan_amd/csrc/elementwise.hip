@@ -189,48 +189,60 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 
 // BatchNorm finalize from the per-tile column sums emitted by the producing conv's epilogue
 // (partials[tile][2][C] floats; summed over tiles in double, fixed order)
+// groups > 1: `groups` independently normalised batches whose tiles follow each other in `partials` (the stacked
+// generator forward): one launch finalises them IN ORDER, so the running statistics see the same sequence of momentum
+// updates as `groups` separate forwards; outputs are [groups][C].
 __global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const float* __restrict__ partials, int tiles, int C, long M,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale_out, float* __restrict__ shift_out) {
+                                   float* __restrict__ scale_out, float* __restrict__ shift_out, int groups) {
   // block = 16 channels x 16 tile-lanes; every lane keeps 4 independent double accumulators so that
   // its loads overlap; lanes and accumulators are combined in a fixed order (deterministic)
   __shared__ double red[16][16][2];
   const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
-  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-  if (c < C) {
-    int k = sl;
-    for (; k + 48 < tiles; k += 64) {
+  float rm = 0.f, rv = 0.f;
+  if (sl == 0 && c < C) { rm = running_mean[c]; rv = running_var[c]; }
+  for (int g = 0; g < groups; ++g) {
+    const float* part = partials + (long)g * tiles * 2 * C;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (c < C) {
+      int k = sl;
+      for (; k + 48 < tiles; k += 64) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a[u] += partials[(long)(k + 16 * u) * 2 * C + c];
-        b[u] += partials[(long)(k + 16 * u) * 2 * C + C + c];
+        for (int u = 0; u < 4; ++u) {
+          a[u] += part[(long)(k + 16 * u) * 2 * C + c];
+          b[u] += part[(long)(k + 16 * u) * 2 * C + C + c];
+        }
       }
+      for (; k < tiles; k += 16) { a[0] += part[(long)k * 2 * C + c]; b[0] += part[(long)k * 2 * C + C + c]; }
     }
-    for (; k < tiles; k += 16) { a[0] += partials[(long)k * 2 * C + c]; b[0] += partials[(long)k * 2 * C + C + c]; }
-  }
-  red[sl][cl][0] = (a[0] + a[1]) + (a[2] + a[3]);
-  red[sl][cl][1] = (b[0] + b[1]) + (b[2] + b[3]);
-  __syncthreads();
-  if (sl != 0 || c >= C) return;
-  double s1 = 0, s2 = 0;
+    if (g > 0) __syncthreads();          // the previous group's reduction has been read
+    red[sl][cl][0] = (a[0] + a[1]) + (a[2] + a[3]);
+    red[sl][cl][1] = (b[0] + b[1]) + (b[2] + b[3]);
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double s1 = 0, s2 = 0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
-  const double m = s1 / (double)M;
-  double v = s2 / (double)M - m * m;
-  v = v < 0 ? 0 : v;
-  const float mean = (float)m, var = (float)v;
-  const float unbiased = M > 1 ? (float)(v * (double)M / (double)(M - 1)) : var;
-  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-  running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-  const float invstd = 1.f / sqrtf(var + eps);
-  const float sc = gamma[c] * invstd;
-  mean_out[c] = mean;
-  invstd_out[c] = invstd;
-  scale_out[c] = sc;
-  shift_out[c] = beta[c] - mean * sc;
+      for (int k = 0; k < 16; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+      const double m = s1 / (double)M;
+      double v = s2 / (double)M - m * m;
+      v = v < 0 ? 0 : v;
+      const float mean = (float)m, var = (float)v;
+      const float unbiased = M > 1 ? (float)(v * (double)M / (double)(M - 1)) : var;
+      rm = (1.f - momentum) * rm + momentum * mean;
+      rv = (1.f - momentum) * rv + momentum * unbiased;
+      const float invstd = 1.f / sqrtf(var + eps);
+      const float sc = gamma[c] * invstd;
+      const long o = (long)g * C + c;
+      mean_out[o] = mean;
+      invstd_out[o] = invstd;
+      scale_out[o] = sc;
+      shift_out[o] = beta[c] - mean * sc;
+    }
+  }
+  if (sl == 0 && c < C) { running_mean[c] = rm; running_var[c] = rv; }
 }
 
 // BatchNorm backward finalize: dgamma += s2, dbeta += s1, coef = {s1/M, s2/M}
@@ -620,12 +632,12 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
 DIAGAN_API int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M, int C, const float* gamma,
                                      const float* beta, float eps, float momentum, float* running_mean,
                                      float* running_var, float* mean_out, float* invstd_out, float* scale_out,
-                                     float* shift_out, void* stream) {
+                                     float* shift_out, int groups, void* stream) {
   DG_REQUIRE(partials && gamma && beta && running_mean && running_var && mean_out && invstd_out && scale_out && shift_out,
              "bn_stats_fused: null pointer");
-  DG_REQUIRE(tiles > 0 && M > 0 && C > 0, "bn_stats_fused: bad dims");
+  DG_REQUIRE(tiles > 0 && M > 0 && C > 0 && groups > 0, "bn_stats_fused: bad dims");
   hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(cdiv(C, 16)), dim3(256), 0, ST, partials, tiles, C, (long)M, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out);
+                     beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, groups);
   return check_launch("bn_stats_fused");
 }
 

@@ -12,7 +12,7 @@ nat.register("diagan_tanh_fwd", [P, P, I64, P])
 nat.register("diagan_tanh_bwd", [P, P, P, I64, P])
 nat.register("diagan_colred_workspace", [I64, I])
 nat.register("diagan_bn_stats", [P, I64, I, P, P, F, F, P, P, I, P, P, P, P, P, P])
-nat.register("diagan_bn_stats_fused", [P, I, I64, I, P, P, F, F, P, P, P, P, P, P, P])
+nat.register("diagan_bn_stats_fused", [P, I, I64, I, P, P, F, F, P, P, P, P, P, P, I, P])
 nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, I, F, P, P, P, I, P, P, P, P, P])
 nat.register("diagan_act_fwd", [P, P, P, F, P, P, I64, I, P])
 nat.register("diagan_act_bwd", [P, P, F, P, P, I64, P])
@@ -120,17 +120,15 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mome
 def bn_stats_fused(partials, tiles, M, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1, groups=1,
                    group_imgs=0):
     """Training-mode BatchNorm context from the per-tile sums emitted by the producing conv's epilogue
-    (groups > 1: the tiles of a group are contiguous; one finalize per group, in order)."""
+    (groups > 1: the tiles of a group are contiguous; the groups are finalised in order by one launch)."""
     C = gamma.numel()
     if tiles % groups or M % groups:
         raise RuntimeError(f"bn_stats_fused: {tiles} tiles / {M} rows do not split into {groups} groups")
     tg, Mg = tiles // groups, M // groups
     ctx = _bn_ctx(C, Mg, True, groups, group_imgs, gamma.device)
-    for g in range(groups):
-        o = g * C * 4
-        nat.call("diagan_bn_stats_fused", ptr(partials) + g * tg * 2 * C * 4, tg, Mg, C, ptr(gamma), ptr(beta), eps,
-                 momentum, ptr(running_mean), ptr(running_var), ptr(ctx.mean) + o, ptr(ctx.invstd) + o,
-                 ptr(ctx.scale) + o, ptr(ctx.shift) + o, st())
+    nat.call("diagan_bn_stats_fused", ptr(partials), tg, Mg, C, ptr(gamma), ptr(beta), eps, momentum,
+             ptr(running_mean), ptr(running_var), ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale), ptr(ctx.shift), groups,
+             st())
     return ctx
 
 
