@@ -168,6 +168,9 @@ def main(phase, argv=None, dataset=None):
     trainer.train()
     dump = os.environ.get("DIAGAN_SG2_DUMP")        # test hook: final flat parameters of every rank
     if dump:
-        torch.save({"g": generator.flat_params.cpu(), "d": discriminator.flat_params.cpu()},
-                   os.path.join(dump, f"rank{rank}_final.pt"))
+        final = {"g": generator.flat_params.cpu(), "d": discriminator.flat_params.cpu()}
+        if phase == 2:
+            final["drs_d"] = extra['drs_discriminator'].flat_params.cpu()
+            final["first_indices"] = list(iter(loader.sampler))[:8]
+        torch.save(final, os.path.join(dump, f"rank{rank}_phase{phase}_final.pt"))
     return trainer

@@ -73,8 +73,24 @@ def test_two_ranks_stay_in_lock_step(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     logits = pickle.load(open(tmp_path / "dp" / "logits_netD.pkl", "rb"))
     assert sorted(logits) == [2, 4] and all(np.abs(v).min() > 0 for v in logits.values())     # every index was filled
-    a, b = (torch.load(tmp_path / f"rank{r}_final.pt") for r in (0, 1))
+    a, b = (torch.load(tmp_path / f"rank{r}_phase1_final.pt") for r in (0, 1))
     assert torch.equal(a["g"], b["g"]) and torch.equal(a["d"], b["d"])
+
+    # phase 2 on two ranks: resumes from the rank-0 checkpoint, keeps the score weights under data parallelism (every
+    # rank takes its stride of ONE weighted draw) and trains D_drs in lock-step too
+    cmd2 = cmd[:cmd.index(os.path.join(ROOT, "stylegan2", "train_ffhq.py"))] + [
+        os.path.join(ROOT, "stylegan2", "train_ffhq_phase2.py"), "-d", "cifar10", "--batch", "4", "--iter", "7",
+        "--num_data", "16", "--work_dir", str(tmp_path), "--exp_name", "dp2", "--baseline_exp_name", "dp", "--p1_step",
+        "4", "--resample_score", "ldrv", "--log_every", "1", "--checkpoint_every", "100", "--d_reg_every", "2",
+        "--g_reg_every", "2"]
+    cmd2[cmd2.index("29533")] = "29534"
+    out = subprocess.run(cmd2, env=env, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    a, b = (torch.load(tmp_path / f"rank{r}_phase2_final.pt") for r in (0, 1))
+    for k in ("g", "d", "drs_d"):
+        assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["drs_d"], a["d"])
+    assert len(a["first_indices"]) > 0 and a["first_indices"] != b["first_indices"]       # disjoint strides of one draw
 
 
 @pytest.mark.timeout(600)
