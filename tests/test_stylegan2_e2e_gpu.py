@@ -53,6 +53,13 @@ def test_phase1_then_phase2(tmp_path):
     assert isinstance(sampler, torch.utils.data.WeightedRandomSampler) and len(sampler.weights) == 24
     ck2 = torch.load(tmp_path / "p2" / "checkpoint" / "000009.pt", map_location="cpu", weights_only=False)
     assert {"drs_d", "drs_d_optim"} <= set(ck2)
+    # sampling script on the phase-2 checkpoint's EMA generator, with truncation towards the mean latent
+    import generate
+    files = generate.main(["--size", "32", "--ckpt", str(tmp_path / "p2" / "checkpoint" / "000009.pt"), "--pics", "2",
+                           "--sample", "3", "--truncation", "0.7", "--truncation_mean", "64", "--out", str(tmp_path / "s")])
+    imgs = [torch.load(f) for f in files]
+    assert len(imgs) == 2 and all(i.shape == (3, 3, 32, 32) and float(i.abs().max()) <= 1 for i in imgs)
+    assert not torch.equal(imgs[0], imgs[1])
     # D_drs started from D's phase-1 weights and has since been trained on uniformly sampled data
     assert not torch.equal(ck2["drs_d"]["final_linear.1.weight"], ckpt["d"]["final_linear.1.weight"])
     assert not torch.equal(ck2["drs_d"]["final_linear.1.weight"], ck2["d"]["final_linear.1.weight"])
