@@ -81,16 +81,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   // conflict-free ds_read_b128 of a lane's 8 k: rows are BK bf16 = 64 (32) bytes, 4 (2) slots of 16 B
   auto xslot = [](int row, int q) { return BK == 32 ? (q ^ ((row >> 2) & 3)) : (q ^ ((row >> 3) & 1)); };
   auto store_x6 = [&](__bf16* tile, int rows, int row, int lq_, f32x4 v) {
-    // whole-vector conversions: one v_cvt_pk_bf16_f32 per PAIR of elements (element-wise code gets one per element)
-    const bf16x4 p0 = __builtin_convertvector(v, bf16x4);
-    const f32x4 r1 = v - __builtin_convertvector(p0, f32x4);          // exact
-    const bf16x4 p1 = __builtin_convertvector(r1, bf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(p1, f32x4);         // exact
-    const bf16x4 p2 = __builtin_convertvector(r2, bf16x4);
+    unsigned a0, a1, a2, b0, b1, b2;
+    x6_split_pair(v[0], v[1], a0, a1, a2);
+    x6_split_pair(v[2], v[3], b0, b1, b2);
+    const u32x2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2};
     const int off = row * BK + (xslot(row, lq_ >> 1) << 3) + ((lq_ & 1) << 2);
-    *reinterpret_cast<u32x2*>(tile + off) = __builtin_bit_cast(u32x2, p0);
-    *reinterpret_cast<u32x2*>(tile + rows * BK + off) = __builtin_bit_cast(u32x2, p1);
-    *reinterpret_cast<u32x2*>(tile + 2 * rows * BK + off) = __builtin_bit_cast(u32x2, p2);
+    *reinterpret_cast<u32x2*>(tile + off) = p0;
+    *reinterpret_cast<u32x2*>(tile + rows * BK + off) = p1;
+    *reinterpret_cast<u32x2*>(tile + 2 * rows * BK + off) = p2;
   };
 
   const ConvGeom& g = a.g;

@@ -416,16 +416,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
   // 3-4, 128-byte rows (64 columns; two pixel rows share a 256-byte bank row) take pixel bit 1 into chunk bit 3
   auto swz = [](int pitch, int ph, int chunk) { return pitch == 128 ? (chunk ^ ((ph & 3) << 3)) : (chunk ^ (((ph >> 1) & 1) << 3)); };
   auto store3 = [&](__bf16* t0, __bf16* t1, __bf16* t2, int pitch, int prow, int chunk, f32x4 v) {
-    const wbf16x4 p0 = __builtin_convertvector(v, wbf16x4);           // one v_cvt_pk_bf16_f32 per pair of elements
-    const f32x4 r1 = v - __builtin_convertvector(p0, f32x4);          // exact
-    const wbf16x4 p1 = __builtin_convertvector(r1, wbf16x4);
-    const f32x4 r2 = r1 - __builtin_convertvector(p1, f32x4);         // exact
-    const wbf16x4 p2 = __builtin_convertvector(r2, wbf16x4);
+    unsigned a0, a1, a2, b0, b1, b2;
+    x6_split_pair(v[0], v[1], a0, a1, a2);
+    x6_split_pair(v[2], v[3], b0, b1, b2);
+    const wu32x2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2};
     const int ph = prow & (HK - 1);
     const int off = ph * pitch + (swz(pitch, ph, chunk) << 2);
-    *reinterpret_cast<wu32x2*>(t0 + off) = __builtin_bit_cast(wu32x2, p0);
-    *reinterpret_cast<wu32x2*>(t1 + off) = __builtin_bit_cast(wu32x2, p1);
-    *reinterpret_cast<wu32x2*>(t2 + off) = __builtin_bit_cast(wu32x2, p2);
+    *reinterpret_cast<wu32x2*>(t0 + off) = p0;
+    *reinterpret_cast<wu32x2*>(t1 + off) = p1;
+    *reinterpret_cast<wu32x2*>(t2 + off) = p2;
   };
   auto store_a = [&](int buf, int j) {
     store3(Ax[buf][0], Ax[buf][1], Ax[buf][2], BNn, ap + APR * j, ac, ra[j]);
