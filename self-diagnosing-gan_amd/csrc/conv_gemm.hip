@@ -317,19 +317,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     for (int u = 0; u < BK / 16; ++u) {
       const int q = 2 * u + fh;                  // lane half h takes k = 8h .. 8h+7 of the chunk
       bf16x8 fa[TM][3], fb[TN][3];
+      // planes in the order the products consume them (a2, b0, a0, b2, a1, b1): the first MFMAs wait for a third of the
+      // LDS reads, not for all of them
+      constexpr int ORD[3] = {2, 0, 1}, ORDB[3] = {0, 2, 1};
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = wm * (TM * 32) + i * 32 + fi;
-        const int off = row * BK + (xslot(row, q) << 3);
+      for (int t = 0; t < 3; ++t) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fa[i][p] = *reinterpret_cast<const bf16x8*>(Ac + p * BM * BK + off);
-      }
+        for (int i = 0; i < TM; ++i) {
+          const int row = wm * (TM * 32) + i * 32 + fi;
+          fa[i][ORD[t]] = *reinterpret_cast<const bf16x8*>(Ac + ORD[t] * BM * BK + row * BK + (xslot(row, q) << 3));
+        }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn * (TN * 32) + j * 32 + fi;
-        const int off = row * BK + (xslot(row, q) << 3);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) fb[j][p] = *reinterpret_cast<const bf16x8*>(Bc + p * BN * BK + off);
+        for (int j = 0; j < TN; ++j) {
+          const int row = wn * (TN * 32) + j * 32 + fi;
+          fb[j][ORDB[t]] = *reinterpret_cast<const bf16x8*>(Bc + ORDB[t] * BN * BK + row * BK + (xslot(row, q) << 3));
+        }
       }
 #pragma unroll
       for (int sidx = 0; sidx < 6; ++sidx) {

@@ -470,14 +470,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
   };
   auto mfma_half = [&](int buf, auto&& slot_work) {
     wbf16x8 fa[TM][3], fb[TN][3];
+    // planes in the order the products consume them (a2, b0, a0, b2, a1, b1): the first MFMAs wait for a third of the
+    // LDS reads, not for all of them
+    constexpr int ORD[3] = {2, 0, 1}, ORDB[3] = {0, 2, 1};
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int t = 0; t < 3; ++t) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[i][p] = read_frag(Ax[buf][p], BNn, wm * (TM * 32) + i * 32);
+      for (int i = 0; i < TM; ++i) fa[i][ORD[t]] = read_frag(Ax[buf][ORD[t]], BNn, wm * (TM * 32) + i * 32);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) fb[j][p] = read_frag(Bx[buf][p], BNk, wn * 64 + j * 32);
+      for (int j = 0; j < TN; ++j) fb[j][ORDB[t]] = read_frag(Bx[buf][ORDB[t]], BNk, wn * 64 + j * 32);
+    }
 #pragma unroll
     for (int sidx = 0; sidx < 6; ++sidx) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
