@@ -571,6 +571,250 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
     }
 }
 
+// ---- fp32 weight gradient with the LDS double buffer at HALF-step granularity (16 pixels) -------------------------------
+// Same arithmetic and the same 32-pixel K-steps as conv_wgrad_kernel (exact fp32 MFMA), but the operand tiles live in
+// 2 x 16-pixel buffers (32 KB instead of 64 KB of LDS): three workgroups per CU instead of two, for a kernel whose
+// matrix-pipe occupancy (0.62-0.72) is bound by latency, not by issue slots.  Pipeline as in the bf16x6 variant above.
+template <int BNn = 128, int PRO = -1, bool P2 = false>
+__global__ __launch_bounds__(256, 3) void conv_wgrad_half_kernel(const WgradArgs a) {
+  constexpr int BNk = 128, BK = 32, HK = 16;
+  constexpr int TM = BNn / 64, TN = 2, AC = BNn / 4, BC = 32, APR = 256 / AC, BPR = 8, AJ = BK / APR, BJ = 4;
+  constexpr int AH = AJ / 2;      // dy pieces per 16-pixel half (2 for 128 columns, 1 for 64)
+  static_assert(BNn == 128 || BNn == 64, "dy tile of 128 or 64 columns");
+  __shared__ __attribute__((aligned(16))) float Ah[2][HK * BNn];      // 32 KB in all: three workgroups per CU
+  __shared__ __attribute__((aligned(16))) float Bh[2][HK * BNk];
+
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_k = (g.Kp + BNk - 1) / BNk;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / a.tiles, tile = logical - split * a.tiles;
+  const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
+  const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
+  const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
+  const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
+
+  const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;
+  const int ac = tid % AC, ap = tid / AC;
+  const int an = n0 + ac * 4;
+  const unsigned a_kill = an < g.Co ? 0u : 0x80000000u;
+  const int bc = tid % BC, bp = tid / BC;
+  const int kf = k0 + bc * 4;
+  const int tap = kf / g.Ci, kc = kf - tap * g.Ci;
+  const int kr = tap / g.S, ks = tap - kr * g.S;
+  const bool b_ok = kf < g.K;
+  const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
+  const int upm = g.up - 1, ush = g.up >> 1;
+  const int pstep = (g.Ci * 4) >> ush;
+  const int img_bytes = g.Hi * g.Wi * g.Ci * 4;
+  const unsigned ylim = (unsigned)g.Hi << ush, xlim = (unsigned)g.Wi << ush;
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (affine && b_ok) {
+    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
+    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
+  }
+  // every piece j advances on its own (pieces 0,1 and 2,3 of a K-step are loaded at different times)
+  int pb[BJ], py[BJ], px[BJ], mst[BJ];
+  unsigned xoff[BJ], aoff[AJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int m = step0 * BK + bp + BPR * j;
+    const unsigned t = fdiv((unsigned)m, a.dWo);
+    px[j] = m - (int)t * g.Wo;
+    const unsigned b = fdiv(t, a.dHo);
+    py[j] = (int)t - (int)b * g.Ho;
+    pb[j] = (int)b;
+    mst[j] = step0 * BK;
+    xoff[j] = (unsigned)((m + dyo * g.Wi + dxo) * g.Ci * 4 + kc * 4);
+  }
+  const unsigned xstep = (unsigned)BK * g.Ci * 4u, astep = (unsigned)BK * g.Co * 4u;
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
+  f32x4 ra[AJ], rb[BJ];
+  unsigned bmask = 0;
+  const bool bias_tile = a.bias_off >= 0 && k0 == 0;
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_a = [&](int j) {
+    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[j] | a_kill, 0, 0));
+    aoff[j] += astep;
+  };
+  auto load_b = [&](int j) {
+    unsigned okb;
+    if (P2 && a.same) {
+      const int m = mst[j] + bp + BPR * j;
+      const int yn = ((m >> a.lgW) & (g.Ho - 1)) + dyo, xn = (m & (g.Wo - 1)) + dxo;
+      okb = (b_ok && m < a.M && (unsigned)yn < (unsigned)g.Hi && (unsigned)xn < (unsigned)g.Wi) ? 1u : 0u;
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[j] | ((okb ^ 1u) << 31), 0, 0));
+      xoff[j] += xstep;
+    } else {
+      int pbj, pyj, pxj;
+      if (P2) {
+        const int m = mst[j] + bp + BPR * j;
+        pxj = m & (g.Wo - 1);
+        pyj = (m >> a.lgW) & (g.Ho - 1);
+        pbj = m >> a.lgHW;
+      } else {
+        pbj = pb[j]; pyj = py[j]; pxj = px[j];
+      }
+      const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
+      okb = (b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0) ? 1u : 0u;
+      const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
+      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      if (!P2) {
+        int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
+        const int cx = x >= g.Wo ? 1 : 0;
+        x -= cx ? g.Wo : 0;
+        y += cx;
+        const int cy = y >= g.Ho ? 1 : 0;
+        y -= cy ? g.Ho : 0;
+        b += cy;
+        px[j] = x; py[j] = y; pb[j] = b;
+      }
+    }
+    bmask = (bmask & ~(1u << j)) | (okb << j);
+    mst[j] += BK;
+  };
+  // exact 3-way bf16 split of four values into the three planes of an LDS tile
+  auto store_a = [&](int buf, int j) {
+    *reinterpret_cast<f32x4*>(&Ah[buf][((ap + APR * j) & (HK - 1)) * BNn + ac * 4]) = ra[j];
+    if (bias_tile) bacc += ra[j];
+  };
+  auto store_b = [&](int buf, int j) {
+    f32x4 v = rb[j];
+    if (pro_mode != PRO_NONE) {
+      if (affine) v = v * psc + psh;
+      if (pro_mode == PRO_LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+      } else if (pro_mode != PRO_AFFINE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (affine) v *= (float)((bmask >> j) & 1u);
+    }
+    *reinterpret_cast<f32x4*>(&Bh[buf][((bp + BPR * j) & (HK - 1)) * BNk + bc * 4]) = v;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fi = lane & 31, fh = lane >> 5;
+  // one 16-pixel half-step: 8 s-steps of 2 pixels; fragments are read one s-step ahead (as in conv_wgrad_kernel)
+  auto mfma_half = [&](int buf, auto&& slot_work) {
+    const float* Ac = Ah[buf];
+    const float* Bc = Bh[buf];
+    float fa[2][TM], fb[2][TN];
+    auto read_frag = [&](int sstep, int set) {
+      const int p = 2 * sstep + fh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[set][i] = Ac[p * BNn + wm * (TM * 32) + i * 32 + fi];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[set][j] = Bc[p * BNk + wn * (TN * 32) + j * 32 + fi];
+    };
+    read_frag(0, 0);
+#pragma unroll
+    for (int sidx = 0; sidx < 8; ++sidx) {
+      if (sidx + 1 < 8) read_frag(sidx + 1, (sidx + 1) & 1);
+      slot_work(sidx);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sidx & 1][i], fb[sidx & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // prologue: the whole first K-step is loaded; its first half goes to buffer 0, and the registers of that half are
+  // re-loaded for the next K-step right away
+  if (step0 < step1) {
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) load_a(j);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) load_b(j);
+#pragma unroll
+    for (int t = 0; t < AH; ++t) store_a(0, t);
+    store_b(0, 0); store_b(0, 1);
+    if (step0 + 1 < step1) {
+#pragma unroll
+      for (int t = 0; t < AH; ++t) load_a(t);
+      load_b(0); load_b(1);
+    }
+  }
+  __syncthreads();
+  // s-steps 0 .. AH+1 of a half-step carry the stores of the OTHER half's pieces (AH dy pieces, 2 gathered pieces),
+  // s-steps 6 and 7 the re-loads of the registers just freed
+  for (int step = step0; step < step1; ++step) {
+    const bool next1 = step + 1 < step1, next2 = step + 2 < step1;
+    mfma_half(0, [&](int sidx) {
+      if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
+      if (sidx < AH) store_a(1, AH + sidx);
+      if (sidx == AH) store_b(1, 2);
+      if (sidx == AH + 1) store_b(1, 3);
+      if (next1 && sidx == 6) {
+#pragma unroll
+        for (int t = 0; t < AH; ++t) load_a(AH + t);
+      }
+      if (next1 && sidx == 7) { load_b(2); load_b(3); }
+    });
+    __syncthreads();
+    mfma_half(1, [&](int sidx) {
+      if (next1) {
+        if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
+        if (sidx < AH) store_a(0, sidx);
+        if (sidx == AH) store_b(0, 0);
+        if (sidx == AH + 1) store_b(0, 1);
+      }
+      if (next2 && sidx == 6) {
+#pragma unroll
+        for (int t = 0; t < AH; ++t) load_a(t);
+      }
+      if (next2 && sidx == 7) { load_b(0); load_b(1); }
+    });
+    __syncthreads();
+  }
+
+  float* out = a.slab + (long)split * a.slab_stride;
+  if (bias_tile) {
+    float* red = &Ah[0][0];      // tiles are done with: [APR][BNn] partial rows
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(red + ap * BNn + ac * 4) = bacc;
+    __syncthreads();
+    if (tid < BNn && n0 + tid < g.Co) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < APR; ++r) t += red[r * BNn + tid];
+      out[a.bias_off + n0 + tid] = t;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
+  const unsigned rowbytes = (unsigned)g.Kp * 4u;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int k = k0 + wn * (TN * 32) + j * 32 + fi;
+      const int nrow = n0 + wm * (TM * 32) + i * 32 + 4 * fh;
+      const unsigned vbase = k < g.Kp ? ((unsigned)nrow * g.Kp + k) * 4u : 0x80000000u;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float av = acc[i][j][e];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), osrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0);
+      }
+    }
+}
+
 // out[i] (+)= sum_s slab[s][i]; optionally per-block partial of <G, W> for the SN backward
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
                                                            long n4, float* __restrict__ out, int accumulate,
@@ -811,6 +1055,17 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
       case PRO_RELU: DG_WGX(BN_, PRO_RELU); break; \
       case PRO_AFFINE_RELU: DG_WGX(BN_, PRO_AFFINE_RELU); break; \
       default: DG_WGX(BN_, -1); break; }
+  static const int half = getenv("DIAGAN_WGRAD_HALF") ? atoi(getenv("DIAGAN_WGRAD_HALF")) : 0;
+#define DG_WGH(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_half_kernel<BN_, PRO_, true>), grid, dim3(256), 0, st, a); \
+                               else hipLaunchKernelGGL((conv_wgrad_half_kernel<BN_, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
+  if (half && bk == 128 && bn == 128 && diagan_get_mfma_mode() == 0) {
+    switch (pro_mode) {
+      case PRO_NONE: DG_WGH(128, PRO_NONE); break;
+      case PRO_RELU: DG_WGH(128, PRO_RELU); break;
+      case PRO_AFFINE_RELU: DG_WGH(128, PRO_AFFINE_RELU); break;
+      default: DG_WGH(128, -1); break;
+    }
+  } else
   if (bk == 128 && diagan_get_mfma_mode() == 1) {      // bf16x6 (opt-in): dy tiles of 128 or 64 columns x 128 packed k
     if (bn == 128) { DG_WGX_ALL(128) } else { DG_WGX_ALL(64) }
   } else if (bn == 64 && bk == 64) {
@@ -820,6 +1075,7 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   } else {
     DG_WG_ALL(128)
   }
+#undef DG_WGH
 #undef DG_WGX_ALL
 #undef DG_WGX
 #undef DG_WG_ALL
@@ -845,8 +1101,10 @@ DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
   if (smax > 256) smax = 256;
   int splits = 1;
   double best = 1e30;
+  static const int half = getenv("DIAGAN_WGRAD_HALF") ? atoi(getenv("DIAGAN_WGRAD_HALF")) : 0;
+  const int slots = (half && bn == 128 && bk == 128 && diagan_get_mfma_mode() == 0) ? 768 : 512;   // 3 workgroups per CU
   for (int s = 1; s <= smax; ++s) {
-    const double t = (double)cdiv(tiles * s, 512) * ((double)total_steps / s + fixed);
+    const double t = (double)cdiv(tiles * s, slots) * ((double)total_steps / s + fixed);
     if (t < best * 0.995) { best = t; splits = s; }   // ties (and near-ties) go to fewer splits: less slab traffic
   }
   if (splits < 1) splits = 1;
