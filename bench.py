@@ -165,10 +165,89 @@ def cpu_baseline(dataset, res, loss_type, batch, n_dis, budget_s=25.0):
             break
     t_d, t_g = min(td), min(tg)
     t_step = n_dis * t_d + t_g
-    return {"value": round(batch / t_step, 3), "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": round(batch / t_step, 3), "unit": "images/s", "cores": cores, "cpu_model": cpu_model_name(),
+            "kind": "port",
             "sample": f"oracle/nets.py (torch CPU ops, {cores} threads of {avail} available): best of {len(td)} "
                       f"D update(s) {t_d:.2f} s and G update(s) {t_g:.2f} s at bs={batch}; one global step = "
                       f"{n_dis}*t_D + t_G = {t_step:.2f} s (warm-up D update {warm:.1f} s not counted)"}
+
+
+def conv_block_excluded(name, shape):
+    """'SNGAN-64 conv blocks' = the 3x3 / 1x1 convolutions of the residual blocks of a4 + a5, forward and
+    backward.  Out: the generator's latent linear l1 (N = 16384), its last conv c6 (forward: the 4-output-channel
+    kernel with the BatchNorm prologue; weight gradient: the 4-channel weight-gradient kernel).  c6's data-gradient
+    (1.2 GFLOP of 4726) has the same (M, N, K) as block1.c1's forward and stays in numerator and denominator alike."""
+    if shape is not None and len(shape) >= 4:
+        M, N, K, tag = shape[:4]
+        if N == 16384:
+            return True
+        if name == "conv3x3_co4_kernel" and str(tag).startswith("pro2"):
+            return True
+    return name == "conv3x3_co4_wgrad_kernel"
+
+
+def sngan64_leg(args, device, steps=10, warmup=3):
+    """north_star's kernel target, on the driver's own line: >= 60 % of the fp32 MFMA roofline on the SNGAN 64x64 conv
+    blocks at bs = 64 (reference nets: diagan-pkg/diagan/models/predefined_models.py:57-59,76-78).  Un-scored leg run
+    after the timed region: `steps` global steps of the CelebA-64 configuration for images/s, then two more with every
+    GEMM launch bracketed by HIP events: numerator = algorithmic FLOP of the residual-block convolutions (forward, data
+    and weight gradients), denominator = the summed launch time of exactly those launches."""
+    from diagan.ops import conv as C
+    dataset, res, desc = WORKLOADS['sngan64']
+    nets = build_models(dataset, args.loss_type, 1, device)
+    gen = torch.Generator().manual_seed(1234)
+    batches = [(torch.rand(args.batch_size, 3, res, res, generator=gen) * 2 - 1).to(device) for _ in range(2 * args.n_dis)]
+    step = make_global_step(*nets, batches, args.n_dis, num_steps=75000, device=device)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    C.TIMER = full = C.KernelTimer()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    C.TIMER = None
+    flop = secs = 0.0
+    flop_all = secs_all = 0.0
+    per_kernel = {}
+    for name, f, s, e, shape in full.records:
+        dt = s.elapsed_time(e) * 1e-3
+        flop_all += f
+        secs_all += dt
+        if conv_block_excluded(name, shape):
+            continue
+        flop += f
+        secs += dt
+        d = per_kernel.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += f
+        d[2] += dt
+    tf = flop / secs / 1e12
+    return {"workload": desc, "steps": steps, "warmup": warmup,
+            "images_per_s": round(args.batch_size * steps / el, 2), "ms_per_step": round(el / steps * 1e3, 3),
+            "tflops": round(tf, 2), "peak": round(MFMA_F32_PEAK / 1e12, 1), "frac": round(tf * 1e12 / MFMA_F32_PEAK, 4),
+            "conv_block_gflop_per_step": round(flop / 2 / 1e9, 1), "conv_block_kernel_ms_per_step": round(secs / 2 * 1e3, 3),
+            "all_gemm_tflops": round(flop_all / secs_all / 1e12, 2),
+            "definition": "algorithmic FLOP (2*M*Co*R*S*Ci per launch) of the residual-block 3x3/1x1 convs of "
+                          "SNGANGenerator64 + SNGANDiscriminator64, fwd + dgrad + wgrad, / summed HIP-event launch "
+                          "time of those launches over 2 un-timed global steps; l1, c6 fwd/wgrad, head, BN, SN, loss, "
+                          "Adam excluded from both",
+            "kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 2 * 1e3, 3)}
+                        for k, v in sorted(per_kernel.items())}}
+
+
+def cpu_model_name():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def scorer_leg(device, N=50000, T=50):
@@ -219,6 +298,8 @@ def main():
     ap.add_argument("--no_kernel_timer", action="store_true")
     ap.add_argument("--no_x6_leg", action="store_true",
                     help="skip the extra (un-scored) measurement of the same steps in the experimental bf16x6 MFMA mode")
+    ap.add_argument("--no_sngan64_leg", action="store_true",
+                    help="skip the extra (un-scored) SNGAN-64 conv-block roofline leg of the default sngan32 run")
     ap.add_argument("--graph", action="store_true",
                     help="replay the global step as one hipGraph (launch-bound workloads: dcgan); single GPU only")
     args = ap.parse_args()
@@ -331,6 +412,16 @@ def main():
             x6, x6_error = None, repr(e)
         finally:
             C.set_mfma_mode(0)
+    # Extra leg: north_star's >= 60 % MFMA-roofline target on the SNGAN-64 conv blocks (default workload, one GPU only)
+    s64, s64_error = None, None
+    if (world == 1 and args.workload == 'sngan32' and args.phase == 1 and not args.no_sngan64_leg and not args.graph
+            and not args.no_kernel_timer and C.get_mfma_mode() == 0):
+        try:
+            s64 = sngan64_leg(args, device)
+        except Exception as e:          # the extra leg must never cost the scored line
+            s64_error = repr(e)
+        finally:
+            C.TIMER = None
     if rank != 0:
         return
 
@@ -371,12 +462,18 @@ def main():
         line["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak / 1e12, 1),
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4), "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, "
+                              "2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this run)" if traffic else None,
             "launches": d['launches'], "avg_launch_us": round(d['seconds'] / d['launches'] * 1e6, 2),
             "algorithmic_gflop_per_launch": round(d['flop'] / d['launches'] / 1e9, 3),
             "all_gemm_kernels_2_untimed_steps": {
                 k: {"launches": v['launches'], "tflops": round(v['flop'] / v['seconds'] / 1e12, 2),
                     "ms_per_step": round(v['seconds'] / 2 * 1e3, 3)} for k, v in sorted(summ_all.items())},
         }
+    if s64 is not None:
+        line["sngan64_conv_blocks"] = s64
+    elif s64_error:
+        line["sngan64_conv_blocks"] = {"error": s64_error}
     if x6_error:
         line["bf16x6_mode"] = {"error": x6_error}
     if x6 is not None:

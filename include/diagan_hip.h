@@ -119,6 +119,20 @@ int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64
                              int Ci, int Kp, void* stream);
 
 int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp); /* tile config chosen when tile_cfg == 0 (host only) */
+/* Tile configurations: 1 = 128x128, 2 = 128x64 (waves 2x2), 3 = 64x64, 4 = 128x64 (waves 4x1), 5 = 256x64,
+ * 6 = 64x64 with 64-wide K-steps (Kp % 64 == 0), 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments.  Rows / columns of one (0 = unknown configuration). */
+int diagan_conv_gemm_tile_rows(int cfg);
+int diagan_conv_gemm_tile_cols(int cfg);
+/* Diagnostics and tuning sweeps only (tools/stamp_report.py, tools/bench_conv.py; no reference counterpart, never
+ * called by the product path).  While a stamp buffer is set, diagan_conv_gemm launches a diagnostic build of its
+ * kernel (prologue modes 0 and 1) in which every workgroup records, at slot blockIdx.y*gridDim.x + blockIdx.x,
+ * 8 x uint64: [0] the 100 MHz real-time counter at entry, [1] at exit, [2..6] shader cycles spent in loader
+ * set-up / first tile / K loop / epilogue issue / store drain, [7] HW_ID | XCC_ID << 32.  buf = NULL ends it.
+ * diagan_conv_gemm_tune: force_ksplit > 0 forces that split-K factor for every tile configuration; flags >= 0 overrides
+ * the kernel's tuning bits (bit 0 / 1: raised wave priority during set-up / epilogue; -1 = production default);
+ * lds_delta_bytes is added to the dynamic LDS request (occupancy probe; negative values: timing only). */
+int diagan_conv_gemm_set_stamp_buffer(unsigned long long* buf, int64_t slots);
+int diagan_conv_gemm_tune(int force_ksplit, int flags, int lds_delta_bytes);
 
 /* Weight gradient, split over pixels: slab[s][n][k] = sum_{m in split s} dy[m][n]*pro(x gathered).
  * Replaces the weight half of conv2d / conv_transpose2d backward (errD.backward()/errG.backward()

@@ -24,6 +24,8 @@
 #include <string.h>
 
 extern "C" int diagan_get_mfma_mode(void);
+extern "C" int diagan_conv_gemm_tile_rows(int cfg);
+extern "C" int diagan_conv_gemm_tile_cols(int cfg);
 
 namespace diagan {
 
@@ -51,6 +53,10 @@ struct ConvGemmArgs {
   int M;                  // B*Ho*Wo
   ConvGeom g;
   FastDiv dWo, dHo;       // pixel index -> (b, oy, ox) without integer division
+  unsigned long long* stamps;   // diagnostic build only (STAMP kernels): [workgroups][8] cycle / real-time stamps
+  int tune;               // tuning sweeps: bit 0 = raised wave priority while the loader state is set up and the first
+                          // tile staged, bit 1 = raised priority in the epilogue (a new / finishing wave otherwise gets
+                          // the vector-issue slots its older MFMA-bound neighbours leave over)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,14 +68,17 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // piece products that are not below 2^-24 relative (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0), each exact in fp32, accumulated
 // in fp32: six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles) per
 // 32x32x16 block.  Measured error against double is at or below the fp32 MFMA's (tools/probe/bf16x6.hip).
-template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool X6 = false>
+template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool X6 = false, bool STAMP = false, bool FP = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int CH = BK / 4;                           // 16-byte chunks per tile row
   constexpr int RP = 256 / CH;                         // tile rows covered by one pass of the 256 loaders
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
   constexpr int AJ = BM / RP, BJ = BN / RP;            // 16-byte chunks per thread per tile
   // XOR swizzle of the chunk index: conflict-free ds_read_b128 fragments (bank row = 256 B)
-  auto swz = [](int row, int q) { return BK == 32 ? (q ^ ((row >> 1) & 7)) : (q ^ ((row >> 2) & 3)); };
+  // (BK = 64: a tile row is a whole 256-byte bank row, so a 16-lane read group needs 16 distinct slots: q ^ (row & 15))
+  auto swz = [](int row, int q) {
+    return BK == 64 ? (q ^ (row & 15)) : BK == 32 ? (q ^ ((row >> 1) & 7)) : (q ^ ((row >> 2) & 3));
+  };
   static_assert(WM * WN == 4, "4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BM*32]
@@ -91,6 +100,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     *reinterpret_cast<u32x2*>(tile + 2 * rows * BK + off) = p2;
   };
 
+  // Diagnostic build (STAMP, reached only through diagan_conv_gemm_set_stamp_buffer): lane 0 of wave 0 records the
+  // shader clock at the phase boundaries of the workgroup plus the constant 100 MHz real-time counter at entry and
+  // exit and the hardware id (XCD, CU), into a buffer of its own that nothing else reads.
+  unsigned long long st_t[6] = {0, 0, 0, 0, 0, 0}, st_r0 = 0;
+  auto stamp = [&](int i) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      st_t[i] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (STAMP) st_r0 = __builtin_amdgcn_s_memrealtime();
+  if (a.tune & 1) __builtin_amdgcn_s_setprio(3);
+  stamp(0);
   const ConvGeom& g = a.g;
   const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;   // compile-time in the specialised kernels: straight-line store phase
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,7 +225,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
     if (p == AJ + BJ - 1) {            // advance (tap, c) to the next K-step
       kc += BK;
-      while (kc >= g.Ci) { kc -= g.Ci; if (++ks == g.S) { ks = 0; ++kr; } }
+      if (g.Ci >= BK) {                // at most one tap boundary per K-step: straight-line selects, no lane-dependent loop
+        const bool w = kc >= g.Ci;
+        kc -= w ? g.Ci : 0;
+        ks += w ? 1 : 0;
+        const bool r = ks == g.S;
+        ks = r ? 0 : ks;
+        kr += r ? 1 : 0;
+      } else {                         // RGB-sized inputs (Ci = 4: two K-steps in all): plain divisions
+        const int kflat = (kk + 1) * BK + lq * 4, tap = kflat / g.Ci;
+        kc = kflat - tap * g.Ci;
+        kr = tap / g.S;
+        ks = tap - kr * g.S;
+      }
     }
   };
   auto load_tiles = [&](int kk) {
@@ -253,6 +288,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
 
   const int fi = lane & 31, fh = lane >> 5;
 
+  stamp(1);
   if (k_begin < k_end) {
     load_tiles(k_begin);
     store_tiles(0);
@@ -267,38 +303,58 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   // 64 cycles after it issues, so the ~15 VALU / LDS-write instructions of a piece ride in its shadow instead of
   // forming a store phase after the MFMAs during which the pipe has nothing from this workgroup.
   constexpr int NE = (BK / 8) * 4, NP = AJ + BJ;
-  static_assert(2 * NP <= NE, "load and store pieces of a tile must not share an e-step");
+  constexpr int PPE = (2 * NP + NE - 1) / NE;      // pieces per e-step (1 for the square tiles; 2 for 256x64)
+  constexpr int LE = (NP + PPE - 1) / PPE;         // e-steps that carry load pieces (first) / store pieces (last)
+  static_assert(2 * LE <= NE, "load and store pieces of a tile must not share an e-step");
+  // FP (one 32x32 accumulator per wave): the fragments of sub-step u + 1 are read into a second register set BEFORE
+  // the MFMAs of sub-step u issue -- with a single accumulator chain the compiler otherwise re-uses the fragment
+  // registers and every sub-step starts with an exposed LDS round trip (ds_read, lgkmcnt(0), 4 MFMAs, ds_read, ...).
   auto kstep = [&](int kk, auto has_next) {
     const int cur = (kk - k_begin) & 1;
     const float* Ac = As + cur * BM * BK;
     const float* Bc = Bs + cur * BN * BK;
-#pragma unroll
-    for (int u = 0; u < BK / 8; ++u) {
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int slot, int u) {
       const int q = 2 * u + fh;
-      f32x4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = wm * (TM * 32) + i * 32 + fi;
-        fa[i] = *reinterpret_cast<const f32x4*>(Ac + row * BK + (swz(row, q) << 2));
+        fa[slot][i] = *reinterpret_cast<const f32x4*>(Ac + row * BK + (swz(row, q) << 2));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = wn * (TN * 32) + j * 32 + fi;
-        fb[j] = *reinterpret_cast<const f32x4*>(Bc + row * BK + (swz(row, q) << 2));
+        fb[slot][j] = *reinterpret_cast<const f32x4*>(Bc + row * BK + (swz(row, q) << 2));
+      }
+    };
+    if constexpr (FP) read_frags(0, 0);
+#pragma unroll
+    for (int u = 0; u < BK / 8; ++u) {
+      const int fs = FP ? (u & 1) : 0;
+      if constexpr (FP) {
+        if (u + 1 < BK / 8) read_frags((u + 1) & 1, u + 1);
+      } else {
+        read_frags(0, u);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int es = u * 4 + e;
-        if (decltype(has_next)::value && es < NP) load_piece(kk + 1, es);   // next tile's global loads: first NP e-steps
-        if (decltype(has_next)::value && es >= NE - NP) {
+        if (decltype(has_next)::value && es < LE) {                          // next tile's global loads: first e-steps
+#pragma unroll
+          for (int pp = 0; pp < PPE; ++pp)
+            if (es * PPE + pp < NP) load_piece(kk + 1, es * PPE + pp);
+        }
+        if (decltype(has_next)::value && es >= NE - LE) {
           __builtin_amdgcn_sched_barrier(0);   // keep the piece HERE: hoisted to the top it would wait for its load first
-          store_piece(cur ^ 1, es - (NE - NP));
+#pragma unroll
+          for (int pp = 0; pp < PPE; ++pp)
+            if ((es - (NE - LE)) * PPE + pp < NP) store_piece(cur ^ 1, (es - (NE - LE)) * PPE + pp);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fs][i][e], fb[fs][j][e], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -355,6 +411,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
     __syncthreads();
   };
+  if (a.tune & 1) __builtin_amdgcn_s_setprio(0);
+  stamp(2);
   if constexpr (X6) {
     using T = std::true_type;
     using F = std::false_type;
@@ -366,6 +424,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
     if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
   }
+  stamp(3);
+  if (a.tune & 2) __builtin_amdgcn_s_setprio(3);
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
   // Straight-line per variant (residual / mask / statistics / raw split-K partials are compile-time flags of the
@@ -468,6 +528,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       p[g.Co + n0 + tid] = t2;
     }
   }
+  if constexpr (STAMP) {
+    stamp(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the workgroup's stores have left the CU
+    stamp(5);
+    if (tid == 0 && a.stamps) {
+      unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+      o[0] = st_r0;
+      o[1] = __builtin_amdgcn_s_memrealtime();
+      for (int i = 0; i < 5; ++i) o[2 + i] = st_t[i + 1] - st_t[i];
+      // HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), 32 bits each
+      o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+             ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+  }
 }
 
 // split-K second stage: y = epi(sum_s slab[s]) (fixed summation order: deterministic)
@@ -501,16 +575,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
 }
 
 static int g_mfma_x6 = -1;       // -1: read DIAGAN_MFMA on first use; 0: fp32 MFMA (default); 1: bf16x6
+static unsigned long long* g_stamps = nullptr;   // diagnostic: stamp buffer of the STAMP kernels (null in production)
+static long g_stamp_slots = 0;
+static int g_force_ksplit = 0;                    // tuning sweeps only (diagan_conv_gemm_tune)
+static int g_tune_flags = -1;                     // -1: production default (see kDefaultTune)
+static long g_lds_delta = 0;
+constexpr int kDefaultTune = 0;
 
-template <int BM, int BN, int WM, int WN, int BK, int PRO, bool X6 = false>
+template <int BM, int BN, int WM, int WN, int BK, int PRO, bool X6 = false, bool STAMP = false, bool FP = false>
 static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
-  const size_t lds = X6 ? (size_t)2 * 3 * (BM + BN) * BK * 2 : (size_t)2 * (BM + BN) * BK * sizeof(float);
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, X6>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // (g_lds_delta: occupancy probe of the tuning sweeps, timing only -- a negative value leaves part of the tile outside
+  //  the allocation, where LDS accesses are dropped by the hardware's range check)
+  const size_t lds = (size_t)((long)(X6 ? (size_t)2 * 3 * (BM + BN) * BK * 2 : (size_t)2 * (BM + BN) * BK * sizeof(float)) + g_lds_delta);
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, X6, STAMP, FP>;
+  static size_t attr_set = 0;
+  if (attr_set < lds) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set = lds;
   }
   hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit), dim3(256), lds, st, a);
   if (a.ksplit > 1) {
@@ -521,32 +603,40 @@ static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   return check_launch("conv_gemm");
 }
 
-// SPEC: one kernel per prologue mode (the two production tiles); otherwise the mode is a run-time argument
-template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false>
+// SPEC: one kernel per prologue mode (the production tiles); otherwise the mode is a run-time argument.
+// X6OK: the tile has a bf16x6 twin (the two square tiles).
+template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false, bool X6OK = false, bool FP = false>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
-  if (diagan_get_mfma_mode() == 1) {        // bf16x6: 16-wide K-steps (48 KB of LDS: two workgroups per CU)
-    static const int xbk = getenv("DIAGAN_X6_BK") ? atoi(getenv("DIAGAN_X6_BK")) : 16;
-    if (xbk == 32) return launch_one<BM, BN, WM, WN, 32, -1, true>(a, st);
-    if (SPEC) {
-      switch (a.pro_mode) {
-        case PRO_NONE: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_NONE : -1, true>(a, st);
-        case PRO_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_RELU : -1, true>(a, st);
-        case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_AFFINE_RELU : -1, true>(a, st);
-        default: break;
+  if constexpr (X6OK) {
+    if (diagan_get_mfma_mode() == 1) {        // bf16x6: 16-wide K-steps (48 KB of LDS: two workgroups per CU)
+      static const int xbk = getenv("DIAGAN_X6_BK") ? atoi(getenv("DIAGAN_X6_BK")) : 16;
+      if (xbk == 32) return launch_one<BM, BN, WM, WN, 32, -1, true>(a, st);
+      if (SPEC) {
+        switch (a.pro_mode) {
+          case PRO_NONE: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_NONE : -1, true>(a, st);
+          case PRO_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_RELU : -1, true>(a, st);
+          case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_AFFINE_RELU : -1, true>(a, st);
+          default: break;
+        }
       }
+      return launch_one<BM, BN, WM, WN, 16, -1, true>(a, st);
     }
-    return launch_one<BM, BN, WM, WN, 16, -1, true>(a, st);
+  }
+  if (a.stamps) {                             // diagnostic build: the two most common prologue modes only
+    if (a.pro_mode == PRO_NONE) return launch_one<BM, BN, WM, WN, BK, PRO_NONE, false, true, FP>(a, st);
+    if (a.pro_mode == PRO_RELU) return launch_one<BM, BN, WM, WN, BK, PRO_RELU, false, true, FP>(a, st);
+    return set_err(DIAGAN_EUNSUP, "conv_gemm: the stamped diagnostic kernels exist for prologue modes 0 and 1");
   }
   if (SPEC) {
     switch (a.pro_mode) {
-      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1>(a, st);
-      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1>(a, st);
-      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1>(a, st);
-      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1>(a, st);
-      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1>(a, st);
+      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1, false, false, FP>(a, st);
+      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1, false, false, FP>(a, st);
+      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1, false, false, FP>(a, st);
+      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1, false, false, FP>(a, st);
+      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1, false, false, FP>(a, st);
     }
   }
-  return launch_one<BM, BN, WM, WN, BK, -1>(a, st);
+  return launch_one<BM, BN, WM, WN, BK, -1, false, false, FP>(a, st);
 }
 
 }  // namespace diagan
@@ -599,9 +689,10 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
 //    GEMM itself 5-8 % faster -- 91 -> 85 us -- but the second-stage launches and slab traffic cost more than that
 //    over a whole training step: 2350 -> 2323 images/s.)
 DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
-  static const int forced = getenv("DIAGAN_KSPLIT") ? atoi(getenv("DIAGAN_KSPLIT")) : 0;   // tuning experiments only
-  if (forced > 0 && !(Co & 3)) return forced < Kp / 32 ? forced : Kp / 32;
-  if (cfg != 3 || (Co & 3)) return 1;
+  static const int env_forced = getenv("DIAGAN_KSPLIT") ? atoi(getenv("DIAGAN_KSPLIT")) : 0;   // tuning experiments only
+  const int forced = g_force_ksplit > 0 ? g_force_ksplit : env_forced;
+  if (forced > 0 && !(Co & 3)) return forced < Kp / 64 ? forced : (Kp / 64 > 0 ? Kp / 64 : 1);
+  if ((cfg != 3 && cfg != 7) || (Co & 3)) return 1;
   const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
   const int nk = Kp / 32;
   if (nk < 16) return 1;
@@ -657,18 +748,62 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   hipStream_t st = (hipStream_t)stream;
   const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp) : tile_cfg;
   a.pro_group_rows = pro_group_rows;
-  DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % (cfg == 1 ? 128 : 64) == 0 && a.M % pro_group_rows == 0)),
-             "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, cfg == 1 ? 128 : 64, a.M);
+  const int bm = diagan_conv_gemm_tile_rows(cfg);
+  DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x64 (4x1 waves), "
+             "5 = 256x64, 6 = 64x64 with 64-wide K-steps)", tile_cfg);
+  DG_REQUIRE(cfg != 6 || Kp % 64 == 0, "conv_gemm: tile_cfg 6 needs Kp %% 64 == 0 (Kp=%d)", Kp);
+  DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % bm == 0 && a.M % pro_group_rows == 0)),
+             "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, bm, a.M);
   a.slab = splitk_ws;
   a.ksplit = 1;
   a.stat_partials = stat_partials;
+  a.tune = g_tune_flags >= 0 ? g_tune_flags : kDefaultTune;
+  a.stamps = nullptr;
+  if (g_stamps) {
+    const long wgs = (long)cdiv(a.M, bm) * cdiv(Co, diagan_conv_gemm_tile_cols(cfg)) * 16;   // room for up to 16 K splits
+    DG_REQUIRE(wgs <= g_stamp_slots, "conv_gemm: stamp buffer has %ld slots, this launch may need %ld", g_stamp_slots, wgs);
+    a.stamps = g_stamps;
+  }
   if (splitk_ws && !stat_partials) {
     const int ks = diagan_conv_gemm_pick_ksplit(a.M, Co, Kp, cfg);
     if (ks > 1 && (int64_t)ks * a.M * Co <= splitk_ws_floats) a.ksplit = ks;
   }
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);
-    case 3: return launch_cfg<64, 64, 2, 2, 32, true>(a, st);
-    default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64)", tile_cfg);
+    case 1: return launch_cfg<128, 128, 2, 2, 32, true, true>(a, st);
+    case 2: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
+    case 3: return launch_cfg<64, 64, 2, 2, 32, true, true>(a, st);
+    case 4: return launch_cfg<128, 64, 4, 1, 32, true>(a, st);
+    case 5: return launch_cfg<256, 64, 4, 1, 32, true>(a, st);
+    case 6: return launch_cfg<64, 64, 2, 2, 64, true>(a, st);
+    case 7: return launch_cfg<64, 64, 2, 2, 32, true, false, true>(a, st);
+    case 8: return launch_cfg<128, 64, 2, 2, 32, true, false, true>(a, st);
+    default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
   }
+}
+
+// rows / columns of a tile configuration (0 for an unknown one)
+DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
+  switch (cfg) { case 1: case 2: case 4: case 8: return 128; case 3: case 6: case 7: return 64; case 5: return 256; default: return 0; }
+}
+DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
+  switch (cfg) { case 1: return 128; case 2: case 3: case 4: case 5: case 6: case 7: case 8: return 64; default: return 0; }
+}
+
+// Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.
+//  * stamp buffer: while set, diagan_conv_gemm launches the STAMP build of the kernel, which records per workgroup
+//    [0] real-time counter (100 MHz) at entry, [1] at exit, [2..6] shader cycles of: loader set-up, first tile
+//    (loads + LDS stores + barrier), K loop, epilogue issue, store drain; [7] HW_ID | XCC_ID << 32.
+//  * diagan_conv_gemm_tune: force_ksplit > 0 overrides the split-K factor for every tile configuration; flags >= 0
+//    overrides the kernel's tune bits (ConvGemmArgs::tune; -1 = production default); lds_delta_bytes is added to the
+//    dynamic LDS request (occupancy probe; a negative value is for TIMING ONLY, results are undefined).
+DIAGAN_API int diagan_conv_gemm_set_stamp_buffer(unsigned long long* buf, int64_t slots) {
+  g_stamps = buf;
+  g_stamp_slots = buf ? (long)slots : 0;
+  return DIAGAN_OK;
+}
+DIAGAN_API int diagan_conv_gemm_tune(int force_ksplit, int flags, int lds_delta_bytes) {
+  g_force_ksplit = force_ksplit;
+  g_tune_flags = flags;
+  g_lds_delta = lds_delta_bytes;
+  return DIAGAN_OK;
 }

@@ -120,6 +120,7 @@ class _Run:
         self.save_path = Path(self.out_dir)
         self.save_path.mkdir(parents=True, exist_ok=True)
         set_seed(args.seed)
+        self.seed = args.seed
         if not torch.cuda.is_available():
             raise SystemExit("the Dia-GAN engine needs an MI355X (no CPU fallback)")
         index = self.local_rank % torch.cuda.device_count() if self.world > 1 else 0
@@ -132,6 +133,8 @@ class _Run:
             for net in nets:
                 net.to(self.device)
                 dist.broadcast_module_(net)
+            # identical replicas, different latent noise / dropout masks per rank (the CPU generators stay shared)
+            dist.seed_device_per_rank(self.seed)
 
 
 def _checkpoint(root, net, step):

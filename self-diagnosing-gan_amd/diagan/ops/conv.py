@@ -11,6 +11,10 @@ P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, I, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I])
+nat.register("diagan_conv_gemm_tile_rows", [I])
+nat.register("diagan_conv_gemm_tile_cols", [I])
+nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
+nat.register("diagan_conv_gemm_tune", [I, I, I])
 nat.register("diagan_conv3x3_co4_supported", [I] * 8)
 nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
 nat.register("diagan_conv3x3_co4_wgrad_supported", [I] * 8)
@@ -30,7 +34,11 @@ nat.register("diagan_get_mfma_mode", [])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
-TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2,32,{pro}>", 3: "conv_gemm_kernel<64,64,2,2,32,{pro}>"}
+TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2,32,{pro}>", 2: "conv_gemm_kernel<128,64,2,2,32,{pro}>",
+              3: "conv_gemm_kernel<64,64,2,2,32,{pro}>", 4: "conv_gemm_kernel<128,64,4,1,32,{pro}>",
+              5: "conv_gemm_kernel<256,64,4,1,32,{pro}>", 6: "conv_gemm_kernel<64,64,2,2,64,{pro}>",
+              7: "conv_gemm_kernel<64,64,2,2,32,{pro},false,false,true>",
+              8: "conv_gemm_kernel<128,64,2,2,32,{pro},false,false,true>"}
 
 
 class KernelTimer:
@@ -167,13 +175,15 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         # M=4096: 60 us unsplit with statistics vs 54 + 6 (second stage) + 20 (column reduction) us)
         M = B * Ho * Wo
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, Kp)
-        tiles = (M + (127 if cfg == 1 else 63)) // (128 if cfg == 1 else 64)
+        bm = nat.fn("diagan_conv_gemm_tile_rows")(cfg)
+        tiles = (M + bm - 1) // bm
         stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
         tile_cfg = cfg
     kname = None
     if TIMER is not None:
         kname = TILE_NAMES[tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp)].format(pro=mode)
-        if get_mfma_mode() == 1:       # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised, X6 = true
+        if get_mfma_mode() == 1 and kname.startswith(("conv_gemm_kernel<128,128", "conv_gemm_kernel<64,64,2,2,32")):
+            # bf16x6 (the two square tiles): 16-wide K-steps, prologue modes 0-2 specialised, X6 = true
             kname = kname.replace(",32,", ",16,").replace(">", ",true>")
             if mode > 2:
                 kname = kname.replace(f",{mode},true>", ",-1,true>")

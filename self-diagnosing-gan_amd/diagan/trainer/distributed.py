@@ -57,6 +57,30 @@ def all_reduce_mean_(flat):
     return flat
 
 
+def all_reduce_sum_(flat, async_op=False):
+    """In-place SUM over ranks of one contiguous slab; the 1/W of the mean is folded into the optimiser's gradient
+    read (FusedAdam.grad_scale), which saves a pass over the slab.  async_op: returns the work handle (the exchange
+    runs on the backend's own stream; `wait()` orders the current stream behind it)."""
+    if get_world_size() == 1:
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def seed_device_per_rank(seed, rank=None, enable=True):
+    """Give every rank's DEVICE generator its own stream (seed + rank) once the replicas have been made identical.
+
+    The CLIs seed every generator with the same value on every rank (diagan-pkg/diagan/utils/settings.py:8-18 is
+    called before the process group exists, stylegan2/train_ffhq.py:497).  The CPU generators MUST stay shared: the
+    strided ShardedSampler and StyleGAN2's `mixing_noise` (random.random()) rely on lock-step draws.  The device
+    generator feeds only the latent noise (`generate_images`) and dropout masks; left shared, every rank would draw the
+    same z and the all-reduced fake-side gradient would be the mean of W copies of ONE fake batch.
+    enable=False keeps the reference's behaviour (StyleGAN2 path default, see stylegan2_cli.py)."""
+    if not enable or seed is None or get_world_size() == 1 or not torch.cuda.is_available():
+        return
+    rank = get_rank() if rank is None else rank
+    torch.cuda.manual_seed(int(seed) + int(rank))
+
+
 def reduce_sum(tensor):
     if get_world_size() == 1:
         return tensor
