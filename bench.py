@@ -111,13 +111,17 @@ def make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, n_dis,
 
     def device_part():
         netG.prefetch_fakes(n_dis * (2 if netD_drs is not None else 1), batches[0].shape[0], device=device)   # as LogTrainer._updates
+        from diagan.trainer import distributed as dist
+        overlap = netD_drs is not None and dist.get_world_size() > 1      # as LogTrainer._updates
         for i in range(n_dis):
             real = fetch()
             netD.train_step(real_batch=real, netG=netG, optD=optD, log_data=log, global_step=state['step'],
-                            device=device)
+                            device=device, **(dict(defer_step=True) if overlap else {}))
             if netD_drs is not None:
                 netD_drs.train_step(real_batch=fetch(), netG=netG, optD=optD_drs, log_data=log,
                                     global_step=state['step'], device=device)
+            if overlap:
+                optD.step()
             if i == n_dis - 1:
                 netG.train_step(real_batch=real, netD=netD, optG=optG, log_data=log, global_step=state['step'],
                                 device=device)
@@ -330,6 +334,7 @@ def main():
             for n in (netG, netD, netD_drs):
                 if n is not None:
                     dist.broadcast_module_(n)
+            dist.seed_device_per_rank(1)        # identical replicas, per-rank latent noise (shared CPU generators)
         gen = torch.Generator().manual_seed(1234 + rank)          # SURVEY §8(d) synthetic inputs
         pool = 2 * args.n_dis
         batches = [(torch.rand(args.batch_size, 3, res, res, generator=gen) * 2 - 1).to(device) for _ in range(pool)]

@@ -118,7 +118,9 @@ int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64
                              const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W,
                              int Ci, int Kp, void* stream);
 
-int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp); /* tile config chosen when tile_cfg == 0 (host only) */
+/* tile config chosen when tile_cfg == 0 (host only); allow_split: split-K is available to the call (workspace given,
+ * no stat_partials) */
+int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split);
 /* Tile configurations: 1 = 128x128, 2 = 128x64 (waves 2x2), 3 = 64x64, 4 = 128x64 (waves 4x1), 5 = 256x64,
  * 6 = 64x64 with 64-wide K-steps (Kp % 64 == 0), 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments.  Rows / columns of one (0 = unknown configuration). */
 int diagan_conv_gemm_tile_rows(int cfg);
@@ -235,10 +237,15 @@ int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const 
 
 /* BatchNorm (training mode) from the per-tile sums written by diagan_conv_gemm(stat_partials).  groups > 1: `groups`
  * independently normalised batches of M rows / `tiles` tiles each, contiguous in `partials`; finalised in order in one
- * launch (the running statistics take `groups` momentum updates); the four outputs are [groups][C]. */
+ * launch (the running statistics take `groups` momentum updates); the four outputs are [groups][C].
+ * workspace (optional, workspace_doubles doubles): long tile lists are first summed by
+ * diagan_bn_stats_fused_splits(tiles, C, groups) workgroups per 16 channels and group (fixed order: deterministic);
+ * needs groups * splits * 2 * C doubles, otherwise the single-stage kernel runs. */
 int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M, int C, const float* gamma, const float* beta,
                           float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
-                          float* invstd_out, float* scale_out, float* shift_out, int groups, void* stream);
+                          float* invstd_out, float* scale_out, float* shift_out, int groups, double* workspace,
+                          int64_t workspace_doubles, void* stream);
+int diagan_bn_stats_fused_splits(int tiles, int C, int groups);
 
 /* Backward of [BatchNorm -> optional (Leaky)ReLU -> optional dropout]: dx (+ residual), dgamma/dbeta (+)=.
  * relu != 0: g' = g * drop * (y > 0 ? 1 : slope), y = scale*x+shift (slope 0 = ReLU).  coef: 2*C floats.
@@ -301,12 +308,16 @@ int diagan_loss_dis(const float* out_real, int n_real, const float* out_fake, in
 /* Generator loss over the k largest logits (TopKGenerator.get_topk, topk_models.py:31-38; k = n: all). */
 int diagan_loss_gen(const float* out_fake, int n, int k, int loss_type, float* d_fake, float* out1, void* stream);
 
-/* torch.optim.Adam.step on one flat buffer (predefined_models.py:32,51,70,89,114,123). */
+/* torch.optim.Adam.step on one flat buffer (predefined_models.py:32,51,70,89,114,123).  grad_scale multiplies the
+ * gradient as it is read: 1/W after a data-parallel SUM all-reduce (the mean of DistributedDataParallel,
+ * stylegan2/train_ffhq.py:572-585, without a separate pass over the slab); 1 otherwise. */
 int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                     float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, void* stream);
-/* The same step with {lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt} read from a DEVICE row of six
- * floats: the launch can be captured in a hipGraph and replayed with values the host writes before each replay. */
-int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper6, void* stream);
+                     float beta2, float eps, float bias_correction1, float bias_correction2_sqrt, float grad_scale,
+                     void* stream);
+/* The same step with {lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt, grad_scale, 0} read from a DEVICE
+ * row of eight floats: the launch can be captured in a hipGraph and replayed with values the host writes before each
+ * replay. */
+int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper8, void* stream);
 
 /* ---- StyleGAN2 native ops (the reference's only native code) -------------- */
 

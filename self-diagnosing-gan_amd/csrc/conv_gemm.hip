@@ -26,6 +26,7 @@
 extern "C" int diagan_get_mfma_mode(void);
 extern "C" int diagan_conv_gemm_tile_rows(int cfg);
 extern "C" int diagan_conv_gemm_tile_cols(int cfg);
+extern "C" int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 
 namespace diagan {
 
@@ -658,26 +659,40 @@ DIAGAN_API int diagan_get_mfma_mode(void) {
   return g_mfma_x6;
 }
 
-// tile selection used when tile_cfg == 0: 1 = 128x128, 3 = 64x64 (2, 4, 5 were sweep-only shapes, retired)
-DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp) {
+// Tile selection used when tile_cfg == 0.  Measured on MI355X (tools/tile_sweep.py, profiles/r02_tile_sweep.md):
+//  * 64-column outputs (the 64x64-resolution blocks of SNGAN-64): a 256x64 tile whose waves own 64x64 sub-tiles needs
+//    half the LDS fragment reads per MFMA of the 64x64 tile and holds a higher clock (2.2-2.3 vs 2.1 GHz): +3-5 %;
+//  * few output tiles but a long K loop (the 4x4 / 8x8 blocks): 128x128 tiles with the K loop split over 2-4 workgroups
+//    (a lone 128x128 workgroup on a CU still runs at 0.84 of the MFMA rate, a lone 64x64 one at 0.58): +4-7 % alone,
+//    nothing inside a training step: opt-in;
+//  * otherwise 128x128 against 64x64 by wave quantisation and column waste, as before -- with FOUR resident 64x64
+//    workgroups per CU (the stamped build shows 4, not the 5 that 160 KB / 32 KB suggests).
+// allow_split: the caller can take the split-K path (workspace present, no fused BatchNorm statistics).
+DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split) {
+  const bool x6 = diagan_get_mfma_mode() == 1;
+  const int small = x6 ? 3 : 7;            // 64x64 (the fp32 kernel with double-buffered fragments)
   // short K loops (first conv of D on RGB, 1x1 shortcuts) are bound by the output stream, not the MFMAs: more,
   // smaller workgroups in flight win (measured 52 -> 46 us at M=131072,N=128,K=36; 27 -> 19 us at K=128)
-  if (Kp <= 128) return 3;
-  // measured on MI355X (tools/bench_conv.py, SWEEP=1): the 64x64 tile (5 blocks/CU) is within ~5 % of
-  // the 128x128 tile everywhere and far better on small grids and narrow outputs; 128x128 wins by
-  // 5-10 % once it has >= 512 tiles (2 resident blocks on every CU) and wastes no columns.
+  if (Kp <= 128) return small;
+  const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128), t64 = (long)cdiv(M, 64) * cdiv(Co, 64);
+  if (!x6) {
+    // (in a training step this is within box-to-box noise of the 64x64 tile -- tools/layer_report.py, 32.8 vs 33.2 ms of
+    //  GEMM time per SNGAN-64 step -- so it stays opt-in: DIAGAN_SPLIT128=1)
+    static const bool split128 = getenv("DIAGAN_SPLIT128") && atoi(getenv("DIAGAN_SPLIT128")) > 0;
+    if (split128 && allow_split && (Co & 127) == 0 && t128 <= 256 && diagan_conv_gemm_pick_ksplit(M, Co, Kp, 1) > 1) return 1;
+    if (Co <= 64 && Kp >= 256) return M >= 65536 ? 5 : (M >= 32768 ? 8 : 7);
+  }
   // Blocks run a whole K loop, so a partially filled last round of blocks costs a full round
   // ("wave quantisation"): weigh each tile shape by tiles / (rounds * resident slots).
-  const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128), t64 = (long)cdiv(M, 64) * cdiv(Co, 64);
-  const long s128 = 256 * 2, s64 = 256 * 5;     // resident workgroups (LDS-limited)
+  const long s128 = 256 * 2, s64 = x6 ? 256 * 3 : 256 * 4;     // resident workgroups
   const double q128 = (double)t128 / (double)(cdiv(t128, s128) * s128);
   const double q64 = (double)t64 / (double)(cdiv(t64, s64) * s64);
   const double waste128 = (double)M * Co / ((double)t128 * 128 * 128);
   const double waste64 = (double)M * Co / ((double)t64 * 64 * 64);
   // (bf16x6 mode: the 128x128 variant gains 1.4-1.6x over its fp32 twin, the latency-bound 64x64 one 1.2x)
   static const double x6_bias = getenv("DIAGAN_X6_TILE_BIAS") ? atof(getenv("DIAGAN_X6_TILE_BIAS")) : 1.3;
-  const double bias = diagan_get_mfma_mode() == 1 ? x6_bias : 1.08;
-  return bias * q128 * waste128 > q64 * waste64 ? 1 : 3;
+  const double bias = x6 ? x6_bias : 1.08;
+  return bias * q128 * waste128 > q64 * waste64 ? 1 : small;
 }
 
 // Split-K factor for the 64x64 tile (1 = none), re-measured with the overlapped K-step schedule
@@ -692,9 +707,17 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   static const int env_forced = getenv("DIAGAN_KSPLIT") ? atoi(getenv("DIAGAN_KSPLIT")) : 0;   // tuning experiments only
   const int forced = g_force_ksplit > 0 ? g_force_ksplit : env_forced;
   if (forced > 0 && !(Co & 3)) return forced < Kp / 64 ? forced : (Kp / 64 > 0 ? Kp / 64 : 1);
-  if ((cfg != 3 && cfg != 7) || (Co & 3)) return 1;
-  const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
+  if (Co & 3) return 1;
   const int nk = Kp / 32;
+  if (cfg == 1) {                      // 128x128 tiles on problems with at most one tile per CU and a long K loop
+    const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128);
+    if (diagan_get_mfma_mode() == 1 || t128 > 256 || nk < 64) return 1;
+    int s = t128 <= 128 ? 4 : 2;
+    while (s > 1 && nk / s < 16) --s;
+    return s;
+  }
+  if (cfg != 3 && cfg != 7) return 1;
+  const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
   if (nk < 16) return 1;
   if (tiles <= 320) {
     // bf16x6: the MFMA phases are 2.67x shorter, so a lone workgroup per CU is even more latency-bound: split sooner
@@ -708,7 +731,7 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
     return s > 4 ? 4 : s;
   }
   if (tiles > 512) return 1;
-  long sp = 1280 / tiles;
+  long sp = 1024 / tiles;          // four resident 64x64 workgroups per CU
   if (sp > nk / 8) sp = nk / 8;       // at least 8 K-steps per split
   return sp < 2 ? 1 : (int)sp;
 }
@@ -746,7 +769,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp) : tile_cfg;
+  const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp, (splitk_ws && !stat_partials) ? 1 : 0) : tile_cfg;
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x64 (4x1 waves), "

@@ -192,7 +192,44 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 // groups > 1: `groups` independently normalised batches whose tiles follow each other in `partials` (the stacked
 // generator forward): one launch finalises them IN ORDER, so the running statistics see the same sequence of momentum
 // updates as `groups` separate forwards; outputs are [groups][C].
-__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const float* __restrict__ partials, int tiles, int C, long M,
+// First stage for long tile lists (a stacked 64x64 generator block has 100 000 tiles for 64 channels, i.e. FOUR
+// 16-channel blocks in the finalize kernel below: 170 us on average, 1 ms at worst): grid (C/16, S, groups), block
+// (s, g) sums tiles [s*chunk, (s+1)*chunk) of group g in double and writes ws[g][s][2][C]; the finalize kernel then
+// runs over the S partial rows.  Fixed split count and fixed order: deterministic.
+__global__ __launch_bounds__(256) void bn_partials_reduce_kernel(const float* __restrict__ partials, int tiles, int C, int S,
+                                                                 double* __restrict__ ws) {
+  __shared__ double red[16][16][2];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl, s = blockIdx.y, g = blockIdx.z;
+  const int chunk = (tiles + S - 1) / S, k0 = s * chunk, k1 = min(tiles, k0 + chunk);
+  const float* part = partials + (long)g * tiles * 2 * C;
+  double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+  if (c < C) {
+    int k = k0 + sl;
+    for (; k + 48 < k1; k += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] += part[(long)(k + 16 * u) * 2 * C + c];
+        b[u] += part[(long)(k + 16 * u) * 2 * C + C + c];
+      }
+    }
+    for (; k < k1; k += 16) { a[0] += part[(long)k * 2 * C + c]; b[0] += part[(long)k * 2 * C + C + c]; }
+  }
+  red[sl][cl][0] = (a[0] + a[1]) + (a[2] + a[3]);
+  red[sl][cl][1] = (b[0] + b[1]) + (b[2] + b[3]);
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double s1 = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s1 += red[k][cl][0]; s2 += red[k][cl][1]; }
+    double* o = ws + ((long)g * S + s) * 2 * C;
+    o[c] = s1;
+    o[C + c] = s2;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const T* __restrict__ partials, int tiles, int C, long M,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean_out, float* __restrict__ invstd_out,
@@ -205,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fused_kernel(const float* __r
   float rm = 0.f, rv = 0.f;
   if (sl == 0 && c < C) { rm = running_mean[c]; rv = running_var[c]; }
   for (int g = 0; g < groups; ++g) {
-    const float* part = partials + (long)g * tiles * 2 * C;
+    const T* part = partials + (long)g * tiles * 2 * C;
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (c < C) {
       int k = sl;
@@ -629,15 +666,35 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
   return check_launch("bn_stats");
 }
 
+// split count of the two-stage path (1 = single stage); the workspace must hold groups * splits * 2 * C doubles
+DIAGAN_API int diagan_bn_stats_fused_splits(int tiles, int C, int groups) {
+  if (tiles < 256) return 1;
+  long s = 1024 / ((long)cdiv(C, 16) * groups);
+  const long smax = tiles / 32;          // at least two tiles per lane of a block
+  if (s > smax) s = smax;
+  return s < 2 ? 1 : (int)s;
+}
+
 DIAGAN_API int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M, int C, const float* gamma,
                                      const float* beta, float eps, float momentum, float* running_mean,
                                      float* running_var, float* mean_out, float* invstd_out, float* scale_out,
-                                     float* shift_out, int groups, void* stream) {
+                                     float* shift_out, int groups, double* workspace, int64_t workspace_doubles,
+                                     void* stream) {
   DG_REQUIRE(partials && gamma && beta && running_mean && running_var && mean_out && invstd_out && scale_out && shift_out,
              "bn_stats_fused: null pointer");
   DG_REQUIRE(tiles > 0 && M > 0 && C > 0 && groups > 0, "bn_stats_fused: bad dims");
-  hipLaunchKernelGGL(bn_finalize_fused_kernel, dim3(cdiv(C, 16)), dim3(256), 0, ST, partials, tiles, C, (long)M, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out, groups);
+  const int S = diagan_bn_stats_fused_splits(tiles, C, groups);
+  if (S > 1 && workspace && workspace_doubles >= (int64_t)groups * S * 2 * C) {
+    hipLaunchKernelGGL(bn_partials_reduce_kernel, dim3(cdiv(C, 16), S, groups), dim3(256), 0, ST, partials, tiles, C, S,
+                       workspace);
+    hipLaunchKernelGGL(bn_finalize_fused_kernel<double>, dim3(cdiv(C, 16)), dim3(256), 0, ST, (const double*)workspace, S,
+                       C, (long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
+                       shift_out, groups);
+  } else {
+    hipLaunchKernelGGL(bn_finalize_fused_kernel<float>, dim3(cdiv(C, 16)), dim3(256), 0, ST, partials, tiles, C, (long)M,
+                       gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out,
+                       groups);
+  }
   return check_launch("bn_stats_fused");
 }
 

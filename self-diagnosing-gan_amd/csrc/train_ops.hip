@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void g_loss_kernel(const float* __restrict__ f
   if (threadIdx.x == 0) out[0] = (float)(ls / k);
 }
 
-struct AdamHyper { float lr, beta1, beta2, eps, bc1, bc2_sqrt; };
+struct AdamHyper { float lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale, pad; };   // 8 floats (device row of the *_dev form)
 
 // torch.optim.Adam (no weight decay, no amsgrad):  m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g;
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const float step_size = h.lr / h.bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * h.grad_scale;   // 1/W of a data-parallel SUM all-reduce (1 otherwise)
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pv = reinterpret_cast<f32x4*>(p)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   const AdamHyper h = *hp;
   const float step_size = h.lr / h.bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i] * h.grad_scale;   // 1/W of a data-parallel SUM all-reduce (1 otherwise)
     f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pv = reinterpret_cast<f32x4*>(p)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -172,9 +172,9 @@ DIAGAN_API int diagan_loss_gen(const float* out_fake, int n, int k, int loss_typ
 
 DIAGAN_API int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, float bias_correction1, float bias_correction2_sqrt,
-                                void* stream) {
+                                float grad_scale, void* stream) {
   DG_REQUIRE(p && g && m && v && n > 0 && (n & 3) == 0, "adam_step: bad args (n must be a multiple of 4)");
-  AdamHyper h{lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt};
+  AdamHyper h{lr, beta1, beta2, eps, bias_correction1, bias_correction2_sqrt, grad_scale, 0.f};
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -182,13 +182,13 @@ DIAGAN_API int diagan_adam_step(float* p, const float* g, float* m, float* v, in
   return check_launch("adam_step");
 }
 
-DIAGAN_API int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper6,
+DIAGAN_API int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper8,
                                     void* stream) {
-  DG_REQUIRE(p && g && m && v && hyper6 && n > 0 && (n & 3) == 0, "adam_step_dev: bad args (n must be a multiple of 4)");
+  DG_REQUIRE(p && g && m && v && hyper8 && n > 0 && (n & 3) == 0, "adam_step_dev: bad args (n must be a multiple of 4)");
   const long n4 = n / 4;
   long blocks = (n4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adam_dev_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4,
-                     reinterpret_cast<const AdamHyper*>(hyper6));
+                     reinterpret_cast<const AdamHyper*>(hyper8));
   return check_launch("adam_step_dev");
 }

@@ -67,6 +67,9 @@ PHASE2_FLAGS = [
     (("--resample_score",), None, str, None),
     (("--gold",), False, _FLAG, None),
     (("--window",), 5000, int, "score window in steps (reference: 5000)"),
+    (("--compat_fetch_quirk",), False, _FLAG, "reproduce mimicry's _fetch_data: an exhausted D_drs iterator restarts on the "
+                                              "WEIGHTED main loader (what the reference's runs did after their first "
+                                              "epoch); default: D_drs keeps its own uniform loader"),
 ]
 # per-dataset phase-1 schedule the reference hard-codes after parsing (train_mimicry_phase1.py:82-92)
 PHASE1_SCHEDULE = {
@@ -213,7 +216,7 @@ def phase2(argv=None):
                          optD_drs=optD_drs, netG_ckpt_file=start['netG'], netD_ckpt_file=start['netD'],
                          netD_drs_ckpt_file=drs_start, n_dis=args.n_dis, num_steps=args.num_steps,
                          lr_decay=args.decay, topk=args.topk, gold=args.gold, gold_step=args.p1_step, print_steps=10,
-                         save_steps=args.save_steps, save_logits=False)
+                         save_steps=args.save_steps, save_logits=False, compat_fetch_quirk=args.compat_fetch_quirk)
     trainer.train()
     return trainer
 
@@ -252,6 +255,8 @@ COLOR_MNIST_PHASE2 = [
     (("--baseline_exp_name",), "colour_mnist", str, "exp name"),
     (("--p1_step",), 10000, int, None),
     (("--use_eval_logits",), None, int, None),
+    (("--compat_fetch_quirk",), False, _FLAG, "as in train_mimicry_phase2.py: restart an exhausted D_drs iterator on the "
+                                              "main (weighted) loader, like mimicry's _fetch_data"),
 ]
 
 
@@ -331,6 +336,6 @@ def color_mnist_phase2(argv=None, dataset=None):
                          netD_drs_ckpt_file=start['netD'], netD_drs=netD_drs, optD_drs=optD_drs,
                          dataloader_drs=loader_drs, n_dis=args.n_dis, num_steps=args.num_steps, save_steps=1000,
                          vis_steps=100, lr_decay=args.decay, dataloader=loader, log_dir=run.out_dir, print_steps=10,
-                         device=run.device, save_logits=False)
+                         device=run.device, save_logits=False, compat_fetch_quirk=args.compat_fetch_quirk)
     trainer.train()
     return trainer

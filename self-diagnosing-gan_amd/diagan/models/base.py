@@ -25,10 +25,9 @@ class BaseModel(FlatNet):
     def restore_checkpoint(self, ckpt_file, optimizer=None):
         if not ckpt_file:
             raise ValueError("No checkpoint file to be restored.")
-        try:
-            ckpt_dict = torch.load(ckpt_file, weights_only=False)
-        except RuntimeError:
-            ckpt_dict = torch.load(ckpt_file, map_location=lambda storage, loc: storage, weights_only=False)
+        # always through host memory: rank 0 saved device tensors of cuda:0, and under torch.distributed.run every rank
+        # would otherwise open a context on GPU 0 just to deserialise; load_state_dict copies into the flat slabs anyway
+        ckpt_dict = torch.load(ckpt_file, map_location='cpu', weights_only=False)
         self.load_state_dict(ckpt_dict['model_state_dict'])
         self.param_version += 1
         if optimizer:
@@ -49,12 +48,6 @@ class BaseModel(FlatNet):
 
     def count_params(self):
         return FlatNet.count_params(self)
-
-    def sync_grads(self):
-        """Data-parallel gradient exchange: ONE all-reduce (mean) of the network's flat gradient
-        slab over RCCL/xGMI (pattern: DistributedDataParallel in stylegan2/train_ffhq.py:572-585)."""
-        from diagan.trainer import distributed as dist
-        dist.all_reduce_mean_(self.flat_grads)
 
 
 class BaseGenerator(BaseModel):
@@ -146,7 +139,7 @@ class BaseGenerator(BaseModel):
         # reference -- zeroed at the next D step before use -- so they are not computed), then G
         g_img = netD.backward_nhwc(dctx, dlogit, need_wgrad=False, need_gx=True)
         self.backward_nhwc(gctx, g_img)
-        self.sync_grads()
+        self.sync_grads(optG)
         optG.step()
         log_data.add_metric('errG', errG[0], group='loss')
         return log_data
@@ -207,8 +200,13 @@ class BaseDiscriminator(BaseModel):
             out3, d_real, d_fake = E.loss_dis(out_real, out_fake, self.loss_type, gold=self.use_gold)
             self.backward_nhwc(ctx_r, d_real, need_wgrad=True, need_gx=False)
             self.backward_nhwc(ctx_f, d_fake, need_wgrad=True, need_gx=False)
-        self.sync_grads()
-        optD.step()
+        # defer_step (LogTrainer, phase 2 under data parallelism): the all-reduce of this update stays in flight and
+        # the caller runs optD.step() after the NEXT network's update has been issued (D and D_drs are independent,
+        # diagan-pkg/diagan/trainer/trainer.py:250-277)
+        defer = bool(kwargs.get('defer_step', False))
+        self.sync_grads(optD, async_op=defer)
+        if not defer:
+            optD.step()
         # device scalars: no host sync here (the reference calls .item() three times per D step)
         log_data.add_metric('errD', out3[0], group='loss')
         log_data.add_metric('D(x)', out3[1], group='prob')

@@ -398,7 +398,7 @@ class SNBatch:
         from diagan import _native as nat
         self.net, self.layers, self.nat = net, layers, nat
         dev = net.flat_params.device
-        self.flat_id = id(net.flat_params)
+        self.slab_generation = net.slab_generation
         desc = np.dtype([('p', np.uint64, 9), ('i', np.int32, 6)])
         self.tables = []
         f32 = dict(dtype=torch.float32, device=dev)
@@ -453,7 +453,8 @@ class SNBatch:
         self.pair_version = None
 
     def stale(self):
-        return self.flat_id != id(self.net.flat_params)
+        self.net.flat_params                      # (builds the slabs if they do not exist yet)
+        return self.slab_generation != self.net.slab_generation
 
     def run_pair(self, training, need_dgrad):
         """Power iterations of BOTH forwards (u is advanced twice, as two sequential forwards would),
@@ -487,12 +488,13 @@ class WgradBatch:
         self.entries = {}        # (layer, slot) -> dict
         self.launched = {}       # slot -> list of layers launched in the current pass
         self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, total_blocks, any_sn)
-        self.flat_id = None
+        self.slab_generation = None
 
     def _entry(self, layer, slot, M, segments=1, dy_shape=None):
-        if self.flat_id != id(self.net.flat_grads):          # gradient slab was re-allocated
+        self.net.flat_grads
+        if self.slab_generation != self.net.slab_generation:          # gradient slab was re-allocated
             self.entries.clear(), self.tables.clear()
-            self.flat_id = id(self.net.flat_grads)
+            self.slab_generation = self.net.slab_generation
         e = self.entries.get((layer, slot))
         if e is None or e['M'] != M:
             g = layer.geom
@@ -568,6 +570,9 @@ class FlatNet(nn.Module):
     def __init__(self):
         super().__init__()
         self.param_version = 0        # bumped whenever parameters change (optimizer step, load)
+        self.slab_generation = 0      # bumped whenever the flat slabs are re-allocated: descriptor tables that bake
+                                      # raw pointers (SNBatch, WgradBatch) compare THIS, not id() of the tensors (ids
+                                      # are recycled once the old slab is freed)
         self._flat = None
         self._flat_grad = None
         object.__setattr__(self, 'wgrad_batch', WgradBatch(self))
@@ -596,6 +601,7 @@ class FlatNet(nn.Module):
             off += _r4(n)
         self._flat, self._flat_grad = flat, grad
         self.param_version += 1
+        self.slab_generation += 1
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn)
@@ -625,6 +631,23 @@ class FlatNet(nn.Module):
     @property
     def device(self):
         return next(self.parameters()).device
+
+    def sync_grads(self, optimizer=None, async_op=False):
+        """Data-parallel gradient exchange: ONE all-reduce of the network's flat gradient slab over RCCL/xGMI
+        (pattern: DistributedDataParallel in stylegan2/train_ffhq.py:572-585).  With the network's FusedAdam given, the
+        ranks exchange the SUM and the optimiser applies 1/W as it reads the gradient (no extra pass over the slab);
+        async_op leaves the collective in flight on the backend's stream until `optimizer.step()` waits for it, so the
+        next update's forward / backward (phase 2: D_drs after D) runs beside it."""
+        from diagan.trainer import distributed as dist
+        world = dist.get_world_size()
+        if world == 1:
+            return
+        if optimizer is not None and hasattr(optimizer, 'grad_scale'):
+            optimizer.grad_scale = 1.0 / world
+            work = dist.all_reduce_sum_(self.flat_grads, async_op=async_op)
+            optimizer.pending = work if async_op else None
+        else:
+            dist.all_reduce_mean_(self.flat_grads)
 
     def export_grads(self):
         """Gradients in the reference's tensor shapes, keyed like state_dict() (tests, debugging)."""

@@ -10,7 +10,7 @@ from diagan import _native as nat
 P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, I, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
-nat.register("diagan_conv_gemm_pick_cfg", [I, I, I])
+nat.register("diagan_conv_gemm_pick_cfg", [I, I, I, I])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_gemm_tile_cols", [I])
 nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
@@ -34,11 +34,17 @@ nat.register("diagan_get_mfma_mode", [])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
-TILE_NAMES = {1: "conv_gemm_kernel<128,128,2,2,32,{pro}>", 2: "conv_gemm_kernel<128,64,2,2,32,{pro}>",
-              3: "conv_gemm_kernel<64,64,2,2,32,{pro}>", 4: "conv_gemm_kernel<128,64,4,1,32,{pro}>",
-              5: "conv_gemm_kernel<256,64,4,1,32,{pro}>", 6: "conv_gemm_kernel<64,64,2,2,64,{pro}>",
-              7: "conv_gemm_kernel<64,64,2,2,32,{pro},false,false,true>",
-              8: "conv_gemm_kernel<128,64,2,2,32,{pro},false,false,true>"}
+# kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO, X6, STAMP, FP; PRO = -1: run-time mode)
+TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3: (64, 64, 2, 2, 32, False),
+               4: (128, 64, 4, 1, 32, False), 5: (256, 64, 4, 1, 32, False), 6: (64, 64, 2, 2, 64, False),
+               7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True)}
+
+
+def gemm_kernel_name(cfg, mode):
+    bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
+    if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
+        return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
+    return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,false,{'true' if fp else 'false'}>"
 
 
 class KernelTimer:
@@ -174,19 +180,15 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         # statistics from the epilogue always win over split-K + a separate reduction pass over y (G-32 block2,
         # M=4096: 60 us unsplit with statistics vs 54 + 6 (second stage) + 20 (column reduction) us)
         M = B * Ho * Wo
-        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, Kp)
+        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, Kp, 0)
         bm = nat.fn("diagan_conv_gemm_tile_rows")(cfg)
         tiles = (M + bm - 1) // bm
         stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
         tile_cfg = cfg
     kname = None
     if TIMER is not None:
-        kname = TILE_NAMES[tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp)].format(pro=mode)
-        if get_mfma_mode() == 1 and kname.startswith(("conv_gemm_kernel<128,128", "conv_gemm_kernel<64,64,2,2,32")):
-            # bf16x6 (the two square tiles): 16-wide K-steps, prologue modes 0-2 specialised, X6 = true
-            kname = kname.replace(",32,", ",16,").replace(">", ",true>")
-            if mode > 2:
-                kname = kname.replace(f",{mode},true>", ",-1,true>")
+        allow = 0 if want_stats else 1
+        kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp, allow), mode)
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,

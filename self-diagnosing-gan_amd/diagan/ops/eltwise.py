@@ -12,7 +12,8 @@ nat.register("diagan_tanh_fwd", [P, P, I64, P])
 nat.register("diagan_tanh_bwd", [P, P, P, I64, P])
 nat.register("diagan_colred_workspace", [I64, I])
 nat.register("diagan_bn_stats", [P, I64, I, P, P, F, F, P, P, I, P, P, P, P, P, P])
-nat.register("diagan_bn_stats_fused", [P, I, I64, I, P, P, F, F, P, P, P, P, P, P, I, P])
+nat.register("diagan_bn_stats_fused", [P, I, I64, I, P, P, F, F, P, P, P, P, P, P, I, P, I64, P])
+nat.register("diagan_bn_stats_fused_splits", [I, I, I])
 nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, I, F, P, P, P, I, P, P, P, P, P])
 nat.register("diagan_act_fwd", [P, P, P, F, P, P, I64, I, P])
 nat.register("diagan_act_bwd", [P, P, F, P, P, I64, P])
@@ -29,7 +30,7 @@ nat.register("diagan_head_bwd", [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P]
 nat.register("diagan_add", [P, P, P, I64, P])
 nat.register("diagan_loss_dis", [P, I, P, I, I, I, P, P, P, P])
 nat.register("diagan_loss_gen", [P, I, I, I, P, P, P])
-nat.register("diagan_adam_step", [P, P, P, P, I64, F, F, F, F, F, F, P])
+nat.register("diagan_adam_step", [P, P, P, P, I64, F, F, F, F, F, F, F, P])
 nat.register("diagan_adam_step_dev", [P, P, P, P, I64, P, P])
 
 LOSS_TYPES = {'gan': 0, 'ns': 1, 'hinge': 2, 'wasserstein': 3}
@@ -126,9 +127,11 @@ def bn_stats_fused(partials, tiles, M, gamma, beta, running_mean, running_var, e
         raise RuntimeError(f"bn_stats_fused: {tiles} tiles / {M} rows do not split into {groups} groups")
     tg, Mg = tiles // groups, M // groups
     ctx = _bn_ctx(C, Mg, True, groups, group_imgs, gamma.device)
+    splits = nat.fn("diagan_bn_stats_fused_splits")(tg, C, groups)
+    ws = torch.empty(groups * splits * 2 * C, dtype=torch.float64, device=gamma.device) if splits > 1 else None
     nat.call("diagan_bn_stats_fused", ptr(partials), tg, Mg, C, ptr(gamma), ptr(beta), eps, momentum,
              ptr(running_mean), ptr(running_var), ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale), ptr(ctx.shift), groups,
-             st())
+             ptr(ws), 0 if ws is None else ws.numel(), st())
     return ctx
 
 
@@ -259,15 +262,16 @@ def loss_gen(out_fake, loss_type, k=None, need_grad=True):
     return out1, d_fake
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
-    nat.call("diagan_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, st())
+    nat.call("diagan_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt,
+             grad_scale, st())
 
 
-def adam_hyper_row(lr, beta1, beta2, eps, step):
-    """the six floats diagan_adam_step_dev reads: same host arithmetic as adam_step"""
-    return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, (1.0 - beta2 ** step) ** 0.5]
+def adam_hyper_row(lr, beta1, beta2, eps, step, grad_scale=1.0):
+    """the eight floats diagan_adam_step_dev reads: same host arithmetic as adam_step"""
+    return [lr, beta1, beta2, eps, 1.0 - beta1 ** step, (1.0 - beta2 ** step) ** 0.5, grad_scale, 0.0]
 
 
 def adam_step_dev(p, g, m, v, hyper_row):

@@ -22,6 +22,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._capturing = False
         self._cursor = 0
         self._updates_per_replay = 0
+        # data parallelism: gradients arrive as the SUM over W ranks (distributed.all_reduce_sum_); the 1/W of the mean
+        # is applied as the kernel reads the gradient.  `pending` is an optional async collective to wait for first.
+        self.grad_scale = 1.0
+        self.pending = None
 
     def _ensure_state(self):
         flat = self.net.flat_params
@@ -37,6 +41,9 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         self._ensure_state()
         g = self.param_groups[0]
+        if self.pending is not None:         # the gradient exchange issued asynchronously by BaseModel.sync_grads
+            self.pending.wait()
+            self.pending = None
         if self._capturing:
             # stream capture: the launch reads its hyper-parameters from device row `cursor`, which
             # `before_replay` fills with the values of the update it will stand for
@@ -47,13 +54,13 @@ class FusedAdam(torch.optim.Optimizer):
         else:
             self._step += 1
             E.adam_step(self.net.flat_params, self.net.flat_grads, self._m, self._v, g['lr'], g['betas'][0],
-                        g['betas'][1], g['eps'], self._step)
+                        g['betas'][1], g['eps'], self._step, grad_scale=self.grad_scale)
         self.net.param_version += 1
 
     # ---- hipGraph support (diagan/utils/graph.py) -------------------------------------------------------------
     def capture_begin(self, max_updates=64):
         self._ensure_state()
-        self._hyper_dev = torch.zeros((max_updates, 6), dtype=torch.float32, device=self.net.flat_params.device)
+        self._hyper_dev = torch.zeros((max_updates, 8), dtype=torch.float32, device=self.net.flat_params.device)
         self._capturing, self._cursor = True, 0
 
     def capture_end(self):
@@ -67,7 +74,8 @@ class FusedAdam(torch.optim.Optimizer):
         k = self._updates_per_replay
         if k == 0:
             return
-        rows = [E.adam_hyper_row(g['lr'], g['betas'][0], g['betas'][1], g['eps'], self._step + 1 + i) for i in range(k)]
+        rows = [E.adam_hyper_row(g['lr'], g['betas'][0], g['betas'][1], g['eps'], self._step + 1 + i, self.grad_scale)
+                for i in range(k)]
         self._hyper_dev[:k].copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=False)
         self._step += k
 

@@ -53,6 +53,9 @@ COMMON = [
     (("--logit_save_steps",), dict(default=100, type=int)),
     # extensions (no reference counterpart)
     (("--num_data",), dict(default=None, type=int, help="size of the synthetic dataset")),
+    (("--rank_noise",), dict(action="store_true", help="data parallel: seed every rank's DEVICE generator with seed + rank "
+                                                      "(distinct latents / noise maps per rank); default: the reference's "
+                                                      "behaviour, one seed for all ranks (stylegan2/train_ffhq.py:497)")),
     (("--log_every",), dict(default=100, type=int)),
     (("--checkpoint_every",), dict(default=5000, type=int)),
 ]
@@ -123,6 +126,7 @@ def main(phase, argv=None, dataset=None):
     g_ema.eval()
     TR.accumulate(g_ema, generator, 0)
     g_optim, d_optim = TR.make_optimizers(generator, discriminator, args.lr, args.g_reg_every, args.d_reg_every)
+    dist.seed_device_per_rank(args.seed, enable=args.rank_noise)       # after the (identically seeded) initialisation
     extra = {}
     ckpt_path = args.ckpt
     if phase == 2:

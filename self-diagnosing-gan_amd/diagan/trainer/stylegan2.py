@@ -184,8 +184,8 @@ class StyleGAN2Trainer:
     def _step(net, optimizer, loss):
         net.zero_grad()
         loss.backward()
-        dist.all_reduce_mean_(net.flat_grads)           # DDP's gradient averaging: one collective per step
-        optimizer.step()
+        net.sync_grads(optimizer)
+        optimizer.step()                                # DDP's gradient averaging: one collective per step
 
     def _d_update(self, D, optim, real_img, fake_img, regularize, tag, losses):
         a = self.args

@@ -45,7 +45,7 @@ class LogTrainer:
                  netG_ckpt_file=None, netD_ckpt_file=None, print_steps=1, vis_steps=500, log_steps=50,
                  save_steps=5000, flush_secs=30, logit_save_steps=500, amp=False, save_logits=True, topk=False,
                  gold=False, gold_step=None, save_logit_after=0, stop_save_logit_after=100000,
-                 save_eval_logits=True, compat_fetch_quirk=False):
+                 save_eval_logits=True, compat_fetch_quirk=False, logit_eval_batch=1024):
         given = dict(locals())
         given.pop('self')
         for name in self._AT_LEAST_ONE:
@@ -121,12 +121,32 @@ class LogTrainer:
         loader, shard = self._eval_loader()
         if eval_mode:
             netD.eval()
+        # The pass walks the TRAINING loader (trainer.py:143), whose batch of 64 leaves the D forward launch-bound
+        # (84 000 images/s); the loader batches are therefore gathered into evaluation batches of >= `logit_eval_batch`
+        # images before the forward.  Placement is by index (`scatter`), so the record is unchanged.  Eval mode only: in
+        # train mode every forward advances spectral norm's power iteration (and DCGAN's BatchNorm / dropout depend on
+        # the batch), so the train-mode record of the colour-MNIST scripts keeps the loader's batches.
+        group = self.logit_eval_batch if eval_mode else 0
+        pend_x, pend_i, pending = [], [], 0
+
+        def flush():
+            nonlocal pend_x, pend_i, pending
+            if not pend_x:
+                return
+            x = pend_x[0] if len(pend_x) == 1 else torch.cat(pend_x)
+            logit = netD(x)
+            if type(logit) is tuple:
+                logit = logit[0]
+            record.scatter(row, pend_i[0] if len(pend_i) == 1 else torch.cat(pend_i), logit.view(-1))
+            pend_x, pend_i, pending = [], [], 0
         with torch.no_grad():
             for data, targets, _, idx in loader:
-                logit = netD(data.to(self.device, non_blocking=True))
-                if type(logit) is tuple:
-                    logit = logit[0]
-                record.scatter(row, idx, logit.view(-1))
+                pend_x.append(data.to(self.device, non_blocking=True))
+                pend_i.append(idx)
+                pending += data.shape[0]
+                if pending >= group:
+                    flush()
+            flush()
         netD.train()
         record.check_bounds()
         if shard is not None:                     # one all-gather of the contiguous shards
@@ -190,10 +210,14 @@ class LogTrainer:
         prefetch = getattr(self.netG, 'prefetch_fakes', None)       # optional part of the generator protocol
         if prefetch is not None:
             prefetch(self.n_dis * (2 if self.train_drs else 1), self.dataloader.batch_size, device=self.device)
+        # data parallel phase 2: D and D_drs are independent (reference trainer.py:250-277), so D's gradient all-reduce
+        # stays in flight under D_drs's forward / backward and D's Adam step follows it
+        overlap = self.train_drs and self.world > 1
         for i in range(self.n_dis):
             streams['main'], batch = self._fetch_data(iter_dataloader=streams['main'])
+            extra = dict(defer_step=True) if overlap else {}
             log = self.netD.train_step(real_batch=batch, netG=self.netG, optD=self.optD, log_data=log,
-                                       global_step=step, device=self.device, scaler=None)
+                                       global_step=step, device=self.device, scaler=None, **extra)
             self.events.append((step, 'D'))
             if self.train_drs:
                 streams['drs'], batch_drs = self._fetch_data(iter_dataloader=streams['drs'],
@@ -201,6 +225,8 @@ class LogTrainer:
                 log = self.netD_drs.train_step(real_batch=batch_drs, netG=self.netG, optD=self.optD_drs,
                                                log_data=log, global_step=step, device=self.device, scaler=None)
                 self.events.append((step, 'D_drs'))
+            if overlap:
+                self.optD.step()
         log = self.netG.train_step(real_batch=batch, netD=self.netD, optG=self.optG, global_step=step, log_data=log,
                                    device=self.device, scaler=None)
         self.events.append((step, 'G'))

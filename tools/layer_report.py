@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 rows = sorted(C.TIMER.by_shape().items(), key=lambda kv: -kv[1]['seconds'])
 tot = sum(v['seconds'] for _, v in rows)
 print(f"total GEMM time {tot/3*1e3:.2f} ms/step")
-for k, v in rows[:40]:
+for k, v in rows[:100]:
     print(f"{k[0]:32s} M={k[1]:7d} N={k[2]:5d} K={k[3]:5d} {k[4]:16s} n/step {v['launches']/3:5.1f} "
           f"avg {v['seconds']/v['launches']*1e6:7.1f} us  {v['flop']/v['seconds']/1e12:6.1f} TF  "
           f"share {v['seconds']/tot:5.1%}")

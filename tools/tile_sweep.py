@@ -96,7 +96,7 @@ def main():
                 torch.cuda.synchronize()
                 times[var].append(s.elapsed_time(e) / iters * 1e-3)
         nat.call("diagan_conv_gemm_tune", 0, -1, 0)
-        auto = nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, geom.Kp)
+        auto = nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, geom.Kp, 1)
         best = None
         for var, _, err in runs:
             cfg, ks, fl, dl = var
