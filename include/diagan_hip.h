@@ -122,9 +122,17 @@ int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64
  * no stat_partials) */
 int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split);
 /* Tile configurations: 1 = 128x128, 2 = 128x64 (waves 2x2), 3 = 64x64, 4 = 128x64 (waves 4x1), 5 = 256x64,
- * 6 = 64x64 with 64-wide K-steps (Kp % 64 == 0), 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments.  Rows / columns of one (0 = unknown configuration). */
+ * 6 = 64x64 with 64-wide K-steps (Kp % 64 == 0), 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments,
+ * 9 = Winograd (below).  Rows / columns of one (0 = unknown configuration). */
 int diagan_conv_gemm_tile_rows(int cfg);
 int diagan_conv_gemm_tile_cols(int cfg);
+/* tile_cfg 9: Winograd F(2x2,3x3) (csrc/conv_wino.hip) for 3x3 / stride 1 / pad 1 layers and their data-gradients --
+ * same arguments, prologues and epilogues as the implicit GEMM, 16/36 of its multiply-accumulates; the weights are
+ * transformed into splitk_ws (16 * roundup(Co, 64) * Ci floats) by a small kernel in front of the launch.  fp32
+ * throughout; results differ from the implicit GEMM by rounding only (~1e-6 relative).  256 pixel rows x 64 columns
+ * per workgroup (stat_partials / pro_group_rows granularity).  Returns 1 when the geometry qualifies. */
+int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                               int up);
 /* Diagnostics and tuning sweeps only (tools/stamp_report.py, tools/bench_conv.py; no reference counterpart, never
  * called by the product path).  While a stamp buffer is set, diagan_conv_gemm launches a diagnostic build of its
  * kernel (prologue modes 0 and 1) in which every workgroup records, at slot blockIdx.y*gridDim.x + blockIdx.x,

@@ -72,6 +72,37 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   return (t + ((n - t) >> 1)) >> (f.shift - 1);
 }
 
+// Arguments of the forward / data-gradient kernels (conv_gemm.hip: implicit GEMM; conv_wino.hip: Winograd F(2x2,3x3))
+struct ConvGemmArgs {
+  const float* x;         // gathered tensor, NHWC [B,Hi,Wi,Ci]
+  const float* w;         // packed weights [Co][Kp]
+  float* y;               // output NHWC [B,Ho,Wo,Co]
+  const float* bias;      // [Co] or null
+  const float* residual;  // same shape as y or null: y += residual
+  const float* mask_src;  // same shape as y or null: y = mask_src > 0 ? y : lrelu_slope*y
+  const float* pro_scale; // [Ci] for PRO_AFFINE*
+  const float* pro_shift;
+  int pro_group_rows;     // > 0: rows [g*pro_group_rows, (g+1)*pro_group_rows) use pro_scale/shift + g*Ci (several
+                          // independently normalised batches -- BatchNorm statistics per group -- in ONE GEMM)
+  float mask_slope;       // 0 for ReLU backward, 0.2 for LeakyReLU backward
+  float out_scale;        // multiplies the accumulator before bias/residual (1.0 normally)
+  const float* scale0;    // optional device scalars: rows m < scale_split use *scale0, the others *scale1
+  const float* scale1;    // (two forwards with different spectral-norm sigmas batched into one GEMM)
+  int scale_split;
+  float* stat_partials;   // optional [tiles_m][2][Co]: per-tile column sums of y and y*y (fused BatchNorm statistics)
+  float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel)
+  int ksplit;             // number of K splits (gridDim.y); 1 = no split
+  int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
+  int pro_mode;
+  int M;                  // B*Ho*Wo
+  ConvGeom g;
+  FastDiv dWo, dHo;       // pixel index -> (b, oy, ox) without integer division
+  unsigned long long* stamps;   // diagnostic build only (STAMP kernels): [workgroups][8] cycle / real-time stamps
+  int tune;               // tuning sweeps: bit 0 = raised wave priority while the loader state is set up and the first
+                          // tile staged, bit 1 = raised priority in the epilogue (a new / finishing wave otherwise gets
+                          // the vector-issue slots its older MFMA-bound neighbours leave over)
+};
+
 // Bijective XCD-aware remap of a linear workgroup id (cdna guide T1): consecutive logical tiles
 // land on the same XCD (= same L2), so neighbouring tiles share halo rows and weight panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -27,38 +27,13 @@ extern "C" int diagan_get_mfma_mode(void);
 extern "C" int diagan_conv_gemm_tile_rows(int cfg);
 extern "C" int diagan_conv_gemm_tile_cols(int cfg);
 extern "C" int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
+extern "C" int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                          int off, int up);
 
 namespace diagan {
+int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
+long wino_ws_floats(int Co, int Ci);
 
-struct ConvGemmArgs {
-  const float* x;         // gathered tensor, NHWC [B,Hi,Wi,Ci]
-  const float* w;         // packed weights [Co][Kp]
-  float* y;               // output NHWC [B,Ho,Wo,Co]
-  const float* bias;      // [Co] or null
-  const float* residual;  // same shape as y or null: y += residual
-  const float* mask_src;  // same shape as y or null: y = mask_src > 0 ? y : lrelu_slope*y
-  const float* pro_scale; // [Ci] for PRO_AFFINE*
-  const float* pro_shift;
-  int pro_group_rows;     // > 0: rows [g*pro_group_rows, (g+1)*pro_group_rows) use pro_scale/shift + g*Ci (several
-                          // independently normalised batches -- BatchNorm statistics per group -- in ONE GEMM)
-  float mask_slope;       // 0 for ReLU backward, 0.2 for LeakyReLU backward
-  float out_scale;        // multiplies the accumulator before bias/residual (1.0 normally)
-  const float* scale0;    // optional device scalars: rows m < scale_split use *scale0, the others *scale1
-  const float* scale1;    // (two forwards with different spectral-norm sigmas batched into one GEMM)
-  int scale_split;
-  float* stat_partials;   // optional [tiles_m][2][Co]: per-tile column sums of y and y*y (fused BatchNorm statistics)
-  float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel)
-  int ksplit;             // number of K splits (gridDim.y); 1 = no split
-  int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
-  int pro_mode;
-  int M;                  // B*Ho*Wo
-  ConvGeom g;
-  FastDiv dWo, dHo;       // pixel index -> (b, oy, ox) without integer division
-  unsigned long long* stamps;   // diagnostic build only (STAMP kernels): [workgroups][8] cycle / real-time stamps
-  int tune;               // tuning sweeps: bit 0 = raised wave priority while the loader state is set up and the first
-                          // tile staged, bit 1 = raised priority in the epilogue (a new / finishing wave otherwise gets
-                          // the vector-issue slots its older MFMA-bound neighbours leave over)
-};
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -659,6 +634,11 @@ DIAGAN_API int diagan_get_mfma_mode(void) {
   return g_mfma_x6;
 }
 
+static bool split128_enabled() {
+  static const bool on = getenv("DIAGAN_SPLIT128") && atoi(getenv("DIAGAN_SPLIT128")) > 0;
+  return on;
+}
+
 // Tile selection used when tile_cfg == 0.  Measured on MI355X (tools/tile_sweep.py, profiles/r02_tile_sweep.md):
 //  * 64-column outputs (the 64x64-resolution blocks of SNGAN-64): a 256x64 tile whose waves own 64x64 sub-tiles needs
 //    half the LDS fragment reads per MFMA of the 64x64 tile and holds a higher clock (2.2-2.3 vs 2.1 GHz): +3-5 %;
@@ -678,8 +658,7 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split)
   if (!x6) {
     // (in a training step this is within box-to-box noise of the 64x64 tile -- tools/layer_report.py, 32.8 vs 33.2 ms of
     //  GEMM time per SNGAN-64 step -- so it stays opt-in: DIAGAN_SPLIT128=1)
-    static const bool split128 = getenv("DIAGAN_SPLIT128") && atoi(getenv("DIAGAN_SPLIT128")) > 0;
-    if (split128 && allow_split && (Co & 127) == 0 && t128 <= 256 && diagan_conv_gemm_pick_ksplit(M, Co, Kp, 1) > 1) return 1;
+    if (split128_enabled() && allow_split && (Co & 127) == 0 && t128 <= 256 && diagan_conv_gemm_pick_ksplit(M, Co, Kp, 1) > 1) return 1;
     if (Co <= 64 && Kp >= 256) return M >= 65536 ? 5 : (M >= 32768 ? 8 : 7);
   }
   // Blocks run a whole K loop, so a partially filled last round of blocks costs a full round
@@ -709,7 +688,8 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   if (forced > 0 && !(Co & 3)) return forced < Kp / 64 ? forced : (Kp / 64 > 0 ? Kp / 64 : 1);
   if (Co & 3) return 1;
   const int nk = Kp / 32;
-  if (cfg == 1) {                      // 128x128 tiles on problems with at most one tile per CU and a long K loop
+  if (cfg == 1) {                      // 128x128 tiles on problems with at most one tile per CU and a long K loop (opt-in)
+    if (!split128_enabled()) return 1;
     const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128);
     if (diagan_get_mfma_mode() == 1 || t128 > 256 || nk < 64) return 1;
     int s = t128 <= 128 ? 4 : 2;
@@ -791,6 +771,14 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     const int ks = diagan_conv_gemm_pick_ksplit(a.M, Co, Kp, cfg);
     if (ks > 1 && (int64_t)ks * a.M * Co <= splitk_ws_floats) a.ksplit = ks;
   }
+  if (cfg == 9) {
+    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up),
+               "conv_gemm: tile_cfg 9 (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0");
+    DG_REQUIRE(splitk_ws && splitk_ws_floats >= wino_ws_floats(Co, Ci),
+               "conv_gemm: tile_cfg 9 needs %ld floats of workspace for the transformed weights", wino_ws_floats(Co, Ci));
+    a.ksplit = 1;
+    return launch_wino(a, splitk_ws, st);
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true, true>(a, st);
     case 2: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
@@ -806,10 +794,18 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 2: case 4: case 8: return 128; case 3: case 6: case 7: return 64; case 5: return 256; default: return 0; }
+  switch (cfg) { case 1: case 2: case 4: case 8: return 128; case 3: case 6: case 7: return 64; case 5: case 9: return 256; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: return 128; case 2: case 3: case 4: case 5: case 6: case 7: case 8: return 64; default: return 0; }
+  switch (cfg) { case 1: return 128; case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: return 64; default: return 0; }
+}
+
+// Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
+// such a layer: dr=-1, off=+1), same spatial size in and out, even H and W, input channels a multiple of 8.
+DIAGAN_API int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                          int off, int up) {
+  return R == 3 && S == 3 && sy == 1 && up == 1 && ((dr == 1 && off == -1) || (dr == -1 && off == 1)) && Hi == Ho &&
+         Wi == Wo && !(Ho & 1) && !(Wo & 1) && (Ci & 7) == 0 && (Co & 3) == 0 && diagan_get_mfma_mode() == 0;
 }
 
 // Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.

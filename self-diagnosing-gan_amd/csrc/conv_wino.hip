@@ -1,0 +1,364 @@
+// Winograd F(2x2, 3x3) forward / data-gradient convolution on the fp32 matrix cores.
+//
+// Replaces the same reference ops as conv_gemm.hip (F.conv2d and its input gradient in mimicry's GBlock / DBlock,
+// selected at diagan-pkg/diagan/models/predefined_models.py:19-21,38-40,57-59,76-78) for the 3x3 / stride 1 / pad 1
+// layers, which carry ~85 % of the SNGAN FLOP:  Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A  per 2x2 output tile --
+// 16 multiply-accumulates per tile, output and input channel instead of 36, i.e. 2.25x fewer MFMA cycles than the
+// implicit GEMM for the same result (fp32 throughout; transform coefficients 0, +-1, 1/2, 1/4).
+//
+// One workgroup = 512 threads = 8 waves = 64 tiles (256 output pixels) x 64 output channels, one per CU (128 KB of LDS).
+//   * K loop over input channels in steps of 8.  Per step the 16 "frequency" GEMMs  M_f[64 x 64] += V_f[64 x 8] U_f[64 x 8]^T
+//     run as v_mfma_f32_32x32x2_f32: wave w owns frequencies 2w, 2w+1 (2 x 2x2 accumulator tiles = 128 registers).
+//   * U (transformed weights) is produced once per launch by wino_weight_kernel in exactly the LDS image order
+//     [64-col block][K-step][f][k-quad][64 cols][4], so a K-step's 32 KB go global -> LDS by LDS-DMA, no registers.
+//   * V (transformed input): thread (tile, channel quad, patch row r) loads its 4 pixels x 4 channels (prologue applied
+//     here), transforms along the row, exchanges with its quad by DPP for the column transform and writes its 4
+//     frequencies (r, j) to LDS.  Planes are [f][k-quad][tile][4 channels]; the tile slot is XOR-ed with (q | r << 1) so the
+//     ds_write_b128 of a quad's 8 lanes hit 8 different bank groups; fragment reads stay conflict-free.
+//   * epilogue: the 16 frequencies of a (tile, channel) live in 8 different waves, so they cross LDS once (two halves of
+//     32 tiles, 128 KB each): every thread then owns (tile, 4 channels), applies A^T . A and the usual epilogue
+//     (per-half 1/sigma, bias, residual, ReLU-backward mask, BatchNorm statistics) and stores four 16-byte pixels.
+//
+// Roofline: MFMA fp32; the kernel executes 16/36 of the direct convolution's multiply-accumulates.
+#include "conv_common.h"
+#include <type_traits>
+
+namespace diagan {
+
+// U[f][co][ci] = (G g G^T)[i][j], f = 4 i + j, written in the LDS image order (see above).  flip: the data-gradient of a
+// stride-1 convolution is the correlation with the taps reversed.
+__global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                         int Kp, int flip) {
+  const int c4 = blockIdx.x, co = blockIdx.y * 64 + threadIdx.x, c = c4 * 4;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+      g[r][s] = co < Co ? *reinterpret_cast<const f32x4*>(w + (long)co * Kp + (rr * 3 + ss) * Ci + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  f32x4 t[4][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    t[0][s] = g[0][s];
+    t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+    t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+    t[3][s] = g[2][s];
+  }
+  const int ks = c >> 3, kq = (c >> 2) & 1;
+  float* base = ug + ((long)blockIdx.y * (Ci >> 3) + ks) * (16 * 2 * 64 * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 u[4];
+    u[0] = t[i][0];
+    u[1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    u[2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    u[3] = t[i][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f32x4*>(base + (((i * 4 + j) * 2 + kq) * 64 + threadIdx.x) * 4) = u[j];
+  }
+}
+
+constexpr int WT = 64;                 // tiles per workgroup
+constexpr int WN = 64;                 // output channels per workgroup
+constexpr int WK = 8;                  // input channels per K-step
+constexpr int W_PLANE = 64 * 4;        // floats of one (f, k-quad) plane: 64 rows x 4 channels
+constexpr int W_STAGE = 2 * 32 * W_PLANE;   // V planes + U planes of one stage (floats)
+
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 32 planes | U 32 planes] = 128 KB
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.Co + WN - 1) / WN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int t0 = (tile / tiles_n) * WT, nb = tile % tiles_n, n0 = nb * WN;
+  const int TW = g.Wo >> 1, TH = g.Ho >> 1;
+  const int MT = g.B * TH * TW;                         // 2x2 output tiles in all
+  const int nk = g.Ci / WK;
+  const bool affine = PRO == PRO_AFFINE_RELU || PRO == PRO_AFFINE;
+
+  // ---- loader role: (tile lt, channel quad q, patch row r); the 4 lanes of a quad hold the 4 rows of one patch ----
+  const int lr = tid & 3, lq = (tid >> 2) & 1, lt = tid >> 3;
+  unsigned off[4], inv[4];                              // byte offsets of this row's 4 patch pixels; inv: bit 31 if outside
+  float keep[4];
+  {
+    const int gt = t0 + lt;
+    const bool tv = gt < MT;
+    const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);          // dWo: divisor TW
+    const int tx = (tv ? gt : 0) - (int)q1 * TW;
+    const unsigned b = fdiv(q1, a.dHo);                                // dHo: divisor TH
+    const int ty = (int)q1 - (int)b * TH;
+    const int iy = 2 * ty - 1 + lr, ix0 = 2 * tx - 1;
+    const bool rv = tv && iy >= 0 && iy < g.Hi;
+    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + lq * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
+      off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0u;
+      inv[c] = ok ? 0u : 0x80000000u;                   // beyond num_records (< 2 GiB): the hardware returns zeros
+      keep[c] = ok ? 1.f : 0.f;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const int pro_group_off = a.pro_group_rows > 0 ? ((t0 * 4) / a.pro_group_rows) * g.Ci : 0;
+  // column-transform coefficients of this lane's row: V[r] = so * t[r] + sc * t[partner], partner by quad_perm [2,2,1,1]
+  const float so = lr == 3 ? -1.f : 1.f, sc = (lr == 1 || lr == 3) ? 1.f : -1.f;
+  // LDS slot of this thread's 4 output planes: plane p = ((r * 4 + j) * 2 + q), slot = tile ^ (q | r << 1)
+  const int vslot = (lt ^ (lq | (lr << 1))) * 4;
+
+  const float* ublock = ug + (long)nb * nk * (32 * W_PLANE);
+
+  f32x4 ra[4], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  auto issue_loads = [&](int kk, int stage) {
+    // U: 32 planes of 1 KB, 4 per wave, straight into LDS (lane-linear image == the global order)
+    float* us = smem + stage * W_STAGE + 32 * W_PLANE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave * 4 + i;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(ublock + (long)kk * (32 * W_PLANE) + p * W_PLANE + lane * 4),
+          (__attribute__((address_space(3))) void*)(us + p * W_PLANE), 16, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (off[c] + (unsigned)kk * (WK * 4u)) | inv[c], 0, 0));
+    if (affine) {
+      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + pro_group_off + kk * WK + lq * 4);
+      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + kk * WK + lq * 4);
+    }
+  };
+  auto transform_store = [&](int stage) {
+    float* vs = smem + stage * W_STAGE;
+    f32x4 d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 v = ra[c];
+      if (PRO != PRO_NONE) {
+        if (affine) v = v * psc + psh;
+        if (PRO == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        } else if (PRO != PRO_AFFINE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (affine) v *= keep[c];                      // padding is zero AFTER the transform
+      }
+      d[c] = v;
+    }
+    f32x4 t[4];
+    t[0] = d[0] - d[2];
+    t[1] = d[1] + d[2];
+    t[2] = d[2] - d[1];
+    t[3] = d[1] - d[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (scalar copy first: a bit_cast of the vector element itself is miscompiled to element 0, as in conv_gemm.hip)
+        const float own = t[j][e];
+        const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x5A, 0xF, 0xF, false);
+        o[e] = fmaf(so, own, sc * __int_as_float(other));
+      }
+      *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * 2 + lq) * W_PLANE + vslot) = o;
+    }
+  };
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[fl][i][j][e] = 0.f;
+
+  const int fi = lane & 31, fh = lane >> 5;
+  issue_loads(0, 0);
+  transform_store(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (a.stamps) {            // diagnostic (tools/wino_debug.py): stage 0 of workgroup 0 as it sits in LDS, then stop
+    if (blockIdx.x == 0)
+      for (int i = tid; i < W_STAGE; i += 512) reinterpret_cast<float*>(a.stamps)[i] = smem[i];
+    if (blockIdx.x == 0 && tid < 64) {
+      float* o = reinterpret_cast<float*>(a.stamps) + W_STAGE + tid * 16;
+      o[0] = 123.f; o[1] = (float)lt; o[2] = (float)lq; o[3] = (float)lr; o[4] = __uint_as_float(off[0]); o[5] = __uint_as_float(inv[0]);
+      o[6] = ra[1][0]; o[7] = (float)MT; o[8] = (float)t0; o[9] = (float)nk; o[10] = (float)g.Ci; o[11] = (float)TW; o[12] = (float)TH;
+      o[13] = __uint_as_float(off[1]); o[14] = __uint_as_float(inv[1]); o[15] = (float)vslot;
+    }
+    return;
+  }
+
+  auto kstep = [&](int kk, auto has_next) {
+    const int cur = kk & 1;
+    const float* vs = smem + cur * W_STAGE;
+    const float* us = vs + 32 * W_PLANE;
+    if (decltype(has_next)::value) issue_loads(kk + 1, cur ^ 1);
+    f32x4 fa[2][2], fb[2][2];
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl) {
+      const int f = wave * 2 + fl, p = f * 2 + fh;
+      const int sw = fh | ((f >> 2) << 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        fa[fl][i] = *reinterpret_cast<const f32x4*>(vs + p * W_PLANE + (((i * 32 + fi) ^ sw) << 2));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[fl][j] = *reinterpret_cast<const f32x4*>(us + p * W_PLANE + ((j * 32 + fi) << 2));
+    }
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl) {
+      if (fl == 1 && decltype(has_next)::value) {
+        __builtin_amdgcn_sched_barrier(0);     // the staging of the next tile rides in the shadow of the second half's MFMAs
+        transform_store(cur ^ 1);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[fl][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fl][i][e], fb[fl][j][e], acc[fl][i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
+    __syncthreads();
+  };
+  for (int kk = 0; kk + 1 < nk; ++kk) kstep(kk, std::true_type{});
+  kstep(nk - 1, std::false_type{});
+
+  // ---- epilogue: 16 frequencies of a (tile, channel) meet in LDS, two halves of 32 tiles ----
+  const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
+  const int split = a.scale0 ? a.scale_split : 0x7fffffff;            // pixel-row index where the second sigma starts
+  const bool hr = a.residual != nullptr, hm = a.mask_src != nullptr, hs = a.stat_partials != nullptr;
+  const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
+  const int et = tid >> 4, ec = (tid & 15) * 4;                       // this thread's tile (within the half) and channel quad
+  const int n = n0 + ec;
+  const bool col_ok = n < g.Co;                                        // Co % 4 == 0
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+  f32x4 cs1 = {0.f, 0.f, 0.f, 0.f}, cs2 = {0.f, 0.f, 0.f, 0.f};
+  float* ms = smem;                                                    // [16 f][32 tiles][64 channels]
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int trow = (e & 3) + 8 * (e >> 2) + 4 * fh;
+          ms[((wave * 2 + fl) * 32 + trow) * 64 + j * 32 + fi] = half == 0 ? acc[fl][0][j][e] : acc[fl][1][j][e];
+        }
+    __syncthreads();
+    f32x4 m[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(ms + ((i * 4 + j) * 32 + et) * 64 + ec);
+    f32x4 s[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i][0] = m[i][0] + m[i][1] + m[i][2];
+      s[i][1] = m[i][1] - m[i][2] - m[i][3];
+    }
+    const int gt = t0 + half * 32 + et;
+    if (gt < MT && col_ok) {
+      const unsigned q1 = fdiv((unsigned)gt, a.dWo);
+      const int tx = gt - (int)q1 * TW;
+      const unsigned b = fdiv(q1, a.dHo);
+      const int ty = (int)q1 - (int)b * TH;
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          f32x4 y = py == 0 ? s[0][px] + s[1][px] + s[2][px] : s[1][px] - s[2][px] - s[3][px];
+          const int prow = ((int)b * g.Ho + 2 * ty + py) * g.Wo + 2 * tx + px;       // pixel (GEMM row) index
+          const long o = (long)prow * g.Co + n;
+          y = y * (prow < split ? sc0 : sc1) + bv;
+          if (hr) {
+            f32x4 r = *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+            y += r;
+          }
+          if (hm) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : y[e] * a.mask_slope;
+          }
+          *reinterpret_cast<f32x4*>(a.y + o) = y;
+          if (hs) {
+            cs1 += y;
+            cs2 += y * y;
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (hs) {
+    // column sums over the workgroup's 256 pixels: lanes with equal (tid & 15) hold the same channels
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs1[e] += __shfl_xor(cs1[e], 16, 64);
+      cs2[e] += __shfl_xor(cs2[e], 16, 64);
+      cs1[e] += __shfl_xor(cs1[e], 32, 64);
+      cs2[e] += __shfl_xor(cs2[e], 32, 64);
+    }
+    float* red = smem;                                                 // [8 waves][2][64]
+    if (lane < 16) {
+      *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * 64 + ec) = cs1;
+      *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * 64 + ec) = cs2;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, col = tid & 63;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[(w * 2 + which) * 64 + col];
+      if (n0 + col < g.Co) a.stat_partials[(long)(tile / tiles_n) * 2 * g.Co + which * g.Co + n0 + col] = t;
+    }
+  }
+}
+
+template <int PRO>
+static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
+  const int MT = a.g.B * (a.g.Ho >> 1) * (a.g.Wo >> 1);
+  const int wgs = cdiv(MT, WT) * cdiv(a.g.Co, WN);
+  const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
+  auto kern = conv_wino_kernel<PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, a, ug);
+  return check_launch("conv_wino");
+}
+
+// floats of workspace the transformed weights need
+long wino_ws_floats(int Co, int Ci) { return (long)cdiv(Co, WN) * WN * Ci * 16; }
+
+// `a` as prepared by diagan_conv_gemm (dWo / dHo re-made here for the TILE grid); ws: wino_ws_floats(Co, Ci) floats
+int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(g.Ci / 4, cdiv(g.Co, WN)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
+                     g.dr < 0 ? 1 : 0);
+  switch (a.pro_mode) {
+    case PRO_NONE: return launch_wino_pro<PRO_NONE>(a, ws, st);
+    case PRO_RELU: return launch_wino_pro<PRO_RELU>(a, ws, st);
+    case PRO_AFFINE_RELU: return launch_wino_pro<PRO_AFFINE_RELU>(a, ws, st);
+    case PRO_LRELU: return launch_wino_pro<PRO_LRELU>(a, ws, st);
+    default: return launch_wino_pro<PRO_AFFINE>(a, ws, st);
+  }
+}
+
+}  // namespace diagan

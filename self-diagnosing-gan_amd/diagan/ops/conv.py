@@ -11,6 +11,7 @@ P, I, F, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] + [I] * 15 + [P, I64, P, I, P])
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I, I])
+nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_gemm_tile_cols", [I])
 nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
@@ -41,6 +42,8 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
 
 
 def gemm_kernel_name(cfg, mode):
+    if cfg == 9:
+        return f"conv_wino_kernel<{mode}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
         return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
