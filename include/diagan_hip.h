@@ -133,6 +133,11 @@ int diagan_conv_gemm_tile_cols(int cfg);
  * per workgroup (stat_partials / pro_group_rows granularity).  Returns 1 when the geometry qualifies. */
 int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
                                int up);
+/* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and
+ * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns
+ * Winograd off. */
+int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                   int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* Diagnostics and tuning sweeps only (tools/stamp_report.py, tools/bench_conv.py; no reference counterpart, never
  * called by the product path).  While a stamp buffer is set, diagan_conv_gemm launches a diagnostic build of its
  * kernel (prologue modes 0 and 1) in which every workgroup records, at slot blockIdx.y*gridDim.x + blockIdx.x,

@@ -27,6 +27,8 @@ extern "C" int diagan_get_mfma_mode(void);
 extern "C" int diagan_conv_gemm_tile_rows(int cfg);
 extern "C" int diagan_conv_gemm_tile_cols(int cfg);
 extern "C" int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
+extern "C" int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                              int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats);
 extern "C" int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                           int off, int up);
 
@@ -749,7 +751,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
   hipStream_t st = (hipStream_t)stream;
-  const int cfg = tile_cfg == 0 ? diagan_conv_gemm_pick_cfg(a.M, Co, Kp, (splitk_ws && !stat_partials) ? 1 : 0) : tile_cfg;
+  const int cfg = tile_cfg != 0 ? tile_cfg
+                                : diagan_conv_gemm_pick_cfg_geom(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp,
+                                                                 (splitk_ws && !stat_partials) ? 1 : 0,
+                                                                 splitk_ws ? splitk_ws_floats : 0);
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x64 (4x1 waves), "
@@ -806,6 +811,23 @@ DIAGAN_API int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo
                                           int off, int up) {
   return R == 3 && S == 3 && sy == 1 && up == 1 && ((dr == 1 && off == -1) || (dr == -1 && off == 1)) && Hi == Ho &&
          Wi == Wo && !(Ho & 1) && !(Wo & 1) && (Ci & 7) == 0 && (Co & 3) == 0 && diagan_get_mfma_mode() == 0;
+}
+
+// Tile configuration for a full geometry (what diagan_conv_gemm does when tile_cfg == 0): Winograd (9) where the layer
+// qualifies, the workspace holds the transformed weights and the launch has enough workgroups; otherwise the
+// implicit-GEMM choice of diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 disables Winograd (A/B runs).
+DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                              int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats) {
+  static const int wino = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  // one 512-thread workgroup per CU: below ~3/4 of the chip the implicit GEMM's smaller tiles win (8x8 / 4x4 blocks at
+  // batch 64: 128 workgroups, 325 vs 317 us; their data-gradients 330 vs 168 us)
+  static const int min_wgs = getenv("DIAGAN_WINO_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_MIN_WGS")) : 192;
+  if (wino && diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) &&
+      ws_floats >= wino_ws_floats(Co, Ci)) {
+    const long wgs = (long)cdiv((long)B * (Ho >> 1) * (Wo >> 1), 64) * cdiv(Co, 64);
+    if (wgs >= min_wgs && Ci >= 16) return 9;
+  }
+  return diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
 }
 
 // Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.

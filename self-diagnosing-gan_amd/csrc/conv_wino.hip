@@ -55,9 +55,12 @@ __global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict
     u[1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
     u[2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
     u[3] = t[i][2];
+    // row i = 3 of V is staged NEGATED (t3 - t1: every lane's column transform is then own + sc * partner); the sign
+    // moves into U so that the products are unchanged
+    const float sg = i == 3 ? -1.f : 1.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(base + (((i * 4 + j) * 2 + kq) * 64 + threadIdx.x) * 4) = u[j];
+      *reinterpret_cast<f32x4*>(base + (((i * 4 + j) * 2 + kq) * 64 + threadIdx.x) * 4) = u[j] * sg;
   }
 }
 
@@ -105,8 +108,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
   const int pro_group_off = a.pro_group_rows > 0 ? ((t0 * 4) / a.pro_group_rows) * g.Ci : 0;
-  // column-transform coefficients of this lane's row: V[r] = so * t[r] + sc * t[partner], partner by quad_perm [2,2,1,1]
-  const float so = lr == 3 ? -1.f : 1.f, sc = (lr == 1 || lr == 3) ? 1.f : -1.f;
+  // column transform of this lane's row: V[r] = t[r] + sc * t[partner], partner by quad_perm [2,2,1,1]
+  // (r = 0: t0 - t2; 1: t1 + t2; 2: t2 - t1; 3: t3 - t1 = -(B^T row 3), compensated in U)
+  const float sc = lr == 1 ? 1.f : -1.f;
   // LDS slot of this thread's 4 output planes: plane p = ((r * 4 + j) * 2 + q), slot = tile ^ (q | r << 1)
   const int vslot = (lt ^ (lq | (lr << 1))) * 4;
 
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
         } else if (PRO != PRO_AFFINE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, __builtin_huge_valf());   // max(v, 0), one instruction
         }
         if (affine) v *= keep[c];                      // padding is zero AFTER the transform
       }
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
         // (scalar copy first: a bit_cast of the vector element itself is miscompiled to element 0, as in conv_gemm.hip)
         const float own = t[j][e];
         const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x5A, 0xF, 0xF, false);
-        o[e] = fmaf(so, own, sc * __int_as_float(other));
+        o[e] = fmaf(sc, __int_as_float(other), own);
       }
       *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * 2 + lq) * W_PLANE + vslot) = o;
     }
@@ -247,6 +251,31 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   float* ms = smem;                                                    // [16 f][32 tiles][64 channels]
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    // this thread's tile and its 4 output pixels; residual / mask loads are issued BEFORE the LDS exchange
+    const int gt = t0 + half * 32 + et;
+    const bool ok = gt < MT && col_ok;
+    long o4[4];
+    int prow4[4];
+    {
+      const unsigned q1 = fdiv((unsigned)(ok ? gt : 0), a.dWo);
+      const int tx = (ok ? gt : 0) - (int)q1 * TW;
+      const unsigned b = fdiv(q1, a.dHo);
+      const int ty = (int)q1 - (int)b * TH;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        prow4[p] = ((int)b * g.Ho + 2 * ty + (p >> 1)) * g.Wo + 2 * tx + (p & 1);       // pixel (GEMM row) index
+        o4[p] = (long)prow4[p] * g.Co + n;
+      }
+    }
+    f32x4 rres[4], rmsk[4];
+    if (hr && ok) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rres[p] = *reinterpret_cast<const f32x4*>(a.residual + o4[p]);
+    }
+    if (hm && ok) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) rmsk[p] = *reinterpret_cast<const f32x4*>(a.mask_src + o4[p]);
+    }
 #pragma unroll
     for (int fl = 0; fl < 2; ++fl)
 #pragma unroll
@@ -257,48 +286,38 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
           ms[((wave * 2 + fl) * 32 + trow) * 64 + j * 32 + fi] = half == 0 ? acc[fl][0][j][e] : acc[fl][1][j][e];
         }
     __syncthreads();
-    f32x4 m[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(ms + ((i * 4 + j) * 32 + et) * 64 + ec);
-    f32x4 s[4][2];
+    // Y = A^T M A, one row of M at a time (row 3: V and U are both staged negated, so M is what it always was)
+    f32x4 y4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s[i][0] = m[i][0] + m[i][1] + m[i][2];
-      s[i][1] = m[i][1] - m[i][2] - m[i][3];
+      f32x4 m[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = *reinterpret_cast<const f32x4*>(ms + ((i * 4 + j) * 32 + et) * 64 + ec);
+      const f32x4 sa = m[0] + m[1] + m[2], sb = m[1] - m[2] - m[3];
+      if (i < 3) { y4[0] += sa; y4[1] += sb; }
+      if (i == 1) { y4[2] += sa; y4[3] += sb; }
+      if (i >= 2) { y4[2] -= sa; y4[3] -= sb; }
     }
-    const int gt = t0 + half * 32 + et;
-    if (gt < MT && col_ok) {
-      const unsigned q1 = fdiv((unsigned)gt, a.dWo);
-      const int tx = gt - (int)q1 * TW;
-      const unsigned b = fdiv(q1, a.dHo);
-      const int ty = (int)q1 - (int)b * TH;
+    if (ok) {
 #pragma unroll
-      for (int py = 0; py < 2; ++py)
+      for (int p = 0; p < 4; ++p) {
+        f32x4 y = y4[p] * (prow4[p] < split ? sc0 : sc1) + bv;
+        if (hr) {
+          f32x4 r = rres[p];
 #pragma unroll
-        for (int px = 0; px < 2; ++px) {
-          f32x4 y = py == 0 ? s[0][px] + s[1][px] + s[2][px] : s[1][px] - s[2][px] - s[3][px];
-          const int prow = ((int)b * g.Ho + 2 * ty + py) * g.Wo + 2 * tx + px;       // pixel (GEMM row) index
-          const long o = (long)prow * g.Co + n;
-          y = y * (prow < split ? sc0 : sc1) + bv;
-          if (hr) {
-            f32x4 r = *reinterpret_cast<const f32x4*>(a.residual + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
-            y += r;
-          }
-          if (hm) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : y[e] * a.mask_slope;
-          }
-          *reinterpret_cast<f32x4*>(a.y + o) = y;
-          if (hs) {
-            cs1 += y;
-            cs2 += y * y;
-          }
+          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+          y += r;
         }
+        if (hm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[e] = rmsk[p][e] > 0.f ? y[e] : y[e] * a.mask_slope;
+        }
+        *reinterpret_cast<f32x4*>(a.y + o4[p]) = y;
+        if (hs) {
+          cs1 += y;
+          cs2 += y * y;
+        }
+      }
     }
     __syncthreads();
   }

@@ -12,6 +12,7 @@ nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] +
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I, I])
 nat.register("diagan_conv_wino_supported", [I] * 12)
+nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_gemm_tile_cols", [I])
 nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
@@ -152,7 +153,7 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None, want_stats=False):
+          res_relu=False, row_scale=None, want_stats=False, wino=True):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
@@ -179,11 +180,14 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
                       (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}"))
         return out
     ws = _splitk_ws(x.device)
+    if tile_cfg == 0 and not wino:        # caller keeps to the implicit GEMM (the StyleGAN2 autograd ops by default)
+        tile_cfg = nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp, 0 if want_stats else 1)
     if want_stats:
         # statistics from the epilogue always win over split-K + a separate reduction pass over y (G-32 block2,
         # M=4096: 60 us unsplit with statistics vs 54 + 6 (second stage) + 20 (column reduction) us)
         M = B * Ho * Wo
-        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(M, Co, Kp, 0)
+        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, 0,
+                                                                    ws.numel())
         bm = nat.fn("diagan_conv_gemm_tile_rows")(cfg)
         tiles = (M + bm - 1) // bm
         stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
@@ -191,7 +195,8 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     kname = None
     if TIMER is not None:
         allow = 0 if want_stats else 1
-        kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg")(B * Ho * Wo, Co, Kp, allow), mode)
+        kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(
+            B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel()), mode)
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
@@ -220,7 +225,7 @@ def _splitk_ws(dev):
 
 
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False, out_scale=1.0):
+             want_stats=False, out_scale=1.0, wino=True):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
@@ -229,11 +234,11 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
-                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats)
+                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,
-               row_scale=None):
+               row_scale=None, wino=True):
     """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci]."""
     B, Ho, Wo, Co = dy.shape
     if Co != geom.Co:
@@ -242,7 +247,7 @@ def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0
     if out is None:
         out = torch.empty((B, Hi, Wi, geom.Ci), dtype=torch.float32, device=dy.device)
     return _gemm(dy, wd, out, geom.dgrad_params(), geom.R, geom.S, geom.Kd, None, residual, mask_src, mask_slope,
-                 None, 1.0, tile_cfg, row_scale=row_scale)
+                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino)
 
 
 _slabs = {}

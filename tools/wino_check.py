@@ -50,7 +50,7 @@ def main():
         msk = torch.randn(B, H, W, Ci, device=dev)
         resx = torch.randn(B, H, W, Ci, device=dev)
         s0, s1 = torch.tensor([0.7], device=dev), torch.tensor([1.3], device=dev)
-        big = B * H * W >= 16384
+        big = B * H * W >= 2048
         variants = {
             "fwd plain": lambda cfg: C.conv_fwd(geom, x, wp, tile_cfg=cfg),
             "fwd relu+bias": lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, pro=(C.PRO_RELU, None, None), tile_cfg=cfg),
