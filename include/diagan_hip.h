@@ -136,6 +136,7 @@ int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, i
 /* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and
  * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns
  * Winograd off. */
+int diagan_conv_gemm_set_wino(int mode);   /* run-time form of DIAGAN_WINO: 0 off, 1 on, -1 environment / default (on) */
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* Diagnostics and tuning sweeps only (tools/stamp_report.py, tools/bench_conv.py; no reference counterpart, never

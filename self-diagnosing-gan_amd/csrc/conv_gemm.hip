@@ -558,6 +558,7 @@ static long g_stamp_slots = 0;
 static int g_force_ksplit = 0;                    // tuning sweeps only (diagan_conv_gemm_tune)
 static int g_tune_flags = -1;                     // -1: production default (see kDefaultTune)
 static long g_lds_delta = 0;
+static int g_wino = -1;                           // -1: DIAGAN_WINO / default (on); 0 / 1: diagan_conv_gemm_set_wino
 constexpr int kDefaultTune = 0;
 
 template <int BM, int BN, int WM, int WN, int BK, int PRO, bool X6 = false, bool STAMP = false, bool FP = false>
@@ -818,7 +819,8 @@ DIAGAN_API int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo
 // implicit-GEMM choice of diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 disables Winograd (A/B runs).
 DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                               int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats) {
-  static const int wino = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  const int wino = g_wino >= 0 ? g_wino : wino_env;
   // one 512-thread workgroup per CU: below ~3/4 of the chip the implicit GEMM's smaller tiles win (8x8 / 4x4 blocks at
   // batch 64: 128 workgroups, 325 vs 317 us; their data-gradients 330 vs 168 us)
   static const int min_wgs = getenv("DIAGAN_WINO_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_MIN_WGS")) : 192;
@@ -828,6 +830,14 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
     if (wgs >= min_wgs && Ci >= 16) return 9;
   }
   return diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
+}
+
+// Run-time form of DIAGAN_WINO (A/B runs and the tests that compare kernels like with like): 0 = implicit GEMM only,
+// 1 = Winograd where it qualifies, -1 = back to the environment's choice.
+DIAGAN_API int diagan_conv_gemm_set_wino(int mode) {
+  DG_REQUIRE(mode >= -1 && mode <= 1, "set_wino: -1, 0 or 1");
+  g_wino = mode;
+  return DIAGAN_OK;
 }
 
 // Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.

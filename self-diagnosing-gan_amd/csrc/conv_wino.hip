@@ -8,16 +8,17 @@
 //
 // One workgroup = 512 threads = 8 waves = 64 tiles (256 output pixels) x 64 output channels, one per CU (128 KB of LDS).
 //   * K loop over input channels in steps of 8.  Per step the 16 "frequency" GEMMs  M_f[64 x 64] += V_f[64 x 8] U_f[64 x 8]^T
-//     run as v_mfma_f32_32x32x2_f32: wave w owns frequencies 2w, 2w+1 (2 x 2x2 accumulator tiles = 128 registers).
+//     run as v_mfma_f32_32x32x2_f32: wave w owns the four frequencies of row i = w >> 1 on column half w & 1 (4 x 2 accumulator
+//     tiles = 128 registers).
 //   * U (transformed weights) is produced once per launch by wino_weight_kernel in exactly the LDS image order
 //     [64-col block][K-step][f][k-quad][64 cols][4], so a K-step's 32 KB go global -> LDS by LDS-DMA, no registers.
 //   * V (transformed input): thread (tile, channel quad, patch row r) loads its 4 pixels x 4 channels (prologue applied
 //     here), transforms along the row, exchanges with its quad by DPP for the column transform and writes its 4
 //     frequencies (r, j) to LDS.  Planes are [f][k-quad][tile][4 channels]; the tile slot is XOR-ed with (q | r << 1) so the
 //     ds_write_b128 of a quad's 8 lanes hit 8 different bank groups; fragment reads stay conflict-free.
-//   * epilogue: the 16 frequencies of a (tile, channel) live in 8 different waves, so they cross LDS once (two halves of
-//     32 tiles, 128 KB each): every thread then owns (tile, 4 channels), applies A^T . A and the usual epilogue
-//     (per-half 1/sigma, bias, residual, ReLU-backward mask, BatchNorm statistics) and stores four 16-byte pixels.
+//   * epilogue: a wave applies the j half of A^T . A to its row in registers; the four rows of a (tile, channel) then meet
+//     in LDS once (128 KB): every thread owns two (tile, 4 channels) items, finishes the transform and the usual epilogue
+//     (per-half 1/sigma, bias, residual, ReLU-backward mask, BatchNorm statistics) and stores 16-byte pixels.
 //
 // Roofline: MFMA fp32; the kernel executes 16/36 of the direct convolution's multiply-accumulates.
 #include "conv_common.h"
@@ -135,9 +136,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + kk * WK + lq * 4);
     }
   };
-  auto transform_store = [&](int stage) {
-    float* vs = smem + stage * W_STAGE;
-    f32x4 d[4];
+  f32x4 d[4], t[4];
+  auto transform_prologue = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x4 v = ra[c];
@@ -154,175 +154,179 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       }
       d[c] = v;
     }
-    f32x4 t[4];
+  };
+  auto transform_rows = [&]() {
     t[0] = d[0] - d[2];
     t[1] = d[1] + d[2];
     t[2] = d[2] - d[1];
     t[3] = d[1] - d[3];
+  };
+  auto transform_store = [&](int stage, int j) {
+    float* vs = smem + stage * W_STAGE;
+    f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // (scalar copy first: a bit_cast of the vector element itself is miscompiled to element 0, as in conv_gemm.hip)
-        const float own = t[j][e];
-        const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x5A, 0xF, 0xF, false);
-        o[e] = fmaf(sc, __int_as_float(other), own);
-      }
-      *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * 2 + lq) * W_PLANE + vslot) = o;
+    for (int e = 0; e < 4; ++e) {
+      // (scalar copy first: a bit_cast of the vector element itself is miscompiled to element 0, as in conv_gemm.hip)
+      const float own = t[j][e];
+      const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x5A, 0xF, 0xF, false);
+      o[e] = fmaf(sc, __int_as_float(other), own);
     }
+    *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * 2 + lq) * W_PLANE + vslot) = o;
   };
 
-  f32x16 acc[2][2][2];
+  // wave w owns the four frequencies of row i = w >> 1 (f = 4 i + j) on column block tn = w & 1: 4 x 2 accumulator
+  // tiles of 32 tiles x 32 channels.  Keeping a whole row in one wave lets it apply the j-half of the output transform
+  // in registers before the frequencies meet in LDS (half the exchange traffic).
+  const int wi = wave >> 1, tn = wave & 1;
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int fl = 0; fl < 2; ++fl)
+  for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[fl][i][j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[fl][i][e] = 0.f;
 
   const int fi = lane & 31, fh = lane >> 5;
+  const int sw = fh | (wi << 1);                          // slot swizzle of this wave's V planes (q | r << 1)
   issue_loads(0, 0);
-  transform_store(0);
+  transform_prologue();
+  transform_rows();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) transform_store(0, j);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (a.stamps) {            // diagnostic (tools/wino_debug.py): stage 0 of workgroup 0 as it sits in LDS, then stop
     if (blockIdx.x == 0)
       for (int i = tid; i < W_STAGE; i += 512) reinterpret_cast<float*>(a.stamps)[i] = smem[i];
-    if (blockIdx.x == 0 && tid < 64) {
-      float* o = reinterpret_cast<float*>(a.stamps) + W_STAGE + tid * 16;
-      o[0] = 123.f; o[1] = (float)lt; o[2] = (float)lq; o[3] = (float)lr; o[4] = __uint_as_float(off[0]); o[5] = __uint_as_float(inv[0]);
-      o[6] = ra[1][0]; o[7] = (float)MT; o[8] = (float)t0; o[9] = (float)nk; o[10] = (float)g.Ci; o[11] = (float)TW; o[12] = (float)TH;
-      o[13] = __uint_as_float(off[1]); o[14] = __uint_as_float(inv[1]); o[15] = (float)vslot;
-    }
     return;
   }
 
+  // One K-step: 16 groups of two MFMAs (frequency fl, k pair e).  The next stage's LDS-DMA pieces and global loads are
+  // issued at the top; its input transform is cut into six pieces (prologue, row transform, four column-transform +
+  // store pieces) that ride in the shadow of groups 8..13, one per group, as in conv_gemm.hip.
   auto kstep = [&](int kk, auto has_next) {
     const int cur = kk & 1;
     const float* vs = smem + cur * W_STAGE;
     const float* us = vs + 32 * W_PLANE;
     if (decltype(has_next)::value) issue_loads(kk + 1, cur ^ 1);
-    f32x4 fa[2][2], fb[2][2];
+    f32x4 fa[4][2], fb[4];
 #pragma unroll
-    for (int fl = 0; fl < 2; ++fl) {
-      const int f = wave * 2 + fl, p = f * 2 + fh;
-      const int sw = fh | ((f >> 2) << 1);
+    for (int fl = 0; fl < 4; ++fl) {
+      const int p = (wi * 4 + fl) * 2 + fh;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         fa[fl][i] = *reinterpret_cast<const f32x4*>(vs + p * W_PLANE + (((i * 32 + fi) ^ sw) << 2));
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        fb[fl][j] = *reinterpret_cast<const f32x4*>(us + p * W_PLANE + ((j * 32 + fi) << 2));
+      fb[fl] = *reinterpret_cast<const f32x4*>(us + p * W_PLANE + ((tn * 32 + fi) << 2));
     }
 #pragma unroll
-    for (int fl = 0; fl < 2; ++fl) {
-      if (fl == 1 && decltype(has_next)::value) {
-        __builtin_amdgcn_sched_barrier(0);     // the staging of the next tile rides in the shadow of the second half's MFMAs
-        transform_store(cur ^ 1);
-      }
+    for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
+        const int grp = fl * 4 + e;
+        if (decltype(has_next)::value && grp >= 8 && grp < 14) {
+          __builtin_amdgcn_sched_barrier(0);             // keep the piece HERE (its loads have had >= 1000 cycles to land)
+          if (grp == 8) transform_prologue();
+          else if (grp == 9) transform_rows();
+          else transform_store(cur ^ 1, grp - 10);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            acc[fl][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fl][i][e], fb[fl][j][e], acc[fl][i][j], 0, 0, 0);
-    }
+          acc[fl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fl][i][e], fb[fl][e], acc[fl][i], 0, 0, 0);
+      }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
     __syncthreads();
   };
   for (int kk = 0; kk + 1 < nk; ++kk) kstep(kk, std::true_type{});
   kstep(nk - 1, std::false_type{});
 
-  // ---- epilogue: 16 frequencies of a (tile, channel) meet in LDS, two halves of 32 tiles ----
+  // ---- epilogue ----
+  // s[i][b] = sum_j A^T[b][j] M[i][j] in registers (b = 0: M0 + M1 + M2; b = 1: M1 - M2 - M3), then the four rows i meet
+  // in LDS ([i][b][64 tiles][64 channels] = 128 KB) and every thread finishes two (tile, 4 channels) items:
+  // Y[a][b] = sum_i A^T[a][i] s[i][b].  (Row 3 of V and of U are both staged negated: M is what it always was.)
   const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
   const int split = a.scale0 ? a.scale_split : 0x7fffffff;            // pixel-row index where the second sigma starts
   const bool hr = a.residual != nullptr, hm = a.mask_src != nullptr, hs = a.stat_partials != nullptr;
   const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
-  const int et = tid >> 4, ec = (tid & 15) * 4;                       // this thread's tile (within the half) and channel quad
+  const int et = tid >> 4, ec = (tid & 15) * 4;                       // this thread's tile (within a half) and channel quad
   const int n = n0 + ec;
   const bool col_ok = n < g.Co;                                        // Co % 4 == 0
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (a.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
   f32x4 cs1 = {0.f, 0.f, 0.f, 0.f}, cs2 = {0.f, 0.f, 0.f, 0.f};
-  float* ms = smem;                                                    // [16 f][32 tiles][64 channels]
+  float* ss = smem;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    // this thread's tile and its 4 output pixels; residual / mask loads are issued BEFORE the LDS exchange
-    const int gt = t0 + half * 32 + et;
-    const bool ok = gt < MT && col_ok;
-    long o4[4];
-    int prow4[4];
-    {
-      const unsigned q1 = fdiv((unsigned)(ok ? gt : 0), a.dWo);
-      const int tx = (ok ? gt : 0) - (int)q1 * TW;
-      const unsigned b = fdiv(q1, a.dHo);
-      const int ty = (int)q1 - (int)b * TH;
+  for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        prow4[p] = ((int)b * g.Ho + 2 * ty + (p >> 1)) * g.Wo + 2 * tx + (p & 1);       // pixel (GEMM row) index
-        o4[p] = (long)prow4[p] * g.Co + n;
-      }
+    for (int e = 0; e < 16; ++e) {
+      const int trow = tm * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      const float m0 = acc[0][tm][e], m1 = acc[1][tm][e], m2 = acc[2][tm][e], m3 = acc[3][tm][e];
+      ss[((wi * 2 + 0) * 64 + trow) * 64 + tn * 32 + fi] = m0 + m1 + m2;
+      ss[((wi * 2 + 1) * 64 + trow) * 64 + tn * 32 + fi] = m1 - m2 - m3;
     }
-    f32x4 rres[4], rmsk[4];
-    if (hr && ok) {
+  // this thread's two tiles and their 4 output pixels each; residual / mask loads are issued BEFORE the barrier
+  long o4[2][4];
+  int prow4[2][4];
+  bool ok2[2];
+  f32x4 rres[2][4], rmsk[2][4];
 #pragma unroll
-      for (int p = 0; p < 4; ++p) rres[p] = *reinterpret_cast<const f32x4*>(a.residual + o4[p]);
+  for (int it = 0; it < 2; ++it) {
+    const int gt = t0 + it * 32 + et;
+    ok2[it] = gt < MT && col_ok;
+    const unsigned q1 = fdiv((unsigned)(ok2[it] ? gt : 0), a.dWo);
+    const int tx = (ok2[it] ? gt : 0) - (int)q1 * TW;
+    const unsigned b = fdiv(q1, a.dHo);
+    const int ty = (int)q1 - (int)b * TH;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      prow4[it][p] = ((int)b * g.Ho + 2 * ty + (p >> 1)) * g.Wo + 2 * tx + (p & 1);       // pixel (GEMM row) index
+      o4[it][p] = (long)prow4[it][p] * g.Co + n;
     }
-    if (hm && ok) {
+    if (hr && ok2[it]) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) rmsk[p] = *reinterpret_cast<const f32x4*>(a.mask_src + o4[p]);
+      for (int p = 0; p < 4; ++p) rres[it][p] = *reinterpret_cast<const f32x4*>(a.residual + o4[it][p]);
     }
+    if (hm && ok2[it]) {
 #pragma unroll
-    for (int fl = 0; fl < 2; ++fl)
+      for (int p = 0; p < 4; ++p) rmsk[it][p] = *reinterpret_cast<const f32x4*>(a.mask_src + o4[it][p]);
+    }
+  }
+  __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int trow = (e & 3) + 8 * (e >> 2) + 4 * fh;
-          ms[((wave * 2 + fl) * 32 + trow) * 64 + j * 32 + fi] = half == 0 ? acc[fl][0][j][e] : acc[fl][1][j][e];
-        }
-    __syncthreads();
-    // Y = A^T M A, one row of M at a time (row 3: V and U are both staged negated, so M is what it always was)
+  for (int it = 0; it < 2; ++it) {
     f32x4 y4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f32x4 m[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m[j] = *reinterpret_cast<const f32x4*>(ms + ((i * 4 + j) * 32 + et) * 64 + ec);
-      const f32x4 sa = m[0] + m[1] + m[2], sb = m[1] - m[2] - m[3];
+      const f32x4 sa = *reinterpret_cast<const f32x4*>(ss + ((i * 2 + 0) * 64 + it * 32 + et) * 64 + ec);
+      const f32x4 sb = *reinterpret_cast<const f32x4*>(ss + ((i * 2 + 1) * 64 + it * 32 + et) * 64 + ec);
       if (i < 3) { y4[0] += sa; y4[1] += sb; }
       if (i == 1) { y4[2] += sa; y4[3] += sb; }
       if (i >= 2) { y4[2] -= sa; y4[3] -= sb; }
     }
-    if (ok) {
+    if (ok2[it]) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        f32x4 y = y4[p] * (prow4[p] < split ? sc0 : sc1) + bv;
+        f32x4 y = y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
         if (hr) {
-          f32x4 r = rres[p];
+          f32x4 r = rres[it][p];
 #pragma unroll
           for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
           y += r;
         }
         if (hm) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = rmsk[p][e] > 0.f ? y[e] : y[e] * a.mask_slope;
+          for (int e = 0; e < 4; ++e) y[e] = rmsk[it][p][e] > 0.f ? y[e] : y[e] * a.mask_slope;
         }
-        *reinterpret_cast<f32x4*>(a.y + o4[p]) = y;
+        *reinterpret_cast<f32x4*>(a.y + o4[it][p]) = y;
         if (hs) {
           cs1 += y;
           cs2 += y * y;
         }
       }
     }
-    __syncthreads();
   }
   if (hs) {
     // column sums over the workgroup's 256 pixels: lanes with equal (tid & 15) hold the same channels
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       cs1[e] += __shfl_xor(cs1[e], 16, 64);

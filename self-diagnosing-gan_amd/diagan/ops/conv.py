@@ -12,6 +12,7 @@ nat.register("diagan_conv_gemm", [P, P, P, P, P, I, P, F, P, P, I, F, P, P, I] +
 nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I, I])
 nat.register("diagan_conv_wino_supported", [I] * 12)
+nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_gemm_tile_cols", [I])
@@ -99,6 +100,12 @@ def set_mfma_mode(mode):
     """0: exact fp32 MFMA (default); 1 or 'bf16x6': experimental fp32-accurate mode on the bf16 matrix pipe (every
     operand split exactly into three bf16 pieces, six piece products accumulated in fp32)"""
     nat.call("diagan_set_mfma_mode", 1 if mode in (1, 'bf16x6') else 0)
+
+
+def set_winograd(mode):
+    """True / False: allow / forbid the Winograd kernel for auto-selected tile configurations; None: the default
+    (on, or what DIAGAN_WINO says)"""
+    nat.call("diagan_conv_gemm_set_wino", -1 if mode is None else (1 if mode else 0))
 
 
 def get_mfma_mode():

@@ -324,10 +324,23 @@ def test_resume_from_torch_adam_state(tmp_path):
             assert (sG[k].cpu() - v).abs().max() < 2e-3, k
 
 
+@pytest.mark.parametrize("winograd,tol", [(False, 2e-6), (True, 1e-5)])
 @pytest.mark.parametrize("dataset", ["cifar10", "celeba"])
-def test_stacked_generator_forward_equals_successive_forwards(dataset):
+def test_stacked_generator_forward_equals_successive_forwards(dataset, winograd, tol):
     """prefetch_fakes: the n_dis generator forwards of a global step as ONE stacked forward with per-batch BatchNorm
-    statistics -- same images, same running statistics (momentum chain in order), same RNG state afterwards."""
+    statistics -- same images, same running statistics (momentum chain in order), same RNG state afterwards.
+    With the implicit GEMM on both sides the images agree to 2e-6; with Winograd allowed the stacked (3x larger) launches
+    and the single-batch ones do not all take the same kernel (launch-size policy), which moves them by rounding: 1e-5."""
+    from diagan.models import base as MB
+    from diagan.ops import conv as C
+    C.set_winograd(winograd)
+    try:
+        _stacked_forward_check(dataset, tol)
+    finally:
+        C.set_winograd(None)
+
+
+def _stacked_forward_check(dataset, tol):
     from diagan.models import base as MB
     (_, _, _, _), (netG, _, _, _) = build(dataset, 'ns')
     ref = copy.deepcopy(netG)
@@ -342,11 +355,11 @@ def test_stacked_generator_forward_equals_successive_forwards(dataset):
     assert torch.equal(after, torch.randn(4, device='cuda'))       # the generator consumed the same random numbers
     for a, b in zip(got, want):
         assert a.shape == b.shape
-        assert (a - b).abs().max().item() < 2e-6
+        assert (a - b).abs().max().item() < tol
     sa, sb = netG.state_dict(), ref.state_dict()
     for k in sb:
         if 'running' in k:
-            assert (sa[k] - sb[k]).abs().max().item() < 1e-6, k
+            assert (sa[k] - sb[k]).abs().max().item() < tol / 2, k
     # a stack that would not fit the 2 GiB tensor limit is cut into several stacked forwards: same images again
     netG.load_state_dict(ref.state_dict())                      # same running statistics as before the chunked run ...
     ref2 = copy.deepcopy(ref)
@@ -357,7 +370,7 @@ def test_stacked_generator_forward_equals_successive_forwards(dataset):
     chunked = [netG.generate_images_nhwc(B)[0] for _ in range(n)]
     torch.manual_seed(22)
     for a in chunked:
-        assert (a - ref2.generate_images_nhwc(B)[0]).abs().max().item() < 2e-6
+        assert (a - ref2.generate_images_nhwc(B)[0]).abs().max().item() < tol
     # ragged request / changed parameters / eval mode invalidate the pool instead of serving stale images
     netG.prefetch_fakes(n, B, device='cuda')
     assert netG.generate_images_nhwc(B - 1)[0].shape[0] == B - 1 and not netG._fake_pool

@@ -1,0 +1,110 @@
+"""GPU: the Winograd F(2x2,3x3) kernel (tile_cfg 9, csrc/conv_wino.hip) against float64 PyTorch references of the same
+convolution (F.conv2d and its input gradient, as used by mimicry's GBlock / DBlock: predefined_models.py:19-21,38-40),
+with every fused prologue and epilogue, and against the implicit-GEMM kernel.  Tolerance: 2e-5 of the output scale
+(the implicit GEMM itself sits at ~1e-6; Winograd's transforms add a factor of a few)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_conv_gpu import close, nchw, nhwc, ref_pro
+
+pytestmark = pytest.mark.gpu
+
+# B, H, W, Ci, Co: square / non-square images, ragged tile counts, Co not a multiple of 64, the SNGAN block shapes
+CASES = [(4, 8, 8, 64, 64), (3, 6, 10, 16, 24), (5, 16, 16, 128, 72), (2, 32, 32, 256, 256), (8, 64, 64, 64, 64),
+         (16, 4, 4, 512, 256), (1, 2, 2, 8, 4)]
+
+
+def make(B, H, W, Ci, Co, seed=0):
+    from diagan.ops import conv as C
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+    return geom, x, w, C.pack_oihw(w, geom.Kp).cuda()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("pro", [0, 1, 2, 3, 4])
+def test_forward_all_prologues_with_bias_and_residual(case, pro):
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(1)
+    bias, scale, shift = torch.randn(Co, generator=g), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    ref = F.conv2d(ref_pro(x.double(), pro, scale.double(), shift.double()), w.double(), bias.double(), padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(),
+                   pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=9)
+    close(nchw(y), ref + res.double(), tol=2e-5)
+
+
+@pytest.mark.parametrize("case", CASES[:6])
+def test_data_gradient_with_mask_and_residual(case):
+    """dx = conv^T(dy) (+ residual) * relu'(mask): the backward of DBlock's c1 / c2 (Winograd with the taps reversed)"""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(2)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double(), padding=1).backward(dy.double())
+    msk, res = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Ci, H, W, generator=g)
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), residual=nhwc(res).cuda(), mask_src=nhwc(msk).cuda(), tile_cfg=9)
+    close(nchw(dx), (xr.grad + res.double()) * (msk > 0).double(), tol=2e-5)
+    dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), mask_src=nhwc(msk).cuda(), mask_slope=0.2, tile_cfg=9)
+    close(nchw(dx), torch.where(msk > 0, xr.grad, 0.2 * xr.grad), tol=2e-5)
+
+
+def test_pair_scales_res_relu_statistics_and_groups():
+    """the remaining epilogue / prologue modes of diagan_conv_gemm on the Winograd path: per-half 1/sigma (D(real) and
+    D(fake) as one pass), max(residual, 0) (DBlock's aliased shortcut), BatchNorm statistics from the epilogue, and the
+    per-group affine prologue of the stacked generator forward"""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = 8, 16, 16, 64, 96
+    geom, x, w, wp = make(B, H, W, Ci, Co, seed=3)
+    g = torch.Generator().manual_seed(4)
+    xg = nhwc(x).cuda()
+    ref = F.conv2d(F.relu(x.double()), w.double(), padding=1)
+    s0, s1 = torch.tensor([0.7]), torch.tensor([1.3])
+    y = C.conv_fwd(geom, xg, wp, pro=(C.PRO_RELU, None, None), row_scale=(s0.cuda(), s1.cuda()), tile_cfg=9)
+    half = torch.cat([ref[: B // 2] * 0.7, ref[B // 2:] * 1.3])
+    close(nchw(y), half, tol=2e-5)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, xg, wp, pro=(C.PRO_RELU, None, None), residual=nhwc(res).cuda(), res_relu=True, tile_cfg=9)
+    close(nchw(y), ref + F.relu(res.double()), tol=2e-5)
+    bias = torch.randn(Co, generator=g)
+    y, st = C.conv_fwd(geom, xg, wp, bias=bias.cuda(), tile_cfg=9, want_stats=True)
+    full = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    close(st[0][:, 0].sum(0), full.sum((0, 2, 3)), tol=2e-5)
+    close(st[0][:, 1].sum(0), (full * full).sum((0, 2, 3)), tol=2e-5)
+    groups = 4                                                   # 2 images per group, 2 * 8 * 8 = 128 tiles... rows 512 = 2 x 256
+    sc, sh = torch.rand(groups, Ci, generator=g) + 0.5, torch.randn(groups, Ci, generator=g) * 0.3
+    y = C.conv_fwd(geom, xg, wp, pro=(C.PRO_AFFINE_RELU, sc.cuda(), sh.cuda(), B // groups), tile_cfg=9)
+    parts = [F.conv2d(F.relu(x[2 * k: 2 * k + 2].double() * sc[k].double().view(1, -1, 1, 1) + sh[k].double().view(1, -1, 1, 1)),
+                      w.double(), padding=1) for k in range(groups)]
+    close(nchw(y), torch.cat(parts), tol=2e-5)
+
+
+def test_auto_selection_and_agreement_with_the_implicit_gemm():
+    """tile_cfg 0 picks Winograd for a qualifying layer with enough workgroups and the implicit GEMM otherwise; both
+    kernels agree to rounding on the same inputs"""
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    pick = nat.fn("diagan_conv_gemm_pick_cfg_geom")
+    ws = 16 << 20
+    assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9          # D32 block1.c2 (pair pass)
+    assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, 1152, 1, ws) == 9          # its data-gradient
+    assert pick(64, 4, 4, 512, 4, 4, 512, 3, 3, 1, 1, -1, 1, 4608, 1, ws) != 9               # too few workgroups
+    assert pick(64, 16, 16, 128, 8, 8, 128, 3, 3, 2, 1, -1, 1, 1152, 1, ws) != 9             # stride 2
+    assert pick(64, 32, 32, 4, 32, 32, 128, 3, 3, 1, 1, -1, 1, 64, 1, ws) != 9               # RGB input
+    assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, 1024) != 9        # no room for the transformed weights
+    geom, x, w, wp = make(16, 16, 16, 128, 128, seed=5)
+    a = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=9)
+    b = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=7)
+    close(a, b, tol=1e-5)
+    with pytest.raises(RuntimeError, match="Winograd"):
+        g2 = C.Geom("conv", 128, 128, 3, 3, 2, 1)
+        C.conv_fwd(g2, nhwc(x).cuda(), wp, tile_cfg=9)

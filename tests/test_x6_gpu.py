@@ -82,8 +82,11 @@ def test_training_step_parity_in_bf16x6_mode(modes):
     updated parameters to a relative L2 of 1e-4 (Adam's first step is a sign step: tiny gradients may flip)"""
     import bench
 
+    from diagan.ops import conv as C
+
     def run(mode):
         modes(mode)
+        C.set_winograd(False)        # like with like: the fp32 leg on the implicit GEMM, as this mode's kernels are
         dev = torch.device("cuda", 0)
         netG, netD, _, optG, optD, _ = bench.build_models('cifar10', 'ns', 1, dev)
         gen = torch.Generator().manual_seed(5)
@@ -99,8 +102,11 @@ def test_training_step_parity_in_bf16x6_mode(modes):
         torch.cuda.synchronize()
         return log.m, netD.flat_params.clone(), netG.flat_params.clone()
 
-    m0, d0, g0 = run(0)
-    m1, d1, g1 = run(1)
+    try:
+        m0, d0, g0 = run(0)
+        m1, d1, g1 = run(1)
+    finally:
+        C.set_winograd(None)
     for k in ('errD', 'errG'):
         assert abs(m0[k] - m1[k]) < 1e-5 * max(1.0, abs(m0[k])), (k, m0[k], m1[k])
     for a, b in ((d0, d1), (g0, g1)):
