@@ -137,6 +137,7 @@ int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, i
  * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns
  * Winograd off. */
 int diagan_conv_gemm_set_wino(int mode);   /* run-time form of DIAGAN_WINO: 0 off, 1 on, -1 environment / default (on) */
+int diagan_conv_gemm_get_wino(void);
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* Diagnostics and tuning sweeps only (tools/stamp_report.py, tools/bench_conv.py; no reference counterpart, never
@@ -161,7 +162,15 @@ int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, 
                       int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B, int Hi, int Wi, int Ci, int Ho,
                       int Wo, int Co, int R, int S, int sy, int dr, int off, int up, int Kp,
                       void* stream);
-int diagan_conv_wgrad_splits(int M, int Co, int Kp); /* host heuristic: number of splits */
+int diagan_conv_wgrad_splits(int M, int Co, int Kp);
+/* The Winograd F(3x3,2x2) weight gradient (csrc/conv_wgrad_wino.hip: 16/36 of the multiply-accumulates, same slab layout
+ * and deferred reduction) takes the 3x3 / stride 1 / pad 1 layers inside diagan_conv_wgrad; uses_wino tells whether a
+ * geometry qualifies (DIAGAN_WINO / diagan_conv_gemm_set_wino / DIAGAN_WINO_WGRAD=0 turn it off), splits_geom the split
+ * count a caller should allocate slabs for on this geometry. */
+int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                                int up, int Kp);
+int diagan_conv_wgrad_splits_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                  int off, int up, int Kp); /* host heuristic: number of splits */
 
 /* Deferred epilogue of a whole backward pass, all layers in two launches: per layer
  * G = sum_s slab[s] (fixed order); plain layers: grad += G; spectral-norm layers:

@@ -103,6 +103,28 @@ struct ConvGemmArgs {
                           // the vector-issue slots its older MFMA-bound neighbours leave over)
 };
 
+// Arguments of the weight-gradient kernels (conv_wgrad.hip: implicit GEMM; conv_wgrad_wino.hip: Winograd F(3x3,2x2))
+struct WgradArgs {
+  const float* dy;        // pixel tensor [M][Co]
+  const float* x;         // gathered tensor NHWC [B,Hi,Wi,Ci]
+  float* slab;            // [splits][Co][Kp]
+  const float* pro_scale;
+  const float* pro_shift;
+  int pro_mode;
+  int M;
+  int steps_per_split;    // K-steps (of 32 pixels) per split
+  int seg_steps;          // K-steps per pixel segment (total steps when there is one segment)
+  int splits_per_seg;     // splits never straddle a segment (= one of several batched forwards)
+  long slab_stride;       // floats between consecutive split slabs (>= Co*Kp)
+  long bias_off;          // >= 0: column sums of dy (bias gradient) go to slab[split][bias_off + n]
+  ConvGeom g;
+  FastDiv dWo, dHo;
+  int adv_b, adv_y, adv_x;  // 32 pixels = adv_b images + adv_y rows + adv_x columns (pixel coordinates advance incrementally)
+  int lgW, lgHW;            // log2(Wo), log2(Ho*Wo) when both are powers of two (P2 kernels)
+  int tiles;                // output tiles (the grid is tiles * splits workgroups)
+  int same;                 // stride-1, un-dilated, same-size conv (Hi == Ho, Wi == Wo): linear gather offsets
+};
+
 // Bijective XCD-aware remap of a linear workgroup id (cdna guide T1): consecutive logical tiles
 // land on the same XCD (= same L2), so neighbouring tiles share halo rows and weight panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

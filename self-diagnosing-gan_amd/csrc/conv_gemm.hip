@@ -834,6 +834,7 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
 
 // Run-time form of DIAGAN_WINO (A/B runs and the tests that compare kernels like with like): 0 = implicit GEMM only,
 // 1 = Winograd where it qualifies, -1 = back to the environment's choice.
+DIAGAN_API int diagan_conv_gemm_get_wino(void) { return g_wino; }
 DIAGAN_API int diagan_conv_gemm_set_wino(int mode) {
   DG_REQUIRE(mode >= -1 && mode <= 1, "set_wino: -1, 0 or 1");
   g_wino = mode;

@@ -20,27 +20,11 @@
 extern "C" int diagan_get_mfma_mode(void);
 
 namespace diagan {
+bool wgrad_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up,
+                          int Kp);                                    // conv_wgrad_wino.hip
+int wgrad_wino_splits(int B, int Ho, int Wo, int Ci, int Co);
+int launch_wgrad_wino(WgradArgs a, int splits, int segments, hipStream_t st);
 
-struct WgradArgs {
-  const float* dy;        // pixel tensor [M][Co]
-  const float* x;         // gathered tensor NHWC [B,Hi,Wi,Ci]
-  float* slab;            // [splits][Co][Kp]
-  const float* pro_scale;
-  const float* pro_shift;
-  int pro_mode;
-  int M;
-  int steps_per_split;    // K-steps (of 32 pixels) per split
-  int seg_steps;          // K-steps per pixel segment (total steps when there is one segment)
-  int splits_per_seg;     // splits never straddle a segment (= one of several batched forwards)
-  long slab_stride;       // floats between consecutive split slabs (>= Co*Kp)
-  long bias_off;          // >= 0: column sums of dy (bias gradient) go to slab[split][bias_off + n]
-  ConvGeom g;
-  FastDiv dWo, dHo;
-  int adv_b, adv_y, adv_x;  // 32 pixels = adv_b images + adv_y rows + adv_x columns (pixel coordinates advance incrementally)
-  int lgW, lgHW;            // log2(Wo), log2(Ho*Wo) when both are powers of two (P2 kernels)
-  int tiles;                // output tiles (the grid is tiles * splits workgroups)
-  int same;                 // stride-1, un-dilated, same-size conv (Hi == Ho, Wi == Wo): linear gather offsets
-};
 
 // P2: Ho and Wo are powers of two -- pixel coordinates come from shifts and masks of the pixel index instead of
 // the incrementally advanced (b, oy, ox) registers (the gather arithmetic is ~7 % of the kernel otherwise)
@@ -970,6 +954,10 @@ __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __r
 }  // namespace diagan
 
 using namespace diagan;
+extern "C" int diagan_conv_gemm_get_wino(void);
+extern "C" int diagan_conv_wgrad_splits(int M, int Co, int Kp);
+extern "C" int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                           int off, int up, int Kp);
 
 DIAGAN_API int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t total_blocks, int any_sn,
                                            void* stream) {
@@ -1029,6 +1017,8 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   a.slab_stride = slab_stride;
   a.bias_off = bias_off;
   hipStream_t st = (hipStream_t)stream;
+  if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp))
+    return launch_wgrad_wino(a, splits, segments, st);
   int bn, bk;
   wgrad_tile(Co, Kp, &bn, &bk);
   const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
@@ -1081,6 +1071,26 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
 #undef DG_WG_ALL
 #undef DG_WG
   return check_launch("conv_wgrad");
+}
+
+// The Winograd F(3x3,2x2) weight gradient (conv_wgrad_wino.hip) takes the 3x3 / stride 1 / pad 1 layers unless
+// DIAGAN_WINO=0 / diagan_conv_gemm_set_wino(0) or the bf16x6 mode is on.
+DIAGAN_API int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                           int off, int up, int Kp) {
+  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  static const int wg_env = getenv("DIAGAN_WINO_WGRAD") ? atoi(getenv("DIAGAN_WINO_WGRAD")) : 1;
+  const int sw = diagan_conv_gemm_get_wino();
+  const int on = sw >= 0 ? sw : wino_env;
+  return on && wg_env && diagan_get_mfma_mode() == 0 &&
+         wgrad_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp);
+}
+
+// split count for a full geometry: the Winograd kernel's own policy where it applies, else diagan_conv_wgrad_splits
+DIAGAN_API int diagan_conv_wgrad_splits_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                             int dr, int off, int up, int Kp) {
+  if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp))
+    return wgrad_wino_splits(B, Ho, Wo, Ci, Co);
+  return diagan_conv_wgrad_splits(B * Ho * Wo, Co, Kp);
 }
 
 // how many splits conv_wgrad should use for this problem (host-side heuristic, no device work)

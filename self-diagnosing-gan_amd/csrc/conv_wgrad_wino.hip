@@ -1,0 +1,307 @@
+// Winograd F(3x3, 2x2) weight gradient on the fp32 matrix cores.
+//
+// Replaces the weight half of conv2d backward (errD.backward() / errG.backward() in the train steps,
+// diagan-pkg/diagan/models/topk_models.py:90, mnist.py:126) for the 3x3 / stride 1 / pad 1 layers, like
+// conv_wgrad.hip but with 16/36 of its multiply-accumulates.  With the output cut into 2x2 tiles, a tile's
+// contribution to dW (3x3) is the correlation of its 4x4 input patch d with its 2x2 gradient tile e, which is the
+// transpose of the forward algorithm of conv_wino.hip:
+//     dW = G^T [ sum_tiles (A e A^T) .* (B^T d B) ] G          (A, B, G: the F(2x2,3x3) matrices)
+// The sum over tiles runs in the transformed domain as 16 GEMMs  N_f[co][ci] += E_f[tile][co] V_f[tile][ci]  (K = tiles);
+// G^T . G is applied once per workgroup at the end and the result goes to the same split-K slab, in the same packed
+// layout [Co][(r*3+s)*Ci + ci] (+ bias column sums), that conv_wgrad_kernel writes -- the deferred reduction
+// (wgrad_finish_*_kernel) does not change.
+//
+// One workgroup = 512 threads = 8 waves = 64 output channels x 64 input channels x one split of the tiles, one per CU
+// (128 KB of LDS, two stages).  K-step = 8 tiles (32 pixels).  Both operands are transformed by the loader:
+//   V: thread (tile, channel quad, patch row r) as in conv_wino.hip (prologue, row transform, DPP column transform);
+//   E: thread (tile, channel quad, row i of A e A^T) loads the tile's 2x2 gradient pixels and forms its row.
+// LDS planes are tile-major [f][8 tiles][64 channels] (16-byte slots XOR-ed with the row index: conflict-free
+// ds_write_b128), MFMA fragments are ds_read_b32 (K = tile).  Wave w owns row i = w >> 1 of the frequencies on the
+// input-channel half w & 1: 4 x 2 accumulator tiles; the j half of G^T . G is applied in registers, the i half after
+// one LDS exchange per 32 output channels.
+#include "conv_common.h"
+#include <type_traits>
+
+namespace diagan {
+
+constexpr int GW_T = 8;                        // tiles per K-step
+constexpr int GW_PLANE = GW_T * 64;            // floats of one frequency plane: 8 tiles x 64 channels
+constexpr int GW_STAGE = 2 * 16 * GW_PLANE;    // V planes + E planes
+
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 16 planes | E 16 planes] = 128 KB
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_ci = (g.Ci + 63) / 64;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / a.tiles, tile = logical - split * a.tiles;
+  const int n0 = (tile / tiles_ci) * 64, c0 = (tile % tiles_ci) * 64;      // first output / input channel
+  const int TW = g.Wo >> 1, TH = g.Ho >> 1;
+  const int MT = g.B * TH * TW;
+  const bool affine = PRO == PRO_AFFINE_RELU || PRO == PRO_AFFINE;
+  // K-step range of this split (a.seg_steps etc. count K-steps of 8 tiles = 32 pixels, as in conv_wgrad_kernel)
+  const int seg = split / a.splits_per_seg, sidx = split - seg * a.splits_per_seg;
+  const int total_steps = (MT + GW_T - 1) / GW_T;
+  const int s_begin = seg * a.seg_steps + sidx * a.steps_per_split;
+  const int s_end = min(min(s_begin + a.steps_per_split, (seg + 1) * a.seg_steps), total_steps);
+
+  // ---- loader role: tile lt of the K-step, channel quad cq, row lr (patch row of V / row i of A e A^T) ----
+  const int lr = tid & 3, cq = (tid >> 2) & 15, lt = wave;
+  const bool ci_ok = c0 + cq * 4 < g.Ci, co_ok = n0 + cq * 4 < g.Co;
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.dy), 0, (int)((unsigned)g.B * g.Ho * g.Wo * g.Co * 4u), 0x00020000);
+  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  if (affine && ci_ok) {
+    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + cq * 4);
+    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + cq * 4);
+  }
+  // column transform of V: own + sc * partner (quad_perm [2,2,1,1]); row 3 is staged negated, as in conv_wino.hip, and
+  // the sign is undone in E's row 3 (ea1 below)
+  const float sc = lr == 1 ? 1.f : -1.f;
+  // row lr of A e A^T: (A e)[lr][x] = ea0 * e[0][x] + ea1 * e[1][x], A = [[1,0],[1,1],[1,-1],[0,-1]]; row 3 negated (+1)
+  const float ea0 = lr == 3 ? 0.f : 1.f, ea1 = lr == 0 ? 0.f : (lr == 2 ? -1.f : 1.f);
+  const int slot = (cq ^ (lr << 1)) * 4;                 // 16-byte slot of this thread's writes (row planes 4 lr .. 4 lr + 3)
+  const bool want_bias = a.bias_off >= 0 && c0 == 0;
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+
+  f32x4 rx[4], re[4];
+  float keep[4];
+  auto issue_loads = [&](int ks) {
+    const int gt = ks * GW_T + lt;
+    const bool tv = gt < MT;
+    const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);          // dWo: divisor TW, dHo: divisor TH
+    const int tx = (tv ? gt : 0) - (int)q1 * TW;
+    const unsigned b = fdiv(q1, a.dHo);
+    const int ty = (int)q1 - (int)b * TH;
+    const int iy = 2 * ty - 1 + lr, ix0 = 2 * tx - 1;
+    const bool rv = tv && ci_ok && iy >= 0 && iy < g.Hi;
+    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + (c0 + cq * 4) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
+      const unsigned o = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0x80000000u;     // outside: beyond num_records -> zeros
+      rx[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, o, 0, 0));
+      keep[c] = ok ? 1.f : 0.f;
+    }
+    const int ebase = (((int)b * g.Ho + 2 * ty) * g.Wo + 2 * tx) * g.Co * 4 + (n0 + cq * 4) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const unsigned o = (tv && co_ok) ? (unsigned)(ebase + ((p >> 1) * g.Wo + (p & 1)) * g.Co * 4) : 0x80000000u;
+      re[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, o, 0, 0));
+    }
+  };
+  f32x4 t[4];
+  auto transform_v = [&]() {                // prologue + row transform of the 4 patch pixels of this row
+    f32x4 d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 v = rx[c];
+      if (PRO != PRO_NONE) {
+        if (affine) v = v * psc + psh;
+        if (PRO == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        } else if (PRO != PRO_AFFINE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, __builtin_huge_valf());
+        }
+        if (affine) v *= keep[c];
+      }
+      d[c] = v;
+    }
+    t[0] = d[0] - d[2];
+    t[1] = d[1] + d[2];
+    t[2] = d[2] - d[1];
+    t[3] = d[1] - d[3];
+  };
+  auto store_v = [&](int stage, int j) {    // column transform (DPP) + one frequency plane
+    float* vs = smem + stage * GW_STAGE;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float own = t[j][e];
+      const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x5A, 0xF, 0xF, false);
+      o[e] = fmaf(sc, __int_as_float(other), own);
+    }
+    *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * GW_T + lt) * 64 + slot) = o;
+  };
+  auto store_e = [&](int stage) {           // row lr of A e A^T: four frequency planes
+    float* es = smem + stage * GW_STAGE + 16 * GW_PLANE;
+    const f32x4 a0 = ea0 * re[0] + ea1 * re[2], a1 = ea0 * re[1] + ea1 * re[3];
+    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 0) * GW_T + lt) * 64 + slot) = a0;
+    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 1) * GW_T + lt) * 64 + slot) = a0 + a1;
+    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 2) * GW_T + lt) * 64 + slot) = a0 - a1;
+    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 3) * GW_T + lt) * 64 + slot) = -a1;
+    if (want_bias && lr == 0) bacc += (re[0] + re[1]) + (re[2] + re[3]);
+  };
+
+  // wave w: row wi = w >> 1 of the frequencies (f = 4 wi + j), output channels 2 x 32 (tm), input channels tn = w & 1
+  const int wi = wave >> 1, tn = wave & 1;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int fl = 0; fl < 4; ++fl)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[fl][i][e] = 0.f;
+  const int fi = lane & 31, fh = lane >> 5;
+  // fragment columns (channel index inside the plane row, un-swizzling the writer's slot XOR with the row index wi)
+  int acol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) acol[i] = ((((i * 32 + fi) >> 2) ^ (wi << 1)) << 2) | (fi & 3);
+  const int bcol = ((((tn * 32 + fi) >> 2) ^ (wi << 1)) << 2) | (fi & 3);
+
+  if (s_begin < s_end) {
+    issue_loads(s_begin);
+    transform_v();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_v(0, j);
+    store_e(0);
+  }
+  __syncthreads();
+
+  auto kstep = [&](int ks, auto has_next) {
+    const int cur = (ks - s_begin) & 1;
+    const float* vs = smem + cur * GW_STAGE;
+    const float* es = vs + 16 * GW_PLANE;
+    if (decltype(has_next)::value) issue_loads(ks + 1);
+#pragma unroll
+    for (int fl = 0; fl < 4; ++fl) {
+      const int f = wi * 4 + fl;
+      float fa[2][4], fb[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = (f * GW_T + 2 * e + fh) * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i][e] = es[row + acol[i]];
+        fb[e] = vs[row + bcol];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int grp = fl * 4 + e;
+        if (decltype(has_next)::value && grp >= 8 && grp < 14) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (grp == 8) transform_v();
+          else if (grp == 9) store_e(cur ^ 1);
+          else store_v(cur ^ 1, grp - 10);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[fl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[e], acc[fl][i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  };
+  for (int ks = s_begin; ks + 1 < s_end; ++ks) kstep(ks, std::true_type{});
+  if (s_begin < s_end) kstep(s_end - 1, std::false_type{});
+
+  // ---- epilogue: dW = G^T N G.  j half in registers (3 values per row), i half after an LDS exchange per co half ----
+  float* out = a.slab + (long)split * a.slab_stride;
+  float* ss = smem;                                      // [4 i][3 s][32 co][64 ci] = 96 KB
+  const int eo = tid >> 4, ec = (tid & 15) * 4;         // this thread's output channel (within the half) and input quad
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * fh;
+      const float m0 = acc[0][tm][e], m1 = acc[1][tm][e], m2 = acc[2][tm][e], m3 = acc[3][tm][e];
+      const float h1 = 0.5f * m1, h2 = 0.5f * m2;
+      ss[((wi * 3 + 0) * 32 + row) * 64 + tn * 32 + fi] = m0 + h1 + h2;
+      ss[((wi * 3 + 1) * 32 + row) * 64 + tn * 32 + fi] = h1 - h2;
+      ss[((wi * 3 + 2) * 32 + row) * 64 + tn * 32 + fi] = h1 + h2 + m3;
+    }
+    __syncthreads();
+    const int co = n0 + tm * 32 + eo, ci = c0 + ec;
+    if (co < g.Co && ci < g.Ci) {
+      float* orow = out + (long)co * g.Kp + ci;
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(ss + ((0 * 3 + sx) * 32 + eo) * 64 + ec);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(ss + ((1 * 3 + sx) * 32 + eo) * 64 + ec);
+        const f32x4 q2 = *reinterpret_cast<const f32x4*>(ss + ((2 * 3 + sx) * 32 + eo) * 64 + ec);
+        const f32x4 q3 = *reinterpret_cast<const f32x4*>(ss + ((3 * 3 + sx) * 32 + eo) * 64 + ec);
+        const f32x4 h1 = 0.5f * q1, h2 = 0.5f * q2;
+        *reinterpret_cast<f32x4*>(orow + (0 * 3 + sx) * g.Ci) = q0 + h1 + h2;
+        *reinterpret_cast<f32x4*>(orow + (1 * 3 + sx) * g.Ci) = h1 - h2;
+        *reinterpret_cast<f32x4*>(orow + (2 * 3 + sx) * g.Ci) = h1 + h2 + q3;
+      }
+    }
+    __syncthreads();
+  }
+  // zero padding of the packed rows (Kp > 9 Ci): written once per output-channel block, by the workgroup of its last
+  // input-channel block (the deferred reduction sums whole [Co][Kp] slabs)
+  if (c0 + 64 >= g.Ci && g.Kp > 9 * g.Ci) {
+    const int npad4 = (g.Kp - 9 * g.Ci) >> 2;
+    for (int idx = tid; idx < 64 * npad4; idx += 512) {
+      const int co = n0 + idx / npad4;
+      if (co < g.Co) *reinterpret_cast<f32x4*>(out + (long)co * g.Kp + 9 * g.Ci + (idx % npad4) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  if (want_bias) {
+    float* red = smem;                                   // [8 tiles-of-the-step lanes = waves][64 channels]
+    if (lr == 0) *reinterpret_cast<f32x4*>(red + wave * 64 + cq * 4) = bacc;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < g.Co) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) tsum += red[w * 64 + tid];
+      out[a.bias_off + n0 + tid] = tsum;
+    }
+  }
+}
+
+// the layers the Winograd weight gradient takes: 3x3 / stride 1 / pad 1 forward geometry, even H and W, channels % 4
+bool wgrad_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up,
+                          int Kp) {
+  return R == 3 && S == 3 && sy == 1 && up == 1 && dr == 1 && off == -1 && Hi == Ho && Wi == Wo && !(Ho & 1) && !(Wo & 1) &&
+         (Ci & 3) == 0 && (Co & 3) == 0 && Ci >= 16 && Co >= 16;
+}
+
+// split count: one round of 256 workgroups when the tile count allows it, at least 8 K-steps (64 tiles) per split
+int wgrad_wino_splits(int B, int Ho, int Wo, int Ci, int Co) {
+  const long MT = (long)B * (Ho >> 1) * (Wo >> 1);
+  const long steps = (MT + GW_T - 1) / GW_T;
+  const int tiles = cdiv(Co, 64) * cdiv(Ci, 64);
+  long s = tiles >= 256 ? 1 : (256 + tiles - 1) / tiles;
+  if (s > steps / 8) s = steps / 8;
+  if (s > 256) s = 256;
+  return s < 1 ? 1 : (int)s;
+}
+
+template <int PRO>
+static void launch_gw(const WgradArgs& a, int wgs, hipStream_t st) {
+  const size_t lds = (size_t)2 * GW_STAGE * sizeof(float);
+  auto kern = conv_wgrad_wino_kernel<PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, a);
+}
+
+// `a` as prepared by diagan_conv_wgrad (M, g, slab, strides, prologue); the K-step bookkeeping is redone for 8-tile steps
+int launch_wgrad_wino(WgradArgs a, int splits, int segments, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
+  const int MT = g.B * (g.Ho >> 1) * (g.Wo >> 1);
+  const int total_steps = cdiv(MT, GW_T);
+  a.seg_steps = cdiv(total_steps, segments);
+  a.splits_per_seg = splits / segments;
+  a.steps_per_split = cdiv(a.seg_steps, a.splits_per_seg);
+  a.tiles = cdiv(g.Co, 64) * cdiv(g.Ci, 64);
+  const int wgs = a.tiles * splits;
+  switch (a.pro_mode) {
+    case PRO_NONE: launch_gw<PRO_NONE>(a, wgs, st); break;
+    case PRO_RELU: launch_gw<PRO_RELU>(a, wgs, st); break;
+    case PRO_AFFINE_RELU: launch_gw<PRO_AFFINE_RELU>(a, wgs, st); break;
+    case PRO_LRELU: launch_gw<PRO_LRELU>(a, wgs, st); break;
+    default: launch_gw<PRO_AFFINE>(a, wgs, st); break;
+  }
+  return check_launch("conv_wgrad_wino");
+}
+
+}  // namespace diagan

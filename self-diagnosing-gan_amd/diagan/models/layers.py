@@ -490,7 +490,7 @@ class WgradBatch:
         self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, total_blocks, any_sn)
         self.slab_generation = None
 
-    def _entry(self, layer, slot, M, segments=1, dy_shape=None):
+    def _entry(self, layer, slot, M, segments=1, dy_shape=None, x_shape=None):
         self.net.flat_grads
         if self.slab_generation != self.net.slab_generation:          # gradient slab was re-allocated
             self.entries.clear(), self.tables.clear()
@@ -504,7 +504,11 @@ class WgradBatch:
             if has_bias and layer.bias.grad.data_ptr() != layer.weight.grad.data_ptr() + 4 * n_w:
                 raise RuntimeError("bias gradient does not follow the weight gradient in the flat slab")
             stride = n_w + n_b
-            splits = max(segments, C.wgrad_splits(M, g.Co, g.Kp) // segments * segments)
+            if dy_shape is not None and x_shape is not None:
+                base = C.wgrad_splits_geom(g, dy_shape[0], x_shape[1], x_shape[2], dy_shape[1], dy_shape[2])
+            else:
+                base = C.wgrad_splits(M, g.Co, g.Kp)
+            splits = max(segments, base // segments * segments)
             if segments == 1 and dy_shape is not None and C.small_co_wgrad(g):
                 splits = C.small_co_wgrad_splits(dy_shape[0], dy_shape[1])
             dev = layer.weight.device
@@ -520,7 +524,7 @@ class WgradBatch:
         """sn_ctx: None (plain layer), one SN context, or a tuple of `segments` contexts (one per
         batched forward; the pixel range is cut accordingly and each part gets its own correction)."""
         M = dy.numel() // dy.shape[-1]
-        e = self._entry(layer, slot, M, segments, tuple(dy.shape))
+        e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape))
         e['sn_ctx'] = sn_ctx
         C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro,
                           segments=segments)

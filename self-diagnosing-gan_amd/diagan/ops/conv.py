@@ -13,6 +13,9 @@ nat.register("diagan_conv_gemm_pick_ksplit", [I, I, I, I])
 nat.register("diagan_conv_gemm_pick_cfg", [I, I, I, I])
 nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_set_wino", [I])
+nat.register("diagan_conv_gemm_get_wino", [])
+nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
+nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_gemm_tile_cols", [I])
@@ -279,17 +282,18 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     for t, n in ((dy, 'dy'), (x, 'x'), (grad, 'grad'), (scale, 'pro_scale'), (shift, 'pro_shift')):
         _chk(t, n)
     M = B * Ho * Wo
-    splits = nat.fn("diagan_conv_wgrad_splits")(M, Co, geom.Kp)
+    splits = wgrad_splits_geom(geom, B, Hi, Wi, Ho, Wo)
     n_elem = Co * geom.Kp
     extra = n_elem if sn is not None else 0
     slab = _slab(dy.device, splits * n_elem + extra)
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
-    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo)) if TIMER is not None else None
+    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if TIMER is not None else None
+    t0 = TIMER.begin(kn) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo), 2.0 * M * Co * geom.R * geom.S * Ci, t0,
+        TIMER.end(kn, 2.0 * M * Co * geom.R * geom.S * Ci, t0,
                   (M, Co, geom.R * geom.S * Ci, f"pro{mode} x{splits}"))
     if sn is None:
         nat.call("diagan_wgrad_reduce", nat.ptr(slab), splits, n_elem, nat.ptr(grad), 1 if accumulate else 0,
@@ -308,6 +312,19 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
 
 def wgrad_splits(M, Co, Kp):
     return nat.fn("diagan_conv_wgrad_splits")(M, Co, Kp)
+
+
+def wgrad_splits_geom(geom, B, Hi, Wi, Ho, Wo):
+    """split count for this layer geometry (the Winograd weight gradient has its own policy)"""
+    sy, dr, off, up = geom.fwd_params()
+    return nat.fn("diagan_conv_wgrad_splits_geom")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up,
+                                                   geom.Kp)
+
+
+def wgrad_uses_wino(geom, Hi, Wi, Ho, Wo):
+    sy, dr, off, up = geom.fwd_params()
+    return bool(nat.fn("diagan_conv_wgrad_uses_wino")(Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up,
+                                                      geom.Kp))
 
 
 def small_co_wgrad(geom):
@@ -338,17 +355,20 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
         if t0 is not None:
             TIMER.end("conv3x3_co4_wgrad_kernel", 2.0 * B * Ho * Wo * Co * 9 * Ci, t0, (B * Ho * Wo, Co, 9 * Ci, f"pro{mode}"))
         return
-    t0 = TIMER.begin(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo)) if TIMER is not None else None
+    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if TIMER is not None else None
+    t0 = TIMER.begin(kn) if TIMER is not None else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
     if t0 is not None:
-        TIMER.end(_wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo), 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
+        TIMER.end(kn, 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
                   (B * Ho * Wo, Co, geom.R * geom.S * Ci, f"pro{mode}"))
 
 
-def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0):
+def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0, wino=False):
     """Kernel name as rocprofv3 prints it (template arguments BNn, BNk, PRO, P2)."""
+    if wino:
+        return f"conv_wgrad_wino_kernel<{mode}>"
     bn, bk = (64 if Co <= 64 else 128), (64 if Kp <= 64 else 128)
     if bn == 128 and bk == 64:
         bn = 64

@@ -94,6 +94,47 @@ def main():
             e = relerr(C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=9), C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=7))
             worst = max(worst, e)
             print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {'fwd grouped bn+relu':22s} err {e:.2e}", flush=True)
+    # ---- weight gradient: Winograd F(3x3,2x2) against the implicit-GEMM weight gradient (same slab API) ----
+    for B, H, W, Ci, Co in shapes:
+        if Ci < 16 or Co < 16:
+            continue
+        geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+        x = torch.randn(B, H, W, Ci, device=dev)
+        dy = torch.randn(B, H, W, Co, device=dev)
+        sc, sh = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.3
+        n_w = Co * geom.Kp
+        stride = n_w + Co
+
+        def run(wino, pro, segments=1):
+            C.set_winograd(wino)
+            try:
+                splits = max(segments, C.wgrad_splits_geom(geom, B, H, W, H, W) // segments * segments)
+                slab = torch.full((splits * stride,), float("nan"), device=dev)
+                C.conv_wgrad_into(geom, dy, x, slab, splits, stride, n_w, pro=pro, segments=segments)
+                torch.cuda.synchronize()
+                return slab.view(splits, stride).sum(0), splits
+            finally:
+                C.set_winograd(None)
+        for name, pro in (("wgrad plain", None), ("wgrad relu", (C.PRO_RELU, None, None)),
+                          ("wgrad bn+relu", (C.PRO_AFFINE_RELU, sc, sh))):
+            ref, s0_ = run(False, pro)
+            got, s1_ = run(True, pro)
+            e = relerr(got[:n_w], ref[:n_w])
+            eb = relerr(got[n_w:], ref[n_w:])
+            worst = max(worst, e, eb)
+            line = f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {name:22s} err {e:.2e} bias err {eb:.2e} splits {s0_}/{s1_}"
+            if B * H * W >= 2048 and name != "wgrad relu":
+                flop = 2.0 * B * H * W * Co * 9 * Ci
+                ta = timeit(lambda: run(False, pro))
+                tw = timeit(lambda: run(True, pro))
+                line += (f" | gemm {ta*1e6:8.1f} us | winograd {tw*1e6:8.1f} us (incl. slab alloc + sum; {ta/tw:4.2f}x)")
+            print(line, flush=True)
+        if B % 2 == 0 and (B // 2) * H * W % 32 == 0:
+            ref, _ = run(False, (C.PRO_RELU, None, None), segments=2)
+            got, _ = run(True, (C.PRO_RELU, None, None), segments=2)
+            e = relerr(got, ref)
+            worst = max(worst, e)
+            print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {'wgrad 2 segments':22s} err {e:.2e}", flush=True)
     print(f"worst relative error {worst:.2e}")
     return 0 if worst < 2e-5 else 1
 
