@@ -246,11 +246,26 @@ def test_full_size_sngan32_g_block4():
     close(nchw(y), ref_fwd("conv", x, w, None, 1, 1))
 
 
-@pytest.mark.parametrize("B,H,Ci,Co,pro", [(128, 32, 128, 128, 1), (64, 32, 256, 256, 2)])
-def test_full_size_backward_sampled(B, H, Ci, Co, pro):
-    """BASELINE-size data- and weight-gradients (D-32 block1.c2 as the batched real+fake pass, G-32 block4.c2)
-    checked on SAMPLED output elements against float64 sums taken straight from the definition, plus two
-    size-independent properties: linearity of the weight gradient in dy, and <dy, conv(x)> == <dW, W>."""
+@pytest.mark.parametrize("winograd", [True, False])
+@pytest.mark.parametrize("B,H,Ci,Co,pro", [
+    (128, 32, 128, 128, 1), (64, 32, 256, 256, 2),             # D-32 block1.c2 (real+fake pass), G-32 block4.c2
+    (64, 64, 64, 64, 1),                                       # SNGAN-64 D block1.c2 / G block5.c2: (M, N, K) = (262144, 64, 576)
+    (64, 8, 1024, 512, 2),                                     # SNGAN-64 G block2.c1: (4096, 512, 9216)
+    (64, 4, 512, 1024, 1)])                                    # SNGAN-64 D block5.c2: (1024, 1024, 4608)
+def test_full_size_backward_sampled(B, H, Ci, Co, pro, winograd):
+    """BASELINE-size data- and weight-gradients of the SNGAN-32 and SNGAN-64 block shapes at batch 64, with the Winograd
+    kernels (the default where they qualify) and with the implicit GEMM only, checked on SAMPLED output elements against
+    float64 sums taken straight from the definition, plus two size-independent properties: linearity of the weight
+    gradient in dy, and <dy, conv(x)> == <dW, W>."""
+    from diagan.ops import conv as C
+    C.set_winograd(winograd)
+    try:
+        _full_size_backward_sampled(B, H, Ci, Co, pro)
+    finally:
+        C.set_winograd(None)
+
+
+def _full_size_backward_sampled(B, H, Ci, Co, pro):
     from diagan.ops import conv as C
     g = torch.Generator().manual_seed(B + Ci)
     x = torch.randn(B, H, H, Ci, generator=g)
@@ -263,7 +278,7 @@ def test_full_size_backward_sampled(B, H, Ci, Co, pro):
     xd, dyd = x.cuda(), dy.cuda()
     pro_t = (pro, scale.cuda(), shift.cuda())
     # weight gradient through the slab path the networks use
-    splits = C.wgrad_splits(B * H * H, Co, geom.Kp)
+    splits = C.wgrad_splits_geom(geom, B, H, H, H, H)
     stride = Co * geom.Kp + Co
     slab = torch.empty(splits * stride, device="cuda")
     C.conv_wgrad_into(geom, dyd, xd, slab, splits, stride, Co * geom.Kp, pro=pro_t)
@@ -345,3 +360,43 @@ def test_spectral_norm_forward_backward():
     before = u_buf.clone()
     C.sn_power_iter(wp, u_buf, s_buf, training=False)
     assert torch.equal(before, u_buf)
+
+
+_HALF_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from diagan.ops import conv as C
+out = {}
+for (B, H, Ci, Co, pro) in ((16, 32, 128, 128, 1), (8, 16, 256, 256, 2), (6, 12, 128, 256, 0)):
+    g = torch.Generator().manual_seed(B + H)
+    x, dy = torch.randn(B, H, H, Ci, generator=g).cuda(), torch.randn(B, H, H, Co, generator=g).cuda()
+    sc, sh = (torch.rand(Ci, generator=g) + 0.5).cuda(), (torch.randn(Ci, generator=g) * 0.3).cuda()
+    geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+    grad = torch.zeros(Co, geom.Kp, device="cuda")
+    C.conv_wgrad(geom, dy, x, grad, accumulate=False, pro=(pro, sc, sh))
+    out[(B, H, Ci, Co, pro)] = grad.cpu()
+torch.save(out, sys.argv[3])
+"""
+
+
+def test_half_step_weight_gradient_kernel_in_a_child_process(tmp_path):
+    """conv_wgrad_half_kernel (DIAGAN_WGRAD_HALF=1, read once per process into a static) against the default fp32
+    implicit-GEMM weight gradient on the same inputs, both with the Winograd path off: equal to summation-order
+    rounding (the opt-in kernel had no test)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import PKG, ROOT
+    script = tmp_path / "child.py"
+    script.write_text(_HALF_CHILD)
+    res = {}
+    for tag, extra in (("default", {}), ("half", {"DIAGAN_WGRAD_HALF": "1"})):
+        env = dict(os.environ, DIAGAN_WINO="0", **extra)
+        out = tmp_path / f"{tag}.pt"
+        r = subprocess.run([sys.executable, str(script), ROOT, PKG, str(out)], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(out)
+    for k, ref in res["default"].items():
+        got = res["half"][k]
+        assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 1e-7, k

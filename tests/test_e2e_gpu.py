@@ -52,6 +52,35 @@ def test_phase1_then_phase2(tmp_path, monkeypatch):
     assert ck['global_step'] == 36 and 'block1.c1.sn_u' in ck['model_state_dict']
 
 
+def test_celeba_phase1_then_phase2_cli(tmp_path, monkeypatch):
+    """BASELINE configs[3] through both command lines: SNGAN-64 phase 1 (record + checkpoints), then phase 2 with the
+    CelebA score `ldr_conf_5.0_ratio_50` (the reference's choice for this dataset), D_drs interleaved."""
+    sys.path.insert(0, ROOT)
+    monkeypatch.setenv("DIAGAN_QUIET", "1")
+    import train_mimicry_phase1 as p1
+    import train_mimicry_phase2 as p2
+    work = str(tmp_path)
+    t1 = p1.main(["--dataset", "celeba", "--work_dir", work, "--exp_name", "c1", "--loss_type", "hinge",
+                  "--num_data", "96", "--max_steps", "12", "--save_steps", "6", "--batch_size", "16"])
+    rec = t1.logit_records['netD_eval']
+    assert rec.steps == [8, 9]                    # the CelebA window 55000..60000 of 75000 steps, scaled to 12
+    logits = pickle.load(open(os.path.join(work, "c1", "logits_netD_eval.pkl"), "rb"))
+    assert all(v.dtype == np.float64 and v.shape == (96,) and np.all(v != 0) for v in logits.values())
+    from diagan.utils.plot import calculate_scores
+    lo, hi = min(logits), max(logits) + 1
+    sd = calculate_scores(logits, lo, hi)
+    ref = osc.calculate_scores_c(logits, lo, hi)
+    assert np.array_equal(sd["ldr_conf_5.0_ratio_50"], ref["ldr_conf_5.0_ratio_50"])
+    t2 = p2.main(["--dataset", "celeba", "--work_dir", work, "--exp_name", "c2", "--baseline_exp_name", "c1",
+                  "--loss_type", "hinge", "--p1_step", "12", "--window", "5", "--num_steps", "14",
+                  "--num_data", "96", "--resample_score", "ldr_conf_5.0_ratio_50", "--batch_size", "16",
+                  "--save_steps", "100"])
+    kinds = [e for _, e in t2.events]
+    assert kinds.count('D') == 10 and kinds.count('D_drs') == 10 and kinds.count('G') == 2      # steps 12, 13
+    ck = torch.load(os.path.join(work, "c2", "checkpoints/netD_drs/netD_drs_14_steps.pth"), weights_only=False)
+    assert ck['global_step'] == 14 and 'block5.c2.sn_u' in ck['model_state_dict']
+
+
 def test_logit_record_matches_direct_eval(tmp_path):
     """_get_logit rows == D(x) of the same weights in eval mode, by dataset index (shuffled loader)."""
     from diagan.datasets.predefined import get_predefined_dataset

@@ -40,7 +40,22 @@ def test_golden_edges_bit_exact(golden_dir, case):
         assert np.array_equal(sd[k], g[f"{case}_values"][j]), (case, k)
 
 
-@pytest.mark.parametrize("N,T", [(1, 3), (63, 2), (257, 7), (5000, 50), (50000, 50)])
+def test_golden_edge_n_equals_one(golden_dir):
+    """Edge set (d): ONE sample.  NumPy reduces the then-contiguous T axis pairwise, so its own result differs from a
+    sequential sum in the last bits (tests/test_oracle_scorer.py::test_n_equals_one_is_pairwise_in_numpy); the HIP
+    scorer walks T sequentially like the C oracle: bit-equal to the oracle, 1e-14 relative to the reference's vector."""
+    from diagan.utils.plot import calculate_scores
+    g = np.load(os.path.join(golden_dir, "scorer_edges.npz"))
+    logits = {int(s): g["d_rec"][i] for i, s in enumerate(g["d_steps"])}
+    sd = calculate_scores(logits, int(g["d_start"]), int(g["d_end"]))
+    ref = osc.calculate_scores_c(logits, int(g["d_start"]), int(g["d_end"]))
+    for j, k in enumerate([str(k) for k in g["keys"]]):
+        assert np.array_equal(sd[k], ref[k]), k
+        np.testing.assert_allclose(sd[k], g["d_values"][j], rtol=1e-14, atol=1e-15, err_msg=k)
+
+
+# N = 162 770: the CelebA training set (BASELINE configs[3]; inclusive_gan.py:94-95), T = 50 snapshots = 65 MB
+@pytest.mark.parametrize("N,T", [(1, 3), (63, 2), (257, 7), (5000, 50), (50000, 50), (162770, 50)])
 def test_vs_oracle_bit_exact(N, T):
     from diagan.utils.plot import calculate_scores
     logits = _rec(N, T, seed=N + T)

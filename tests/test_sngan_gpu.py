@@ -95,8 +95,23 @@ def test_forward_eval_and_train(dataset, res):
             relclose(sD[k], v, 1e-4, k)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp32-implicit-gemm", "bf16x6"])
 @pytest.mark.parametrize("dataset,res,loss", [("cifar10", 32, "ns"), ("cifar10", 32, "hinge"), ("celeba", 64, "ns")])
-def test_train_steps_match_oracle(dataset, res, loss):
+def test_train_steps_match_oracle(dataset, res, loss, mode):
+    """two D + G updates against the CPU oracle in every arithmetic mode of the GEMM kernels: the default (fp32 MFMA,
+    Winograd where it qualifies), fp32 MFMA on the implicit GEMM only, and the opt-in bf16x6 mode (DIAGAN_MFMA=bf16x6)"""
+    from diagan.ops import conv as C
+    start = C.get_mfma_mode()
+    C.set_mfma_mode(1 if mode == "bf16x6" else 0)
+    C.set_winograd(False if mode == "fp32-implicit-gemm" else None)
+    try:
+        _train_steps_match_oracle(dataset, res, loss)
+    finally:
+        C.set_mfma_mode(start)
+        C.set_winograd(None)
+
+
+def _train_steps_match_oracle(dataset, res, loss):
     (oG, oD, ooptG, ooptD), (netG, netD, optG, optD) = build(dataset, loss)
     B = 8 if res == 32 else 4
     g = torch.Generator().manual_seed(3)
