@@ -342,6 +342,26 @@ int diagan_adam_step(float* p, const float* g, float* m, float* v, int64_t n, fl
  * replay. */
 int diagan_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper8, void* stream);
 
+/* ---- data-parallel exchange (RCCL over xGMI; csrc/comm.hip) ------------------------------------------------------
+ * An explicit context per process (one process per GPU) holding the RCCL communicator; RCCL itself is dlopen-ed at
+ * context creation (no link-time dependency, single-process runs never load it).
+ *   diagan_comm_unique_id: 128 bytes made by rank 0 and handed to every rank by the launcher (any host channel);
+ *   diagan_ctx_create: collective over all `world` ranks (ncclCommInitRank) on HIP device `device`;
+ *   diagan_allreduce_grads: in-place SUM of a network's flat fp32 gradient slab on `stream` -- the gradient averaging of
+ *     DistributedDataParallel (stylegan2/train_ffhq.py:572-585); the 1/W is applied by diagan_adam_step(grad_scale);
+ *   diagan_allgather_logits: rank-major concatenation of equally sized per-rank rows (elem_bytes 4 / 8: fp32 logits /
+ *     float64 record shards; copied, never summed) -- concat_all_gather of stylegan2/train_ffhq.py:150-161.
+ * Both collectives are stream-ordered launches: no host synchronisation, capturable in a hipGraph. */
+typedef struct diagan_ctx diagan_ctx;
+int diagan_comm_unique_id(void* id128);
+int diagan_ctx_create(diagan_ctx** out, const void* id128, int rank, int world, int device);
+int diagan_ctx_destroy(diagan_ctx* ctx);
+int diagan_ctx_rank(const diagan_ctx* ctx);
+int diagan_ctx_world(const diagan_ctx* ctx);
+int diagan_allreduce_grads(diagan_ctx* ctx, float* slab, int64_t n, void* stream);
+int diagan_allgather_logits(diagan_ctx* ctx, const void* send, void* recv, int64_t n_per_rank, int elem_bytes,
+                            void* stream);
+
 /* ---- StyleGAN2 native ops (the reference's only native code) -------------- */
 
 /* fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale), fused_bias_act.cpp:4-20:

@@ -12,6 +12,55 @@ import torch
 import torch.distributed as dist
 
 
+# ---- native exchange: RCCL behind the C ABI (csrc/comm.hip) ---------------------------------------------------------
+# DIAGAN_COMM=rccl: the gradient all-reduce and the logit all-gather go through diagan_allreduce_grads /
+# diagan_allgather_logits on an explicit diagan_ctx (stream-ordered launches on torch's current stream: no host wait,
+# capturable in a hipGraph) instead of torch.distributed's process group, which then only carries the 128-byte
+# unique id and the barriers.  Default: torch.distributed ('nccl' = RCCL on ROCm) -- the native path cannot be
+# exercised with more than one rank on the single-GPU test box (RCCL refuses two ranks on one device).
+_NATIVE = {'ctx': None}
+
+
+def native_ctx():
+    return _NATIVE['ctx']
+
+
+def _register_native():
+    from diagan import _native as nat
+    P, I, I64 = nat.c_void_p, nat.c_int, nat.c_i64
+    for name, sig in (("diagan_comm_unique_id", [P]), ("diagan_ctx_create", [P, P, I, I, I]), ("diagan_ctx_destroy", [P]),
+                      ("diagan_ctx_rank", [P]), ("diagan_ctx_world", [P]), ("diagan_allreduce_grads", [P, P, I64, P]),
+                      ("diagan_allgather_logits", [P, P, P, I64, I, P])):
+        nat.register(name, sig)
+    return nat
+
+
+def init_native_comm(rank, world, device_index):
+    """Create the process's diagan_ctx: rank 0 draws the unique id, every rank receives it (torch.distributed object
+    broadcast when a process group exists, else world must be 1), all ranks enter ncclCommInitRank together."""
+    import ctypes
+    nat = _register_native()
+    ident = ctypes.create_string_buffer(128)
+    if rank == 0:
+        nat.call("diagan_comm_unique_id", ctypes.cast(ident, ctypes.c_void_p))
+    if world > 1:
+        box = [ident.raw]
+        dist.broadcast_object_list(box, src=0)
+        ident = ctypes.create_string_buffer(box[0], 128)
+    handle = ctypes.c_void_p()
+    nat.call("diagan_ctx_create", ctypes.cast(ctypes.pointer(handle), ctypes.c_void_p), ctypes.cast(ident, ctypes.c_void_p),
+             rank, world, device_index)
+    _NATIVE['ctx'] = handle
+    return handle
+
+
+def destroy_native_comm():
+    if _NATIVE['ctx'] is not None:
+        nat = _register_native()
+        nat.call("diagan_ctx_destroy", _NATIVE['ctx'])
+        _NATIVE['ctx'] = None
+
+
 def is_dist():
     return dist.is_available() and dist.is_initialized()
 
@@ -39,6 +88,8 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
         synchronize()
+        if os.environ.get("DIAGAN_COMM") == "rccl" and torch.cuda.is_available():
+            init_native_comm(rank, world, local_rank % max(torch.cuda.device_count(), 1))
     return rank, local_rank, world
 
 
@@ -63,6 +114,10 @@ def all_reduce_sum_(flat, async_op=False):
     runs on the backend's own stream; `wait()` orders the current stream behind it)."""
     if get_world_size() == 1:
         return None
+    if _NATIVE['ctx'] is not None and flat.is_cuda:
+        from diagan import _native as nat
+        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], flat.data_ptr(), flat.numel(), nat.current_stream())
+        return None                              # ordered on the current stream: nothing to wait for
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
@@ -117,6 +172,13 @@ def all_gather_cat(tensor):
     world = get_world_size()
     if world == 1:
         return tensor
+    if _NATIVE['ctx'] is not None and tensor.is_cuda and tensor.element_size() in (1, 4, 8):
+        from diagan import _native as nat
+        send = tensor.contiguous()
+        recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        nat.call("diagan_allgather_logits", _NATIVE['ctx'], send.data_ptr(), recv.data_ptr(), send.numel(),
+                 send.element_size(), nat.current_stream())
+        return recv
     out = [torch.empty_like(tensor) for _ in range(world)]
     dist.all_gather(out, tensor.contiguous())
     return torch.cat(out, dim=0)

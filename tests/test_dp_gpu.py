@@ -137,6 +137,30 @@ def test_ranks_draw_different_noise_and_stay_in_lock_step(tmp_path):
     assert r[0]['scale'] == 0.5
 
 
+def test_native_rccl_context_single_rank():
+    """SURVEY 8(b) exports diagan_ctx / diagan_allreduce_grads / diagan_allgather_logits (csrc/comm.hip): a one-rank RCCL
+    communicator on this box's GPU (RCCL refuses two ranks on one device, so W > 1 is the driver's 8-GPU run):
+    the all-reduce leaves the slab as it is, the all-gather returns the shard, both on torch's current stream."""
+    import ctypes
+    from diagan import _native as nat
+    from diagan.trainer import distributed as D
+    ctx = D.init_native_comm(0, 1, torch.cuda.current_device())
+    try:
+        assert nat.fn("diagan_ctx_world")(ctx) == 1 and nat.fn("diagan_ctx_rank")(ctx) == 0
+        g = torch.randn(1 << 20, device='cuda')
+        ref = g.clone()
+        nat.call("diagan_allreduce_grads", ctx, g.data_ptr(), g.numel(), nat.current_stream())
+        row = torch.randn(4096, dtype=torch.float64, device='cuda')
+        out = torch.zeros_like(row)
+        nat.call("diagan_allgather_logits", ctx, row.data_ptr(), out.data_ptr(), row.numel(), 8, nat.current_stream())
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref) and torch.equal(out, row)
+        with pytest.raises(RuntimeError, match="allreduce_grads"):
+            nat.call("diagan_allreduce_grads", ctx, None, 0, nat.current_stream())
+    finally:
+        D.destroy_native_comm()
+
+
 @pytest.mark.timeout(900)
 def test_bench_two_ranks_prints_one_json_line():
     """The driver's N > 1 launch of bench.py (torch.distributed.run, one process per rank) end to end, with both

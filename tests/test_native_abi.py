@@ -34,6 +34,8 @@ def test_binding_table_matches_header():
     from diagan import _native as nat
     import diagan.ops  # noqa: F401  (registers the op signatures)
     import diagan.trainer.compute_pr  # noqa: F401  (registers the precision/recall entry points)
+    from diagan.trainer import distributed as D
+    D._register_native()                 # the RCCL context entry points (csrc/comm.hip)
     declared = set(_declared()) - {"diagan_last_error", "diagan_target_arch"}
     assert declared == set(nat._SIGS), declared ^ set(nat._SIGS)
 
