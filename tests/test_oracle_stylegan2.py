@@ -94,3 +94,21 @@ def test_generator_loss_and_path_length_second_order():
     check_norms("path_grad", sg, rtol=1e-3)
     ref = G["path_grad_input"]
     np.testing.assert_allclose(sg["input.input"].grad.numpy(), ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+
+
+def test_oracle_at_256_with_unequal_channel_counts():
+    """BASELINE configs[4]'s resolution: the oracle's generator / discriminator forward and the logistic loss at 256 x 256,
+    channel_multiplier 1 (Ci != Co layers 512 -> 256 -> 128 -> 64) against the reference's own classes
+    (tests/golden/stylegan2_256.npz, tools/gen_goldens_stylegan2.py 256)."""
+    from test_oracle_models import expand_check
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "stylegan2_256.npz"))
+    size, cm = int(g["size"]), int(g["channel_multiplier"])
+    sg = O.seeded_state(O.generator_shapes(size, mult=cm), int(g["seed_g"]))
+    sd = O.seeded_state(O.discriminator_shapes(size, mult=cm), int(g["seed_d"]))
+    assert set(g["g_loss_grad_keys"]) == {k for k in sg if not k.startswith("noises.")}
+    assert set(g["d_loss_grad_keys"]) == set(sd)
+    with torch.no_grad():
+        img, lat = O.generator(sg, size, [torch.from_numpy(g["z1"])])
+        np.testing.assert_allclose(img[:, :, :8, :8].numpy(), g["g_image_corner"], rtol=1e-4, atol=1e-5)
+        expand_check(img.numpy(), g["g_image"], 1e-4)
+        np.testing.assert_allclose(O.discriminator(sd, size, img).numpy(), g["d_fake_pred"], rtol=1e-4, atol=1e-5)

@@ -279,3 +279,90 @@ def test_training_trajectory_vs_oracle():
     # zero may step the other way, so the comparison is a global relative L2 error, not element-wise
     assert rel_err(D, pd) < 1e-3 and rel_err(G, pg) < 1e-3
     assert float((D.state_dict()["final_linear.1.weight"].cpu() - sd_["final_linear.1.weight"]).abs().max()) > 1e-3
+
+
+# ---- BASELINE configs[4]'s resolution: 256 x 256 (VERDICT r1 Missing 7) ----------------------------------------------
+# tests/golden/stylegan2_256.npz comes from the reference's own classes at size 256, channel_multiplier 1, batch 2
+# (tools/gen_goldens_stylegan2.py 256): the upper pyramid layers have Ci != Co (512 -> 256 -> 128 -> 64), which the
+# size-16 / 32 vectors never reach.  Images are stored as checksums + strided samples (test_oracle_models.expand_check).
+G256_PATH = os.path.join(os.path.dirname(__file__), "golden", "stylegan2_256.npz")
+needs_256 = pytest.mark.skipif(not os.path.exists(G256_PATH), reason="tests/golden/stylegan2_256.npz not generated")
+
+
+def _build256(kind, g256):
+    from diagan.models import stylegan2 as M
+    size, cm = int(g256["size"]), int(g256["channel_multiplier"])
+    net = (M.StyleGANGenerator if kind == "g" else M.StyleGANDiscriminator)(size=size, channel_multiplier=cm)
+    shapes = O.generator_shapes(size, mult=cm) if kind == "g" else O.discriminator_shapes(size, mult=cm)
+    missing, unexpected = net.load_state_dict(O.seeded_state(shapes, int(g256["seed_g" if kind == "g" else "seed_d"])), strict=False)
+    assert not unexpected and all(k.endswith("kernel") for k in missing), (missing, unexpected)
+    return net.cuda()
+
+
+def _check_norms256(g256, tag, net, rtol=2e-3):
+    ours = grad_norms(net)
+    keys = [str(k) for k in g256[f"{tag}_keys"]]
+    assert sorted(ours) == keys
+    got, want = np.array([ours[k] for k in keys]), g256[f"{tag}_norms"]
+    # a NoiseInjection strength is ONE scalar: the sum of B*H*W*C products of either sign (2 M terms of size ~1e-2 at the
+    # 64 x 64 layer, result ~1e-3).  Its value is set by fp32 summation order at the 1e-5 ABSOLUTE level on any device
+    # (the reference's own CPU value included), hence the absolute floor for these entries only.
+    tol = lambda k, b: (1e-2 * abs(b) + 1e-4) if k.endswith("noise.weight") else (rtol * abs(b) + 1e-6)
+    bad = [(k, a, b) for k, a, b in zip(keys, got, want) if abs(a - b) > tol(k, b)]
+    assert not bad, f"{tag}: gradient norms off: {bad}"
+
+
+@needs_256
+def test_256_generator_discriminator_losses_and_regularisers_vs_reference():
+    from test_oracle_models import expand_check
+    from diagan.trainer import stylegan2 as TR
+    g = np.load(G256_PATH)
+    size, batch = int(g["size"]), int(g["batch"])
+    G, D = _build256("g", g), _build256("d", g)
+    z1, z2 = torch.from_numpy(g["z1"]).cuda(), torch.from_numpy(g["z2"]).cuda()
+    with torch.no_grad():
+        img, lat = G([z1], return_latents=True, randomize_noise=False)
+        mix, _ = G([z1, z2], inject_index=5, randomize_noise=False)
+    assert img.shape == (batch, 3, size, size)
+    close(lat[:, :2], g["g_latent"], what="latent")
+    close(img[:, :, :8, :8], g["g_image_corner"], what="image corner")
+    expand_check(img.cpu().numpy(), g["g_image"], 1e-3)
+    expand_check(mix.cpu().numpy(), g["g_image_mix"], 1e-3)
+    # the "real" batch is re-drawn from its seed (a 393 216-value tensor is not stored); its checksum is
+    gen = torch.Generator().manual_seed(7)
+    torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen)                 # z1, z2
+    x = torch.randn(batch, 3, size, size, generator=gen).clamp_(-2, 2) * 0.5
+    expand_check(x.numpy(), g["d_real_check"], 1e-6)
+    D.zero_grad()
+    rp, fp = D(x.cuda()), D(img.detach())
+    close(rp, g["d_real_pred"], what="real logits")
+    close(fp, g["d_fake_pred"], what="fake logits")
+    d_loss = TR.d_logistic_loss(rp, fp)
+    close(d_loss, g["d_loss"])
+    d_loss.backward()
+    _check_norms256(g, "d_loss_grad", D)
+    D.zero_grad()
+    xr = x.cuda().requires_grad_(True)
+    rp = D(xr)
+    r1 = TR.d_r1_loss(rp, xr)
+    close(r1, g["r1"])
+    (10.0 / 2 * r1 * 16 + 0 * rp[0]).backward()
+    _check_norms256(g, "r1_grad", D)
+    TR.requires_grad(D, False)
+    G.zero_grad()
+    fake, _ = G([z1], randomize_noise=False)
+    g_loss = TR.g_nonsaturating_loss(D(fake))
+    close(g_loss, g["g_loss"])
+    g_loss.backward()
+    _check_norms256(g, "g_loss_grad", G)
+    G.zero_grad()
+    zp = torch.randn(1, 512, generator=gen)
+    pl_noise = torch.randn(1, 3, size, size, generator=gen)
+    np.testing.assert_array_equal(zp.numpy(), g["zp"])
+    expand_check(pl_noise.numpy(), g["pl_noise_check"], 1e-6)
+    fake, lat = G([zp.cuda()], return_latents=True, randomize_noise=False)
+    pl, mean_path, lengths = TR.g_path_regularize(fake, lat, 0.3, noise=pl_noise.cuda())
+    close(lengths, g["path_lengths"])
+    close(pl, g["path_loss"])
+    (2.0 * 4 * pl + 0 * fake[0, 0, 0, 0]).backward()
+    _check_norms256(g, "path_grad", G)
