@@ -35,6 +35,7 @@ extern "C" int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo
 namespace diagan {
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
 long wino_ws_floats(int Co, int Ci);
+int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -782,8 +783,26 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                "conv_gemm: tile_cfg 9 (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0");
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wino_ws_floats(Co, Ci),
                "conv_gemm: tile_cfg 9 needs %ld floats of workspace for the transformed weights", wino_ws_floats(Co, Ci));
-    a.ksplit = 1;
-    return launch_wino(a, splitk_ws, st);
+    // transformed weights first, split-K slab (if any) behind them
+    const long wfl = wino_ws_floats(Co, Ci);
+    int ks = 1;
+    if (tile_cfg == 0 && !stat_partials) {
+      ks = wino_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 192);
+      if (ks < 1) ks = 1;
+    } else if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats &&
+               Ci / 8 / g_force_ksplit >= 1) {
+      ks = g_force_ksplit;
+    }
+    a.ksplit = ks;
+    a.slab = splitk_ws + wfl;
+    int rc = launch_wino(a, splitk_ws, st);
+    if (rc == DIAGAN_OK && ks > 1) {
+      long blocks = ((long)a.M * (Co / 4) + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+      rc = check_launch("conv_wino split-K epilogue");
+    }
+    return rc;
   }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true, true>(a, st);
@@ -825,9 +844,9 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
   // batch 64: 128 workgroups, 325 vs 317 us; their data-gradients 330 vs 168 us)
   static const int min_wgs = getenv("DIAGAN_WINO_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_MIN_WGS")) : 192;
   if (wino && diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) &&
-      ws_floats >= wino_ws_floats(Co, Ci)) {
-    const long wgs = (long)cdiv((long)B * (Ho >> 1) * (Wo >> 1), 64) * cdiv(Co, 64);
-    if (wgs >= min_wgs && Ci >= 16) return 9;
+      ws_floats >= wino_ws_floats(Co, Ci) && Ci >= 16) {
+    static const int wsplit = getenv("DIAGAN_WINO_SPLIT") ? atoi(getenv("DIAGAN_WINO_SPLIT")) : 1;
+    if (wino_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs) > 0) return 9;
   }
   return diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
 }

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   const int TW = g.Wo >> 1, TH = g.Ho >> 1;
   const int MT = g.B * TH * TW;                         // 2x2 output tiles in all
   const int nk = g.Ci / WK;
+  // K-step range of this workgroup (split-K over gridDim.y for launches with few output tiles: raw partial outputs go
+  // to a.slab and splitk_epilogue_kernel of conv_gemm.hip applies the epilogue after a fixed-order sum)
+  const int k_per = (nk + a.ksplit - 1) / a.ksplit;
+  const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk);
   const bool affine = PRO == PRO_AFFINE_RELU || PRO == PRO_AFFINE;
 
   // ---- loader role: (tile lt, channel quad q, patch row r); the 4 lanes of a quad hold the 4 rows of one patch ----
@@ -188,11 +192,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
 
   const int fi = lane & 31, fh = lane >> 5;
   const int sw = fh | (wi << 1);                          // slot swizzle of this wave's V planes (q | r << 1)
-  issue_loads(0, 0);
-  transform_prologue();
-  transform_rows();
+  if (k_begin < k_end) {
+    issue_loads(k_begin, 0);
+    transform_prologue();
+    transform_rows();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) transform_store(0, j);
+    for (int j = 0; j < 4; ++j) transform_store(0, j);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (a.stamps) {            // diagnostic (tools/wino_debug.py): stage 0 of workgroup 0 as it sits in LDS, then stop
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   // issued at the top; its input transform is cut into six pieces (prologue, row transform, four column-transform +
   // store pieces) that ride in the shadow of groups 8..13, one per group, as in conv_gemm.hip.
   auto kstep = [&](int kk, auto has_next) {
-    const int cur = kk & 1;
+    const int cur = (kk - k_begin) & 1;
     const float* vs = smem + cur * W_STAGE;
     const float* us = vs + 32 * W_PLANE;
     if (decltype(has_next)::value) issue_loads(kk + 1, cur ^ 1);
@@ -236,8 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
     __syncthreads();
   };
-  for (int kk = 0; kk + 1 < nk; ++kk) kstep(kk, std::true_type{});
-  kstep(nk - 1, std::false_type{});
+  for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+  if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
 
   // ---- epilogue ----
   // s[i][b] = sum_j A^T[b][j] M[i][j] in registers (b = 0: M0 + M1 + M2; b = 1: M1 - M2 - M3), then the four rows i meet
@@ -245,13 +251,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   // Y[a][b] = sum_i A^T[a][i] s[i][b].  (Row 3 of V and of U are both staged negated: M is what it always was.)
   const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
   const int split = a.scale0 ? a.scale_split : 0x7fffffff;            // pixel-row index where the second sigma starts
-  const bool hr = a.residual != nullptr, hm = a.mask_src != nullptr, hs = a.stat_partials != nullptr;
+  const bool raw = a.ksplit > 1;                                       // split-K: un-scaled partial sums to the slab
+  const bool hr = !raw && a.residual != nullptr, hm = !raw && a.mask_src != nullptr, hs = !raw && a.stat_partials != nullptr;
+  float* ydst = raw ? a.slab + (long)blockIdx.y * a.M * g.Co : a.y;
   const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
   const int et = tid >> 4, ec = (tid & 15) * 4;                       // this thread's tile (within a half) and channel quad
   const int n = n0 + ec;
   const bool col_ok = n < g.Co;                                        // Co % 4 == 0
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+  if (!raw && a.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
   f32x4 cs1 = {0.f, 0.f, 0.f, 0.f}, cs2 = {0.f, 0.f, 0.f, 0.f};
   float* ss = smem;
 #pragma unroll
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
     if (ok2[it]) {
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        f32x4 y = y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
+        f32x4 y = raw ? y4[p] : y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
         if (hr) {
           f32x4 r = rres[it][p];
 #pragma unroll
@@ -316,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[e] = rmsk[it][p][e] > 0.f ? y[e] : y[e] * a.mask_slope;
         }
-        *reinterpret_cast<f32x4*>(a.y + o4[it][p]) = y;
+        *reinterpret_cast<f32x4*>(ydst + o4[it][p]) = y;
         if (hs) {
           cs1 += y;
           cs2 += y * y;
@@ -361,12 +369,27 @@ static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t s
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, a, ug);
+  hipLaunchKernelGGL(kern, dim3(wgs, a.ksplit), dim3(512), lds, st, a, ug);
   return check_launch("conv_wino");
 }
 
 // floats of workspace the transformed weights need
 long wino_ws_floats(int Co, int Ci) { return (long)cdiv(Co, WN) * WN * Ci * 16; }
+
+// Split-K factor for launches with fewer workgroups than ~3/4 of the chip (the 4x4 / 8x8 blocks at batch 64): enough
+// splits to reach 128+ workgroups, each with at least 16 K-steps (128 input channels: with 8, M=8192 / Ci=128 runs
+// 35.7 us against the implicit GEMM's 31.6); 0 = such a launch is better served by the implicit GEMM's smaller tiles.  allow_split: a slab can be used (workspace, no fused statistics).
+int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs) {
+  const long wgs = (long)cdiv((long)B * (Ho >> 1) * (Wo >> 1), WT) * cdiv(Co, WN);
+  if (wgs >= min_wgs) return 1;
+  if (!allow_split) return 0;
+  const int nk = Ci / WK;
+  for (int ks = 2; ks <= 4; ++ks) {
+    if (nk / ks < 16) break;
+    if (wgs * ks >= 128 && wino_ws_floats(Co, Ci) + (long)ks * B * Ho * Wo * Co <= ws_floats) return ks;
+  }
+  return 0;
+}
 
 // `a` as prepared by diagan_conv_gemm (dWo / dHo re-made here for the TILE grid); ws: wino_ws_floats(Co, Ci) floats
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st) {

@@ -97,7 +97,9 @@ def test_auto_selection_and_agreement_with_the_implicit_gemm():
     ws = 16 << 20
     assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9          # D32 block1.c2 (pair pass)
     assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, 1152, 1, ws) == 9          # its data-gradient
-    assert pick(64, 4, 4, 512, 4, 4, 512, 3, 3, 1, 1, -1, 1, 4608, 1, ws) != 9               # too few workgroups
+    assert pick(64, 4, 4, 512, 4, 4, 512, 3, 3, 1, 1, -1, 1, 4608, 1, ws) == 9               # few tiles, long channel loop: split-K
+    assert pick(64, 4, 4, 512, 4, 4, 512, 3, 3, 1, 1, -1, 1, 4608, 0, ws) != 9               # ... not without a slab
+    assert pick(128, 8, 8, 128, 8, 8, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) != 9              # too few workgroups AND channels
     assert pick(64, 16, 16, 128, 8, 8, 128, 3, 3, 2, 1, -1, 1, 1152, 1, ws) != 9             # stride 2
     assert pick(64, 32, 32, 4, 32, 32, 128, 3, 3, 1, 1, -1, 1, 64, 1, ws) != 9               # RGB input
     assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, 1024) != 9        # no room for the transformed weights
@@ -105,6 +107,13 @@ def test_auto_selection_and_agreement_with_the_implicit_gemm():
     a = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=9)
     b = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=7)
     close(a, b, tol=1e-5)
+    # split-K of the Winograd kernel (raw partial outputs + the shared second stage) on a few-tile, many-channel layer
+    geom, x, w, wp = make(64, 4, 4, 512, 512, seed=6)
+    g = torch.Generator().manual_seed(7)
+    bias, res = torch.randn(512, generator=g), torch.randn(64, 512, 4, 4, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(), pro=(C.PRO_RELU, None, None))
+    ref = F.conv2d(F.relu(x.double()), w.double(), bias.double(), padding=1) + res.double()
+    close(nchw(y), ref, tol=2e-5)
     with pytest.raises(RuntimeError, match="Winograd"):
-        g2 = C.Geom("conv", 128, 128, 3, 3, 2, 1)
+        g2 = C.Geom("conv", 512, 512, 3, 3, 2, 1)
         C.conv_fwd(g2, nhwc(x).cuda(), wp, tile_cfg=9)

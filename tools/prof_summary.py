@@ -9,7 +9,7 @@ title = sys.argv[4] if len(sys.argv) > 4 else out
 rows = list(csv.DictReader(open(src)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 gemm = sum(float(r['TotalDurationNs']) for r in rows if 'conv_gemm' in r['Name'] or 'conv_wgrad' in r['Name']
-           or 'conv3x3_co4' in r['Name'])
+           or 'conv3x3_co4' in r['Name'] or 'conv_wino' in r['Name'] or 'wino_weight' in r['Name'])
 with open(out, 'w') as f:
     f.write(f"# {title}\n\n")
     f.write(f"Total kernel time {tot / steps / 1e6:.2f} ms per global step ({steps:g} steps profiled); "

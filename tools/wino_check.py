@@ -94,6 +94,29 @@ def main():
             e = relerr(C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=9), C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=7))
             worst = max(worst, e)
             print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {'fwd grouped bn+relu':22s} err {e:.2e}", flush=True)
+    # ---- split-K of the forward kernel (few output tiles, long channel loop) ----
+    from diagan import _native as nat
+    for B, H, W, Ci, Co in ((64, 8, 8, 1024, 512), (128, 4, 4, 512, 1024), (128, 8, 8, 256, 256), (128, 8, 8, 128, 128)):
+        geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+        x = torch.randn(B, H, W, Ci, device=dev)
+        wp = torch.randn(Co, geom.Kp, device=dev) * (9 * Ci) ** -0.5
+        bias, res = torch.randn(Co, device=dev), torch.randn(B, H, W, Co, device=dev)
+        f = lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, residual=res, pro=(C.PRO_RELU, None, None), tile_cfg=cfg)
+        ref = f(7)
+        flop = 2.0 * B * H * W * Co * 9 * Ci
+        line = f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} split-K:"
+        for ks in (1, 2, 4):
+            nat.call("diagan_conv_gemm_tune", ks, -1, 0)
+            e = relerr(f(9), ref)
+            worst = max(worst, e)
+            t = timeit(lambda: f(9))
+            line += f"  ks{ks} err {e:.1e} {t*1e6:7.1f} us"
+        nat.call("diagan_conv_gemm_tune", 0, -1, 0)
+        C.set_winograd(False)
+        td = timeit(lambda: f(0))
+        C.set_winograd(None)
+        ta = timeit(lambda: f(0))
+        print(line + f"  | implicit GEMM {td*1e6:7.1f} us | auto {ta*1e6:7.1f} us ({flop/ta/1e12:5.1f} TF-eq)", flush=True)
     # ---- weight gradient: Winograd F(3x3,2x2) against the implicit-GEMM weight gradient (same slab API) ----
     for B, H, W, Ci, Co in shapes:
         if Ci < 16 or Co < 16:
