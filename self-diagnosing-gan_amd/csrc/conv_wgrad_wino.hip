@@ -106,7 +106,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
         } else if (PRO != PRO_AFFINE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], 0.f, __builtin_huge_valf());
+          for (int e = 0; e < 4; ++e) {               // max(v, 0) as one v_max_i32 on the bits
+            const float q = v[e];
+            v[e] = __int_as_float(max(__float_as_int(q), 0));
+          }
         }
         if (affine) v *= keep[c];
       }
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float own = t[j][e];
-      const int other = __builtin_amdgcn_update_dpp(0, __float_as_int(own), 0x5A, 0xF, 0xF, false);
+      const int other = __builtin_amdgcn_update_dpp(__float_as_int(own), __float_as_int(own), 0x5A, 0xF, 0xF, false);
       o[e] = fmaf(sc, __int_as_float(other), own);
     }
     *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * GW_T + lt) * 64 + slot) = o;
