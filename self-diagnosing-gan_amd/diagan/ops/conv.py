@@ -63,6 +63,10 @@ class KernelTimer:
         self.records = []          # (kernel name, flop, start event, stop event)
         self.only = only           # optional set of kernel names: launches of other kernels are not bracketed
 
+    def wants_any(self):
+        """False for a timer that brackets nothing (bench.py's timed region on launch-bound workloads)"""
+        return self.only is None or len(self.only) > 0
+
     def begin(self, name=None):
         if self.only is not None and name not in self.only:
             return None
@@ -97,6 +101,7 @@ class KernelTimer:
 
 
 TIMER = None      # set to a KernelTimer by bench.py
+_NAME_CACHE = {}
 
 
 def set_mfma_mode(mode):
@@ -203,10 +208,18 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
         tile_cfg = cfg
     kname = None
-    if TIMER is not None:
-        allow = 0 if want_stats else 1
-        kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(
-            B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel()), mode)
+    if TIMER is not None and TIMER.wants_any():
+        # (cached per call signature: on launch-bound workloads the name lookup itself was 6 ms of host time per step)
+        key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats)
+        kname = _NAME_CACHE.get(key)
+        if kname is None or _NAME_CACHE.get('modes') != (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")()):
+            if _NAME_CACHE.get('modes') != (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")()):
+                _NAME_CACHE.clear()
+                _NAME_CACHE['modes'] = (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")())
+            allow = 0 if want_stats else 1
+            kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(
+                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel()), mode)
+            _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
@@ -288,8 +301,9 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     slab = _slab(dy.device, splits * n_elem + extra)
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
-    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if TIMER is not None else None
-    t0 = TIMER.begin(kn) if TIMER is not None else None
+    timed = TIMER is not None and TIMER.wants_any()
+    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if timed else None
+    t0 = TIMER.begin(kn) if timed else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
     if t0 is not None:
@@ -355,8 +369,9 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
         if t0 is not None:
             TIMER.end("conv3x3_co4_wgrad_kernel", 2.0 * B * Ho * Wo * Co * 9 * Ci, t0, (B * Ho * Wo, Co, 9 * Ci, f"pro{mode}"))
         return
-    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if TIMER is not None else None
-    t0 = TIMER.begin(kn) if TIMER is not None else None
+    timed = TIMER is not None and TIMER.wants_any()
+    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if timed else None
+    t0 = TIMER.begin(kn) if timed else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
