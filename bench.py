@@ -181,7 +181,7 @@ WINO_MAC_RATIO = 16.0 / 36.0    # Winograd F(2x2,3x3): multiply-accumulates exec
 
 def executed_flop(name, flop):
     """FLOP the matrix pipe actually executes for `flop` algorithmic (direct-convolution, 2*M*Co*R*S*Ci) FLOP"""
-    return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel")) else flop
+    return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wino_s_kernel", "conv_wgrad_wino_kernel")) else flop
 
 
 def conv_block_excluded(name, shape):

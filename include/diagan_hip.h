@@ -133,6 +133,12 @@ int diagan_conv_gemm_tile_cols(int cfg);
  * per workgroup (stat_partials / pro_group_rows granularity).  Returns 1 when the geometry qualifies. */
 int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
                                int up);
+/* tile_cfg 10: the same Winograd kernel with a staged input (csrc/conv_wino_s.hip): 256-thread workgroups of 32 tiles
+ * (8x4 tiles of one image, 4x4 of two, ...) x 64 columns, two per CU; the block's input region goes global -> LDS once
+ * (LDS-DMA, 16 channels per request) instead of once per tile.  Needs, on top of diagan_conv_wino_supported, Ci % 16 == 0
+ * and blocks that tile the batch (and the prologue groups) exactly -- this query; 128 pixel rows x 64 columns per
+ * workgroup (stat_partials granularity).  tile_cfg 0 prefers it over 9 where it applies (DIAGAN_WINO_STAGED=0: never). */
+int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
 /* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and
  * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns
  * Winograd off. */

@@ -29,6 +29,7 @@ extern "C" int diagan_conv_gemm_tile_cols(int cfg);
 extern "C" int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 extern "C" int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                               int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats);
+extern "C" int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
 extern "C" int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                           int off, int up);
 
@@ -36,6 +37,9 @@ namespace diagan {
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
 long wino_ws_floats(int Co, int Ci);
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
+int launch_wino_s(ConvGemmArgs a, float* ws, hipStream_t st);    // conv_wino_s.hip
+int wino_s_block(int B, int Ho, int Wo, int Ci, int pro_group_rows);
+int wino_s_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -778,24 +782,32 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     const int ks = diagan_conv_gemm_pick_ksplit(a.M, Co, Kp, cfg);
     if (ks > 1 && (int64_t)ks * a.M * Co <= splitk_ws_floats) a.ksplit = ks;
   }
-  if (cfg == 9) {
+  if (cfg == 9 || cfg == 10) {
     DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up),
-               "conv_gemm: tile_cfg 9 (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0");
+               "conv_gemm: tile_cfg %d (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0", cfg);
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wino_ws_floats(Co, Ci),
-               "conv_gemm: tile_cfg 9 needs %ld floats of workspace for the transformed weights", wino_ws_floats(Co, Ci));
+               "conv_gemm: tile_cfg %d needs %ld floats of workspace for the transformed weights", cfg, wino_ws_floats(Co, Ci));
+    // the staged kernel (10) wants blocks that tile the batch and the prologue groups; the automatic choice falls back
+    bool staged = cfg == 10;
+    if (staged && !wino_s_block(B, Ho, Wo, Ci, pro_group_rows)) {
+      DG_REQUIRE(tile_cfg == 0, "conv_gemm: tile_cfg 10 (staged Winograd) needs Ci %% 16 == 0 and 32-tile blocks (8x4 tiles of one "
+                 "image, 4x4 of two, ...) that tile the batch and the prologue groups exactly");
+      staged = false;
+    }
     // transformed weights first, split-K slab (if any) behind them
     const long wfl = wino_ws_floats(Co, Ci);
     int ks = 1;
     if (tile_cfg == 0 && !stat_partials) {
-      ks = wino_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 192);
+      ks = staged ? wino_s_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 256)
+                  : wino_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 192);
       if (ks < 1) ks = 1;
     } else if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats &&
-               Ci / 8 / g_force_ksplit >= 1) {
+               Ci / 16 / g_force_ksplit >= 1) {
       ks = g_force_ksplit;
     }
     a.ksplit = ks;
     a.slab = splitk_ws + wfl;
-    int rc = launch_wino(a, splitk_ws, st);
+    int rc = staged ? launch_wino_s(a, splitk_ws, st) : launch_wino(a, splitk_ws, st);
     if (rc == DIAGAN_OK && ks > 1) {
       long blocks = ((long)a.M * (Co / 4) + 255) / 256;
       if (blocks > 4096) blocks = 4096;
@@ -819,10 +831,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 2: case 4: case 8: return 128; case 3: case 6: case 7: return 64; case 5: case 9: return 256; default: return 0; }
+  switch (cfg) { case 1: case 2: case 4: case 8: case 10: return 128; case 3: case 6: case 7: return 64; case 5: case 9: return 256; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: return 128; case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: return 64; default: return 0; }
+  switch (cfg) { case 1: return 128; case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -846,9 +858,21 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
   if (wino && diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) &&
       ws_floats >= wino_ws_floats(Co, Ci) && Ci >= 16) {
     static const int wsplit = getenv("DIAGAN_WINO_SPLIT") ? atoi(getenv("DIAGAN_WINO_SPLIT")) : 1;
+    // the staged kernel (32-tile blocks, two workgroups per CU) where its blocks tile the batch
+    static const int staged_env = getenv("DIAGAN_WINO_STAGED") ? atoi(getenv("DIAGAN_WINO_STAGED")) : 0;
+    static const int min_wgs_s = getenv("DIAGAN_WINO_S_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_S_MIN_WGS")) : 256;
+    if (staged_env && wino_s_block(B, Ho, Wo, Ci, 0) &&
+        wino_s_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs_s) > 0)
+      return 10;
     if (wino_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs) > 0) return 9;
   }
   return diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
+}
+
+// whether the staged Winograd kernel (tile_cfg 10) takes a batch / prologue-group shape (the geometry itself must pass
+// diagan_conv_wino_supported)
+DIAGAN_API int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows) {
+  return wino_s_block(B, Ho, Wo, Ci, pro_group_rows) ? 1 : 0;
 }
 
 // Run-time form of DIAGAN_WINO (A/B runs and the tests that compare kernels like with like): 0 = implicit GEMM only,

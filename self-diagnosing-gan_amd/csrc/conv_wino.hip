@@ -28,8 +28,11 @@ namespace diagan {
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 4 i + j, written in the LDS image order (see above).  flip: the data-gradient of a
 // stride-1 convolution is the correlation with the taps reversed.
+// staged: the plane order of conv_wino_s.hip -- element (column, channel) of a (f, k-quad) plane sits at
+// (((channel >> 1) * 32 + (column & 31)) * 2 + (column >> 5)) * 2 + (channel & 1): an MFMA lane's two k values of both column
+// halves are 16 contiguous bytes.
 __global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                         int Kp, int flip) {
+                                                         int Kp, int flip, int staged) {
   const int c4 = blockIdx.x, co = blockIdx.y * 64 + threadIdx.x, c = c4 * 4;
   f32x4 g[3][3];
 #pragma unroll
@@ -60,8 +63,19 @@ __global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict
     // moves into U so that the products are unchanged
     const float sg = i == 3 ? -1.f : 1.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f32x4*>(base + (((i * 4 + j) * 2 + kq) * 64 + threadIdx.x) * 4) = u[j] * sg;
+    for (int j = 0; j < 4; ++j) {
+      float* plane = base + ((i * 4 + j) * 2 + kq) * 256;
+      const f32x4 v = u[j] * sg;
+      if (!staged) {
+        *reinterpret_cast<f32x4*>(plane + threadIdx.x * 4) = v;
+      } else {
+        const int fi = threadIdx.x & 31, h = threadIdx.x >> 5;
+        plane[((0 * 32 + fi) * 2 + h) * 2 + 0] = v[0];
+        plane[((0 * 32 + fi) * 2 + h) * 2 + 1] = v[1];
+        plane[((1 * 32 + fi) * 2 + h) * 2 + 0] = v[2];
+        plane[((1 * 32 + fi) * 2 + h) * 2 + 1] = v[3];
+      }
+    }
   }
 }
 
@@ -71,9 +85,22 @@ constexpr int WK = 8;                  // input channels per K-step
 constexpr int W_PLANE = 64 * 4;        // floats of one (f, k-quad) plane: 64 rows x 4 channels
 constexpr int W_STAGE = 2 * 32 * W_PLANE;   // V planes + U planes of one stage (floats)
 
+// Diagnostic build only (make CXXFLAGS+=-DDIAGAN_WINO_ABLATE; tools/wino_ablate.py, tools/wino_stamps.py): ConvGemmArgs::tune
+// bits switch parts of the K loop off (bit 4 transform, 5 input loads, 6 weight DMA, 7 barrier, 8 MFMAs, 9 epilogue: the
+// results are then garbage) so that their cost can be read off the launch time, and bit 10 makes every wave sum the
+// s_memtime cycles of the phases of its K-steps into the stamp buffer.  Findings: profiles/r02_wino_ablation.md.
+#ifdef DIAGAN_WINO_ABLATE
+#define WINO_ON(bit) (!(a.tune & (bit)))
+#else
+#define WINO_ON(bit) true
+#endif
+
 template <int PRO>
 __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 32 planes | U 32 planes] = 128 KB
+#ifdef DIAGAN_WINO_ABLATE
+  const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (g.Co + WN - 1) / WN;
@@ -118,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   const float sc = lr == 1 ? 1.f : -1.f;
   // LDS slot of this thread's 4 output planes: plane p = ((r * 4 + j) * 2 + q), slot = tile ^ (q | r << 1)
   const int vslot = (lt ^ (lq | (lr << 1))) * 4;
+  float* const vst0 = smem + (lr * 8 + lq) * W_PLANE + vslot;
 
   const float* ublock = ug + (long)nb * nk * (32 * W_PLANE);
 
@@ -125,22 +153,34 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   auto issue_loads = [&](int kk, int stage) {
     // U: 32 planes of 1 KB, 4 per wave, straight into LDS (lane-linear image == the global order)
     float* us = smem + stage * W_STAGE + 32 * W_PLANE;
+    if (WINO_ON(64))
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int p = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(ublock + (long)kk * (32 * W_PLANE) + p * W_PLANE + lane * 4),
-          (__attribute__((address_space(3))) void*)(us + p * W_PLANE), 16, 0, 0);
+      // wave-uniform base in scalar registers + the lane's 32-bit offset: no 64-bit vector add per instruction
+      const unsigned long long ub = (unsigned long long)(ublock + (long)kk * (32 * W_PLANE) + p * W_PLANE);
+      const unsigned long long us64 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32;
+      const float* up = reinterpret_cast<const float*>(us64);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(up + (unsigned)(lane * 4)),
+                                       (__attribute__((address_space(3))) void*)(us + p * W_PLANE), 16, 0, 0);
     }
+    if (WINO_ON(32))
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (off[c] + (unsigned)kk * (WK * 4u)) | inv[c], 0, 0));
+      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off[c] | inv[c], kk * (WK * 4), 0));   // step offset: scalar
     if (affine) {
       psc = *reinterpret_cast<const f32x4*>(a.pro_scale + pro_group_off + kk * WK + lq * 4);
       psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + kk * WK + lq * 4);
     }
   };
-  f32x4 d[4], t[4];
+  f32x4 d[4];
+  float t[4][4];                                        // row-transformed patch row: [column j][channel]
+  // (vector instructions are NOT hidden behind this wave's MFMAs -- tools/micro/mfma_valu.hip: every one costs its ~4 issue
+  //  cycles of the SIMD -- so each prologue is written for the fewest of them)
+  int kbound[4];                                        // BatchNorm + ReLU: upper clamp of the activation, 0 on padding pixels
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kbound[c] = keep[c] != 0.f ? 0x7fffffff : 0;
   auto transform_prologue = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -149,36 +189,58 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
         if (affine) v = v * psc + psh;
         if (PRO == PRO_LRELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-        } else if (PRO != PRO_AFFINE) {
+          for (int e = 0; e < 4; ++e) {               // max(x, 0.2 x) without fmaxf's canonicalising extra v_max
+            const float q = v[e], q2 = 0.2f * q;
+            float r;
+            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(q2));
+            v[e] = r;
+          }
+        } else if (PRO == PRO_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {               // max(v, 0) as ONE v_max_i32 on the bits (fmaxf costs a canonicalising
             const float q = v[e];                     // v_max first; negative floats are negative integers)
             v[e] = __int_as_float(max(__float_as_int(q), 0));
           }
+        } else if (PRO == PRO_AFFINE_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {               // ReLU and "padding is zero AFTER the transform" as ONE v_med3_i32:
+            const float q = v[e];                     // clamp of the bits to [0, kbound] (positive floats order like integers)
+            float r;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(q), "v"(kbound[c]));
+            v[e] = r;
+          }
+        } else {
+          v *= keep[c];                                // padding is zero AFTER the transform
         }
-        if (affine) v *= keep[c];                      // padding is zero AFTER the transform
       }
       d[c] = v;
     }
   };
   auto transform_rows = [&]() {
-    t[0] = d[0] - d[2];
-    t[1] = d[1] + d[2];
-    t[2] = d[2] - d[1];
-    t[3] = d[1] - d[3];
-  };
-  auto transform_store = [&](int stage, int j) {
-    float* vs = smem + stage * W_STAGE;
-    f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      // (scalar copy first: a bit_cast of the vector element itself is miscompiled to element 0, as in conv_gemm.hip)
-      const float own = t[j][e];
-      const int other = __builtin_amdgcn_update_dpp(__float_as_int(own), __float_as_int(own), 0x5A, 0xF, 0xF, false);
-      o[e] = fmaf(sc, __int_as_float(other), own);
+      t[0][e] = d[0][e] - d[2][e];
+      t[1][e] = d[1][e] + d[2][e];
+      t[2][e] = d[2][e] - d[1][e];
+      t[3][e] = d[1][e] - d[3][e];
     }
-    *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * 2 + lq) * W_PLANE + vslot) = o;
+  };
+  auto transform_store = [&](int stage, int j) {
+    float* vs = vst0 + stage * W_STAGE;                // plane p = ((r * 4 + j) * 2 + q) of the stage, this thread's slot
+    // V[r][j] = t[r][j] + sc * t[partner][j] as ONE v_fmac_f32 whose first factor comes through DPP (quad_perm [2,2,1,1]):
+    // every lane reads its partner's OLD value before any lane writes (the builtin + fma pair costs the DPP move and the
+    // fma, and vector instructions do not hide behind this wave's MFMAs)
+    float o0 = t[j][0], o1 = t[j][1], o2 = t[j][2], o3 = t[j][3];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(sc));
+    const f32x4 o = {o0, o1, o2, o3};
+    *reinterpret_cast<f32x4*>(vs + j * 2 * W_PLANE) = o;
   };
 
   // wave w owns the four frequencies of row i = w >> 1 (f = 4 i + j) on column block tn = w & 1: 4 x 2 accumulator
@@ -204,7 +266,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+#ifdef DIAGAN_WINO_ABLATE
+  const bool stamping = a.stamps && (a.tune & 1024);
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = t_entry;
+  auto tick = [&](int i) {
+    if (stamping) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[i] += now - tlast;
+      tlast = now;
+    }
+  };
+  tick(6);                   // set-up + first stage
+  if (a.stamps && !stamping) {
+#else
   if (a.stamps) {            // diagnostic (tools/wino_debug.py): stage 0 of workgroup 0 as it sits in LDS, then stop
+#endif
     if (blockIdx.x == 0)
       for (int i = tid; i < W_STAGE; i += 512) reinterpret_cast<float*>(a.stamps)[i] = smem[i];
     return;
@@ -213,41 +289,77 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   // One K-step: 16 groups of two MFMAs (frequency fl, k pair e).  The next stage's LDS-DMA pieces and global loads are
   // issued at the top; its input transform is cut into six pieces (prologue, row transform, four column-transform +
   // store pieces) that ride in the shadow of groups 8..13, one per group, as in conv_gemm.hip.
+  // (fragment addresses = one base per operand + the stage: address arithmetic inside the loop is not free)
+  const float* const fa_base = smem + (wi * 8 + fh) * W_PLANE + ((fi ^ sw) << 2);
+  const float* const fb_base = smem + (32 + wi * 8 + fh) * W_PLANE + ((tn * 32 + fi) << 2);
   auto kstep = [&](int kk, auto has_next) {
     const int cur = (kk - k_begin) & 1;
-    const float* vs = smem + cur * W_STAGE;
-    const float* us = vs + 32 * W_PLANE;
     if (decltype(has_next)::value) issue_loads(kk + 1, cur ^ 1);
     f32x4 fa[4][2], fb[4];
 #pragma unroll
     for (int fl = 0; fl < 4; ++fl) {
-      const int p = (wi * 4 + fl) * 2 + fh;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        fa[fl][i] = *reinterpret_cast<const f32x4*>(vs + p * W_PLANE + (((i * 32 + fi) ^ sw) << 2));
-      fb[fl] = *reinterpret_cast<const f32x4*>(us + p * W_PLANE + ((tn * 32 + fi) << 2));
+      for (int i = 0; i < 2; ++i)          // ((i * 32 + fi) ^ sw) == i * 32 + (fi ^ sw): sw < 8
+        fa[fl][i] = *reinterpret_cast<const f32x4*>(fa_base + cur * W_STAGE + fl * 2 * W_PLANE + i * 128);
+      fb[fl] = *reinterpret_cast<const f32x4*>(fb_base + cur * W_STAGE + fl * 2 * W_PLANE);
     }
+#ifdef DIAGAN_WINO_ABLATE
+    if (stamping) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tick(0);               // DMA / load issue + fragment reads
+    }
+#endif
 #pragma unroll
     for (int fl = 0; fl < 4; ++fl)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int grp = fl * 4 + e;
-        if (decltype(has_next)::value && grp >= 8 && grp < 14) {
+        if (decltype(has_next)::value && grp >= 8 && grp < 14 && WINO_ON(16)) {
           __builtin_amdgcn_sched_barrier(0);             // keep the piece HERE (its loads have had >= 1000 cycles to land)
+#ifdef DIAGAN_WINO_ABLATE
+          if (grp == 8 && stamping) {
+            tick(1);           // first 16 MFMAs issued
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tick(2);           // wait for the input loads
+          }
+#endif
           if (grp == 8) transform_prologue();
           else if (grp == 9) transform_rows();
           else transform_store(cur ^ 1, grp - 10);
         }
+        if (WINO_ON(256))
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           acc[fl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fl][i][e], fb[fl][e], acc[fl][i], 0, 0, 0);
       }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
-    __syncthreads();
+#ifdef DIAGAN_WINO_ABLATE
+    tick(3);                   // second 16 MFMAs + transform
+#endif
+    if (WINO_ON(128)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's LDS-DMA pieces of the next stage have landed
+#ifdef DIAGAN_WINO_ABLATE
+      tick(4);                 // wait for the weight DMA
+#endif
+      __syncthreads();
+#ifdef DIAGAN_WINO_ABLATE
+      tick(5);                 // barrier
+#endif
+    }
   };
   for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
   if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
 
+#ifdef DIAGAN_WINO_ABLATE
+  if (stamping && lane == 0) {
+    unsigned long long* o = a.stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+    for (int i = 0; i < 7; ++i) o[i] = tacc[i];
+    o[7] = __builtin_amdgcn_s_memtime() - t_entry;       // up to the epilogue
+  }
+  if (a.tune & 512) {
+    if (acc[0][0][0] == 123.456f) a.y[0] = acc[1][1][3] + acc[2][0][5] + acc[3][1][7];
+    return;
+  }
+#endif
   // ---- epilogue ----
   // s[i][b] = sum_j A^T[b][j] M[i][j] in registers (b = 0: M0 + M1 + M2; b = 1: M1 - M2 - M3), then the four rows i meet
   // in LDS ([i][b][64 tiles][64 channels] = 128 KB) and every thread finishes two (tile, 4 channels) items:
@@ -376,6 +488,10 @@ static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t s
   return check_launch("conv_wino");
 }
 
+void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, int staged, hipStream_t st) {
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(Ci / 4, cdiv(Co, WN)), dim3(64), 0, st, w, ug, Co, Ci, Kp, flip, staged);
+}
+
 // floats of workspace the transformed weights need
 long wino_ws_floats(int Co, int Ci) { return (long)cdiv(Co, WN) * WN * Ci * 16; }
 
@@ -399,8 +515,7 @@ int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(g.Ci / 4, cdiv(g.Co, WN)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
-                     g.dr < 0 ? 1 : 0);
+  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, 0, st);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino_pro<PRO_NONE>(a, ws, st);
     case PRO_RELU: return launch_wino_pro<PRO_RELU>(a, ws, st);

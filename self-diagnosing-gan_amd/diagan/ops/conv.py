@@ -18,6 +18,7 @@ nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_tile_rows", [I])
+nat.register("diagan_conv_wino_staged_supported", [I] * 5)
 nat.register("diagan_conv_gemm_tile_cols", [I])
 nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
 nat.register("diagan_conv_gemm_tune", [I, I, I])
@@ -49,6 +50,8 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
 def gemm_kernel_name(cfg, mode):
     if cfg == 9:
         return f"conv_wino_kernel<{mode}>"
+    if cfg == 10:
+        return f"conv_wino_s_kernel<{mode}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
         return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
@@ -203,6 +206,8 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         M = B * Ho * Wo
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, 0,
                                                                     ws.numel())
+        if cfg == 10 and not nat.fn("diagan_conv_wino_staged_supported")(B, Ho, Wo, Ci, group_imgs * Ho * Wo):
+            cfg = 9                       # prologue groups that the staged kernel's image blocks straddle
         bm = nat.fn("diagan_conv_gemm_tile_rows")(cfg)
         tiles = (M + bm - 1) // bm
         stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)

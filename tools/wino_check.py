@@ -32,7 +32,7 @@ def relerr(a, b):
 def main():
     torch.manual_seed(0)
     dev = "cuda"
-    shapes = [(4, 8, 8, 64, 64), (3, 6, 10, 16, 24), (2, 4, 4, 8, 4), (5, 16, 16, 128, 72), (64, 32, 32, 256, 256),
+    shapes = [(4, 8, 8, 64, 64), (2, 16, 16, 32, 64), (4, 4, 16, 16, 8), (3, 6, 10, 16, 24), (2, 4, 4, 8, 4), (5, 16, 16, 128, 72), (64, 32, 32, 256, 256),
               (128, 64, 64, 64, 64), (64, 8, 8, 1024, 512), (128, 4, 4, 512, 1024), (128, 16, 16, 128, 256),
               (320, 32, 32, 256, 128), (64, 64, 64, 128, 64)]
     worst = 0.0
@@ -51,6 +51,8 @@ def main():
         resx = torch.randn(B, H, W, Ci, device=dev)
         s0, s1 = torch.tensor([0.7], device=dev), torch.tensor([1.3], device=dev)
         big = B * H * W >= 2048
+        from diagan import _native as nat
+        staged = bool(nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, 0))
         variants = {
             "fwd plain": lambda cfg: C.conv_fwd(geom, x, wp, tile_cfg=cfg),
             "fwd relu+bias": lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, pro=(C.PRO_RELU, None, None), tile_cfg=cfg),
@@ -74,11 +76,18 @@ def main():
             e = relerr(got, ref)
             worst = max(worst, e)
             line = f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {name:22s} err {e:.2e}"
+            if staged and not (name.startswith("dgrad") and Co % 16):
+                es = relerr(f(10), ref)
+                worst = max(worst, es)
+                line += f" staged {es:.2e}"
             if big and name in ("fwd plain", "fwd bn+relu+bias+res", "dgrad mask+res"):
                 flop = 2.0 * B * H * W * Co * 9 * Ci
                 ta, tw = timeit(lambda: f(0)), timeit(lambda: f(9))
                 line += (f" | auto {ta*1e6:8.1f} us {flop/ta/1e12:6.1f} TF | winograd {tw*1e6:8.1f} us "
                          f"{flop/tw/1e12:6.1f} TF-equivalent ({ta/tw:4.2f}x; MFMA util {flop/2.25/tw/PEAK:5.1%})")
+                if staged:
+                    ts = timeit(lambda: f(10))
+                    line += f" | staged {ts*1e6:8.1f} us {flop/ts/1e12:6.1f} TF-eq (util {flop/2.25/ts/PEAK:5.1%})"
             print(line, flush=True)
         # fused BatchNorm statistics
         y7, st7 = C.conv_fwd(geom, x, wp, bias=bias, tile_cfg=7, want_stats=True)
@@ -86,12 +95,18 @@ def main():
         a, b = st7[0].sum(0), st9[0].sum(0)
         e = relerr(b, a)
         worst = max(worst, e)
+        if staged:
+            y10, st10 = C.conv_fwd(geom, x, wp, bias=bias, tile_cfg=10, want_stats=True)
+            e = max(e, relerr(st10[0].sum(0), a), relerr(y10, y7))
+            worst = max(worst, e)
         print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {'fwd stats (col sums)':22s} err {e:.2e}", flush=True)
         # stacked forward: per-group affine prologue
         if B % 4 == 0 and (B // 4) * H * W % 256 == 0:
             gsc, gsh = torch.rand(4, Ci, device=dev) + 0.5, torch.randn(4, Ci, device=dev) * 0.3
             pro = (C.PRO_AFFINE_RELU, gsc, gsh, B // 4)
             e = relerr(C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=9), C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=7))
+            if staged and nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, (B // 4) * H * W):
+                e = max(e, relerr(C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=10), C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=7)))
             worst = max(worst, e)
             print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {'fwd grouped bn+relu':22s} err {e:.2e}", flush=True)
     # ---- split-K of the forward kernel (few output tiles, long channel loop) ----
@@ -111,6 +126,14 @@ def main():
             worst = max(worst, e)
             t = timeit(lambda: f(9))
             line += f"  ks{ks} err {e:.1e} {t*1e6:7.1f} us"
+        if nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, 0):
+            line += " | staged"
+            for ks in (1, 2, 4):
+                nat.call("diagan_conv_gemm_tune", ks, -1, 0)
+                e = relerr(f(10), ref)
+                worst = max(worst, e)
+                t = timeit(lambda: f(10))
+                line += f"  ks{ks} err {e:.1e} {t*1e6:7.1f} us"
         nat.call("diagan_conv_gemm_tune", 0, -1, 0)
         C.set_winograd(False)
         td = timeit(lambda: f(0))
