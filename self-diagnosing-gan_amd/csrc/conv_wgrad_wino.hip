@@ -49,10 +49,6 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
   // ---- loader role: tile lt of the K-step, channel quad cq, row lr (patch row of V / row i of A e A^T) ----
   const int lr = tid & 3, cq = (tid >> 2) & 15, lt = wave;
   const bool ci_ok = c0 + cq * 4 < g.Ci, co_ok = n0 + cq * 4 < g.Co;
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.dy), 0, (int)((unsigned)g.B * g.Ho * g.Wo * g.Co * 4u), 0x00020000);
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   if (affine && ci_ok) {
     psc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + cq * 4);
@@ -61,14 +57,28 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
   // column transform of V: own + sc * partner (quad_perm [2,2,1,1]); row 3 is staged negated, as in conv_wino.hip, and
   // the sign is undone in E's row 3 (ea1 below)
   const float sc = lr == 1 ? 1.f : -1.f;
-  // row lr of A e A^T: (A e)[lr][x] = ea0 * e[0][x] + ea1 * e[1][x], A = [[1,0],[1,1],[1,-1],[0,-1]]; row 3 negated (+1)
+  // row lr of A e A^T: (A e)[lr][x] = ea0 * e[0][x] + ea1 * e[1][x], A = [[1,0],[1,1],[1,-1],[0,-1]]; row 3 negated (+1).
+  // Column 3 (-a1) is staged as +a1: the sign moves into the epilogue's m3 terms.
   const float ea0 = lr == 3 ? 0.f : 1.f, ea1 = lr == 0 ? 0.f : (lr == 2 ? -1.f : 1.f);
   const int slot = (cq ^ (lr << 1)) * 4;                 // 16-byte slot of this thread's writes (row planes 4 lr .. 4 lr + 3)
   const bool want_bias = a.bias_off >= 0 && c0 == 0;
   f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
 
+  // Loads.  The tile of a K-step is the wave's (lt = wave): its coordinates, the base addresses and the border conditions
+  // are wave-uniform and live in scalar registers; a lane contributes only loop-invariant byte offsets relative to the
+  // tile's patch origin (pixel (2 ty - 1, 2 tx - 1)) resp. gradient origin (2 ty, 2 tx), bit 31 set where its channels do
+  // not exist.  Vector instructions do not hide behind the MFMAs (profiles/r02_wino_ablation.md): per step the address
+  // side costs two ANDs and four ORs.
+  unsigned xoff[4], eoff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) xoff[c] = ci_ok ? (unsigned)(((lr * g.Wi + c) * g.Ci + c0 + cq * 4) * 4) : 0x80000000u;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    eoff[p] = co_ok ? (unsigned)((((p >> 1) * g.Wo + (p & 1)) * g.Co + n0 + cq * 4) * 4) : 0x80000000u;
+  const unsigned L0 = lr == 0 ? 0xffffffffu : 0u, L3 = lr == 3 ? 0xffffffffu : 0u;
+
   f32x4 rx[4], re[4];
-  float keep[4];
+  unsigned vo[4];                                        // bit 31: this patch pixel is padding (or not there at all)
   auto issue_loads = [&](int ks) {
     const int gt = ks * GW_T + lt;
     const bool tv = gt < MT;
@@ -76,24 +86,25 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
     const int tx = (tv ? gt : 0) - (int)q1 * TW;
     const unsigned b = fdiv(q1, a.dHo);
     const int ty = (int)q1 - (int)b * TH;
-    const int iy = 2 * ty - 1 + lr, ix0 = 2 * tx - 1;
-    const bool rv = tv && ci_ok && iy >= 0 && iy < g.Hi;
-    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + (c0 + cq * 4) * 4;
+    // descriptors based AT the tile (a tile beyond the batch: zero records, every load returns zeros)
+    const long xpix = (long)((int)b * g.Hi + 2 * ty - 1) * g.Wi + (2 * tx - 1);
+    const long epix = (long)((int)b * g.Ho + 2 * ty) * g.Wo + 2 * tx;
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + xpix * g.Ci, 0,
+                                                                          tv ? 0x7fffffff : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy) + epix * g.Co, 0,
+                                                                          tv ? 0x7fffffff : 0, 0x00020000);
+    const unsigned B0 = ty == 0 ? 0x80000000u : 0u, B3 = ty == TH - 1 ? 0x80000000u : 0u;
+    const unsigned C0 = tx == 0 ? 0x80000000u : 0u, C3 = tx == TW - 1 ? 0x80000000u : 0u;
+    const unsigned rowbits = (L0 & B0) | (L3 & B3);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
-      const unsigned o = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0x80000000u;     // outside: beyond num_records -> zeros
-      rx[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, o, 0, 0));
-      keep[c] = ok ? 1.f : 0.f;
+      vo[c] = xoff[c] | rowbits | (c == 0 ? C0 : (c == 3 ? C3 : 0u));
+      rx[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, vo[c], 0, 0));
     }
-    const int ebase = (((int)b * g.Ho + 2 * ty) * g.Wo + 2 * tx) * g.Co * 4 + (n0 + cq * 4) * 4;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const unsigned o = (tv && co_ok) ? (unsigned)(ebase + ((p >> 1) * g.Wo + (p & 1)) * g.Co * 4) : 0x80000000u;
-      re[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, o, 0, 0));
-    }
+    for (int p = 0; p < 4; ++p) re[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, eoff[p], 0, 0));
   };
-  f32x4 t[4];
+  float t[4][4];
   auto transform_v = [&]() {                // prologue + row transform of the 4 patch pixels of this row
     f32x4 d[4];
 #pragma unroll
@@ -103,41 +114,62 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
         if (affine) v = v * psc + psh;
         if (PRO == PRO_LRELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-        } else if (PRO != PRO_AFFINE) {
+          for (int e = 0; e < 4; ++e) {               // max(x, 0.2 x) without fmaxf's canonicalising extra v_max
+            const float q = v[e], q2 = 0.2f * q;
+            float r;
+            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(q2));
+            v[e] = r;
+          }
+        } else if (PRO == PRO_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {               // max(v, 0) as one v_max_i32 on the bits
             const float q = v[e];
             v[e] = __int_as_float(max(__float_as_int(q), 0));
           }
+        } else {
+          // padding is zero AFTER the transform: ReLU + that as ONE v_med3_i32 (clamp of the bits to [0, padding ? 0 : max])
+          const int kb = (int)vo[c] < 0 ? 0 : 0x7fffffff;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float q = v[e];
+            float r;
+            if (PRO == PRO_AFFINE_RELU) asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(q), "v"(kb));
+            else r = kb ? q : 0.f;
+            v[e] = r;
+          }
         }
-        if (affine) v *= keep[c];
       }
       d[c] = v;
     }
-    t[0] = d[0] - d[2];
-    t[1] = d[1] + d[2];
-    t[2] = d[2] - d[1];
-    t[3] = d[1] - d[3];
-  };
-  auto store_v = [&](int stage, int j) {    // column transform (DPP) + one frequency plane
-    float* vs = smem + stage * GW_STAGE;
-    f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float own = t[j][e];
-      const int other = __builtin_amdgcn_update_dpp(__float_as_int(own), __float_as_int(own), 0x5A, 0xF, 0xF, false);
-      o[e] = fmaf(sc, __int_as_float(other), own);
+      t[0][e] = d[0][e] - d[2][e];
+      t[1][e] = d[1][e] + d[2][e];
+      t[2][e] = d[2][e] - d[1][e];
+      t[3][e] = d[1][e] - d[3][e];
     }
-    *reinterpret_cast<f32x4*>(vs + ((lr * 4 + j) * GW_T + lt) * 64 + slot) = o;
   };
-  auto store_e = [&](int stage) {           // row lr of A e A^T: four frequency planes
-    float* es = smem + stage * GW_STAGE + 16 * GW_PLANE;
+  float* const vst = smem + (lr * 4 * GW_T + lt) * 64 + slot;           // plane (lr, j = 0) of stage 0, this thread's slot
+  auto store_v = [&](int stage, int j) {    // column transform + one frequency plane: ONE v_fmac_f32_dpp per element
+    float o0 = t[j][0], o1 = t[j][1], o2 = t[j][2], o3 = t[j][3];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(sc));
+    const f32x4 o = {o0, o1, o2, o3};
+    *reinterpret_cast<f32x4*>(vst + stage * GW_STAGE + j * GW_PLANE) = o;
+  };
+  auto store_e = [&](int stage) {           // row lr of A e A^T: four frequency planes (the last one with its sign flipped)
+    float* es = vst + stage * GW_STAGE + 16 * GW_PLANE;
     const f32x4 a0 = ea0 * re[0] + ea1 * re[2], a1 = ea0 * re[1] + ea1 * re[3];
-    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 0) * GW_T + lt) * 64 + slot) = a0;
-    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 1) * GW_T + lt) * 64 + slot) = a0 + a1;
-    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 2) * GW_T + lt) * 64 + slot) = a0 - a1;
-    *reinterpret_cast<f32x4*>(es + ((lr * 4 + 3) * GW_T + lt) * 64 + slot) = -a1;
+    *reinterpret_cast<f32x4*>(es + 0 * GW_PLANE) = a0;
+    *reinterpret_cast<f32x4*>(es + 1 * GW_PLANE) = a0 + a1;
+    *reinterpret_cast<f32x4*>(es + 2 * GW_PLANE) = a0 - a1;
+    *reinterpret_cast<f32x4*>(es + 3 * GW_PLANE) = a1;
     if (want_bias && lr == 0) bacc += (re[0] + re[1]) + (re[2] + re[3]);
   };
 
@@ -166,21 +198,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
   }
   __syncthreads();
 
+  // fragment addresses: one base per operand (+ the stage); everything else is an instruction offset
+  const float* const fb_base = smem + (wi * 4 * GW_T + fh) * 64 + bcol;
+  const float* const fa_base0 = smem + 16 * GW_PLANE + (wi * 4 * GW_T + fh) * 64 + acol[0];
+  const float* const fa_base1 = smem + 16 * GW_PLANE + (wi * 4 * GW_T + fh) * 64 + acol[1];
   auto kstep = [&](int ks, auto has_next) {
     const int cur = (ks - s_begin) & 1;
-    const float* vs = smem + cur * GW_STAGE;
-    const float* es = vs + 16 * GW_PLANE;
     if (decltype(has_next)::value) issue_loads(ks + 1);
 #pragma unroll
     for (int fl = 0; fl < 4; ++fl) {
-      const int f = wi * 4 + fl;
       float fa[2][4], fb[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int row = (f * GW_T + 2 * e + fh) * 64;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i][e] = es[row + acol[i]];
-        fb[e] = vs[row + bcol];
+        const int row = cur * GW_STAGE + (fl * GW_T + 2 * e) * 64;
+        fa[0][e] = fa_base0[row];
+        fa[1][e] = fa_base1[row];
+        fb[e] = fb_base[row];
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -213,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
       const float h1 = 0.5f * m1, h2 = 0.5f * m2;
       ss[((wi * 3 + 0) * 32 + row) * 64 + tn * 32 + fi] = m0 + h1 + h2;
       ss[((wi * 3 + 1) * 32 + row) * 64 + tn * 32 + fi] = h1 - h2;
-      ss[((wi * 3 + 2) * 32 + row) * 64 + tn * 32 + fi] = h1 + h2 + m3;
+      ss[((wi * 3 + 2) * 32 + row) * 64 + tn * 32 + fi] = h1 + h2 - m3;       // (column 3 of E is staged with its sign flipped)
     }
     __syncthreads();
     const int co = n0 + tm * 32 + eo, ci = c0 + ec;
