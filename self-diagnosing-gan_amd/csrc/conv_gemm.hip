@@ -181,9 +181,64 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   f32x4 ra[AJ], rb[BJ], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   unsigned a_ok = 0;
 
+  // Uniform-tap path (Ci % BK == 0, the bf16x6 kernels excepted): a K-step then lies inside ONE tap for every lane, so the
+  // tap walk (ukr, uks, ukc) is wave-uniform scalar work, a row's gather offset avo[j] (bit 31 = outside the image) changes
+  // only when the tap does, and the K-step's channel / weight-column offsets ride in the loads' scalar offset.  Vector
+  // instructions do not hide behind MFMAs on this hardware (profiles/r02_wino_ablation.md): the general walk below costs
+  // ~45 of them per K-step, this one none between tap changes.
+  const bool ut = !X6 && (g.Ci % BK) == 0;
+  int ukr = 0, uks = 0, ukc = 0;
+  unsigned avo[AJ], tap_ok = 0;
+  auto tap_setup = [&]() {
+    const int toff = ukr * rowstep + uks * colstep + lq * 16;
+    const int r_ = min(ukr, 15), s_ = 16 + uks;     // K-padding taps (ukr >= R) hit a zero mask bit
+    tap_ok = 0;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+      const unsigned okb = (vmask[j] >> r_) & (vmask[j] >> s_) & 1u;
+      avo[j] = (unsigned)(base[j] + toff) | ((okb ^ 1u) << 31);
+      tap_ok |= okb << j;
+    }
+  };
+  if (ut) {
+    const int kflat0 = k_begin * BK, tap0 = kflat0 / g.Ci;
+    ukc = kflat0 - tap0 * g.Ci;
+    ukr = tap0 / g.S;
+    uks = tap0 - ukr * g.S;
+    tap_setup();
+  }
+  const float* const pro_sc_lane = a.pro_scale ? a.pro_scale + pro_group_off + lq * 4 : nullptr;
+  const float* const pro_sh_lane = a.pro_shift ? a.pro_shift + pro_group_off + lq * 4 : nullptr;
+
   // one 16-byte global load of the next tile (p < AJ: gathered activation rows; else weight rows)
   int tapoff = 0, krs = 0, kss = 0;
-  auto load_piece = [&](int kk, int p) {
+  auto load_piece = [&](int kk, int p, auto utc) {
+    if constexpr (decltype(utc)::value) {
+      if (p == 0) {
+        a_ok = tap_ok;
+        if (affine) {
+          psc = *reinterpret_cast<const f32x4*>(pro_sc_lane + ukc);
+          psh = *reinterpret_cast<const f32x4*>(pro_sh_lane + ukc);
+        }
+      }
+      if (p < AJ) {
+        ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, avo[p], ukc * 4, 0));
+      } else {
+        rb[p - AJ] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wbase[p - AJ], kk * (BK * 4), 0));
+      }
+      if (p == AJ + BJ - 1) {            // advance the (uniform) tap walk to the next K-step
+        ukc += BK;
+        if (ukc >= g.Ci) {
+          ukc = 0;
+          if (++uks == g.S) {
+            uks = 0;
+            ++ukr;
+          }
+          tap_setup();
+        }
+      }
+      return;
+    }
     if (p == 0) {
       tapoff = kr * rowstep + ks * colstep + kc * 4;
       krs = min(kr, 15);               // K-padding taps (kr >= R) hit a zero mask bit
@@ -224,8 +279,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
   };
   auto load_tiles = [&](int kk) {
+    if (ut) {
 #pragma unroll
-    for (int p = 0; p < AJ + BJ; ++p) load_piece(kk, p);
+      for (int p = 0; p < AJ + BJ; ++p) load_piece(kk, p, std::true_type{});
+    } else {
+#pragma unroll
+      for (int p = 0; p < AJ + BJ; ++p) load_piece(kk, p, std::false_type{});
+    }
   };
   // one 16-byte piece of the next tile: prologue on its way from the staging registers to LDS
   auto store_piece = [&](int buf, int p) {
@@ -270,6 +330,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int fi = lane & 31, fh = lane >> 5;
+  // uniform-tap path: LDS addresses of the fragments of sub-step u and of the staged pieces, per buffer, held in registers
+  // (with the buffer a compile-time constant of the step, see kstep_u: no address arithmetic inside the loop).  The swizzle
+  // of a row only depends on the row modulo 32 (16 for BK = 64), so tiles i / j and pieces p differ by constant offsets.
+  int fao[BK / 8], fbo[BK / 8];
+#pragma unroll
+  for (int u = 0; u < BK / 8; ++u) {
+    const int ra_ = wm * (TM * 32) + fi, rb_ = wn * (TN * 32) + fi;
+    fao[u] = ra_ * BK + (swz(ra_, 2 * u + fh) << 2);
+    fbo[u] = 2 * BM * BK + rb_ * BK + (swz(rb_, 2 * u + fh) << 2);
+  }
+  const int sto = lrow * BK + (swz(lrow, lq) << 2);      // this thread's slot in a tile (A and B alike)
 
   stamp(1);
   if (k_begin < k_end) {
@@ -325,13 +396,78 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         if (decltype(has_next)::value && es < LE) {                          // next tile's global loads: first e-steps
 #pragma unroll
           for (int pp = 0; pp < PPE; ++pp)
-            if (es * PPE + pp < NP) load_piece(kk + 1, es * PPE + pp);
+            if (es * PPE + pp < NP) load_piece(kk + 1, es * PPE + pp, std::false_type{});
         }
         if (decltype(has_next)::value && es >= NE - LE) {
           __builtin_amdgcn_sched_barrier(0);   // keep the piece HERE: hoisted to the top it would wait for its load first
 #pragma unroll
           for (int pp = 0; pp < PPE; ++pp)
             if ((es - (NE - LE)) * PPE + pp < NP) store_piece(cur ^ 1, (es - (NE - LE)) * PPE + pp);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fs][i][e], fb[fs][j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  };
+  // The same step on the uniform-tap path: buffer index as a compile-time constant (the loop below is unrolled by two), all
+  // LDS addresses = a register + an instruction offset.
+  auto kstep_u = [&](int kk, auto curc, auto has_next) {
+    constexpr int cur = decltype(curc)::value;
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int slot, int u) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[slot][i] = *reinterpret_cast<const f32x4*>(smem + fao[u] + cur * BM * BK + i * 32 * BK);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[slot][j] = *reinterpret_cast<const f32x4*>(smem + fbo[u] + cur * BN * BK + j * 32 * BK);
+    };
+    auto store_piece_u = [&](int p) {          // store_piece(cur ^ 1, p) with constant offsets
+      if (p < AJ) {
+        f32x4 v = ra[p];
+        if (pro_mode != PRO_NONE) {
+          if (affine) v = v * psc + psh;
+          if (pro_mode == PRO_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+          } else if (pro_mode != PRO_AFFINE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (affine) {                            // padding is zero AFTER the transform
+            const float keep = (float)((a_ok >> p) & 1u);
+            v *= keep;
+          }
+        }
+        *reinterpret_cast<f32x4*>(smem + sto + (cur ^ 1) * BM * BK + p * RP * BK) = v;
+      } else {
+        *reinterpret_cast<f32x4*>(smem + sto + 2 * BM * BK + (cur ^ 1) * BN * BK + (p - AJ) * RP * BK) = rb[p - AJ];
+      }
+    };
+    if constexpr (FP) read_frags(0, 0);
+#pragma unroll
+    for (int u = 0; u < BK / 8; ++u) {
+      const int fs = FP ? (u & 1) : 0;
+      if constexpr (FP) {
+        if (u + 1 < BK / 8) read_frags((u + 1) & 1, u + 1);
+      } else {
+        read_frags(0, u);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int es = u * 4 + e;
+        if (decltype(has_next)::value && es < LE) {                          // next tile's global loads: first e-steps
+#pragma unroll
+          for (int pp = 0; pp < PPE; ++pp)
+            if (es * PPE + pp < NP) load_piece(kk + 1, es * PPE + pp, std::true_type{});
+        }
+        if (decltype(has_next)::value && es >= NE - LE) {
+          __builtin_amdgcn_sched_barrier(0);   // keep the piece HERE: hoisted to the top it would wait for its load first
+#pragma unroll
+          for (int pp = 0; pp < PPE; ++pp)
+            if ((es - (NE - LE)) * PPE + pp < NP) store_piece_u((es - (NE - LE)) * PPE + pp);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -382,8 +518,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
         }
         if (decltype(has2)::value && es >= NS - LS) {
           const int p0 = 2 * (es - (NS - LS));
-          load_piece(kk + 2, p0);
-          if (p0 + 1 < NP) load_piece(kk + 2, p0 + 1);
+          load_piece(kk + 2, p0, std::false_type{});
+          if (p0 + 1 < NP) load_piece(kk + 2, p0 + 1, std::false_type{});
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -404,8 +540,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     if (kk + 1 < k_end) { kstep_x6(kk, T{}, F{}); ++kk; }
     if (kk < k_end) kstep_x6(kk, F{}, F{});
   } else {
-    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
-    if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+    if (ut) {
+      const std::integral_constant<int, 0> b0;
+      const std::integral_constant<int, 1> b1;
+      int kk = k_begin;
+      for (; kk + 2 < k_end; kk += 2) {
+        kstep_u(kk, b0, std::true_type{});
+        kstep_u(kk + 1, b1, std::true_type{});
+      }
+      if (kk + 1 < k_end) {
+        kstep_u(kk, b0, std::true_type{});
+        kstep_u(kk + 1, b1, std::false_type{});
+      } else if (kk < k_end) {
+        kstep_u(kk, b0, std::false_type{});
+      }
+    } else {
+      for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+      if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+    }
   }
   stamp(3);
   if (a.tune & 2) __builtin_amdgcn_s_setprio(3);
@@ -763,9 +915,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                                                                  splitk_ws ? splitk_ws_floats : 0);
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
-  DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x64 (4x1 waves), "
-             "5 = 256x64, 6 = 64x64 with 64-wide K-steps)", tile_cfg);
-  DG_REQUIRE(cfg != 6 || Kp % 64 == 0, "conv_gemm: tile_cfg 6 needs Kp %% 64 == 0 (Kp=%d)", Kp);
+  DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 = 64x64 with fragment "
+             "prefetch, 8 = 128x64 with fragment prefetch, 9 / 10 = Winograd; 2, 4, 6 were retired after the round-2 sweeps)", tile_cfg);
   DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % bm == 0 && a.M % pro_group_rows == 0)),
              "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, bm, a.M);
   a.slab = splitk_ws;
@@ -818,11 +969,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true, true>(a, st);
-    case 2: return launch_cfg<128, 64, 2, 2, 32, true>(a, st);
     case 3: return launch_cfg<64, 64, 2, 2, 32, true, true>(a, st);
-    case 4: return launch_cfg<128, 64, 4, 1, 32, true>(a, st);
     case 5: return launch_cfg<256, 64, 4, 1, 32, true>(a, st);
-    case 6: return launch_cfg<64, 64, 2, 2, 64, true>(a, st);
     case 7: return launch_cfg<64, 64, 2, 2, 32, true, false, true>(a, st);
     case 8: return launch_cfg<128, 64, 2, 2, 32, true, false, true>(a, st);
     default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
@@ -831,10 +979,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 2: case 4: case 8: case 10: return 128; case 3: case 6: case 7: return 64; case 5: case 9: return 256; default: return 0; }
+  switch (cfg) { case 1: case 8: case 10: return 128; case 3: case 7: return 64; case 5: case 9: return 256; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: return 128; case 2: case 3: case 4: case 5: case 6: case 7: case 8: case 9: case 10: return 64; default: return 0; }
+  switch (cfg) { case 1: return 128; case 3: case 5: case 7: case 8: case 9: case 10: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
