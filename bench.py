@@ -371,7 +371,7 @@ def main():
         # launch-bound workloads (MNIST-DCGAN: hundreds of ~10 us launches of the dominant kernel per step): a pair of HIP
         # events per launch would slow the very thing being timed (16 vs 10 ms per step); its launches are then bracketed
         # in the un-timed steps after the timed region instead
-        dominant_outside = dstat['launches'] > 150
+        dominant_outside = dstat['launches'] > 60
         C.TIMER = None
     if not args.no_kernel_timer:
         timer = C.KernelTimer(only=(set() if dominant_outside else {dominant}) if dominant else None)

@@ -107,8 +107,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_s_kernel(const ConvGemmArgs 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int f = wave * 4 + i;
+      const unsigned long long ub = (unsigned long long)(ublock + ((long)(s_abs >> 1) * 32 + f * 2 + (s_abs & 1)) * ZUP);
+      const unsigned long long us64 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32;
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(ublock + ((long)(s_abs >> 1) * 32 + f * 2 + (s_abs & 1)) * ZUP + lane * 4),
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const float*>(us64) + (unsigned)(lane * 4)),
           (__attribute__((address_space(3))) void*)(us + f * ZUP), 16, 0, 0);
     }
   };
@@ -119,8 +122,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_s_kernel(const ConvGemmArgs 
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
 
-  f32x4 d[4], t[4];
+  f32x4 d[4];
+  float t[4][4];
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  int kbound[4];                                        // BatchNorm + ReLU: upper clamp of the activation, 0 on padding pixels
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kbound[c] = keep[c] != 0.f ? 0x7fffffff : 0;
   auto tr_read = [&](int s_abs) {                                   // this row's 4 pixels x 4 channels of step s_abs
     const float* src = raw + (((s_abs >> 2) - R0) & 1) * rawf + rpix + (s_abs & 3) * 4;
 #pragma unroll
@@ -130,43 +137,55 @@ __global__ __launch_bounds__(256, 2) void conv_wino_s_kernel(const ConvGemmArgs 
       psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + s_abs * 4);
     }
   };
+  // (vector instructions are not hidden behind this wave's MFMAs -- profiles/r02_wino_ablation.md -- so every piece below
+  //  is written for the fewest of them, as in conv_wino.hip)
   auto tr_prologue = [&]() {
     if (PRO == PRO_NONE) return;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       f32x4 v = d[c];
       if (affine) v = v * psc + psh;
-      if (PRO == PRO_LRELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-      } else if (PRO != PRO_AFFINE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {                 // max(v, 0) as ONE v_max_i32 on the bits (negative floats are negative integers)
-          const float q = v[e];
-          v[e] = __int_as_float(max(__float_as_int(q), 0));
+      for (int e = 0; e < 4; ++e) {
+        const float q = v[e];
+        float r;
+        if (PRO == PRO_LRELU) {
+          const float q2 = 0.2f * q;
+          asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(q2));
+        } else if (PRO == PRO_RELU) {
+          r = __int_as_float(max(__float_as_int(q), 0));
+        } else if (PRO == PRO_AFFINE_RELU) {
+          asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(q), "v"(kbound[c]));      // ReLU + zero padding in one clamp
+        } else {
+          r = q * keep[c];                               // padding is zero AFTER the transform
         }
+        v[e] = r;
       }
-      if (affine) v *= keep[c];                        // padding is zero AFTER the transform
       d[c] = v;
     }
   };
   auto tr_rows = [&]() {
-    t[0] = d[0] - d[2];
-    t[1] = d[1] + d[2];
-    t[2] = d[2] - d[1];
-    t[3] = d[1] - d[3];
-  };
-  auto tr_store = [&](int stage, int j) {
-    float* vs = smem + stage * ZSTAGE;
-    f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      // (scalar copy first: a bit_cast of the vector element itself is miscompiled to element 0, as in conv_gemm.hip)
-      const float own = t[j][e];
-      const int other = __builtin_amdgcn_update_dpp(__float_as_int(own), __float_as_int(own), 0x5A, 0xF, 0xF, false);
-      o[e] = fmaf(sc, __int_as_float(other), own);
+      t[0][e] = d[0][e] - d[2][e];
+      t[1][e] = d[1][e] + d[2][e];
+      t[2][e] = d[2][e] - d[1][e];
+      t[3][e] = d[1][e] - d[3][e];
     }
-    *reinterpret_cast<f32x4*>(vs + (lr * 4 + j) * ZVP + vslot) = o;
+  };
+  float* const vst0 = smem + lr * 4 * ZVP + vslot;
+  auto tr_store = [&](int stage, int j) {
+    float o0 = t[j][0], o1 = t[j][1], o2 = t[j][2], o3 = t[j][3];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(sc));
+    const f32x4 o = {o0, o1, o2, o3};
+    *reinterpret_cast<f32x4*>(vst0 + stage * ZSTAGE + j * ZVP) = o;
   };
 
   f32x16 acc[4][2];
