@@ -121,9 +121,9 @@ int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64
 /* tile config chosen when tile_cfg == 0 (host only); allow_split: split-K is available to the call (workspace given,
  * no stat_partials) */
 int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split);
-/* Tile configurations: 1 = 128x128, 2 = 128x64 (waves 2x2), 3 = 64x64, 4 = 128x64 (waves 4x1), 5 = 256x64,
- * 6 = 64x64 with 64-wide K-steps (Kp % 64 == 0), 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments,
- * 9 = Winograd (below).  Rows / columns of one (0 = unknown configuration). */
+/* Tile configurations: 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments
+ * (2, 4 and 6 -- other 128x64 wave layouts, 64-wide K-steps -- were retired after the round-2 sweeps); rows / columns of a
+ * configuration (0 for an unknown one): */
 int diagan_conv_gemm_tile_rows(int cfg);
 int diagan_conv_gemm_tile_cols(int cfg);
 /* tile_cfg 9: Winograd F(2x2,3x3) (csrc/conv_wino.hip) for 3x3 / stride 1 / pad 1 layers and their data-gradients --
@@ -137,7 +137,7 @@ int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, i
  * (8x4 tiles of one image, 4x4 of two, ...) x 64 columns, two per CU; the block's input region goes global -> LDS once
  * (LDS-DMA, 16 channels per request) instead of once per tile.  Needs, on top of diagan_conv_wino_supported, Ci % 16 == 0
  * and blocks that tile the batch (and the prologue groups) exactly -- this query; 128 pixel rows x 64 columns per
- * workgroup (stat_partials granularity).  tile_cfg 0 prefers it over 9 where it applies (DIAGAN_WINO_STAGED=0: never). */
+ * workgroup (stat_partials granularity).  Measured 10 % slower than tile_cfg 9 (profiles/r02_wino_ablation.md): tile_cfg 0 picks it only with DIAGAN_WINO_STAGED=1. */
 int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
 /* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and
  * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns

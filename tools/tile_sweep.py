@@ -46,7 +46,7 @@ SHAPES = [
 ]
 # (tile cfg, forced split-K (0 = auto), tune flags (-1 = production default), LDS delta in bytes (timing only when < 0))
 VARIANTS = [(3, 0, 0, 0), (3, 0, 1, 0), (3, 0, 3, 0), (7, 0, 0, 0), (7, 0, 3, 0), (1, 0, 0, 0), (1, 0, 3, 0),
-            (2, 0, 0, 0), (8, 0, 0, 0), (8, 0, 3, 0), (5, 0, 0, 0), (5, 0, 3, 0), (1, 2, 3, 0), (1, 4, 3, 0),
+            (8, 0, 0, 0), (8, 0, 3, 0), (5, 0, 0, 0), (5, 0, 3, 0), (1, 2, 3, 0), (1, 4, 3, 0),
             (3, 0, 0, 8192), (3, 0, 0, 20480), (7, 0, 3, 8192)]
 if os.environ.get("VARIANTS"):
     VARIANTS = [tuple(int(v) for v in t.split(",")) for t in os.environ["VARIANTS"].split(";")]
