@@ -153,17 +153,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   auto issue_loads = [&](int kk, int stage) {
     // U: 32 planes of 1 KB, 4 per wave, straight into LDS (lane-linear image == the global order)
     float* us = smem + stage * W_STAGE + 32 * W_PLANE;
-    if (WINO_ON(64))
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = wave * 4 + i;
-      // wave-uniform base in scalar registers + the lane's 32-bit offset: no 64-bit vector add per instruction
-      const unsigned long long ub = (unsigned long long)(ublock + (long)kk * (32 * W_PLANE) + p * W_PLANE);
+    if (WINO_ON(64)) {
+      // ONE wave-uniform base (scalar registers) + the lane's 32-bit offset for the wave's four planes: the instruction's
+      // immediate offset (applied to the global AND the LDS address) steps through them, 1 KB apart on both sides
+      const unsigned long long ub = (unsigned long long)(ublock + (long)kk * (32 * W_PLANE) + wave * 4 * W_PLANE);
       const unsigned long long us64 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub) |
                                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32;
-      const float* up = reinterpret_cast<const float*>(us64);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(up + (unsigned)(lane * 4)),
-                                       (__attribute__((address_space(3))) void*)(us + p * W_PLANE), 16, 0, 0);
+      const float* up = reinterpret_cast<const float*>(us64) + (unsigned)(lane * 4);
+      float* ul = us + wave * 4 * W_PLANE;
+#define WINO_DMA(I)                                                                              \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)up,                \
+                                   (__attribute__((address_space(3))) void*)ul, 16, (I) * W_PLANE * 4, 0)
+      WINO_DMA(0);
+      WINO_DMA(1);
+      WINO_DMA(2);
+      WINO_DMA(3);
+#undef WINO_DMA
     }
     if (WINO_ON(32))
 #pragma unroll
