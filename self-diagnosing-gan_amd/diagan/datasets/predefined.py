@@ -30,6 +30,13 @@ class WeightedDataset(Dataset):
     def __len__(self):
         return len(self.dataset)
 
+    def fetch_range(self, lo, hi):
+        """(data[lo:hi], indices) of a contiguous index range without per-item Python -- the logit pass uses it when the
+        wrapped dataset is tensor-backed (it offers `fetch_range` itself); None otherwise (the pass then walks a loader)."""
+        f = getattr(self.dataset, 'fetch_range', None)
+        data = f(lo, hi) if f is not None else None
+        return None if data is None else (data, torch.arange(lo, hi))
+
 
 class SyntheticImages(Dataset):
     """Deterministic stand-in with the input contract of datasets/transform.py:9-10:
@@ -50,6 +57,9 @@ class SyntheticImages(Dataset):
 
     def __len__(self):
         return self.num
+
+    def fetch_range(self, lo, hi):
+        return self.data[lo:hi] if self.data is not None else None
 
 
 def get_predefined_dataset(dataset_name, root=None, weights=None, num_data=None, dataset=None, **kwargs):
