@@ -21,7 +21,9 @@ from diagan.ops import conv as K
 
 # The StyleGAN2 ops keep to the implicit-GEMM kernels by default: its parity tests follow three training iterations
 # against the oracle at 5e-3, and the Winograd kernel's (equally valid, ~1e-6) rounding moves that chaotic trajectory by
-# 6e-3 at the third.  DIAGAN_SG2_WINO=1 lets the 3x3 / stride-1 layers take the Winograd kernel (faster).
+# 6e-3 at the third; at 256 x 256 the gradient of one NoiseInjection strength (a cancelling sum of 2 M products) lands 1.2 %
+# from the reference's CPU value, its golden tolerance being 1 %.  DIAGAN_SG2_WINO=1 lets the 3x3 / stride-1 layers take the
+# Winograd kernel (+21 % on the 256 x 256 iteration: 82 -> 99 images/s).
 SG2_WINO = os.environ.get("DIAGAN_SG2_WINO", "0") == "1"
 
 
