@@ -205,15 +205,26 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
   auto kstep = [&](int ks, auto has_next) {
     const int cur = (ks - s_begin) & 1;
     if (decltype(has_next)::value) issue_loads(ks + 1);
-#pragma unroll
-    for (int fl = 0; fl < 4; ++fl) {
-      float fa[2][4], fb[4];
+    // all 48 fragment words of the step are requested before the first MFMA (two groups of 24: the second while the first
+    // is consumed) instead of 12 per frequency with a wait each: the LDS round trip is paid once per step, not four times
+    float fa[4][2][4], fb[4][4];
+    auto read_frags = [&](int fl) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int row = cur * GW_STAGE + (fl * GW_T + 2 * e) * 64;
-        fa[0][e] = fa_base0[row];
-        fa[1][e] = fa_base1[row];
-        fb[e] = fb_base[row];
+        fa[fl][0][e] = fa_base0[row];
+        fa[fl][1][e] = fa_base1[row];
+        fb[fl][e] = fb_base[row];
+      }
+    };
+    read_frags(0);
+    read_frags(1);
+#pragma unroll
+    for (int fl = 0; fl < 4; ++fl) {
+      if (fl == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(2);
+        read_frags(3);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -225,7 +236,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
           else store_v(cur ^ 1, grp - 10);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[fl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[e], acc[fl][i], 0, 0, 0);
+        for (int i = 0; i < 2; ++i)
+          acc[fl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[fl][i][e], fb[fl][e], acc[fl][i], 0, 0, 0);
       }
     }
     __syncthreads();
