@@ -111,7 +111,8 @@ class BaseGenerator(BaseModel):
         if not pool:
             return None
         if pool[0].shape[0] != num_images or self._fake_pool_version != self.param_version or not self.training:
-            self._fake_pool = []        # ragged last batch, changed parameters or eval mode: fall back
+            self._fake_pool = []        # changed parameters, eval mode, or a caller that asks for another batch size
+                                        # (LogTrainer does not prefetch a step that contains a ragged batch): fall back
             return None
         return pool.pop(0)
 

@@ -219,23 +219,34 @@ class LogTrainer:
     # the G update on the LAST D batch, step += 1, LR schedule, then the periodic duties in the order
     # summaries, console line, sample grid, logit snapshot, checkpoint (+ pickle of the record).
     def _updates(self, step, streams, log):
-        # the fake batches of all the D (and D_drs) updates of this step in one stacked generator forward
+        # The real batches of the step are fetched first, in the order the updates consume them (main, drs, main, ...: the
+        # iterators advance -- and restart at an epoch's end -- in the reference's order).  Knowing their sizes keeps the
+        # stacked generator forward honest: it draws the noise of all the D (and D_drs) updates up front, which equals the
+        # reference's draw order only when every update sees a full batch; a step that contains an epoch's ragged last
+        # batch therefore draws its noise update by update, like the reference.
+        batches, batches_drs = [], []
+        for i in range(self.n_dis):
+            streams['main'], b = self._fetch_data(iter_dataloader=streams['main'])
+            batches.append(b)
+            if self.train_drs:
+                streams['drs'], b = self._fetch_data(iter_dataloader=streams['drs'], dataloader=self.dataloader_drs)
+                batches_drs.append(b)
         prefetch = getattr(self.netG, 'prefetch_fakes', None)       # optional part of the generator protocol
         if prefetch is not None:
-            prefetch(self.n_dis * (2 if self.train_drs else 1), self.dataloader.batch_size, device=self.device)
+            full = all(b[0].shape[0] == self.dataloader.batch_size for b in batches + batches_drs)
+            prefetch(self.n_dis * (2 if self.train_drs else 1) if full else 0, self.dataloader.batch_size,
+                     device=self.device)
         # data parallel phase 2: D and D_drs are independent (reference trainer.py:250-277), so D's gradient all-reduce
         # stays in flight under D_drs's forward / backward and D's Adam step follows it
         overlap = self.train_drs and self.world > 1
         for i in range(self.n_dis):
-            streams['main'], batch = self._fetch_data(iter_dataloader=streams['main'])
+            batch = batches[i]
             extra = dict(defer_step=True) if overlap else {}
             log = self.netD.train_step(real_batch=batch, netG=self.netG, optD=self.optD, log_data=log,
                                        global_step=step, device=self.device, scaler=None, **extra)
             self.events.append((step, 'D'))
             if self.train_drs:
-                streams['drs'], batch_drs = self._fetch_data(iter_dataloader=streams['drs'],
-                                                             dataloader=self.dataloader_drs)
-                log = self.netD_drs.train_step(real_batch=batch_drs, netG=self.netG, optD=self.optD_drs,
+                log = self.netD_drs.train_step(real_batch=batches_drs[i], netG=self.netG, optD=self.optD_drs,
                                                log_data=log, global_step=step, device=self.device, scaler=None)
                 self.events.append((step, 'D_drs'))
             if overlap:

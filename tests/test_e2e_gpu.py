@@ -103,6 +103,39 @@ def test_logit_record_matches_direct_eval(tmp_path):
     np.testing.assert_allclose(row, direct, rtol=2e-6, atol=2e-6)
 
 
+def test_ragged_step_draws_noise_update_by_update(tmp_path):
+    """A global step that contains an epoch's ragged last batch does not use the stacked generator forward (which draws
+    the noise of all updates up front, i.e. in another order than the reference's update-by-update draws): the device
+    generator ends the step exactly where n_dis successive updates leave it, and full steps still prefetch."""
+    from diagan.datasets.predefined import get_predefined_dataset
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.trainer.trainer import LogTrainer
+    from diagan.trainer.logger import MetricLog
+    torch.manual_seed(5)
+    netG, netD, optG, optD = get_gan_model('cifar10', model='sngan', loss_type='hinge')
+    ds = get_predefined_dataset('cifar10', num_data=200)           # batches of 64, 64, 64, 8
+    dl = torch.utils.data.DataLoader(ds, batch_size=64, shuffle=False)
+    t = LogTrainer(output_path=tmp_path, netD=netD, netG=netG, optD=optD, optG=optG, dataloader=dl, num_steps=3, n_dis=2,
+                   log_dir=str(tmp_path), device='cuda')
+    counts, orig = [], netG.prefetch_fakes
+
+    def spy(count, batch_size, device=None):
+        counts.append(count)
+        return orig(count, batch_size, device=device)
+    netG.prefetch_fakes = spy
+    streams = {'main': iter(dl)}
+    t._updates(0, streams, MetricLog())                             # 64, 64: prefetched
+    assert counts == [2]
+    torch.cuda.manual_seed(77)
+    t._updates(1, streams, MetricLog())                             # 64, 8: noise drawn update by update
+    assert counts == [2, 0]
+    after = torch.cuda.get_rng_state()
+    torch.cuda.manual_seed(77)
+    for n in (64, 8, 8):                                            # D, D, then the G update (size of the last D batch)
+        torch.randn((n, netG.nz), device='cuda')
+    assert torch.equal(after, torch.cuda.get_rng_state())
+
+
 def test_drs_generates_on_gpu():
     """DRS wrapper (reference models/drs.py:9-68) over the HIP nets: burn-in maximum equals the max over the
     same 50 batches evaluated directly, accepted images come from the generator's batch, count is exact."""
