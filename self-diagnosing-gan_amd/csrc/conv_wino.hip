@@ -85,7 +85,7 @@ constexpr int WK = 8;                  // input channels per K-step
 constexpr int W_PLANE = 64 * 4;        // floats of one (f, k-quad) plane: 64 rows x 4 channels
 constexpr int W_STAGE = 2 * 32 * W_PLANE;   // V planes + U planes of one stage (floats)
 
-// Diagnostic build only (make CXXFLAGS+=-DDIAGAN_WINO_ABLATE; tools/wino_ablate.py, tools/wino_stamps.py): ConvGemmArgs::tune
+// Diagnostic build only (make EXTRA=-DDIAGAN_WINO_ABLATE; tools/wino_ablate.py, tools/wino_stamps.py): ConvGemmArgs::tune
 // bits switch parts of the K loop off (bit 4 transform, 5 input loads, 6 weight DMA, 7 barrier, 8 MFMAs, 9 epilogue: the
 // results are then garbage) so that their cost can be read off the launch time, and bit 10 makes every wave sum the
 // s_memtime cycles of the phases of its K-steps into the stamp buffer.  Findings: profiles/r02_wino_ablation.md.
