@@ -45,6 +45,8 @@ CASES = [
     ("convT", 2, 8, 8, 96, 48, 4, 2, 1),         # DCGAN G
     ("convT", 4, 1, 1, 384, 192, 4, 1, 0),       # DCGAN G first layer
     ("conv", 64, 4, 4, 256, 256, 3, 1, 1),
+    ("conv", 2, 16, 16, 64, 32, 3, 2, 1),        # strided conv on the uniform-tap loader path (Ci % 32 == 0)
+    ("conv", 3, 8, 8, 32, 64, 4, 2, 1),          # 4x4 / stride 2 (DCGAN D shape), uniform-tap path, odd batch
 ]
 
 
