@@ -500,18 +500,21 @@ void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int 
 // floats of workspace the transformed weights need
 long wino_ws_floats(int Co, int Ci) { return (long)cdiv(Co, WN) * WN * Ci * 16; }
 
-// Split-K factor for launches with fewer workgroups than ~3/4 of the chip (the 4x4 / 8x8 blocks at batch 64): enough
-// splits to reach 128+ workgroups, each with at least 16 K-steps (128 input channels: with 8, M=8192 / Ci=128 runs
-// 35.7 us against the implicit GEMM's 31.6); 0 = such a launch is better served by the implicit GEMM's smaller tiles.  allow_split: a slab can be used (workspace, no fused statistics).
+// Split-K factor for launches with fewer workgroups than ~3/4 of the chip (the 4x4 / 8x8 blocks at batch 64): the smallest
+// split that fills the chip (256 workgroups) with at least 8 K-steps each (64 x 8x8 x 256 -> 256: split 4 = 40.7 us
+// against 53.2 with split 2 and 51.0 on the implicit GEMM), else the smallest that reaches 128 workgroups with at least 16
+// K-steps each (with 8, M = 8192 / Ci = 128 runs 35.0 us against the implicit GEMM's 28.0); 0 = such a launch is better
+// served by the implicit GEMM's smaller tiles.  allow_split: a slab can be used (workspace, no fused statistics).
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs) {
   const long wgs = (long)cdiv((long)B * (Ho >> 1) * (Wo >> 1), WT) * cdiv(Co, WN);
   if (wgs >= min_wgs) return 1;
   if (!allow_split) return 0;
   const int nk = Ci / WK;
-  for (int ks = 2; ks <= 4; ++ks) {
-    if (nk / ks < 16) break;
-    if (wgs * ks >= 128 && wino_ws_floats(Co, Ci) + (long)ks * B * Ho * Wo * Co <= ws_floats) return ks;
-  }
+  auto fits = [&](int ks) { return wino_ws_floats(Co, Ci) + (long)ks * B * Ho * Wo * Co <= ws_floats; };
+  for (int ks = 2; ks <= 4; ++ks)
+    if (nk / ks >= 8 && wgs * ks >= 256 && fits(ks)) return ks;
+  for (int ks = 2; ks <= 4; ++ks)
+    if (nk / ks >= 16 && wgs * ks >= 128 && fits(ks)) return ks;
   return 0;
 }
 
