@@ -247,7 +247,9 @@ def _splitk_ws(dev):
     stream right after it is written)."""
     w = _skws.get(dev.index)
     if w is None:
-        w = torch.empty(16 << 20, dtype=torch.float32, device=dev)      # 64 MiB
+        # 256 MiB: the transformed weights of the largest Winograd layer (1024 -> 1024 channels: 64 MiB) plus the split-K
+        # slab of the same launch (with 64 MiB the 4x4 / 1024-channel layers of D-64 could not split: 330 vs 177 us)
+        w = torch.empty(64 << 20, dtype=torch.float32, device=dev)
         _skws[dev.index] = w
     return w
 
