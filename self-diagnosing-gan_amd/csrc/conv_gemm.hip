@@ -812,8 +812,9 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split)
   const bool x6 = diagan_get_mfma_mode() == 1;
   const int small = x6 ? 3 : 7;            // 64x64 (the fp32 kernel with double-buffered fragments)
   // short K loops (first conv of D on RGB, 1x1 shortcuts) are bound by the output stream, not the MFMAs: more,
-  // smaller workgroups in flight win (measured 52 -> 46 us at M=131072,N=128,K=36; 27 -> 19 us at K=128)
-  if (Kp <= 128) return small;
+  // smaller workgroups in flight win (measured 52 -> 46 us at M=131072,N=128,K=36; 27 -> 19 us at K=128; round 2, fp32:
+  // K = 256 at N = 256: 45.6 -> 33.4 us at M=20480, 118.8 -> 110.5 at M=81920, 27.2 -> 25.0 at M=16384)
+  if (Kp <= (x6 ? 128 : 256)) return small;
   const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128), t64 = (long)cdiv(M, 64) * cdiv(Co, 64);
   if (!x6) {
     // (in a training step this is within box-to-box noise of the 64x64 tile -- tools/layer_report.py, 32.8 vs 33.2 ms of
