@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __r
     if (i < L.n_w) {
       const float inv = L.state[c][1];
       const float coef = (float)(sdot[c] * (double)inv);
-      const int n = (int)(i / L.Kp), k = (int)(i - (long)n * L.Kp);
+      const int n = (int)((unsigned)i / (unsigned)L.Kp), k = (int)i - n * L.Kp;       // (i < n_w < 2^31: no 64-bit division)
       const f32x4 vv = *reinterpret_cast<const f32x4*>(L.v[c] + k);
       o += (g - (L.u[c][n] * coef) * vv) * inv;
     } else {
