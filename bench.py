@@ -19,6 +19,7 @@ Extra objects on the line:
                 rank 0 at N = 1 only, on a bounded sample of the same workload
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -51,7 +52,8 @@ def make_stylegan2_step(size, batch, phase, device):
     from diagan.models.stylegan2 import StyleGANDiscriminator, StyleGANGenerator
     from diagan.trainer import stylegan2 as TR
     from diagan.utils.settings import set_seed
-    set_seed(1)
+    with contextlib.redirect_stdout(sys.stderr):        # (the reference's seed banner: stdout carries the JSON line only)
+        set_seed(1)
     G, D = StyleGANGenerator(size=size).to(device), StyleGANDiscriminator(size=size).to(device)
     g_ema = StyleGANGenerator(size=size).to(device).eval()
     TR.accumulate(g_ema, G, 0)
@@ -85,7 +87,8 @@ class NullLog:
 def build_models(dataset, loss_type, phase, device):
     from diagan.models.predefined_models import get_gan_model
     from diagan.utils.settings import set_seed
-    set_seed(1)
+    with contextlib.redirect_stdout(sys.stderr):        # (the reference's seed banner: stdout carries the JSON line only)
+        set_seed(1)
     if phase == 2:
         netG, netD, netD_drs, optG, optD, optD_drs = get_gan_model(dataset, model='sngan', loss_type=loss_type, drs=True)
     else:
