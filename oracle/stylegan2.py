@@ -52,7 +52,7 @@ def _blur_kernel(taps=(1, 3, 3, 1), gain=1.0):                                  
 
 
 def _fir(x, k, up=1, down=1, pad=(0, 0)):
-    return upfirdn2d(x, k, up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    return upfirdn2d(x, k.to(x.dtype), up, up, down, down, pad[0], pad[1], pad[0], pad[1])
 
 
 def equal_linear(sd, p, x, lr_mul=1.0, activation=False):                       # stylegan2.py:132-161

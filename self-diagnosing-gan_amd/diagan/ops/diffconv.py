@@ -19,12 +19,12 @@ import os
 
 from diagan.ops import conv as K
 
-# The StyleGAN2 ops keep to the implicit-GEMM kernels by default: its parity tests follow three training iterations
-# against the oracle at 5e-3, and the Winograd kernel's (equally valid, ~1e-6) rounding moves that chaotic trajectory by
-# 6e-3 at the third; at 256 x 256 the gradient of one NoiseInjection strength (a cancelling sum of 2 M products) lands 1.2 %
-# from the reference's CPU value, its golden tolerance being 1 %.  DIAGAN_SG2_WINO=1 lets the 3x3 / stride-1 layers take the
-# Winograd kernel (+21 % on the 256 x 256 iteration: 82 -> 99 images/s).
-SG2_WINO = os.environ.get("DIAGAN_SG2_WINO", "0") == "1"
+# The 3x3 / stride-1 layers of the StyleGAN2 ops take the Winograd kernels like the SNGAN layers do (+21 % on the 256 x 256
+# iteration: 82 -> 99 images/s).  Measured against the oracle in float64 the two convolution paths are equally far from
+# the truth: the three-iteration trajectory at 8 x 8 and 16 x 16 (tools/sg2_trajectory.py) and the ill-conditioned
+# NoiseInjection strength gradients at 256 x 256 (tools/sg2_noise_grad.py); profiles/r02_sg2_winograd.md.
+# DIAGAN_SG2_WINO=0 keeps these ops on the implicit GEMM.
+SG2_WINO = os.environ.get("DIAGAN_SG2_WINO", "1") == "1"
 
 
 def _c(t):

@@ -304,10 +304,18 @@ def _check_norms256(g256, tag, net, rtol=2e-3):
     keys = [str(k) for k in g256[f"{tag}_keys"]]
     assert sorted(ours) == keys
     got, want = np.array([ours[k] for k in keys]), g256[f"{tag}_norms"]
-    # a NoiseInjection strength is ONE scalar: the sum of B*H*W*C products of either sign (2 M terms of size ~1e-2 at the
-    # 64 x 64 layer, result ~1e-3).  Its value is set by fp32 summation order at the 1e-5 ABSOLUTE level on any device
-    # (the reference's own CPU value included), hence the absolute floor for these entries only.
-    tol = lambda k, b: (1e-2 * abs(b) + 1e-4) if k.endswith("noise.weight") else (rtol * abs(b) + 1e-6)
+    # a NoiseInjection strength is ONE scalar: the sum of B*H*W*C products g * noise of either sign (up to 8 M terms,
+    # |sum| down to 1/5000 of the sum of |terms|), so an fp32 evaluation is only good to some 1e-5 of the sum of |terms|
+    # on any device.  Against the oracle in float64 (tools/sg2_noise_grad.py, profiles/r02_sg2_winograd.md) the
+    # reference's own CPU values -- this fixture -- are off by up to 27e-6 of it, this engine by up to 28e-6 on either
+    # convolution path (<= 10e-6 on all but the well-conditioned sums, where rtol covers it).  The fixture records the
+    # sum of |terms| (`*_noise_abs`, from the reference with the strength expanded per element); the allowance next to
+    # rtol is 5e-5 of it: the two measured deviations added, since fixture and engine may err to opposite sides.
+    if f"{tag}_noise_abs" in g256.files:
+        term_sum = dict(zip((str(k) for k in g256[f"{tag}_noise_keys"]), g256[f"{tag}_noise_abs"]))
+        tol = lambda k, b: rtol * abs(b) + (5e-5 * term_sum[k] if k in term_sum else 1e-6)
+    else:
+        tol = lambda k, b: (1e-2 * abs(b) + 1e-4) if k.endswith("noise.weight") else (rtol * abs(b) + 1e-6)
     bad = [(k, a, b) for k, a, b in zip(keys, got, want) if abs(a - b) > tol(k, b)]
     assert not bad, f"{tag}: gradient norms off: {bad}"
 

@@ -224,6 +224,47 @@ def main_256(size=256, cm=1, batch=2):
     out.update(zp=zp.numpy(), pl_noise_seed=np.array(7), pl_noise_check=compact(pl_noise), path_loss=np.array(path_loss.item()),
                mean_path=np.array(mean_path.item()), path_lengths=path_lengths.detach().numpy())
     put_norms("path_grad", grad_norms(G))
+
+    # How well-conditioned each NoiseInjection strength's gradient is.  The strength is ONE scalar whose gradient sums
+    # g * noise over B*C*H*W elements of either sign (up to 8 M terms, |sum| down to 1/5000 of the sum of |terms|): any
+    # fp32 evaluation is only good to ~1e-6 of the sum of |terms|.  That sum is recorded here so the consumer can state
+    # its tolerance against it: the strength is expanded to one value per element, whose .grad then holds the terms.
+    def noise_term_sums(z, backward):
+        mods = {n: m for n, m in G.named_modules() if type(m).__name__ == "NoiseInjection"}
+        shapes, saved = {}, {n: m.weight for n, m in mods.items()}
+        hooks = [m.register_forward_hook(lambda mod, inp, o, n=n: shapes.__setitem__(n, tuple(o.shape))) for n, m in mods.items()]
+        with torch.no_grad():
+            G([z], randomize_noise=False)
+        for h in hooks:
+            h.remove()
+        for n, m in mods.items():
+            m.weight = torch.nn.Parameter(saved[n].data.reshape(1, 1, 1, 1).expand(shapes[n]).clone())
+        G.zero_grad()
+        backward()
+        sums = {n + ".weight": (float(m.weight.grad.double().abs().sum()), float(m.weight.grad.double().sum())) for n, m in mods.items()}
+        for n, m in mods.items():
+            m.weight = saved[n]
+        return sums
+
+    def g_pass():
+        fake, _ = G([z1], randomize_noise=False)
+        losses.g_nonsaturating_loss(D(fake)).backward()
+
+    def path_pass():
+        fake, latents = G([zp], return_latents=True, randomize_noise=False)
+        torch.randn_like = lambda t: pl_noise
+        try:
+            path_loss, _, _ = losses.g_path_regularize(fake, latents, 0.3)
+        finally:
+            torch.randn_like = real_randn_like
+        (2.0 * 4 * path_loss + 0 * fake[0, 0, 0, 0]).backward()
+
+    for tag, sums in (("g_loss_grad", noise_term_sums(z1, g_pass)), ("path_grad", noise_term_sums(zp, path_pass))):
+        keys = [str(k) for k in out[f"{tag}_keys"]]
+        for k, (a, s_) in sums.items():                       # the expanded pass must reproduce the scalar gradient
+            assert abs(abs(s_) - out[f"{tag}_norms"][keys.index(k)]) <= 2e-5 * a, (tag, k, s_, a)
+        out[f"{tag}_noise_keys"] = np.array(sorted(sums))
+        out[f"{tag}_noise_abs"] = np.array([sums[k][0] for k in sorted(sums)])
     np.savez_compressed(os.path.join(OUT, "stylegan2_256.npz"), **out)
     print({k: (v.shape if hasattr(v, 'shape') else v) for k, v in out.items() if not k.endswith('keys')})
 
