@@ -67,7 +67,11 @@ int diagan_logit_scatter(const float* logit, const int64_t* idx, int64_t n, void
 
 /* Forward conv / transposed conv / data-gradient:
  *   y[b,oy,ox,n] = epi(out_scale * sum_{r,s,c} pro(x[b,iy,ix,c]) * w[n][(r*S+s)*Ci+c])
- *   epi: + bias[n], + residual (or max(residual,0) if res_relu), then (mask_src > 0 ? v : mask_slope*v).
+ *   epi: + bias[n], + residual (or max(residual,0) if res_relu & 1), then (mask_src > 0 ? v : mask_slope*v).
+ *        res_relu & 2: `residual` is a HALF-resolution tensor [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling
+ *        (align_corners = false, the arithmetic of diagan_upsample2x) is added -- mimicry GBlock's up-sampled shortcut
+ *        without the full-resolution tensor; Winograd kernel only (diagan_conv_gemm_pick_cfg_geom(...) == 9), no mask,
+ *        no ReLU on it.
  * Replaces F.conv2d / nn.ConvTranspose2d forward and their input gradient
  * (SNGAN blocks: SURVEY §8 a2-a7; DCGAN: diagan-pkg/diagan/models/mnist.py:55-71,163-190).
  * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto, 1 = 128x128, 3 = 64x64.

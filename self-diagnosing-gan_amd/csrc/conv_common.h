@@ -66,6 +66,24 @@ static inline FastDiv make_fastdiv(unsigned d) {
   f.shift = l;
   return f;
 }
+// bilinear x2 (align_corners = false) of a half-resolution NHWC tensor r[B][H][W][C] at output pixel (oy, ox), channels
+// c .. c+3: same taps, weights and grouping of the sums as upsample2x_kernel (elementwise.hip)
+__device__ __forceinline__ f32x4 residual_up2(const float* __restrict__ r, int b, int oy, int ox, int H, int W, int C, int c) {
+  const int jy = oy >> 1, jx = ox >> 1;
+  const int y0 = (oy & 1) ? jy : max(jy - 1, 0), y1 = (oy & 1) ? min(jy + 1, H - 1) : jy;
+  const int x0 = (ox & 1) ? jx : max(jx - 1, 0), x1 = (ox & 1) ? min(jx + 1, W - 1) : jx;
+  const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
+  const float wy1 = 1.f - wy0, wx1 = 1.f - wx0;
+  const float* base = r + (long)b * H * W * C + c;
+  const f32x4 a00 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x0) * C);
+  const f32x4 a01 = *reinterpret_cast<const f32x4*>(base + ((long)y0 * W + x1) * C);
+  const f32x4 a10 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x0) * C);
+  const f32x4 a11 = *reinterpret_cast<const f32x4*>(base + ((long)y1 * W + x1) * C);
+  const f32x4 top = wx0 * a00 + wx1 * a01;
+  const f32x4 bot = wx0 * a10 + wx1 * a11;
+  return wy0 * top + wy1 * bot;
+}
+
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   if (f.d == 1) return n;
   const unsigned t = __umulhi(n, f.mul);
@@ -93,6 +111,8 @@ struct ConvGemmArgs {
   float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel)
   int ksplit;             // number of K splits (gridDim.y); 1 = no split
   int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
+  int res_up;             // residual is a HALF-resolution tensor [B,Ho/2,Wo/2,Co]: its bilinear x2 up-sampling is added
+                          // (GBlock's up-sampled shortcut; Winograd kernel and its split-K epilogue only)
   int pro_mode;
   int M;                  // B*Ho*Wo
   ConvGeom g;

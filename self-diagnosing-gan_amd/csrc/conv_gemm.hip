@@ -693,7 +693,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
     s *= sc;
     if (a.bias) s += reinterpret_cast<const f32x4*>(a.bias)[c4];
     if (a.residual) {
-      f32x4 r = reinterpret_cast<const f32x4*>(a.residual)[i];
+      f32x4 r;
+      if (a.res_up) {
+        const int ox = m % a.g.Wo, q = m / a.g.Wo, oy = q % a.g.Ho, b = q / a.g.Ho;
+        r = residual_up2(a.residual, b, oy, ox, a.g.Ho >> 1, a.g.Wo >> 1, a.g.Co, c4 * 4);
+      } else {
+        r = reinterpret_cast<const f32x4*>(a.residual)[i];
+      }
       if (a.res_relu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
@@ -905,7 +911,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.scale0 = scale0; a.scale1 = scale1; a.scale_split = scale_split;
   DG_REQUIRE(!scale0 || scale1, "conv_gemm: scale0 and scale1 must be given together");
   DG_REQUIRE(!(stat_partials && mask_src), "conv_gemm: stat_partials (forward statistics) and mask_src (backward mask) are exclusive");
-  a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu;
+  a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu & 1; a.res_up = (res_relu >> 1) & 1;
+  DG_REQUIRE((res_relu & ~3) == 0, "conv_gemm: res_relu=%d (bit 0: relu(residual), bit 1: half-resolution residual)", res_relu);
+  DG_REQUIRE(!a.res_up || (residual && !(Ho & 1) && !(Wo & 1) && !mask_src && !a.res_relu),
+             "conv_gemm: a half-resolution residual needs the tensor, even Ho / Wo, no backward mask and no ReLU on it");
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
@@ -941,6 +950,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                "conv_gemm: tile_cfg %d needs %ld floats of workspace for the transformed weights", cfg, wino_ws_floats(Co, Ci));
     // the staged kernel (10) wants blocks that tile the batch and the prologue groups; the automatic choice falls back
     bool staged = cfg == 10;
+    DG_REQUIRE(!(a.res_up && staged && tile_cfg != 0), "conv_gemm: tile_cfg 10 takes no half-resolution residual");
+    if (staged && a.res_up) staged = false;
     if (staged && !wino_s_block(B, Ho, Wo, Ci, pro_group_rows)) {
       DG_REQUIRE(tile_cfg == 0, "conv_gemm: tile_cfg 10 (staged Winograd) needs Ci %% 16 == 0 and 32-tile blocks (8x4 tiles of one "
                  "image, 4x4 of two, ...) that tile the batch and the prologue groups exactly");
@@ -968,6 +979,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     }
     return rc;
   }
+  DG_REQUIRE(!a.res_up, "conv_gemm: a half-resolution residual is added by the Winograd kernel only (tile_cfg 9; ask "
+             "diagan_conv_gemm_pick_cfg_geom first)");
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true, true>(a, st);
     case 3: return launch_cfg<64, 64, 2, 2, 32, true, true>(a, st);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
   long o4[2][4];
   int prow4[2][4];
   bool ok2[2];
-  f32x4 rres[2][4], rmsk[2][4];
+  f32x4 rres[2][9], rmsk[2][4];   // residual: 4 output pixels, or the 3x3 half-resolution neighbourhood (res_up)
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int gt = t0 + it * 32 + et;
@@ -410,8 +410,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       o4[it][p] = (long)prow4[it][p] * g.Co + n;
     }
     if (hr && ok2[it]) {
+      if (a.res_up) {
+        // the tile's 2x2 output pixels blend the 3x3 neighbourhood of half-resolution pixel (ty, tx), edges clamped
+        const float* rb = a.residual + ((long)b * TH * TW) * g.Co + n;
+        const int yy[3] = {max(ty - 1, 0), ty, min(ty + 1, TH - 1)}, xx[3] = {max(tx - 1, 0), tx, min(tx + 1, TW - 1)};
 #pragma unroll
-      for (int p = 0; p < 4; ++p) rres[it][p] = *reinterpret_cast<const f32x4*>(a.residual + o4[it][p]);
+        for (int q = 0; q < 9; ++q)
+          rres[it][q] = *reinterpret_cast<const f32x4*>(rb + ((long)yy[q / 3] * TW + xx[q % 3]) * g.Co);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rres[it][p] = *reinterpret_cast<const f32x4*>(a.residual + o4[it][p]);
+      }
     }
     if (hm && ok2[it]) {
 #pragma unroll
@@ -435,9 +444,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       for (int p = 0; p < 4; ++p) {
         f32x4 y = raw ? y4[p] : y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
         if (hr) {
-          f32x4 r = rres[it][p];
+          f32x4 r;
+          if (a.res_up) {
+            // upsample2x_kernel's arithmetic: (w0 * a + w1 * b) along x inside the y blend
+            const int ya = p >> 1, xa = p & 1;
+            const float wy0 = ya ? 0.75f : 0.25f, wx0 = xa ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx1 = 1.f - wx0;
+            const f32x4 top = wx0 * rres[it][ya * 3 + xa] + wx1 * rres[it][ya * 3 + xa + 1];
+            const f32x4 bot = wx0 * rres[it][ya * 3 + 3 + xa] + wx1 * rres[it][ya * 3 + 3 + xa + 1];
+            r = wy0 * top + wy1 * bot;
+          } else {
+            r = rres[it][p];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+          }
           y += r;
         }
         if (hm) {

@@ -145,19 +145,31 @@ class ConvLayer(nn.Module):
         sc = getattr(self, '_slot_ctx', None)
         return sc[slot] if (sc is not None and isinstance(slot, int)) else None
 
-    def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0):
-        return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
-                          residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale)
+    def _res_up(self, x, residual, res_up, want_stats, tile_cfg=0):
+        """res_up: `residual` is at half resolution and its bilinear x2 is to be added.  The Winograd kernel blends it in
+        its epilogue; launches that take another kernel get the up-sampled tensor."""
+        if not res_up:
+            return residual, False
+        fused = tile_cfg == 9 or (tile_cfg == 0 and C.res_up_fused(self.geom, x.shape[0], x.shape[1], x.shape[2],
+                                                                  want_stats=want_stats))
+        return (residual, True) if fused else (E.upsample2x(residual), False)
 
-    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1):
+    def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0, res_up=False):
+        residual, res_up = self._res_up(x, residual, res_up, False, tile_cfg)
+        return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
+                          residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale,
+                          res_up=res_up)
+
+    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1, res_up=False):
         """Forward + the BatchNorm statistics of the layer that consumes the output, taken from the GEMM
         epilogue's per-tile sums (no second pass over the activation).  Returns (y, bn context).
         groups > 1: the batch is `groups` stacked batches with separate statistics (tiles never straddle groups)."""
         if not training:
-            y = self.fwd(ctx, x, pro=pro, residual=residual)
+            y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up)
             return y, bn.stats(y, False)
+        residual, res_up = self._res_up(x, residual, res_up, True)
         y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
-                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True)
+                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up)
         M = y.numel() // y.shape[-1]
         if stats is None or stats[1] % groups or (M // groups) % (M // stats[1]):
             return y, bn.stats(y, True, groups=groups)

@@ -59,20 +59,21 @@ class GBlock(nn.Module):
         k1 = self.c1.prepare(training, need_dgrad)
         h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro, groups=groups)
         # shortcut: a 1x1 conv commutes with the (linear) bilinear upsampling, so c_sc runs on the LOW
-        # resolution input (4x fewer FLOP) and its output is upsampled: c_sc(up(x)) == up(c_sc(x))
+        # resolution input (4x fewer FLOP): c_sc(up(x)) == up(c_sc(x)); the up-sampling itself is blended into c2's
+        # epilogue from the low-resolution tensor (res_up), which is never written out at full resolution
         if self.learnable_sc:
             ksc = self.c_sc.prepare(training, need_dgrad)
             sc = self.c_sc.fwd(ksc, x)
-            if self.upsample:
-                sc = E.upsample2x(sc)
         else:
             ksc, sc = None, x
+        sc_up = self.learnable_sc and self.upsample
         k2 = self.c2.prepare(training, need_dgrad)
         bn_out = None
         if next_bn is not None:
-            out, bn_out = self.c2.fwd_bn(k2, h1, next_bn, training, pro=_bn_pro(bn2), residual=sc, groups=groups)
+            out, bn_out = self.c2.fwd_bn(k2, h1, next_bn, training, pro=_bn_pro(bn2), residual=sc, groups=groups,
+                                         res_up=sc_up)
         else:
-            out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc)
+            out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc, res_up=sc_up)
         if save:
             ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, ksc=ksc, k2=k2)
         return out, ctx, bn_out

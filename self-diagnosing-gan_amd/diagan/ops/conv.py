@@ -171,7 +171,7 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None, want_stats=False, wino=True):
+          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
@@ -184,8 +184,11 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     if w.shape != (Co, Kp):
         raise RuntimeError(f"conv_gemm: packed weight shape {tuple(w.shape)} != ({Co}, {Kp})")
     for t, n in ((residual, 'residual'), (mask_src, 'mask_src')):
-        if t is not None and t.shape != out.shape:
-            raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != output {tuple(out.shape)}")
+        want = (B, Ho // 2, Wo // 2, Co) if (res_up and n == 'residual') else tuple(out.shape)
+        if t is not None and tuple(t.shape) != want:
+            raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != {want}")
+    if res_up and (residual is None or res_relu or not wino):
+        raise RuntimeError("conv_gemm: res_up needs a half-resolution residual, no ReLU on it, and the Winograd kernel")
     sy, dr, off, up = geo_params
     stats = None
     if (mask_src is None and row_scale is None and out_scale == 1.0 and not res_relu and tile_cfg == 0
@@ -227,7 +230,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
-             1 if res_relu else 0, nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
+             (1 if res_relu else 0) | (2 if res_up else 0), nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
              (B // 2) * Ho * Wo if row_scale else 0,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
@@ -254,9 +257,21 @@ def _splitk_ws(dev):
     return w
 
 
+def res_up_fused(geom, B, Hi, Wi, want_stats=False):
+    """Will conv_fwd(geom, x[B,Hi,Wi,Ci], ..., res_up=True) run?  The bilinear x2 of a half-resolution residual is blended in
+    by the Winograd kernel's epilogue (and its split-K second stage) only: True iff the automatic choice for this launch
+    is that kernel (tile_cfg 9); otherwise the caller up-samples the residual itself (diagan_upsample2x)."""
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    sy, dr, off, up = geom.fwd_params()
+    ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
+    return 9 == nat.fn("diagan_conv_gemm_pick_cfg_geom")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up,
+                                                         geom.Kp, 0 if want_stats else 1, ws.numel())
+
+
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False, out_scale=1.0, wino=True):
-    """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co]."""
+             want_stats=False, out_scale=1.0, wino=True, res_up=False):
+    """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co].
+    res_up: `residual` is [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling is added (see res_up_fused)."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
         raise RuntimeError(f"conv_fwd: input has {Ci} channels, layer expects {geom.Ci}")
@@ -264,7 +279,7 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
-                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino)
+                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,

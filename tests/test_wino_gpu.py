@@ -174,3 +174,55 @@ def test_auto_selection_and_agreement_with_the_implicit_gemm():
     with pytest.raises(RuntimeError, match="Winograd"):
         g2 = C.Geom("conv", 512, 512, 3, 3, 2, 1)
         C.conv_fwd(g2, nhwc(x).cuda(), wp, tile_cfg=9)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (3, 6, 10, 16, 24), (5, 16, 16, 128, 72), (64, 4, 4, 512, 512)])
+def test_half_resolution_residual_is_upsampled_in_the_epilogue(case):
+    """mimicry GBlock's shortcut is c_sc(interpolate(x, scale_factor=2, mode='bilinear')) (= interpolate(c_sc(x)), a 1x1
+    convolution): the Winograd epilogue and its split-K second stage blend the x2 up-sampling of the half-resolution
+    residual themselves (res_relu bit 1).  Against F.interpolate in float64, and against the same launch given the
+    tensor diagan_upsample2x materialises (same blend arithmetic: equal to an fp32 rounding of the blend)."""
+    from diagan.ops import conv as C, eltwise as E
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=11)
+    g = torch.Generator().manual_seed(12)
+    bias, low = torch.randn(Co, generator=g), torch.randn(B, Co, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1) + \
+        F.interpolate(low.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    lo = nhwc(low).cuda()
+    for cfg in (9, 0):                                     # forced, and the automatic choice (split-K on the 4x4 case)
+        if cfg == 0 and not C.res_up_fused(geom, B, H, W):
+            with pytest.raises(RuntimeError, match="Winograd"):
+                C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=lo, res_up=True)
+            continue
+        y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=lo, res_up=True, tile_cfg=cfg)
+        close(nchw(y), ref, tol=2e-5)
+        z = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=E.upsample2x(lo), tile_cfg=cfg)
+        assert (y - z).abs().max().item() <= 1e-6 * max(1.0, z.abs().max().item())
+    # fused BatchNorm statistics see the blended residual
+    y, st = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=lo, res_up=True, tile_cfg=9, want_stats=True)
+    close(st[0][:, 0].sum(0), y.double().sum((0, 1, 2)), tol=1e-5)
+    with pytest.raises(RuntimeError, match="Winograd"):
+        C.conv_fwd(geom, nhwc(x).cuda(), wp, residual=lo, res_up=True, tile_cfg=7)
+    with pytest.raises(RuntimeError, match="residual"):
+        C.conv_fwd(geom, nhwc(x).cuda(), wp, residual=E.upsample2x(lo), res_up=True, tile_cfg=9)
+
+
+def test_gblock_shortcut_fused_equals_materialised_upsampling():
+    """GBlock forward with the shortcut's up-sampling blended into c2's epilogue (Winograd launches) against the same
+    block with Winograd off, where ConvLayer falls back to diagan_upsample2x."""
+    from diagan.models.sngan import GBlock
+    from diagan.ops import conv as C
+    torch.manual_seed(3)
+    blk = GBlock(256, 256, upsample=True).cuda()
+    x = torch.randn(16, 16, 16, 256, device="cuda")
+    outs = []
+    for on in (None, False):
+        C.set_winograd(on)
+        try:
+            out, ctx, _ = blk.forward(x, True)
+            outs.append(out)
+        finally:
+            C.set_winograd(None)
+    assert C.res_up_fused(blk.c2.geom, 16, 32, 32)
+    close(outs[0], outs[1], tol=2e-5)
