@@ -182,8 +182,13 @@ def cpu_baseline(dataset, res, loss_type, batch, n_dis, budget_s=25.0):
 WINO_MAC_RATIO = 16.0 / 36.0    # Winograd F(2x2,3x3): multiply-accumulates executed per direct-convolution multiply-accumulate
 
 
+WINO_POOL_MAC_RATIO = 9.0 / 36.0    # ... followed by a 2x2 average pool (conv_wino_pool.hip): 9 of the 16 products suffice
+
+
 def executed_flop(name, flop):
     """FLOP the matrix pipe actually executes for `flop` algorithmic (direct-convolution, 2*M*Co*R*S*Ci) FLOP"""
+    if name.startswith("conv_wino_pool_kernel"):
+        return flop * WINO_POOL_MAC_RATIO
     return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wino_s_kernel", "conv_wgrad_wino_kernel")) else flop
 
 
@@ -499,7 +504,8 @@ def main():
             "algorithmic_tflops": round(algorithmic, 2),
             "accounting": "achieved / frac = multiply-accumulates the kernel EXECUTES on the matrix pipe (x2) per second; "
                           "for conv_wino_kernel (Winograd F(2x2,3x3)) that is 16/36 of the direct convolution's "
-                          "2*M*Co*9*Ci, which algorithmic_tflops counts in full (the convolution the reference runs)",
+                          "2*M*Co*9*Ci (9/36 for conv_wino_pool_kernel, the convolution + average pool launch), which "
+                          "algorithmic_tflops counts in full (the convolution the reference runs)",
             "all_gemm_kernels_2_untimed_steps": {
                 k: {"launches": v['launches'], "tflops": round(v['flop'] / v['seconds'] / 1e12, 2),
                     "mfma_executed_tflops": round(executed_flop(k, v['flop']) / v['seconds'] / 1e12, 2),

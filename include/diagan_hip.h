@@ -143,6 +143,17 @@ int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, i
  * and blocks that tile the batch (and the prologue groups) exactly -- this query; 128 pixel rows x 64 columns per
  * workgroup (stat_partials granularity).  Measured 10 % slower than tile_cfg 9 (profiles/r02_wino_ablation.md): tile_cfg 0 picks it only with DIAGAN_WINO_STAGED=1. */
 int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
+/* tile_cfg 11: Winograd F(2x2,3x3) FOLLOWED BY F.avg_pool2d(., 2) in one launch (csrc/conv_wino_pool.hip) -- the end of
+ * mimicry's DBlock / DBlockOptimized with downsample=True (predefined_models.py:38-40,76-78).  A Winograd tile is one
+ * pooling window and the window's sum needs only 9 of the 16 transform-domain products (c = (1,2,0,-1): frequency row /
+ * column 2 drops out): 9/36 of the direct convolution's multiply-accumulates, and the full-resolution activation is never
+ * written.  With tile_cfg 11, `y` and `residual` of diagan_conv_gemm are the POOLED tensors [B,Ho/2,Wo/2,Co]
+ * (y = avg_pool(out_scale * conv + bias) + residual; Ho, Wo stay the convolution's output size); forward geometry only,
+ * Co % 128 == 0, prologue 0 / 1, no mask / statistics / prologue groups; 64 pooled pixels x 128 columns per workgroup.
+ * Never chosen by tile_cfg 0 (the output shape differs): this query says whether the launch qualifies and is worth it
+ * (enough workgroups, with split-K over the slab behind the transformed weights where needed). */
+int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                    int off, int up, int pro_mode, int64_t ws_floats);
 /* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and
  * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns
  * Winograd off. */

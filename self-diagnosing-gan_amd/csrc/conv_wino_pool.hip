@@ -1,0 +1,258 @@
+// Winograd F(2x2, 3x3) convolution FOLLOWED BY a 2x2 average pool, in 9 instead of 16 multiplies per tile.
+//
+// Replaces F.avg_pool2d(c2(relu(h)), 2) at the end of mimicry's DBlock / DBlockOptimized (downsample=True; selected at
+// diagan-pkg/diagan/models/predefined_models.py:38-40,76-78).  A Winograd tile IS one pooling window: with
+// Y = A^T M A (A^T = [[1,1,1,0],[0,1,-1,-1]]) the window's sum is  sum_ab Y[a][b] = c^T M c  with c = 1^T A^T = (1, 2, 0, -1):
+// frequency row / column 2 never contributes, so only the 9 products M[i][j], i, j in {0, 1, 3}, are computed --
+// 9/16 of the matrix work of conv_wino.hip (1/4 of the direct convolution's) and the full-resolution activation is
+// neither written nor read back.
+//
+// One workgroup = 512 threads = 8 waves = 64 tiles (= 64 pooled pixels) x 128 output channels; wave (th, cq) owns ALL nine
+// frequencies of its 32 tiles x 32 channels (144 accumulator registers), so the pooled value is finished in registers:
+// no exchange through LDS in the epilogue.  K loop, input loader / transform and the transformed weights are those of
+// conv_wino.hip (same `ug` image from wino_weight_kernel; only the live planes are fetched):
+//   V planes [(ri, ji, q)] = 18 KB, U planes [(column block, ri)][8 slots (j, kq), the j = 2 slots unused] = 48 KB per stage.
+// Roofline: MFMA fp32; executes 9/36 of the direct convolution's multiply-accumulates.
+#include "conv_common.h"
+#include <type_traits>
+
+namespace diagan {
+
+constexpr int PT = 64;                  // tiles per workgroup
+constexpr int PN = 128;                 // output channels per workgroup
+constexpr int PK = 8;                   // input channels per K-step
+constexpr int P_PLANE = 64 * 4;         // floats of one plane: 64 rows x 4 channels
+constexpr int P_VPL = 18, P_UPL = 48;   // planes per stage
+constexpr int P_STAGE = (P_VPL + P_UPL) * P_PLANE;
+
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 18 planes | U 48 planes] = 132 KB
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = g.Co / PN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int t0 = (tile / tiles_n) * PT, nb = tile % tiles_n, n0 = nb * PN;
+  const int TW = g.Wo >> 1, TH = g.Ho >> 1;
+  const int MT = g.B * TH * TW;                         // 2x2 output tiles = pooled pixels
+  const int nk = g.Ci / PK;
+  const int k_per = (nk + a.ksplit - 1) / a.ksplit;
+  const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk);
+
+  // ---- loader role (as in conv_wino.hip): (tile lt, channel quad q, patch row r) ----
+  const int lr = tid & 3, lq = (tid >> 2) & 1, lt = tid >> 3;
+  unsigned off[4], inv[4];
+  {
+    const int gt = t0 + lt;
+    const bool tv = gt < MT;
+    const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);          // dWo: divisor TW
+    const int tx = (tv ? gt : 0) - (int)q1 * TW;
+    const unsigned b = fdiv(q1, a.dHo);                                // dHo: divisor TH
+    const int ty = (int)q1 - (int)b * TH;
+    const int iy = 2 * ty - 1 + lr, ix0 = 2 * tx - 1;
+    const bool rv = tv && iy >= 0 && iy < g.Hi;
+    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + lq * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
+      off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0u;
+      inv[c] = ok ? 0u : 0x80000000u;                   // beyond num_records: the hardware returns zeros (relu(0) = 0)
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const float sc = lr == 1 ? 1.f : -1.f;                 // column transform: V[r] = t[r] + sc * t[partner]
+  const int lri = lr == 3 ? 2 : lr;                      // live row index (row 2 is a partner only: it stores nothing)
+  const int vslot = (lt ^ (lq | (lr << 1))) * 4;
+  float* const vst0 = smem + ((lri * 3) * 2 + lq) * P_PLANE + vslot;
+  const bool vlive = lr != 2;
+
+  // weight DMA role: waves 0..5 fetch the six live planes pairs of one (column block, frequency row)
+  const int dcb = wave / 3, dri = wave - dcb * 3, di = dri == 2 ? 3 : dri;
+  const float* const ublock = ug + (long)(nb * 2 + dcb) * nk * (32 * P_PLANE) + di * 8 * P_PLANE;
+
+  f32x4 ra[4];
+  auto issue_loads = [&](int kk, int stage) {
+    if (wave < 6) {
+      float* ul = smem + stage * P_STAGE + (P_VPL + (dcb * 3 + dri) * 8) * P_PLANE;
+      const unsigned long long ub = (unsigned long long)(ublock + (long)kk * (32 * P_PLANE));
+      const unsigned long long us64 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32;
+      const float* up = reinterpret_cast<const float*>(us64) + (unsigned)(lane * 4);
+      const float* up6 = up + 6 * P_PLANE;               // planes (j = 3, kq): beyond the 4 KB immediate range
+      float* ul6 = ul + 6 * P_PLANE;
+#define POOL_DMA(G, L, I)                                                                        \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(G),               \
+                                   (__attribute__((address_space(3))) void*)(L), 16, (I) * P_PLANE * 4, 0)
+      POOL_DMA(up, ul, 0);
+      POOL_DMA(up, ul, 1);
+      POOL_DMA(up, ul, 2);
+      POOL_DMA(up, ul, 3);
+      POOL_DMA(up6, ul6, 0);
+      POOL_DMA(up6, ul6, 1);
+#undef POOL_DMA
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off[c] | inv[c], kk * (PK * 4), 0));
+  };
+  float t[4][4];                                        // row-transformed patch row: [column j][channel] (j = 2 unused)
+  auto transform_rows = [&]() {
+    f32x4 d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 v = ra[c];
+      if (PRO == PRO_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __int_as_float(max(__float_as_int(v[e]), 0));   // one v_max_i32 on the bits
+      }
+      d[c] = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[0][e] = d[0][e] - d[2][e];
+      t[1][e] = d[1][e] + d[2][e];
+      t[3][e] = d[1][e] - d[3][e];
+    }
+  };
+  auto transform_store = [&](int stage, int j, int ji) {
+    float o0 = t[j][0], o1 = t[j][1], o2 = t[j][2], o3 = t[j][3];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+        : "v"(sc));
+    const f32x4 o = {o0, o1, o2, o3};
+    if (vlive) *reinterpret_cast<f32x4*>(vst0 + stage * P_STAGE + ji * 2 * P_PLANE) = o;
+  };
+
+  // wave (th, cq): tiles th * 32 .. + 31, channels cq * 32 .. + 31, all nine frequencies f = ri * 3 + ji
+  const int th = wave >> 2, cq = wave & 3;
+  f32x16 acc[9];
+#pragma unroll
+  for (int f = 0; f < 9; ++f)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[f][e] = 0.f;
+  const int fi = lane & 31, fh = lane >> 5;
+  const float* fa_base[3];
+  const float* fb_base[3];
+#pragma unroll
+  for (int ri = 0; ri < 3; ++ri) {
+    const int r = ri == 2 ? 3 : ri;
+    fa_base[ri] = smem + ((ri * 3) * 2 + fh) * P_PLANE + (((th * 32 + fi) ^ (fh | (r << 1))) << 2);
+    fb_base[ri] = smem + (P_VPL + ((cq >> 1) * 3 + ri) * 8 + fh) * P_PLANE + (((cq & 1) * 32 + fi) << 2);
+  }
+
+  if (k_begin < k_end) {
+    issue_loads(k_begin, 0);
+    transform_rows();
+    transform_store(0, 0, 0);
+    transform_store(0, 1, 1);
+    transform_store(0, 3, 2);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto kstep = [&](int kk, auto has_next) {
+    const int cur = (kk - k_begin) & 1;
+    if (decltype(has_next)::value) issue_loads(kk + 1, cur ^ 1);
+    f32x4 fa[2][3], fb[2][3];
+    auto read_row = [&](int ri) {
+#pragma unroll
+      for (int ji = 0; ji < 3; ++ji) {
+        const int j = ji == 2 ? 3 : ji;
+        fa[ri & 1][ji] = *reinterpret_cast<const f32x4*>(fa_base[ri] + cur * P_STAGE + ji * 2 * P_PLANE);
+        fb[ri & 1][ji] = *reinterpret_cast<const f32x4*>(fb_base[ri] + cur * P_STAGE + j * 2 * P_PLANE);
+      }
+    };
+    read_row(0);
+#pragma unroll
+    for (int ri = 0; ri < 3; ++ri) {
+      if (ri < 2) read_row(ri + 1);
+#pragma unroll
+      for (int ji = 0; ji < 3; ++ji)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int grp = (ri * 3 + ji) * 4 + e;
+          if (decltype(has_next)::value && (grp == 18 || grp == 21 || grp == 24 || grp == 27)) {
+            __builtin_amdgcn_sched_barrier(0);           // the next stage's input transform, in four pieces
+            if (grp == 18) transform_rows();
+            else if (grp == 21) transform_store(cur ^ 1, 0, 0);
+            else if (grp == 24) transform_store(cur ^ 1, 1, 1);
+            else transform_store(cur ^ 1, 3, 2);
+          }
+          acc[ri * 3 + ji] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ri & 1][ji][e], fb[ri & 1][ji][e], acc[ri * 3 + ji], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces of the next stage have landed
+    __syncthreads();
+  };
+  for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+  if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+
+  // ---- epilogue: pooled = 1/4 c^T M c, c = (1, 2, -1) over the live rows / columns; all in this wave's registers ----
+  const bool raw = a.ksplit > 1;
+  const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
+  const int split = a.scale0 ? (a.scale_split >> 2) : 0x7fffffff;     // tile index where the second sigma starts
+  const int n = n0 + cq * 32 + fi;
+  const float bv = (!raw && a.bias) ? a.bias[n] : 0.f;
+  const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
+  float* ydst = raw ? a.slab + (long)blockIdx.y * MT * g.Co : a.y;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int gt = t0 + th * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+    float s = (acc[0][e] + 2.f * acc[1][e] - acc[2][e]) + 2.f * (acc[3][e] + 2.f * acc[4][e] - acc[5][e]) -
+              (acc[6][e] + 2.f * acc[7][e] - acc[8][e]);
+    s *= 0.25f;
+    if (gt < MT) {
+      const long o = (long)gt * g.Co + n;
+      if (!raw) {
+        s = s * (gt < split ? sc0 : sc1) + bv;
+        if (a.residual) s += fmaxf(a.residual[o], rfloor);
+      }
+      ydst[o] = s;
+    }
+  }
+}
+
+template <int PRO>
+static int launch_wino_pool_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
+  const int MT = a.g.B * (a.g.Ho >> 1) * (a.g.Wo >> 1);
+  const int wgs = cdiv(MT, PT) * (a.g.Co / PN);
+  const size_t lds = (size_t)2 * P_STAGE * sizeof(float);
+  auto kern = conv_wino_pool_kernel<PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs, a.ksplit), dim3(512), lds, st, a, ug);
+  return check_launch("conv_wino_pool");
+}
+
+void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, int staged, hipStream_t st);   // conv_wino.hip
+
+// Split-K factor of the pooled kernel: 1 when the launch has >= min_wgs workgroups, else the smallest split that reaches
+// 256 workgroups with at least 8 K-steps each; 0 = neither (the caller keeps the separate convolution + pooling).
+int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs) {
+  const long MT = (long)B * (Ho >> 1) * (Wo >> 1);
+  const long wgs = cdiv(MT, PT) * (Co / PN);
+  if (wgs >= min_wgs) return 1;
+  const int nk = Ci / PK;
+  for (int ks = 2; ks <= 8; ++ks)
+    if (wgs * ks >= 256 && nk / ks >= 8 && (long)ks * MT * Co <= slab_floats) return ks;
+  return 0;
+}
+
+int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
+  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, 0, st);
+  return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU>(a, ws, st) : launch_wino_pool_pro<PRO_NONE>(a, ws, st);
+}
+
+}  // namespace diagan

@@ -160,6 +160,14 @@ class ConvLayer(nn.Module):
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale,
                           res_up=res_up)
 
+    def fwd_pool(self, ctx, x, pro=None, residual=None):
+        """avg_pool2d(conv(pro(x)) + bias, 2) + residual (the end of a down-sampling DBlock): ONE launch on 9/16 of the
+        Winograd products where the layer qualifies (C.pool_fused), else the convolution followed by diagan_avgpool2."""
+        if C.pool_fused(self.geom, x.shape[0], x.shape[1], x.shape[2], pro):
+            return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data, residual=residual,
+                              pro=pro, row_scale=ctx.row_scale, pool=True)
+        return E.avgpool2(self.fwd(ctx, x, pro=pro), residual=residual)
+
     def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1, res_up=False):
         """Forward + the BatchNorm statistics of the layer that consumes the output, taken from the GEMM
         epilogue's per-tile sums (no second pass over the activation).  Returns (y, bn context).

@@ -128,7 +128,7 @@ class DBlock(nn.Module):
             ksc = self.c_sc.prepare(training, need_dgrad, slot)
             xp = E.avgpool2(x, relu_in=True)
             sc = self.c_sc.fwd(ksc, xp)
-            out = E.avgpool2(self.c2.fwd(k2, h1, pro=RELU), residual=sc)
+            out = self.c2.fwd_pool(k2, h1, pro=RELU, residual=sc)
         elif self.learnable_sc:
             ksc = self.c_sc.prepare(training, need_dgrad, slot)
             sc = self.c_sc.fwd(ksc, x, pro=RELU)
@@ -182,8 +182,7 @@ class DBlockOptimized(nn.Module):
         h1 = self.c1.fwd(k1, x)
         xp = E.avgpool2(x)
         sc = self.c_sc.fwd(ksc, xp)
-        h2 = self.c2.fwd(k2, h1, pro=RELU)
-        out = E.avgpool2(h2, residual=sc)
+        out = self.c2.fwd_pool(k2, h1, pro=RELU, residual=sc)
         ctx = dict(x=x, xp=xp, h1=h1, k1=k1, k2=k2, ksc=ksc, slot=0 if slot is None else slot) if save else {}
         return out, ctx
 

@@ -19,6 +19,7 @@ nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_wino_staged_supported", [I] * 5)
+nat.register("diagan_conv_wino_pool_supported", [I] * 14 + [I64])
 nat.register("diagan_conv_gemm_tile_cols", [I])
 nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
 nat.register("diagan_conv_gemm_tune", [I, I, I])
@@ -52,6 +53,8 @@ def gemm_kernel_name(cfg, mode):
         return f"conv_wino_kernel<{mode}>"
     if cfg == 10:
         return f"conv_wino_s_kernel<{mode}>"
+    if cfg == 11:
+        return f"conv_wino_pool_kernel<{mode}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
         return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
@@ -171,11 +174,15 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False):
+          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
+    if pool:                              # `out` (and `residual`) are the 2x2-average-pooled tensors: tile_cfg 11
+        Ho, Wo, tile_cfg = 2 * Ho, 2 * Wo, 11
+        if want_stats or res_up or mask_src is not None:
+            raise RuntimeError("conv_gemm: the pooled launch takes no statistics, mask or half-resolution residual")
     # pro = (mode, scale, shift[, group_imgs]): group_imgs > 0 -> scale / shift are [G, Ci], one row per group of images
     mode, scale, shift, group_imgs = (tuple(pro) + (0,))[:4] if pro is not None else (PRO_NONE, None, None, 0)
     for t, n in ((x, 'x'), (w, 'w'), (out, 'out'), (bias, 'bias'), (residual, 'residual'),
@@ -268,18 +275,33 @@ def res_up_fused(geom, B, Hi, Wi, want_stats=False):
                                                          geom.Kp, 0 if want_stats else 1, ws.numel())
 
 
+def pool_fused(geom, B, Hi, Wi, pro=None):
+    """Will conv_fwd(geom, x[B,Hi,Wi,Ci], ..., pool=True) run?  True iff avg_pool2d(conv(pro(x)), 2) of this layer qualifies
+    for the one-launch Winograd + pooling kernel (tile_cfg 11: 9 of the 16 transform-domain products) and the launch is
+    large enough; otherwise the caller pools the convolution's output itself (diagan_avgpool2)."""
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    sy, dr, off, up = geom.fwd_params()
+    mode = pro[0] if pro is not None else PRO_NONE
+    ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
+    return bool(nat.fn("diagan_conv_wino_pool_supported")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up,
+                                                          mode, ws.numel()))
+
+
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False, out_scale=1.0, wino=True, res_up=False):
+             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co].
-    res_up: `residual` is [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling is added (see res_up_fused)."""
+    res_up: `residual` is [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling is added (see res_up_fused).
+    pool: y = avg_pool2d(conv(pro(x)) + bias, 2) + residual, y and residual [B,Ho/2,Wo/2,Co] (see pool_fused)."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
         raise RuntimeError(f"conv_fwd: input has {Ci} channels, layer expects {geom.Ci}")
     Ho, Wo = geom.out_hw(Hi, Wi)
+    if pool:
+        Ho, Wo = Ho // 2, Wo // 2
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
-                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up)
+                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up, pool=pool)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,

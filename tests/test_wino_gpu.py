@@ -226,3 +226,55 @@ def test_gblock_shortcut_fused_equals_materialised_upsampling():
             C.set_winograd(None)
     assert C.res_up_fused(blk.c2.geom, 16, 32, 32)
     close(outs[0], outs[1], tol=2e-5)
+
+
+POOL_CASES = [(4, 32, 32, 128, 128), (6, 16, 16, 64, 256), (3, 6, 10, 16, 128), (16, 8, 8, 256, 128), (2, 4, 4, 256, 128)]
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+@pytest.mark.parametrize("pro", [0, 1])
+def test_convolution_plus_average_pool_in_one_launch(case, pro):
+    """tile_cfg 11 (csrc/conv_wino_pool.hip): F.avg_pool2d(conv3x3(pro(x)) + bias, 2) + residual -- the end of mimicry's
+    DBlock / DBlockOptimized with downsample=True -- from 9 of the 16 Winograd products, against float64 PyTorch and
+    against the two-launch path (Winograd convolution + diagan_avgpool2); with the pair pass's two 1/sigma scalars."""
+    from diagan.ops import conv as C, eltwise as E
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=21)
+    g = torch.Generator().manual_seed(22)
+    bias, res = torch.randn(Co, generator=g), torch.randn(B, Co, H // 2, W // 2, generator=g)
+    ref = F.avg_pool2d(F.conv2d(ref_pro(x.double(), pro, None, None), w.double(), bias.double(), padding=1), 2) + res.double()
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(), pro=(pro, None, None), pool=True)
+    assert tuple(y.shape) == (B, H // 2, W // 2, Co)
+    close(nchw(y), ref, tol=2e-5)
+    two = E.avgpool2(C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), pro=(pro, None, None), tile_cfg=9),
+                     residual=nhwc(res).cuda())
+    close(y, two, tol=5e-6)
+    if B % 2 == 0:
+        s0, s1 = torch.tensor([0.7]).cuda(), torch.tensor([1.9]).cuda()
+        y = C.conv_fwd(geom, nhwc(x).cuda(), wp, pro=(pro, None, None), row_scale=(s0, s1), pool=True)
+        ref = F.avg_pool2d(F.conv2d(ref_pro(x.double(), pro, None, None), w.double(), padding=1), 2)
+        ref[:B // 2] *= 0.7
+        ref[B // 2:] *= 1.9
+        close(nchw(y), ref, tol=2e-5)
+
+
+def test_pooled_launch_selection_and_refusals():
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    ok = nat.fn("diagan_conv_wino_pool_supported")
+    ws = 64 << 20
+    assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 1          # D32 block1.c2, pair pass
+    assert ok(128, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 1          # D32 block2.c2: split-K
+    assert ok(128, 32, 32, 128, 32, 32, 64, 3, 3, 1, 1, -1, 1, 1, ws) == 0           # 64 output channels
+    assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, 1, ws) == 0          # a data-gradient
+    assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 2, ws) == 0          # BatchNorm prologue
+    assert ok(2, 4, 4, 256, 4, 4, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 0                # too small to be worth it
+    assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, 1024) == 0        # no room for the weights
+    geom, x, w, wp = make(4, 8, 8, 64, 64, seed=23)
+    with pytest.raises(RuntimeError, match="tile_cfg 11"):
+        C.conv_fwd(geom, nhwc(x).cuda(), wp, pool=True)                              # Co = 64
+    C.set_winograd(False)
+    try:
+        assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 0
+    finally:
+        C.set_winograd(None)
