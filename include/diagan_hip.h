@@ -154,6 +154,13 @@ int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_gro
  * (enough workgroups, with split-K over the slab behind the transformed weights where needed). */
 int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                     int off, int up, int pro_mode, int64_t ws_floats);
+/* tile_cfg 12: the data-gradient of such a layer straight from the pooled gradient, dx = conv^T(avg_pool2d_backward(g)) (the
+ * backward of the same DBlocks): `x` of diagan_conv_gemm is the HALF-resolution gradient [B,Ho/2,Wo/2,Ci] (data-gradient
+ * geometry: dr = -1, off = +1; Hi = Ho, Wi = Wo the full resolution), y / residual / mask_src full resolution.  The
+ * up-sampled gradient is constant over each pooling window, so again only nine transform-domain products are non-zero;
+ * the loader reads 9 instead of 16 pixels per tile.  Co % 128 == 0 (the layer's INPUT channels), no prologue. */
+int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                      int off, int up, int64_t ws_floats);
 /* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and
  * ws_floats holds the transformed weights, else diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 in the environment turns
  * Winograd off. */

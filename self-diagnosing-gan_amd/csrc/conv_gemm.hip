@@ -39,6 +39,7 @@ long wino_ws_floats(int Co, int Ci);
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
 int launch_wino_s(ConvGemmArgs a, float* ws, hipStream_t st);    // conv_wino_s.hip
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
+int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs);
 int wino_s_block(int B, int Ho, int Wo, int Ci, int pro_group_rows);
 int wino_s_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
@@ -928,7 +929,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 = 64x64 with fragment "
-             "prefetch, 8 = 128x64 with fragment prefetch, 9 / 10 = Winograd, 11 = Winograd + average pool; 2, 4, 6 were retired after the round-2 sweeps)", tile_cfg);
+             "prefetch, 8 = 128x64 with fragment prefetch, 9 / 10 = Winograd, 11 / 12 = Winograd + average pool and its data-gradient; 2, 4, 6 were retired after the round-2 sweeps)", tile_cfg);
   DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % bm == 0 && a.M % pro_group_rows == 0)),
              "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, bm, a.M);
   a.slab = splitk_ws;
@@ -967,6 +968,28 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, e);
       rc = check_launch("conv_wino_pool split-K epilogue");
+    }
+    return rc;
+  }
+  if (cfg == 12) {
+    // data-gradient of (Winograd convolution + 2x2 average pool): x is the HALF-resolution gradient [B, Ho/2, Wo/2, Ci]
+    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && dr == -1 && Co % 128 == 0 &&
+                   pro_mode == PRO_NONE && !stat_partials && !a.res_up && pro_group_rows == 0,
+               "conv_gemm: tile_cfg 12 (data-gradient through an average pool, Winograd) needs the data-gradient geometry of a "
+               "3x3 / stride 1 / pad 1 layer with even H, W, Ci %% 8 == 0, Co %% 128 == 0, no prologue, statistics or half-resolution residual");
+    const long wfl = wino_ws_floats(Co, Ci);
+    DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 12 needs %ld floats of workspace for the transformed weights", wfl);
+    long slab_tiles = ((long)splitk_ws_floats - wfl) / 4;             // a split's partial is the FULL-resolution output: 4 pixels per tile
+    int ks = wino_pool_ksplit(B, Ho, Wo, Ci, Co, slab_tiles, 192);
+    if (ks < 1) ks = 1;
+    a.ksplit = ks;
+    a.slab = splitk_ws + wfl;
+    int rc = launch_wino_unpool(a, splitk_ws, st);
+    if (rc == DIAGAN_OK && ks > 1) {
+      long blocks = ((long)a.M * (Co / 4) + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+      rc = check_launch("conv_wino_unpool split-K epilogue");
     }
     return rc;
   }
@@ -1020,10 +1043,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: case 10: return 128; case 3: case 7: return 64; case 5: case 9: case 11: return 256; default: return 0; }
+  switch (cfg) { case 1: case 8: case 10: return 128; case 3: case 7: return 64; case 5: case 9: case 11: case 12: return 256; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: return 128; case 3: case 5: case 7: case 8: case 9: case 10: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 10: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -1048,6 +1071,19 @@ DIAGAN_API int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, in
   const long wfl = wino_ws_floats(Co, Ci);
   if (ws_floats < wfl) return 0;
   return wino_pool_ksplit(B, Ho, Wo, Ci, Co, (long)ws_floats - wfl, 192) > 0 ? 1 : 0;
+}
+
+// tile_cfg 12: the data-gradient of such a layer from the HALF-resolution gradient (same nine products, see conv_wino_pool.hip)
+DIAGAN_API int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                                 int dr, int off, int up, int64_t ws_floats) {
+  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  static const int pool_env = getenv("DIAGAN_WINO_POOL") ? atoi(getenv("DIAGAN_WINO_POOL")) : 1;
+  const int wino = g_wino >= 0 ? g_wino : wino_env;
+  if (!wino || !pool_env || dr != -1 || Co % 128 != 0 || Ci < 16) return 0;
+  if (!diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
+  const long wfl = wino_ws_floats(Co, Ci);
+  if (ws_floats < wfl) return 0;
+  return wino_pool_ksplit(B, Ho, Wo, Ci, Co, ((long)ws_floats - wfl) / 4, 192) > 0 ? 1 : 0;
 }
 
 // Tile configuration for a full geometry (what diagan_conv_gemm does when tile_cfg == 0): Winograd (9) where the layer

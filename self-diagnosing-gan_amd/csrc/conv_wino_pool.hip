@@ -12,6 +12,12 @@
 // no exchange through LDS in the epilogue.  K loop, input loader / transform and the transformed weights are those of
 // conv_wino.hip (same `ug` image from wino_weight_kernel; only the live planes are fetched):
 //   V planes [(ri, ji, q)] = 18 KB, U planes [(column block, ri)][8 slots (j, kq), the j = 2 slots unused] = 48 KB per stage.
+//
+// UNPOOL = true is the adjoint situation, the data-gradient of such a layer: dx = conv^T(avg_pool2d_backward(g)).  The
+// up-sampled gradient is constant over every pooling window, the 4x4 input patch of a tile reads (a, b, b, c) along each
+// axis, and B^T (a, b, b, c) = (a - b, 2b, 0, b - c): again only the nine frequencies i, j in {0, 1, 3} are non-zero.  The
+// loader reads the 3x3 HALF-resolution neighbourhood of the tile (9 instead of 16 pixels), the K loop is the same, and
+// the epilogue applies A^T . A to the nine products in registers and writes the tile's four full-resolution pixels.
 // Roofline: MFMA fp32; executes 9/36 of the direct convolution's multiply-accumulates.
 #include "conv_common.h"
 #include <type_traits>
@@ -25,7 +31,7 @@ constexpr int P_PLANE = 64 * 4;         // floats of one plane: 64 rows x 4 chan
 constexpr int P_VPL = 18, P_UPL = 48;   // planes per stage
 constexpr int P_STAGE = (P_VPL + P_UPL) * P_PLANE;
 
-template <int PRO>
+template <int PRO, bool UNPOOL>
 __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 18 planes | U 48 planes] = 132 KB
   const ConvGeom& g = a.g;
@@ -41,7 +47,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmAr
 
   // ---- loader role (as in conv_wino.hip): (tile lt, channel quad q, patch row r) ----
   const int lr = tid & 3, lq = (tid >> 2) & 1, lt = tid >> 3;
-  unsigned off[4], inv[4];
+  constexpr int NLD = UNPOOL ? 3 : 4;                    // pixels per loader row
+  unsigned off[NLD], inv[NLD];
   {
     const int gt = t0 + lt;
     const bool tv = gt < MT;
@@ -49,19 +56,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmAr
     const int tx = (tv ? gt : 0) - (int)q1 * TW;
     const unsigned b = fdiv(q1, a.dHo);                                // dHo: divisor TH
     const int ty = (int)q1 - (int)b * TH;
-    const int iy = 2 * ty - 1 + lr, ix0 = 2 * tx - 1;
-    const bool rv = tv && iy >= 0 && iy < g.Hi;
-    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + lq * 16;
+    if (!UNPOOL) {
+      const int iy = 2 * ty - 1 + lr, ix0 = 2 * tx - 1;
+      const bool rv = tv && iy >= 0 && iy < g.Hi;
+      const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + lq * 16;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
-      off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0u;
-      inv[c] = ok ? 0u : 0x80000000u;                   // beyond num_records: the hardware returns zeros (relu(0) = 0)
+      for (int c = 0; c < NLD; ++c) {
+        const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
+        off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0u;
+        inv[c] = ok ? 0u : 0x80000000u;                 // beyond num_records: the hardware returns zeros (relu(0) = 0)
+      }
+    } else {
+      // half-resolution gradient [B][TH][TW][Ci]: lanes r = 0, 1, 3 of the quad hold rows ty - 1, ty, ty + 1 (r = 2: nothing);
+      // outside the image the up-sampled gradient is the convolution's zero padding
+      const int u = lr == 3 ? 2 : lr;
+      const int iy = ty - 1 + u, ix0 = tx - 1;
+      const bool rv = tv && lr != 2 && iy >= 0 && iy < TH;
+      const int rowbase = (((int)b * TH + iy) * TW + ix0) * g.Ci * 4 + lq * 16;
+#pragma unroll
+      for (int c = 0; c < NLD; ++c) {
+        const bool ok = rv && ix0 + c >= 0 && ix0 + c < TW;
+        off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0u;
+        inv[c] = ok ? 0u : 0x80000000u;
+      }
     }
   }
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
-  const float sc = lr == 1 ? 1.f : -1.f;                 // column transform: V[r] = t[r] + sc * t[partner]
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * (UNPOOL ? TH * TW : g.Hi * g.Wi) * g.Ci * 4u), 0x00020000);
+  // column transform as ONE fmac through DPP: V[r] = t[r] + sc * t[partner].  pooled forward: partner by quad_perm
+  // [2,2,1,1] (rows 0: t0 - t2, 1: t1 + t2, 3: t3 - t1 = -(B^T row 3), compensated in U); UNPOOL: every lane's partner is
+  // lane 1 (rows 0: u0 - u1, 1: u1 + u1, 3: u2 - u1 = -(b - c))
+  const float sc = lr == 1 ? 1.f : -1.f;
   const int lri = lr == 3 ? 2 : lr;                      // live row index (row 2 is a partner only: it stores nothing)
   const int vslot = (lt ^ (lq | (lr << 1))) * 4;
   float* const vst0 = smem + ((lri * 3) * 2 + lq) * P_PLANE + vslot;
@@ -71,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmAr
   const int dcb = wave / 3, dri = wave - dcb * 3, di = dri == 2 ? 3 : dri;
   const float* const ublock = ug + (long)(nb * 2 + dcb) * nk * (32 * P_PLANE) + di * 8 * P_PLANE;
 
-  f32x4 ra[4];
+  f32x4 ra[NLD];
   auto issue_loads = [&](int kk, int stage) {
     if (wave < 6) {
       float* ul = smem + stage * P_STAGE + (P_VPL + (dcb * 3 + dri) * 8) * P_PLANE;
@@ -93,14 +118,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmAr
 #undef POOL_DMA
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < NLD; ++c)
       ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off[c] | inv[c], kk * (PK * 4), 0));
   };
   float t[4][4];                                        // row-transformed patch row: [column j][channel] (j = 2 unused)
   auto transform_rows = [&]() {
-    f32x4 d[4];
+    f32x4 d[NLD];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NLD; ++c) {
       f32x4 v = ra[c];
       if (PRO == PRO_RELU) {
 #pragma unroll
@@ -110,21 +135,37 @@ __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmAr
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      t[0][e] = d[0][e] - d[2][e];
-      t[1][e] = d[1][e] + d[2][e];
-      t[3][e] = d[1][e] - d[3][e];
+      if (!UNPOOL) {
+        t[0][e] = d[0][e] - d[2][e];
+        t[1][e] = d[1][e] + d[2][e];
+        t[3][e] = d[1][e] - d[NLD - 1][e];
+      } else {                                          // B^T (a, b, b, c) = (a - b, 2 b, 0, b - c)
+        t[0][e] = d[0][e] - d[1][e];
+        t[1][e] = d[1][e] + d[1][e];
+        t[3][e] = d[1][e] - d[2][e];
+      }
     }
   };
   auto transform_store = [&](int stage, int j, int ji) {
     float o0 = t[j][0], o1 = t[j][1], o2 = t[j][2], o3 = t[j][3];
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
-        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
-        : "v"(sc));
+    if (!UNPOOL)
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+          : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+          : "v"(sc));
+    else
+      asm volatile(
+          "s_nop 1\n\t"
+          "v_fmac_f32_dpp %0, %0, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f32_dpp %1, %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f32_dpp %2, %2, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+          "v_fmac_f32_dpp %3, %3, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
+          : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3)
+          : "v"(sc));
     const f32x4 o = {o0, o1, o2, o3};
     if (vlive) *reinterpret_cast<f32x4*>(vst0 + stage * P_STAGE + ji * 2 * P_PLANE) = o;
   };
@@ -193,37 +234,68 @@ __global__ __launch_bounds__(512, 2) void conv_wino_pool_kernel(const ConvGemmAr
   for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
   if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
 
-  // ---- epilogue: pooled = 1/4 c^T M c, c = (1, 2, -1) over the live rows / columns; all in this wave's registers ----
+  // ---- epilogue, all in this wave's registers ----
   const bool raw = a.ksplit > 1;
   const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
-  const int split = a.scale0 ? (a.scale_split >> 2) : 0x7fffffff;     // tile index where the second sigma starts
   const int n = n0 + cq * 32 + fi;
   const float bv = (!raw && a.bias) ? a.bias[n] : 0.f;
   const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
-  float* ydst = raw ? a.slab + (long)blockIdx.y * MT * g.Co : a.y;
+  if (!UNPOOL) {
+    // pooled = 1/4 c^T M c, c = (1, 2, -1) over the live rows / columns
+    const int split = a.scale0 ? (a.scale_split >> 2) : 0x7fffffff;   // tile index where the second sigma starts
+    float* ydst = raw ? a.slab + (long)blockIdx.y * MT * g.Co : a.y;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int gt = t0 + th * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-    float s = (acc[0][e] + 2.f * acc[1][e] - acc[2][e]) + 2.f * (acc[3][e] + 2.f * acc[4][e] - acc[5][e]) -
-              (acc[6][e] + 2.f * acc[7][e] - acc[8][e]);
-    s *= 0.25f;
-    if (gt < MT) {
-      const long o = (long)gt * g.Co + n;
-      if (!raw) {
-        s = s * (gt < split ? sc0 : sc1) + bv;
-        if (a.residual) s += fmaxf(a.residual[o], rfloor);
+    for (int e = 0; e < 16; ++e) {
+      const int gt = t0 + th * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      float s = (acc[0][e] + 2.f * acc[1][e] - acc[2][e]) + 2.f * (acc[3][e] + 2.f * acc[4][e] - acc[5][e]) -
+                (acc[6][e] + 2.f * acc[7][e] - acc[8][e]);
+      s *= 0.25f;
+      if (gt < MT) {
+        const long o = (long)gt * g.Co + n;
+        if (!raw) {
+          s = s * (gt < split ? sc0 : sc1) + bv;
+          if (a.residual) s += fmaxf(a.residual[o], rfloor);
+        }
+        ydst[o] = s;
       }
-      ydst[o] = s;
+    }
+  } else {
+    // Y = A^T M A over the live frequencies: rows / columns weigh (1, 1, 0) for pixel 0 and (0, 1, -1) for pixel 1; the 1/4
+    // of the pooling's backward is applied here
+    const int split = a.scale0 ? a.scale_split : 0x7fffffff;          // pixel-row index where the second sigma starts
+    float* ydst = raw ? a.slab + (long)blockIdx.y * a.M * g.Co : a.y;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int gt = t0 + th * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+      if (gt >= MT) continue;
+      const unsigned q1 = fdiv((unsigned)gt, a.dWo);
+      const int tx = gt - (int)q1 * TW;
+      const unsigned b = fdiv(q1, a.dHo);
+      const int ty = (int)q1 - (int)b * TH;
+      const float y4[4] = {(acc[0][e] + acc[1][e]) + (acc[3][e] + acc[4][e]), (acc[1][e] - acc[2][e]) + (acc[4][e] - acc[5][e]),
+                           (acc[3][e] + acc[4][e]) - (acc[6][e] + acc[7][e]), (acc[4][e] - acc[5][e]) - (acc[7][e] - acc[8][e])};
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int prow = ((int)b * g.Ho + 2 * ty + (p >> 1)) * g.Wo + 2 * tx + (p & 1);
+        const long o = (long)prow * g.Co + n;
+        float y = 0.25f * y4[p];
+        if (!raw) {
+          y = y * (prow < split ? sc0 : sc1) + bv;
+          if (a.residual) y += fmaxf(a.residual[o], rfloor);
+          if (a.mask_src) y = a.mask_src[o] > 0.f ? y : y * a.mask_slope;
+        }
+        ydst[o] = y;
+      }
     }
   }
 }
 
-template <int PRO>
+template <int PRO, bool UNPOOL>
 static int launch_wino_pool_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
   const int MT = a.g.B * (a.g.Ho >> 1) * (a.g.Wo >> 1);
   const int wgs = cdiv(MT, PT) * (a.g.Co / PN);
   const size_t lds = (size_t)2 * P_STAGE * sizeof(float);
-  auto kern = conv_wino_pool_kernel<PRO>;
+  auto kern = conv_wino_pool_kernel<PRO, UNPOOL>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -252,7 +324,16 @@ int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
   launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, 0, st);
-  return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU>(a, ws, st) : launch_wino_pool_pro<PRO_NONE>(a, ws, st);
+  return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU, false>(a, ws, st) : launch_wino_pool_pro<PRO_NONE, false>(a, ws, st);
+}
+
+// tile_cfg 12: a.x is the HALF-resolution gradient [B][Ho/2][Wo/2][Ci]; y / mask_src / residual are full resolution
+int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
+  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, 0, st);
+  return launch_wino_pool_pro<PRO_NONE, true>(a, ws, st);
 }
 
 }  // namespace diagan

@@ -183,6 +183,15 @@ class ConvLayer(nn.Module):
             return y, bn.stats(y, True, groups=groups)
         return y, bn.stats_fused(stats[0], stats[1], M, groups=groups, group_imgs=y.shape[0] // groups)
 
+    def dgrad_unpool_fused(self, B, in_hw):
+        return C.unpool_fused(self.geom, B, in_hw[0], in_hw[1])
+
+    def dgrad_unpool(self, ctx, dy_pooled, in_hw, residual=None, mask_src=None, mask_slope=0.0):
+        """conv^T(avg_pool2d_backward(dy_pooled)): the data-gradient of a layer whose output was average-pooled, from the
+        pooled gradient in one launch (callers check dgrad_unpool_fused first)"""
+        return C.conv_dgrad(self.geom, dy_pooled, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
+                            mask_slope=mask_slope, row_scale=ctx.row_scale, unpool=True)
+
     def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
                             mask_slope=mask_slope, row_scale=ctx.row_scale)

@@ -144,10 +144,17 @@ class DBlock(nn.Module):
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
         x, xp, h1, slot = ctx['x'], ctx['xp'], ctx['h1'], ctx['slot']
         hw = x.shape[1:3]
-        g_full = E.avgpool2_bwd(gout) if self.downsample else gout
+        # c2's data-gradient through the pooling comes straight from the pooled gradient where the layer qualifies (nine
+        # Winograd products instead of sixteen); the up-sampled gradient is then only needed by the weight gradients
+        unpool = self.downsample and self.c2.dgrad_unpool_fused(gout.shape[0], hw)
+        lo_path = xp is not None
+        g_full = E.avgpool2_bwd(gout) if self.downsample and (need_wgrad or not unpool or not lo_path) else gout
         if need_wgrad:
             self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
-        g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
+        if unpool:
+            g_h1 = self.c2.dgrad_unpool(ctx['k2'], gout, hw, mask_src=h1)
+        else:
+            g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
         if need_wgrad:
             self.c1.wgrad(ctx['k1'], g_h1, x, pro=RELU, slot=slot)
             if xp is not None:
@@ -189,11 +196,15 @@ class DBlockOptimized(nn.Module):
     def backward(self, ctx, gout, need_wgrad=True, need_gx=True):
         x, xp, h1, slot = ctx['x'], ctx['xp'], ctx['h1'], ctx['slot']
         hw = x.shape[1:3]
-        g_full = E.avgpool2_bwd(gout)
+        unpool = self.c2.dgrad_unpool_fused(gout.shape[0], hw)
+        g_full = E.avgpool2_bwd(gout) if (need_wgrad or not unpool) else None
         if need_wgrad:
             self.c_sc.wgrad(ctx['ksc'], gout, xp, slot=slot)
             self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
-        g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
+        if unpool:
+            g_h1 = self.c2.dgrad_unpool(ctx['k2'], gout, hw, mask_src=h1)
+        else:
+            g_h1 = self.c2.dgrad(ctx['k2'], g_full, hw, mask_src=h1)
         if need_wgrad:
             self.c1.wgrad(ctx['k1'], g_h1, x, slot=slot)
         if not need_gx:

@@ -20,6 +20,7 @@ nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_wino_staged_supported", [I] * 5)
 nat.register("diagan_conv_wino_pool_supported", [I] * 14 + [I64])
+nat.register("diagan_conv_wino_unpool_supported", [I] * 13 + [I64])
 nat.register("diagan_conv_gemm_tile_cols", [I])
 nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
 nat.register("diagan_conv_gemm_tune", [I, I, I])
@@ -54,7 +55,9 @@ def gemm_kernel_name(cfg, mode):
     if cfg == 10:
         return f"conv_wino_s_kernel<{mode}>"
     if cfg == 11:
-        return f"conv_wino_pool_kernel<{mode}>"
+        return f"conv_wino_pool_kernel<{mode},false>"
+    if cfg == 12:
+        return "conv_wino_pool_kernel<0,true>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
         return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
@@ -174,11 +177,13 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False):
+          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
+    if unpool:                            # `x` is the half-resolution (pooled) gradient: tile_cfg 12
+        Hi, Wi, tile_cfg = 2 * Hi, 2 * Wi, 12
     if pool:                              # `out` (and `residual`) are the 2x2-average-pooled tensors: tile_cfg 11
         Ho, Wo, tile_cfg = 2 * Ho, 2 * Wo, 11
         if want_stats or res_up or mask_src is not None:
@@ -305,16 +310,32 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,
-               row_scale=None, wino=True):
-    """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci]."""
+               row_scale=None, wino=True, unpool=False):
+    """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci].
+    unpool: dy is the gradient of the 2x2-average-POOLED output, [B,Ho/2,Wo/2,Co]: dx = conv^T(avg_pool2d_backward(dy))
+    in one launch (see unpool_fused)."""
     B, Ho, Wo, Co = dy.shape
     if Co != geom.Co:
         raise RuntimeError(f"conv_dgrad: dy has {Co} channels, layer has {geom.Co}")
     Hi, Wi = in_hw
+    if unpool and (2 * Ho, 2 * Wo) != tuple(geom.out_hw(Hi, Wi)):
+        raise RuntimeError(f"conv_dgrad: pooled gradient {Ho}x{Wo} does not match the layer's output {geom.out_hw(Hi, Wi)}")
     if out is None:
         out = torch.empty((B, Hi, Wi, geom.Ci), dtype=torch.float32, device=dy.device)
     return _gemm(dy, wd, out, geom.dgrad_params(), geom.R, geom.S, geom.Kd, None, residual, mask_src, mask_slope,
-                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino)
+                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino, unpool=unpool)
+
+
+def unpool_fused(geom, B, Hi, Wi):
+    """Will conv_dgrad(geom, dy_pooled, ..., unpool=True) run for a layer with input [B,Hi,Wi,Ci]?  (tile_cfg 12: the
+    data-gradient through the average pool from nine Winograd products; else the caller up-samples the gradient with
+    diagan_avgpool2_bwd and takes the ordinary data-gradient.)"""
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    sy, dr, off, up = geom.dgrad_params()
+    ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
+    # the data-gradient gathers from the layer's OUTPUT tensor: its channels are the GEMM's K, the layer's inputs its columns
+    return bool(nat.fn("diagan_conv_wino_unpool_supported")(B, Ho, Wo, geom.Co, Hi, Wi, geom.Ci, geom.R, geom.S, sy, dr, off, up,
+                                                            ws.numel()))
 
 
 _slabs = {}

@@ -278,3 +278,33 @@ def test_pooled_launch_selection_and_refusals():
         assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 0
     finally:
         C.set_winograd(None)
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_data_gradient_through_the_average_pool_in_one_launch(case):
+    """tile_cfg 12: dx = conv^T(avg_pool2d_backward(g)) * relu'(mask) (+ residual) from the pooled gradient -- the backward
+    of the down-sampling DBlocks' c2 -- against float64 autograd of avg_pool2d(conv2d(x)) and against the two-launch path
+    (diagan_avgpool2_bwd + Winograd data-gradient); with the pair pass's two 1/sigma scalars."""
+    from diagan.ops import conv as C, eltwise as E
+    B, H, W, Co, Ci = case                                  # the data-gradient's 128-multiple is the layer's INPUT channels
+    geom, x, w, wp = make(B, H, W, Ci, Co, seed=31)
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    g = torch.Generator().manual_seed(32)
+    gp = torch.randn(B, Co, H // 2, W // 2, generator=g)
+    mask, res = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Ci, H, W, generator=g)
+    xx = x.double().requires_grad_(True)
+    F.avg_pool2d(F.conv2d(xx, w.double(), padding=1), 2).backward(gp.double())
+    ref = (xx.grad + res.double()) * (mask.double() > 0)
+    dx = C.conv_dgrad(geom, nhwc(gp).cuda(), wd, (H, W), residual=nhwc(res).cuda(), mask_src=nhwc(mask).cuda(), unpool=True)
+    close(nchw(dx), ref, tol=2e-5)
+    two = C.conv_dgrad(geom, E.avgpool2_bwd(nhwc(gp).cuda()), wd, (H, W), residual=nhwc(res).cuda(), mask_src=nhwc(mask).cuda(),
+                       tile_cfg=9)
+    close(dx, two, tol=5e-6)
+    if B % 2 == 0:
+        s0, s1 = torch.tensor([0.7]).cuda(), torch.tensor([1.9]).cuda()
+        dx = C.conv_dgrad(geom, nhwc(gp).cuda(), wd, (H, W), row_scale=(s0, s1), unpool=True)
+        ref = xx.grad.clone()
+        ref[:B // 2] *= 0.7
+        ref[B // 2:] *= 1.9
+        close(nchw(dx), ref, tol=2e-5)
