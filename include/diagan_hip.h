@@ -321,6 +321,11 @@ int diagan_upsample2x_bwd(const float* g, float* out, int B, int H, int W, int C
 /* out = avgpool2x2(relu_in ? max(x,0) : x) + residual */
 int diagan_avgpool2(const float* x, float* out, int B, int H, int W, int C, const float* residual, int relu_in,
                     void* stream);
+/* out[B][H+1][W+1][C] = 0.25 * (2x2 box sums of act(x), zero outside the image; act = ReLU if relu_in): the weight gradient
+ * of avg_pool2d(conv3x3(act(x)), 2) -- mimicry's down-sampling DBlocks -- equals the weight gradient of a 3x3 / stride 2 /
+ * pad 0 convolution over this image against the POOLED output gradient (diagan_conv_wgrad with sy = 2, off = 0): 9 instead
+ * of 36 multiply-accumulates per pooled pixel, weight and tap, with no transform at all. */
+int diagan_boxsum2(const float* x, float* out, int B, int H, int W, int C, int relu_in, void* stream);
 int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int W, int C, const float* residual,
                         void* stream);
 

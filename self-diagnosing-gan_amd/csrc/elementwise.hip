@@ -442,6 +442,37 @@ __global__ void avgpool2_bwd_kernel(const float* __restrict__ g, float* __restri
   }
 }
 
+// out[b, y', x', c] = 0.25 * sum over the 2x2 window of act(x) whose LOWER-RIGHT corner is pixel (y', x') (zero outside the
+// image), y' = 0 .. H, x' = 0 .. W: the weight gradient of avg_pool2d(conv3x3(act(x)), 2) is the weight gradient of a 3x3 /
+// stride 2 / pad 0 convolution over this (H+1) x (W+1) image against the POOLED gradient -- a quarter of the pixels
+__global__ void boxsum2_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C, int relu_in) {
+  const int C4 = C >> 2, Ho = H + 1, Wo = W + 1;
+  const long n4 = (long)B * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long p = i / C4;
+    const int xx = (int)(p % Wo); p /= Wo;
+    const int yy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 0; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 0; ++dx) {
+        const int y = yy + dy, xq = xx + dx;
+        if (y >= 0 && y < H && xq >= 0 && xq < W) {
+          f32x4 v = reinterpret_cast<const f32x4*>(x)[(((long)b * H + y) * W + xq) * C4 + c4];
+          if (relu_in) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          s += v;
+        }
+      }
+    reinterpret_cast<f32x4*>(out)[i] = s * 0.25f;
+  }
+}
+
 // ---- discriminator head: ReLU -> sum over H,W -> (SN) linear to one logit ----------------------
 // pooled[b][c] = sum_hw relu(x[b,hw,c])           grid (C4/64, B)
 __global__ __launch_bounds__(EW_T) void relu_sumpool_kernel(const float* __restrict__ x, float* __restrict__ pooled,
@@ -767,6 +798,14 @@ DIAGAN_API int diagan_avgpool2_bwd(const float* g, float* out, int B, int H, int
   hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(EW_T), 0, ST, g, out, B, H, W,
                      C, residual);
   return check_launch("avgpool2_bwd");
+}
+
+DIAGAN_API int diagan_boxsum2(const float* x, float* out, int B, int H, int W, int C, int relu_in, void* stream) {
+  DG_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "boxsum2: bad args");
+  DG_REQUIRE((long)B * (H + 1) * (W + 1) * C * 4 < (1L << 31), "boxsum2: output must be smaller than 2 GiB");
+  hipLaunchKernelGGL(boxsum2_kernel, dim3(ew_blocks((long)B * (H + 1) * (W + 1) * C / 4)), dim3(EW_T), 0, ST, x, out, B, H, W,
+                     C, relu_in);
+  return check_launch("boxsum2");
 }
 
 DIAGAN_API int diagan_head_fwd(const float* x, const float* w, const float* inv_sigma, const float* inv_sigma1,

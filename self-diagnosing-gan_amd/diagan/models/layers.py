@@ -7,6 +7,8 @@ all-reduce is one RCCL call per network.  state_dict()/load_state_dict() present
 tensor shapes (OIHW conv weights, [out,in] linear weights, mimicry's sn_u / sn_sigma buffers).
 """
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -196,19 +198,35 @@ class ConvLayer(nn.Module):
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
                             mask_slope=mask_slope, row_scale=ctx.row_scale)
 
-    def wgrad(self, ctx, dy, x, pro=None, slot=0):
+    def wgrad_pooled_ok(self, dy_pooled, x):
+        """The weight gradient of avg_pool2d(conv3x3(act(x)), 2) from the POOLED gradient: a 3x3 / stride 2 / pad 0 weight
+        gradient over the (H+1) x (W+1) image of 2x2 box sums of act(x) -- a quarter of the multiply-accumulates, no
+        transform.  Worth the box-sum pass from ~1 M input values on (smaller layers keep the up-sampled gradient)."""
+        g = self.geom
+        return (g.kind == 'conv' and g.R == 3 and g.S == 3 and g.stride == 1 and g.pad == 1 and x.shape[1] % 2 == 0
+                and x.shape[2] % 2 == 0 and x.numel() >= (1 << 20)
+                and (dy_pooled.numel() // dy_pooled.shape[-1]) % 64 == 0 and C.get_mfma_mode() == 0
+                and os.environ.get("DIAGAN_WGRAD_POOLED", "1") != "0")
+
+    def wgrad_pooled(self, ctx, dy_pooled, x, relu_in=False, slot=0):
+        if getattr(self, '_geom_s2', None) is None:
+            g = self.geom
+            object.__setattr__(self, '_geom_s2', C.Geom('conv', g.Ci, g.Co, 3, 3, 2, 0))
+        self.wgrad(ctx, dy_pooled, E.boxsum2(x, relu_in=relu_in), pro=None, slot=slot, geom=self._geom_s2)
+
+    def wgrad(self, ctx, dy, x, pro=None, slot=0, geom=None):
         """Accumulates into weight.grad / bias.grad (views of the net's flat gradient buffer).
         Inside a network the split-K partials go to a per-layer slab and are reduced for all layers at
         once by WgradBatch.finish(); standalone layers reduce immediately."""
         net = getattr(self, '_net', None)
         if net is not None and self.sn and slot == 'pair':
-            net.wgrad_batch.launch(self, slot, dy, x, pro, ctx.pair, segments=2)
+            net.wgrad_batch.launch(self, slot, dy, x, pro, ctx.pair, segments=2, geom=geom)
             return
         if net is not None and (not self.sn or ctx is self._slot_ctx_or_none(slot)):
-            net.wgrad_batch.launch(self, slot, dy, x, pro, ctx if self.sn else None)
+            net.wgrad_batch.launch(self, slot, dy, x, pro, ctx if self.sn else None, geom=geom)
             return
         sn = (self.weight.data, ctx.u, ctx.v, ctx.state) if self.sn else None
-        C.conv_wgrad(self.geom, dy, x, self.weight.grad, accumulate=True, pro=pro, sn=sn)
+        C.conv_wgrad(geom if geom is not None else self.geom, dy, x, self.weight.grad, accumulate=True, pro=pro, sn=sn)
         if self.bias is not None:
             E.colsum(dy, self.bias.grad, accumulate=True)
 
@@ -519,14 +537,14 @@ class WgradBatch:
         self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, total_blocks, any_sn)
         self.slab_generation = None
 
-    def _entry(self, layer, slot, M, segments=1, dy_shape=None, x_shape=None):
+    def _entry(self, layer, slot, M, segments=1, dy_shape=None, x_shape=None, geom=None):
         self.net.flat_grads
         if self.slab_generation != self.net.slab_generation:          # gradient slab was re-allocated
             self.entries.clear(), self.tables.clear()
             self.slab_generation = self.net.slab_generation
         e = self.entries.get((layer, slot))
         if e is None or e['M'] != M:
-            g = layer.geom
+            g = geom if geom is not None else layer.geom       # (an equivalent geometry with the same packed layout)
             n_w = g.Co * g.Kp
             has_bias = layer.bias is not None
             n_b = layer.bias.numel() if has_bias else 0
@@ -549,14 +567,15 @@ class WgradBatch:
             self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
         return e
 
-    def launch(self, layer, slot, dy, x, pro, sn_ctx, segments=1):
+    def launch(self, layer, slot, dy, x, pro, sn_ctx, segments=1, geom=None):
         """sn_ctx: None (plain layer), one SN context, or a tuple of `segments` contexts (one per
-        batched forward; the pixel range is cut accordingly and each part gets its own correction)."""
+        batched forward; the pixel range is cut accordingly and each part gets its own correction).
+        geom: gather geometry of THIS launch when it differs from the layer's (ConvLayer.wgrad_pooled)."""
         M = dy.numel() // dy.shape[-1]
-        e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape))
+        e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape), geom)
         e['sn_ctx'] = sn_ctx
-        C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro,
-                          segments=segments)
+        C.conv_wgrad_into(geom if geom is not None else layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'],
+                          pro=pro, segments=segments, pooled=geom is not None)
         self.launched.setdefault(slot, []).append(layer)
 
     def finish(self, slot):

@@ -146,10 +146,15 @@ class DBlock(nn.Module):
         hw = x.shape[1:3]
         # c2's data-gradient through the pooling comes straight from the pooled gradient where the layer qualifies (nine
         # Winograd products instead of sixteen); the up-sampled gradient is then only needed by the weight gradients
+        # ... and c2's weight gradient from the pooled gradient and 2x2 box sums of relu(h1) (a quarter of the products)
         unpool = self.downsample and self.c2.dgrad_unpool_fused(gout.shape[0], hw)
+        pooled_w = self.downsample and need_wgrad and self.c2.wgrad_pooled_ok(gout, h1)
         lo_path = xp is not None
-        g_full = E.avgpool2_bwd(gout) if self.downsample and (need_wgrad or not unpool or not lo_path) else gout
-        if need_wgrad:
+        need_full = self.downsample and ((need_wgrad and not pooled_w) or not unpool or not lo_path)
+        g_full = E.avgpool2_bwd(gout) if need_full else gout
+        if pooled_w:
+            self.c2.wgrad_pooled(ctx['k2'], gout, h1, relu_in=True, slot=slot)
+        elif need_wgrad:
             self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
         if unpool:
             g_h1 = self.c2.dgrad_unpool(ctx['k2'], gout, hw, mask_src=h1)
@@ -197,10 +202,14 @@ class DBlockOptimized(nn.Module):
         x, xp, h1, slot = ctx['x'], ctx['xp'], ctx['h1'], ctx['slot']
         hw = x.shape[1:3]
         unpool = self.c2.dgrad_unpool_fused(gout.shape[0], hw)
-        g_full = E.avgpool2_bwd(gout) if (need_wgrad or not unpool) else None
+        pooled_w = need_wgrad and self.c2.wgrad_pooled_ok(gout, h1)
+        g_full = E.avgpool2_bwd(gout) if ((need_wgrad and not pooled_w) or not unpool) else None
         if need_wgrad:
             self.c_sc.wgrad(ctx['ksc'], gout, xp, slot=slot)
-            self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
+            if pooled_w:
+                self.c2.wgrad_pooled(ctx['k2'], gout, h1, relu_in=True, slot=slot)
+            else:
+                self.c2.wgrad(ctx['k2'], g_full, h1, pro=RELU, slot=slot)
         if unpool:
             g_h1 = self.c2.dgrad_unpool(ctx['k2'], gout, hw, mask_src=h1)
         else:

@@ -417,9 +417,11 @@ def small_co_wgrad_splits(B, H):
     return nat.fn("diagan_conv3x3_co4_wgrad_splits")(B, H)
 
 
-def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segments=1):
+def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segments=1, pooled=False):
     """Split-K weight (+bias) gradient partials into a caller-owned slab [splits][stride]; the sum over
-    splits is done later for all layers at once (diagan_wgrad_finish_batched)."""
+    splits is done later for all layers at once (diagan_wgrad_finish_batched).
+    pooled: this launch is ConvLayer.wgrad_pooled's strided form of a stride-1 layer's weight gradient (the kernel timer
+    then books the reference convolution's FLOP, 4x what the launch executes, under a marked kernel name)."""
     B, Ho, Wo, Co = dy.shape
     _, Hi, Wi, Ci = x.shape
     mode, scale, shift = _pro3(pro)
@@ -436,13 +438,18 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
         return
     timed = TIMER is not None and TIMER.wants_any()
     kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if timed else None
+    if kn is not None and pooled:
+        kn += POOLED_TAG
     t0 = TIMER.begin(kn) if timed else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, segments, stride, bias_off, nat.ptr(scale),
              nat.ptr(shift), mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
              nat.current_stream())
     if t0 is not None:
-        TIMER.end(kn, 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci, t0,
-                  (B * Ho * Wo, Co, geom.R * geom.S * Ci, f"pro{mode}"))
+        px = B * Ho * Wo * (4 if pooled else 1)
+        TIMER.end(kn, 2.0 * px * Co * geom.R * geom.S * Ci, t0, (px, Co, geom.R * geom.S * Ci, f"pro{mode}"))
+
+
+POOLED_TAG = " [pooled gradient]"     # kernel-timer name suffix of ConvLayer.wgrad_pooled's launches
 
 
 def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0, wino=False):

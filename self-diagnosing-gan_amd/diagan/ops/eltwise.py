@@ -25,6 +25,7 @@ nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, I, P])
 nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
 nat.register("diagan_avgpool2", [P, P, I, I, I, I, P, I, P])
 nat.register("diagan_avgpool2_bwd", [P, P, I, I, I, I, P, P])
+nat.register("diagan_boxsum2", [P, P, I, I, I, I, I, P])
 nat.register("diagan_head_fwd", [P, P, P, P, I, P, P, P, I, I, I, P])
 nat.register("diagan_head_bwd", [P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, P])
 nat.register("diagan_add", [P, P, P, I64, P])
@@ -166,6 +167,14 @@ def upsample2x_bwd(g, residual=None):
     B, H2, W2, C = g.shape
     out = _f32((B, H2 // 2, W2 // 2, C), g.device)
     nat.call("diagan_upsample2x_bwd", ptr(g), ptr(out), B, H2 // 2, W2 // 2, C, ptr(residual), st())
+    return out
+
+
+def boxsum2(x, relu_in=False):
+    """0.25 * 2x2 box sums of (relu) x on an (H+1) x (W+1) grid (zero outside the image): see diagan_boxsum2"""
+    B, H, W, C = x.shape
+    out = _f32((B, H + 1, W + 1, C), x.device)
+    nat.call("diagan_boxsum2", ptr(x), ptr(out), B, H, W, C, 1 if relu_in else 0, st())
     return out
 
 

@@ -308,3 +308,24 @@ def test_data_gradient_through_the_average_pool_in_one_launch(case):
         ref[:B // 2] *= 0.7
         ref[B // 2:] *= 1.9
         close(nchw(dx), ref, tol=2e-5)
+
+
+@pytest.mark.parametrize("case", [(4, 32, 32, 128, 128), (6, 16, 16, 64, 256), (2, 6, 10, 16, 24)])
+def test_weight_gradient_through_the_average_pool_as_a_strided_convolution(case):
+    """d/dW of avg_pool2d(conv3x3(relu(x)), 2) against the pooled gradient g: the weight gradient of a 3x3 / stride 2 / pad 0
+    convolution over diagan_boxsum2(x) ((H+1) x (W+1) box sums, x 1/4) against g -- what ConvLayer.wgrad_pooled launches --
+    equals float64 autograd and the ordinary path (diagan_avgpool2_bwd + the layer's own weight gradient)."""
+    from diagan.ops import conv as C, eltwise as E
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=41)
+    g2 = C.Geom("conv", Ci, Co, 3, 3, 2, 0)
+    assert g2.Kp == geom.Kp
+    gp = torch.randn(B, Co, H // 2, W // 2, generator=torch.Generator().manual_seed(42))
+    ww = w.double().requires_grad_(True)
+    F.avg_pool2d(F.conv2d(F.relu(x.double()), ww, padding=1), 2).backward(gp.double())
+    ref = C.pack_oihw(ww.grad.float(), geom.Kp)
+    ga, gb = torch.zeros(Co, geom.Kp, device="cuda"), torch.zeros(Co, geom.Kp, device="cuda")
+    C.conv_wgrad(g2, nhwc(gp).cuda(), E.boxsum2(nhwc(x).cuda(), relu_in=True), ga, accumulate=False)
+    close(ga, ref, tol=2e-5)
+    C.conv_wgrad(geom, E.avgpool2_bwd(nhwc(gp).cuda()), nhwc(x).cuda(), gb, accumulate=False, pro=(C.PRO_RELU, None, None))
+    close(ga, gb, tol=1e-5)
