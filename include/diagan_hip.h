@@ -149,7 +149,8 @@ int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_gro
  * column 2 drops out): 9/36 of the direct convolution's multiply-accumulates, and the full-resolution activation is never
  * written.  With tile_cfg 11, `y` and `residual` of diagan_conv_gemm are the POOLED tensors [B,Ho/2,Wo/2,Co]
  * (y = avg_pool(out_scale * conv + bias) + residual; Ho, Wo stay the convolution's output size); forward geometry only,
- * Co % 128 == 0, prologue 0 / 1, no mask / statistics / prologue groups; 64 pooled pixels x 128 columns per workgroup.
+ * Co % 64 == 0, prologue 0 / 1, no mask / statistics / prologue groups; 64 pooled pixels x 128 columns per workgroup
+ * (128 x 64 when Co is not a multiple of 128).
  * Never chosen by tile_cfg 0 (the output shape differs): this query says whether the launch qualifies and is worth it
  * (enough workgroups, with split-K over the slab behind the transformed weights where needed). */
 int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
@@ -158,7 +159,7 @@ int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, int Ho, int W
  * backward of the same DBlocks): `x` of diagan_conv_gemm is the HALF-resolution gradient [B,Ho/2,Wo/2,Ci] (data-gradient
  * geometry: dr = -1, off = +1; Hi = Ho, Wi = Wo the full resolution), y / residual / mask_src full resolution.  The
  * up-sampled gradient is constant over each pooling window, so again only nine transform-domain products are non-zero;
- * the loader reads 9 instead of 16 pixels per tile.  Co % 128 == 0 (the layer's INPUT channels), no prologue. */
+ * the loader reads 9 instead of 16 pixels per tile.  Co % 64 == 0 (the layer's INPUT channels), no prologue. */
 int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                       int off, int up, int64_t ws_floats);
 /* The configuration diagan_conv_gemm uses for tile_cfg == 0 on this geometry: 9 (Winograd) where the layer qualifies and

@@ -948,10 +948,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   }
   if (cfg == 11) {
     // Winograd + 2x2 average pool (conv_wino_pool.hip): y and residual are [B, Ho/2, Wo/2, Co]
-    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && dr == 1 && Co % 128 == 0 &&
+    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && dr == 1 && Co % 64 == 0 &&
                    (pro_mode == PRO_NONE || pro_mode == PRO_RELU) && !mask_src && !stat_partials && !a.res_up && pro_group_rows == 0,
                "conv_gemm: tile_cfg 11 (Winograd + average pool) needs a forward 3x3 / stride 1 / pad 1 geometry with even H, W, "
-               "Ci %% 8 == 0, Co %% 128 == 0, prologue none / ReLU, no mask, statistics or half-resolution residual");
+               "Ci %% 8 == 0, Co %% 64 == 0, prologue none / ReLU, no mask, statistics or half-resolution residual");
     const long wfl = wino_ws_floats(Co, Ci);
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 11 needs %ld floats of workspace for the transformed weights", wfl);
     int ks = wino_pool_ksplit(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats - wfl, 192);
@@ -973,10 +973,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   }
   if (cfg == 12) {
     // data-gradient of (Winograd convolution + 2x2 average pool): x is the HALF-resolution gradient [B, Ho/2, Wo/2, Ci]
-    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && dr == -1 && Co % 128 == 0 &&
+    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && dr == -1 && Co % 64 == 0 &&
                    pro_mode == PRO_NONE && !stat_partials && !a.res_up && pro_group_rows == 0,
                "conv_gemm: tile_cfg 12 (data-gradient through an average pool, Winograd) needs the data-gradient geometry of a "
-               "3x3 / stride 1 / pad 1 layer with even H, W, Ci %% 8 == 0, Co %% 128 == 0, no prologue, statistics or half-resolution residual");
+               "3x3 / stride 1 / pad 1 layer with even H, W, Ci %% 8 == 0, Co %% 64 == 0, no prologue, statistics or half-resolution residual");
     const long wfl = wino_ws_floats(Co, Ci);
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 12 needs %ld floats of workspace for the transformed weights", wfl);
     long slab_tiles = ((long)splitk_ws_floats - wfl) / 4;             // a split's partial is the FULL-resolution output: 4 pixels per tile
@@ -1066,7 +1066,7 @@ DIAGAN_API int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, in
   static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
   static const int pool_env = getenv("DIAGAN_WINO_POOL") ? atoi(getenv("DIAGAN_WINO_POOL")) : 1;
   const int wino = g_wino >= 0 ? g_wino : wino_env;
-  if (!wino || !pool_env || dr != 1 || Co % 128 != 0 || Ci < 16 || !(pro_mode == PRO_NONE || pro_mode == PRO_RELU)) return 0;
+  if (!wino || !pool_env || dr != 1 || Co % 64 != 0 || Ci < 16 || !(pro_mode == PRO_NONE || pro_mode == PRO_RELU)) return 0;
   if (!diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
   const long wfl = wino_ws_floats(Co, Ci);
   if (ws_floats < wfl) return 0;
@@ -1079,7 +1079,7 @@ DIAGAN_API int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, 
   static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
   static const int pool_env = getenv("DIAGAN_WINO_POOL") ? atoi(getenv("DIAGAN_WINO_POOL")) : 1;
   const int wino = g_wino >= 0 ? g_wino : wino_env;
-  if (!wino || !pool_env || dr != -1 || Co % 128 != 0 || Ci < 16) return 0;
+  if (!wino || !pool_env || dr != -1 || Co % 64 != 0 || Ci < 16) return 0;
   if (!diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
   const long wfl = wino_ws_floats(Co, Ci);
   if (ws_floats < wfl) return 0;

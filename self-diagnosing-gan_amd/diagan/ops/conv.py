@@ -49,15 +49,15 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
                7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True)}
 
 
-def gemm_kernel_name(cfg, mode):
+def gemm_kernel_name(cfg, mode, Co=128):
     if cfg == 9:
         return f"conv_wino_kernel<{mode}>"
     if cfg == 10:
         return f"conv_wino_s_kernel<{mode}>"
     if cfg == 11:
-        return f"conv_wino_pool_kernel<{mode},false>"
+        return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
-        return "conv_wino_pool_kernel<0,true>"
+        return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
         return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
@@ -238,7 +238,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
                 _NAME_CACHE['modes'] = (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")())
             allow = 0 if want_stats else 1
             kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(
-                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel()), mode)
+                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel()), mode, Co)
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),

@@ -228,7 +228,8 @@ def test_gblock_shortcut_fused_equals_materialised_upsampling():
     close(outs[0], outs[1], tol=2e-5)
 
 
-POOL_CASES = [(4, 32, 32, 128, 128), (6, 16, 16, 64, 256), (3, 6, 10, 16, 128), (16, 8, 8, 256, 128), (2, 4, 4, 256, 128)]
+POOL_CASES = [(4, 32, 32, 128, 128), (6, 16, 16, 64, 256), (3, 6, 10, 16, 128), (16, 8, 8, 256, 128), (2, 4, 4, 256, 128),
+              (4, 32, 32, 64, 64), (3, 6, 10, 16, 192), (5, 16, 16, 128, 64)]      # ... 64 / 192 columns: 128-tile x 64-column workgroups
 
 
 @pytest.mark.parametrize("case", POOL_CASES)
@@ -265,14 +266,15 @@ def test_pooled_launch_selection_and_refusals():
     ws = 64 << 20
     assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 1          # D32 block1.c2, pair pass
     assert ok(128, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 1          # D32 block2.c2: split-K
-    assert ok(128, 32, 32, 128, 32, 32, 64, 3, 3, 1, 1, -1, 1, 1, ws) == 0           # 64 output channels
+    assert ok(128, 32, 32, 128, 32, 32, 64, 3, 3, 1, 1, -1, 1, 1, ws) == 1           # 64 output channels: 128-tile workgroups
+    assert ok(128, 32, 32, 128, 32, 32, 32, 3, 3, 1, 1, -1, 1, 1, ws) == 0           # 32 output channels
     assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, 1, ws) == 0          # a data-gradient
     assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 2, ws) == 0          # BatchNorm prologue
     assert ok(2, 4, 4, 256, 4, 4, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 0                # too small to be worth it
     assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, 1024) == 0        # no room for the weights
-    geom, x, w, wp = make(4, 8, 8, 64, 64, seed=23)
+    geom, x, w, wp = make(4, 8, 8, 64, 32, seed=23)
     with pytest.raises(RuntimeError, match="tile_cfg 11"):
-        C.conv_fwd(geom, nhwc(x).cuda(), wp, pool=True)                              # Co = 64
+        C.conv_fwd(geom, nhwc(x).cuda(), wp, pool=True)                              # Co = 32
     C.set_winograd(False)
     try:
         assert ok(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 0
