@@ -331,3 +331,31 @@ def test_weight_gradient_through_the_average_pool_as_a_strided_convolution(case)
     close(ga, ref, tol=2e-5)
     C.conv_wgrad(geom, E.avgpool2_bwd(nhwc(gp).cuda()), nhwc(x).cuda(), gb, accumulate=False, pro=(C.PRO_RELU, None, None))
     close(ga, gb, tol=1e-5)
+
+
+@pytest.mark.parametrize("case", [(128, 32, 32, 128, 128), (64, 64, 64, 64, 64), (128, 16, 16, 128, 256)])
+def test_pooled_launches_at_the_discriminators_full_sizes(case):
+    """The three fused launches at the SNGAN-32 / SNGAN-64 discriminator's own sizes (pair pass of B = 128, 64 x 64 maps,
+    split-K), against the two-launch path on the same inputs: a size-independent property (both paths are held to float64
+    on the small cases above)."""
+    from diagan.ops import conv as C, eltwise as E
+    B, H, W, Ci, Co = case
+    g = torch.Generator(device="cuda").manual_seed(51)
+    geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+    x = torch.randn(B, H, W, Ci, device="cuda", generator=g)
+    wp = torch.randn(Co, geom.Kp, device="cuda", generator=g) * (9 * Ci) ** -0.5
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    bias = torch.randn(Co, device="cuda", generator=g)
+    sc = torch.randn(B, H // 2, W // 2, Co, device="cuda", generator=g)
+    gp = torch.randn(B, H // 2, W // 2, Co, device="cuda", generator=g)
+    relu = (C.PRO_RELU, None, None)
+    assert C.pool_fused(geom, B, H, W, relu) and C.unpool_fused(geom, B, H, W)
+    close(C.conv_fwd(geom, x, wp, bias=bias, pro=relu, residual=sc, pool=True),
+          E.avgpool2(C.conv_fwd(geom, x, wp, bias=bias, pro=relu, tile_cfg=9), residual=sc), tol=5e-6)
+    close(C.conv_dgrad(geom, gp, wd, (H, W), mask_src=x, unpool=True),
+          C.conv_dgrad(geom, E.avgpool2_bwd(gp), wd, (H, W), mask_src=x, tile_cfg=9), tol=5e-6)
+    ga, gb = torch.zeros(Co, geom.Kp, device="cuda"), torch.zeros(Co, geom.Kp, device="cuda")
+    C.conv_wgrad(C.Geom("conv", Ci, Co, 3, 3, 2, 0), gp, E.boxsum2(x, relu_in=True), ga, accumulate=False)
+    C.conv_wgrad(geom, E.avgpool2_bwd(gp), x, gb, accumulate=False, pro=relu)
+    close(ga, gb, tol=2e-5)
