@@ -18,8 +18,13 @@
 // up-sampled gradient is constant over every pooling window, the 4x4 input patch of a tile reads (a, b, b, c) along each
 // axis, and B^T (a, b, b, c) = (a - b, 2b, 0, b - c): again only the nine frequencies i, j in {0, 1, 3} are non-zero.  The
 // loader reads the 3x3 HALF-resolution neighbourhood of the tile (9 instead of 16 pixels), the K loop is the same, and
-// the epilogue applies A^T . A to the nine products in registers and writes the tile's four full-resolution pixels.
-// Roofline: MFMA fp32; executes 9/36 of the direct convolution's multiply-accumulates.
+// the epilogue applies A^T . A to the nine products in registers, turns each wave's 32 tiles x 4 pixels x 32 channels
+// through 16 KB of LDS and writes full-resolution pixels (mask, residual, 1/sigma applied) in 16-byte pieces.
+//
+// The weight gradient of such a layer needs no kernel of its own: against the pooled gradient it is the weight gradient of
+// a 3x3 / stride-2 / pad-0 convolution over the (H+1) x (W+1) image of 2x2 box sums of relu(h) (diagan_boxsum2 +
+// diagan_conv_wgrad; ConvLayer.wgrad_pooled) -- also a quarter of the products.
+// Roofline: MFMA fp32; executes 9/36 of the direct convolution's multiply-accumulates.  Measured: profiles/r02_winograd.md.
 #include "conv_common.h"
 #include <type_traits>
 
