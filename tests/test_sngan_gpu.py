@@ -156,6 +156,43 @@ def _train_steps_match_oracle(dataset, res, loss):
         assert (sD[k].cpu() - v).abs().max() < 2e-3, k
 
 
+@pytest.mark.parametrize("dataset,res", [("cifar10", 32), ("celeba", 64)])
+def test_full_batch_updates_match_oracle_through_the_fused_kernels(dataset, res):
+    """One D and one G update at the REAL batch size (64; the D pair pass stacks 128 images) against the CPU oracle.  The
+    small batches of the tests above never reach the launch sizes at which the engine switches to its fused launches --
+    convolution + average pool in nine Winograd products (tile_cfg 11), its data gradient from the pooled gradient (12),
+    the weight gradient over box sums, the shortcut's bilinear x2 blended into c2's epilogue -- so this is the test in
+    which those run inside the networks; it asserts that they are indeed selected."""
+    from diagan.ops import conv as C
+    (oG, oD, ooptG, ooptD), (netG, netD, optG, optD) = build(dataset, "ns")
+    B = 64
+    c2 = netD.block1.c2
+    relu = (C.PRO_RELU, None, None)
+    assert C.pool_fused(c2.geom, 2 * B, res, res, relu) and C.unpool_fused(c2.geom, 2 * B, res, res)
+    last = netG.block4 if res == 32 else netG.block5                 # the generator's last up-sampling block, at full size
+    assert C.res_up_fused(last.c2.geom, B, res, res, want_stats=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, res, res, generator=g) * 2 - 1
+    zd, zg = torch.randn(B, 128, generator=g), torch.randn(B, 128, generator=g)
+    errD, D_x, D_Gz = oD.train_step((x, None), oG, ooptD, noise=zd)
+    log = netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=zd.cuda())
+    assert abs(log.m['errD'].item() - errD) < 1e-3, (log.m['errD'].item(), errD)
+    assert abs(log.m['D(x)'].item() - D_x) < 1e-3 and abs(log.m['D(G(z))'].item() - D_Gz) < 1e-3
+    gr = netD.export_grads()
+    for k, p in oD.named_parameters():
+        l2close(gr[k], p.grad, 1e-2, f"D grad {k}")
+    errG = oG.train_step((x, None), oD, ooptG, noise=zg)
+    log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda', noise=zg.cuda())
+    assert abs(log.m['errG'].item() - errG) < 5e-3 * max(1.0, abs(errG)), (log.m['errG'].item(), errG)
+    gr = netG.export_grads()
+    wscale = max(p.grad.norm().item() for p in oG.parameters())
+    for k, p in oG.named_parameters():
+        if is_dead_bias(k):
+            assert gr[k].abs().max().item() < 1e-4 * wscale, k
+        else:
+            l2close(gr[k], p.grad, 5e-2, f"G grad {k}")
+
+
 def test_generator_backward_isolated():
     """Same upstream gradient into both generators: no ReLU-flip noise from D on the path."""
     from diagan.ops import eltwise as E
