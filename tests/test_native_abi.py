@@ -46,3 +46,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(nat, "LIB_PATH", "/nonexistent/libdiagan_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         nat.lib()
+
+
+def test_launch_selection_queries_are_host_logic():
+    """Which kernel a convolution launch takes is decided on the host (no device call): the Winograd kernel for a
+    qualifying 3x3 layer with enough workgroups, the nine-product convolution + average-pool launch and its data gradient
+    for the down-sampling DBlocks' c2 (mimicry DBlock, predefined_models.py:38-40,76-78) -- checked here without a GPU."""
+    from diagan import _native as nat
+    import diagan.ops  # noqa: F401
+    pick = nat.fn("diagan_conv_gemm_pick_cfg_geom")
+    pool, unpool = nat.fn("diagan_conv_wino_pool_supported"), nat.fn("diagan_conv_wino_unpool_supported")
+    ws = 64 << 20
+    assert nat.fn("diagan_get_mfma_mode")() == 0
+    assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9      # D-32 block1.c2, pair pass
+    assert pick(128, 8, 8, 128, 8, 8, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) != 9          # 8x8 / 128 channels: implicit GEMM
+    assert pick(64, 16, 16, 128, 8, 8, 128, 3, 3, 2, 1, -1, 1, 1152, 1, ws) != 9         # stride 2
+    assert pool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 1            # ... + average pool: tile_cfg 11
+    assert pool(128, 64, 64, 64, 64, 64, 64, 3, 3, 1, 1, -1, 1, 1, ws) == 1              # D-64 block1.c2: 128-tile workgroups
+    assert pool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 2, ws) == 0            # BatchNorm prologue: not this kernel
+    assert pool(8, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 0              # batch 8: too few workgroups
+    assert unpool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, ws) == 1             # its data gradient: tile_cfg 12
+    assert unpool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, ws) == 0             # (a forward geometry)
+    assert nat.fn("diagan_conv_gemm_tile_rows")(11) == 256 and nat.fn("diagan_conv_gemm_tile_cols")(12) == 128
