@@ -113,7 +113,7 @@ def make_global_step(netG, netD, netD_drs, optG, optD, optD_drs, batches, n_dis,
         return (b, None)
 
     def device_part():
-        netG.prefetch_fakes(n_dis * (2 if netD_drs is not None else 1), batches[0].shape[0], device=device)   # as LogTrainer._updates
+        netG.prefetch_fakes(n_dis * (2 if netD_drs is not None else 1), batches[0].shape[0], device=device, g_step=True)   # as LogTrainer._updates
         from diagan.trainer import distributed as dist
         overlap = netD_drs is not None and dist.get_world_size() > 1      # as LogTrainer._updates
         for i in range(n_dis):

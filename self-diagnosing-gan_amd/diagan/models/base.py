@@ -15,6 +15,9 @@ from diagan.ops import eltwise as E
 
 
 PREFETCH_FAKES = os.environ.get("DIAGAN_PREFETCH_FAKES", "1") != "0"
+# the generator update's own forward (with its backward context) rides as the LAST batch of the same stacked forward
+# (+1.8 % on the SNGAN-32 step: its 8x8 / 16x16 launches at batch 64 run at low occupancy on their own); 0 = separate
+STACK_G_STEP = os.environ.get("DIAGAN_STACK_G_STEP", "1") != "0"
 
 
 class BaseModel(FlatNet):
@@ -78,6 +81,11 @@ class BaseGenerator(BaseModel):
                     out.copy_(ready)
                     ready = out
                 return ready, None
+        if noise is None and save and out is None:
+            ready = getattr(self, '_g_step_ready', None)
+            self._g_step_ready = None
+            if ready is not None and ready[0].shape[0] == num_images and ready[2] == self.param_version and self.training:
+                return ready[0], ready[1]
         if noise is None:
             noise = torch.randn((num_images, self.nz), device=device)
         return self.forward_nhwc(noise, self.training, save=save, out=out)
@@ -90,14 +98,27 @@ class BaseGenerator(BaseModel):
     supports_stacked_forward = False
     max_stacked_images = 0        # largest stacked batch whose activations stay below 2 GiB
 
-    def prefetch_fakes(self, count, batch_size, device=None):
-        self._fake_pool = []
+    def prefetch_fakes(self, count, batch_size, device=None, g_step=False):
+        """g_step: the global step ends with this generator's own update on a batch of the same size (trainer.py:279-284 of
+        the reference).  Its noise is then drawn right after the discriminator updates' -- the order in which the updates
+        would draw them: nothing else consumes the device generator in between for the models that stack -- and its
+        forward, WITH the context for its backward, is the last batch of the stacked forward;
+        generate_images_nhwc(save=True) hands it out (DIAGAN_STACK_G_STEP=0: separate forward as before)."""
+        self._fake_pool, self._g_step_ready = [], None
         if not (self.supports_stacked_forward and self.training and count > 1 and PREFETCH_FAKES):
             return
         device = self.device if device is None else device
         # every activation of the stacked forward must stay below 2 GiB (32-bit buffer offsets in the kernels)
         per_chunk = min(count, self.max_stacked_images // max(batch_size, 1))
         if per_chunk < 2:
+            return
+        if g_step and STACK_G_STEP and (count + 1) * batch_size <= self.max_stacked_images:
+            noise = [torch.randn((batch_size, self.nz), device=device) for _ in range(count + 1)]   # in update order
+            imgs, ctx = self.forward_nhwc(torch.cat(noise), True, save=True, groups=count + 1, save_group=count)
+            parts = imgs.split(batch_size)
+            self._fake_pool.extend(parts[:count])
+            self._fake_pool_version = self.param_version
+            self._g_step_ready = (parts[count], ctx, self.param_version)
             return
         noise = [torch.randn((batch_size, self.nz), device=device) for _ in range(count)]   # in update order
         for lo in range(0, count, per_chunk):

@@ -43,13 +43,14 @@ class GBlock(nn.Module):
             self.c_sc = ConvLayer('conv', in_channels, out_channels, 1, 1, 0)
             self.c_sc.xavier_(1.0)
 
-    def forward(self, x, training, save=True, need_dgrad=True, bn1=None, next_bn=None, groups=1):
+    def forward(self, x, training, save=True, need_dgrad=True, bn1=None, next_bn=None, groups=1, save_group=None):
         """bn1: statistics of x if the producer already reduced them; next_bn: the BatchNorm module that will
         consume this block's output (its statistics are then taken from the last conv's epilogue).
-        groups > 1 (forward only): x stacks `groups` batches that are batch-normalised independently."""
+        groups > 1: x stacks `groups` batches that are batch-normalised independently; forward only, except that the
+        context of ONE of them (save_group) can be kept for a backward pass (views of the stacked tensors)."""
         ctx = {}
-        if groups > 1 and save:
-            raise RuntimeError("GBlock: stacked batches are a forward-only path")
+        if groups > 1 and save and save_group is None:
+            raise RuntimeError("GBlock: a stacked forward keeps the context of one group only (save_group)")
         if bn1 is None:
             bn1 = self.b1.stats(x, training, groups=groups)
         if self.upsample:
@@ -74,7 +75,13 @@ class GBlock(nn.Module):
                                          res_up=sc_up)
         else:
             out = self.c2.fwd(k2, h1, pro=_bn_pro(bn2), residual=sc, res_up=sc_up)
-        if save:
+        if save and groups > 1:
+            b = x.shape[0] // groups
+            sl = slice(save_group * b, (save_group + 1) * b)
+            g1 = E.bn_ctx_group(bn1, save_group)
+            ctx = dict(x=x[sl], bn1=g1, c1_in=c1_in[sl], c1_pro=None if c1_pro is None else _bn_pro(g1), k1=k1, h1=h1[sl],
+                       bn2=E.bn_ctx_group(bn2, save_group), ksc=ksc, k2=k2)
+        elif save:
             ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, ksc=ksc, k2=k2)
         return out, ctx, bn_out
 
@@ -230,10 +237,10 @@ class SNGANBaseGenerator(BaseGenerator):
     def _blocks(self):
         raise NotImplementedError
 
-    def forward_nhwc(self, z, training, save=True, out=None, groups=1):
-        """groups > 1 (forward only, save=False): z stacks `groups` noise batches; the result equals `groups`
-        successive forwards (BatchNorm statistics and running-statistics updates per batch, in order) at the GEMM
-        efficiency of the large batch."""
+    def forward_nhwc(self, z, training, save=True, out=None, groups=1, save_group=None):
+        """groups > 1: z stacks `groups` noise batches; the result equals `groups` successive forwards (BatchNorm
+        statistics and running-statistics updates per batch, in order) at the GEMM efficiency of the large batch.
+        Forward only (save=False), or with the backward context of ONE batch (save=True, save_group)."""
         z = z.to(dtype=self.l1.weight.dtype)
         x0, h = self.l1.fwd(z)
         bctx = []
@@ -241,12 +248,18 @@ class SNGANBaseGenerator(BaseGenerator):
         bn = None
         for i, blk in enumerate(blocks):
             nxt = blocks[i + 1].b1 if i + 1 < len(blocks) else self._last_bn
-            h, c, bn = blk.forward(h, training, save=save, need_dgrad=save, bn1=bn, next_bn=nxt, groups=groups)
+            h, c, bn = blk.forward(h, training, save=save, need_dgrad=save, bn1=bn, next_bn=nxt, groups=groups,
+                                   save_group=save_group)
             bctx.append(c)
         k = self._last_conv.prepare(training, need_dgrad=save)
         y_pre = self._last_conv.fwd(k, h, pro=_bn_pro(bn))
         y = E.tanh_fwd(y_pre, out=out)
-        ctx = dict(x0=x0, bctx=bctx, h=h, bn=bn, k=k, y=y) if save else None
+        if save and groups > 1:
+            b = z.shape[0] // groups
+            sl = slice(save_group * b, (save_group + 1) * b)
+            ctx = dict(x0=x0[sl], bctx=bctx, h=h[sl], bn=E.bn_ctx_group(bn, save_group), k=k, y=y[sl])
+        else:
+            ctx = dict(x0=x0, bctx=bctx, h=h, bn=bn, k=k, y=y) if save else None
         return y, ctx
 
     def backward_nhwc(self, ctx, g_img):

@@ -101,6 +101,16 @@ def _bn_ctx(C, M, training, groups, group_imgs, dev):
     return ctx
 
 
+def bn_ctx_group(ctx, g):
+    """The context of group g of a grouped BatchNorm application as a plain one-batch context (views, no copy)."""
+    if ctx is None or not ctx.group_imgs:
+        return ctx
+    out = BNCtx()
+    out.mean, out.invstd, out.scale, out.shift = ctx.mean[g], ctx.invstd[g], ctx.scale[g], ctx.shift[g]
+    out.M, out.C, out.training, out.group_imgs = ctx.M, ctx.C, ctx.training, 0
+    return out
+
+
 def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, groups=1):
     """groups > 1: x holds `groups` equally sized batches along dim 0, each normalised with its OWN statistics; the
     running statistics take the momentum updates in group order (as `groups` successive forwards would)."""

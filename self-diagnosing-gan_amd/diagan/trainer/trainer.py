@@ -235,7 +235,7 @@ class LogTrainer:
         if prefetch is not None:
             full = all(b[0].shape[0] == self.dataloader.batch_size for b in batches + batches_drs)
             prefetch(self.n_dis * (2 if self.train_drs else 1) if full else 0, self.dataloader.batch_size,
-                     device=self.device)
+                     device=self.device, g_step=True)
         # data parallel phase 2: D and D_drs are independent (reference trainer.py:250-277), so D's gradient all-reduce
         # stays in flight under D_drs's forward / backward and D's Adam step follows it
         overlap = self.train_drs and self.world > 1

@@ -119,9 +119,9 @@ def test_ragged_step_draws_noise_update_by_update(tmp_path):
                    log_dir=str(tmp_path), device='cuda')
     counts, orig = [], netG.prefetch_fakes
 
-    def spy(count, batch_size, device=None):
+    def spy(count, batch_size, device=None, **kw):
         counts.append(count)
-        return orig(count, batch_size, device=device)
+        return orig(count, batch_size, device=device, **kw)
     netG.prefetch_fakes = spy
     streams = {'main': iter(dl)}
     t._updates(0, streams, MetricLog())                             # 64, 64: prefetched

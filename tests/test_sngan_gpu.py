@@ -446,3 +446,41 @@ def test_d_updates_with_prefetched_fakes_match(monkeypatch):
     for a, b in zip(logs, logs2):
         assert abs(a.m['errD'].item() - b.m['errD'].item()) < 1e-5
     assert (netD.flat_params - netD2.flat_params).abs().max().item() < 1e-6
+
+
+def test_generator_update_stacked_onto_the_fake_batches(monkeypatch):
+    """DIAGAN_STACK_G_STEP=1: the generator update's own forward is the last batch of the stacked forward that makes the
+    n_dis fake batches (same weights; its noise is drawn right after theirs, as successive updates would) and keeps the
+    context for its backward.  Same fakes, same generator gradients and same device-generator state as the separate path."""
+    from diagan.models import base
+    B, n = 16, 3
+
+    def run(stack):
+        monkeypatch.setattr(base, "STACK_G_STEP", stack)
+        (_, _, _, _), (netG, netD, optG, optD) = build("cifar10", "ns", seed=7)
+        netG.train(), netD.train()
+        torch.cuda.manual_seed(123)
+        netG.prefetch_fakes(n, B, device='cuda', g_step=True)
+        fakes = [netG.generate_images_nhwc(B)[0].clone() for _ in range(n)]
+        x = torch.zeros(B, 3, 32, 32)
+        netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda')
+        return fakes, netG.export_grads(), netG.state_dict(), torch.cuda.get_rng_state()
+
+    fa, ga, sa, ra = run(False)
+    fb, gb, sb, rb = run(True)
+    assert torch.equal(ra, rb)
+    for a, b in zip(fa, fb):
+        relclose(a, b, 1e-5, "fake batch")
+    # (the update's fake batch differs by rounding between the two paths -- other launch sizes, other kernels -- which flips
+    #  a few of D's ReLU masks: gradients agree in L2 like any two fp32 implementations, see l2close)
+    wscale = max(v.norm().item() for v in ga.values())
+    for k in ga:
+        if is_dead_bias(k):
+            assert gb[k].abs().max().item() < 1e-4 * wscale, k
+        else:
+            l2close(gb[k], ga[k], 1e-2, f"G grad {k}")
+    num = sum(float((sb[k].double() - v.double()).pow(2).sum()) for k, v in sa.items() if v.dtype.is_floating_point)
+    den = sum(float(v.double().pow(2).sum()) for v in sa.values() if v.dtype.is_floating_point)
+    assert (num / den) ** 0.5 < 1e-3
+    for k in ("block2.b1.running_mean", "b5.running_var"):            # BatchNorm saw n + 1 batches, in order, on both paths
+        relclose(sb[k], sa[k], 1e-5, k)
