@@ -168,9 +168,10 @@ def test_full_batch_updates_match_oracle_through_the_fused_kernels(dataset, res)
     B = 64
     c2 = netD.block1.c2
     relu = (C.PRO_RELU, None, None)
-    assert C.pool_fused(c2.geom, 2 * B, res, res, relu) and C.unpool_fused(c2.geom, 2 * B, res, res)
-    last = netG.block4 if res == 32 else netG.block5                 # the generator's last up-sampling block, at full size
-    assert C.res_up_fused(last.c2.geom, B, res, res, want_stats=True)
+    if C.get_mfma_mode() == 0:                                        # (DIAGAN_MFMA=bf16x6 for the whole suite: implicit GEMM only)
+        assert C.pool_fused(c2.geom, 2 * B, res, res, relu) and C.unpool_fused(c2.geom, 2 * B, res, res)
+        last = netG.block4 if res == 32 else netG.block5             # the generator's last up-sampling block, at full size
+        assert C.res_up_fused(last.c2.geom, B, res, res, want_stats=True)
     g = torch.Generator().manual_seed(5)
     x = torch.rand(B, 3, res, res, generator=g) * 2 - 1
     zd, zg = torch.randn(B, 128, generator=g), torch.randn(B, 128, generator=g)

@@ -8,7 +8,16 @@ import torch.nn.functional as F
 
 from test_conv_gpu import close, nchw, nhwc, ref_pro
 
-pytestmark = pytest.mark.gpu
+def _fp32_mode():
+    try:
+        from diagan.ops import conv as C
+        return C.get_mfma_mode() == 0
+    except Exception:            # no library here (CPU collection): the gpu mark deselects these anyway
+        return True
+
+
+# the Winograd kernels are fp32-MFMA kernels: with DIAGAN_MFMA=bf16x6 forced for the whole suite they are never selected
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _fp32_mode(), reason="Winograd kernels belong to the fp32 MFMA mode")]
 
 # B, H, W, Ci, Co: square / non-square images, ragged tile counts, Co not a multiple of 64, the SNGAN block shapes
 CASES = [(4, 8, 8, 64, 64), (3, 6, 10, 16, 24), (5, 16, 16, 128, 72), (2, 32, 32, 256, 256), (8, 64, 64, 64, 64),
