@@ -1,8 +1,13 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of the SNGAN G+D training step (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Started bare with --gpus N > 1 (no WORLD_SIZE in the environment) the script launches the second form itself as a
+CHILD process (one rank per GPU, like the reference's `torch.distributed.launch --nproc_per_node=4`, README.md:149 /
+stylegan2/train_ffhq.py:503-506), relays rank 0's JSON line and exits with the child's code.  A world size that
+differs from --gpus is an error (non-zero exit, no JSON line).
 
 One "step" = one global step of LogTrainer.train (diagan-pkg/diagan/trainer/trainer.py:250-299):
 n_dis = 5 discriminator updates + 1 generator update (+ the LR scheduler) at batch 64 PER GPU
@@ -311,6 +316,31 @@ def scorer_leg(device, N=50000, T=50):
             "cpu_oracle_ms_1_core": round(cpu_ms, 1), "algorithmic_GBps": round(bytes_alg / gpu_ms / 1e6, 1)}
 
 
+def self_launch(args):
+    """--gpus N > 1 without a torch.distributed.run environment: start the N ranks as a child process group and relay
+    its output.  Runs before anything touches the GPU (device_count() does not initialise it); never os.exec."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or args.gpus) // args.gpus)))
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (the device path has no CPU fallback)")
+    if ndev < args.gpus and "DIAGAN_DIST_BACKEND" not in env:
+        # fewer devices than ranks (a one-GPU test box): the ranks share devices, which RCCL refuses -> gloo;
+        # a functional run of the N-rank path, not a scaling measurement (config.devices says so)
+        print(f"WARNING: --gpus {args.gpus} on a node with {ndev} device(s): ranks share devices, exchange over gloo",
+              file=sys.stderr)
+        env["DIAGAN_DIST_BACKEND"] = "gloo"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -331,17 +361,28 @@ def main():
                     help="replay the global step as one hipGraph (launch-bound workloads: dcgan); single GPU only")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     from diagan.trainer import distributed as dist
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if env_world != args.gpus:             # before any rendezvous: every rank sees the same mismatch and leaves
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(f"ERROR: --gpus {args.gpus} but WORLD_SIZE={env_world}: refusing to report a line for a job of a "
+                  f"different size", file=sys.stderr)
+        sys.exit(2)
     rank, local_rank, world = dist.init_from_env()
-    if world != args.gpus:
-        if rank == 0 and world > 1:
-            print(f"WARNING: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the device path has no CPU fallback)")
     dev_index = local_rank % torch.cuda.device_count()     # == local_rank on a real multi-GPU node
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dataset, res, desc = WORKLOADS[args.workload]
+    devices = [dev_index]
+    if world > 1:
+        devices = [int(d) for d in dist.all_gather(dev_index)]
 
     if args.workload == 'stylegan2':
         if args.graph:
@@ -477,6 +518,7 @@ def main():
         "config": {"workload": desc + (" + D_drs (phase 2)" if args.phase == 2 else ""),
                    "global_batch": args.batch_size * world, "n_dis": args.n_dis, "loss_type": args.loss_type,
                    "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager",
+                   "comm": dist.comm_description(), "ranks": world, "devices": devices,
                    "steps_per_s": round(args.steps / elapsed, 3),
                    "D_updates_per_s": round(args.steps * args.n_dis / elapsed, 3)},
     }

@@ -169,6 +169,13 @@ int diagan_conv_gemm_set_wino(int mode);   /* run-time form of DIAGAN_WINO: 0 of
 int diagan_conv_gemm_get_wino(void);
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
+/* The same choice for a launch with a GROUPED prologue (pro_group_rows > 0: one affine row per group of that many GEMM
+ * rows -- the stacked generator forward, BaseGenerator.prefetch_fakes): a tile must not straddle two groups, so a choice
+ * whose tile height does not divide pro_group_rows falls back to diagan_conv_gemm_pick_cfg's and then to the 64-row
+ * tile.  This is exactly what diagan_conv_gemm does for tile_cfg == 0; callers that size the statistics buffer or ask
+ * whether a half-resolution residual will be fused use it to get the launch's own answer. */
+int diagan_conv_gemm_pick_cfg_grouped(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                      int off, int up, int Kp, int allow_split, int64_t ws_floats, int pro_group_rows);
 /* Diagnostics and tuning sweeps only (tools/stamp_report.py, tools/bench_conv.py; no reference counterpart, never
  * called by the product path).  While a stamp buffer is set, diagan_conv_gemm launches a diagnostic build of its
  * kernel (prologue modes 0 and 1) in which every workgroup records, at slot blockIdx.y*gridDim.x + blockIdx.x,

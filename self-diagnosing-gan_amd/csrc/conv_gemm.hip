@@ -30,6 +30,9 @@ extern "C" int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 extern "C" int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                               int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats);
 extern "C" int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
+extern "C" int diagan_conv_gemm_pick_cfg_grouped(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                                 int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats,
+                                                 int pro_group_rows);
 extern "C" int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                           int off, int up);
 
@@ -923,9 +926,9 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.dHo = make_fastdiv((unsigned)Ho);
   hipStream_t st = (hipStream_t)stream;
   const int cfg = tile_cfg != 0 ? tile_cfg
-                                : diagan_conv_gemm_pick_cfg_geom(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp,
-                                                                 (splitk_ws && !stat_partials) ? 1 : 0,
-                                                                 splitk_ws ? splitk_ws_floats : 0);
+                                : diagan_conv_gemm_pick_cfg_grouped(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp,
+                                                                    (splitk_ws && !stat_partials) ? 1 : 0,
+                                                                    splitk_ws ? splitk_ws_floats : 0, pro_group_rows);
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 = 64x64 with fragment "
@@ -1108,6 +1111,23 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
     if (wino_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs) > 0) return 9;
   }
   return diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
+}
+
+// The automatic choice for a launch whose prologue has one affine row per group of `pro_group_rows` GEMM rows (the stacked
+// generator forward): a tile must not straddle two groups, so a choice whose tile height does not divide the group falls
+// back to the implicit GEMM's pick and then to its 64-row tile (batch 50 at 8x8: 3200 rows per group = 25 x 128, not a
+// multiple of the Winograd kernel's 256).  pro_group_rows == 0: same as diagan_conv_gemm_pick_cfg_geom.  This is what
+// diagan_conv_gemm itself does for tile_cfg 0, so a caller that sizes the statistics buffer (tile count) or asks whether
+// the half-resolution residual will be fused gets the launch's own answer.
+DIAGAN_API int diagan_conv_gemm_pick_cfg_grouped(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                                 int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats,
+                                                 int pro_group_rows) {
+  int cfg = diagan_conv_gemm_pick_cfg_geom(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow_split, ws_floats);
+  if (pro_group_rows > 0 && pro_group_rows % diagan_conv_gemm_tile_rows(cfg) != 0) {
+    cfg = diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
+    if (pro_group_rows % diagan_conv_gemm_tile_rows(cfg) != 0) cfg = 3;
+  }
+  return cfg;
 }
 
 // whether the staged Winograd kernel (tile_cfg 10) takes a batch / prologue-group shape (the geometry itself must pass

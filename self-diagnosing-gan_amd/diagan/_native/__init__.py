@@ -86,6 +86,20 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = None
+
+
 def current_stream():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    """hipStream_t of torch's current stream on the current device.  `torch.cuda.current_stream().cuda_stream` builds a
+    Stream object through four Python layers (8 us per call, ~30 % of the host time of a training step); the raw
+    getter underneath is one C call."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get, cur = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", torch.cuda.current_device)
+        if get is None:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+        else:
+            torch.cuda.init()
+            _raw_stream = lambda: get(cur())
+    return _raw_stream()

@@ -147,17 +147,18 @@ class ConvLayer(nn.Module):
         sc = getattr(self, '_slot_ctx', None)
         return sc[slot] if (sc is not None and isinstance(slot, int)) else None
 
-    def _res_up(self, x, residual, res_up, want_stats, tile_cfg=0):
+    def _res_up(self, x, residual, res_up, want_stats, tile_cfg=0, pro=None):
         """res_up: `residual` is at half resolution and its bilinear x2 is to be added.  The Winograd kernel blends it in
         its epilogue; launches that take another kernel get the up-sampled tensor."""
         if not res_up:
             return residual, False
+        group_imgs = pro[3] if (pro is not None and len(pro) > 3) else 0
         fused = tile_cfg == 9 or (tile_cfg == 0 and C.res_up_fused(self.geom, x.shape[0], x.shape[1], x.shape[2],
-                                                                  want_stats=want_stats))
+                                                                  want_stats=want_stats, group_imgs=group_imgs))
         return (residual, True) if fused else (E.upsample2x(residual), False)
 
     def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0, res_up=False):
-        residual, res_up = self._res_up(x, residual, res_up, False, tile_cfg)
+        residual, res_up = self._res_up(x, residual, res_up, False, tile_cfg, pro)
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale,
                           res_up=res_up)
@@ -177,7 +178,7 @@ class ConvLayer(nn.Module):
         if not training:
             y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up)
             return y, bn.stats(y, False)
-        residual, res_up = self._res_up(x, residual, res_up, True)
+        residual, res_up = self._res_up(x, residual, res_up, True, pro=pro)
         y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                               residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up)
         M = y.numel() // y.shape[-1]

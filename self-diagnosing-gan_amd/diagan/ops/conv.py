@@ -17,6 +17,7 @@ nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
+nat.register("diagan_conv_gemm_pick_cfg_grouped", [I] * 15 + [I64, I])
 nat.register("diagan_conv_gemm_tile_rows", [I])
 nat.register("diagan_conv_wino_staged_supported", [I] * 5)
 nat.register("diagan_conv_wino_pool_supported", [I] * 14 + [I64])
@@ -219,8 +220,8 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         # statistics from the epilogue always win over split-K + a separate reduction pass over y (G-32 block2,
         # M=4096: 60 us unsplit with statistics vs 54 + 6 (second stage) + 20 (column reduction) us)
         M = B * Ho * Wo
-        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, 0,
-                                                                    ws.numel())
+        cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, 0,
+                                                                       ws.numel(), group_imgs * Ho * Wo)
         if cfg == 10 and not nat.fn("diagan_conv_wino_staged_supported")(B, Ho, Wo, Ci, group_imgs * Ho * Wo):
             cfg = 9                       # prologue groups that the staged kernel's image blocks straddle
         bm = nat.fn("diagan_conv_gemm_tile_rows")(cfg)
@@ -230,15 +231,15 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     kname = None
     if TIMER is not None and TIMER.wants_any():
         # (cached per call signature: on launch-bound workloads the name lookup itself was 6 ms of host time per step)
-        key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats)
+        key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats, group_imgs)
         kname = _NAME_CACHE.get(key)
         if kname is None or _NAME_CACHE.get('modes') != (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")()):
             if _NAME_CACHE.get('modes') != (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")()):
                 _NAME_CACHE.clear()
                 _NAME_CACHE['modes'] = (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")())
             allow = 0 if want_stats else 1
-            kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_geom")(
-                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel()), mode, Co)
+            kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(
+                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co)
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
@@ -269,15 +270,18 @@ def _splitk_ws(dev):
     return w
 
 
-def res_up_fused(geom, B, Hi, Wi, want_stats=False):
+def res_up_fused(geom, B, Hi, Wi, want_stats=False, group_imgs=0):
     """Will conv_fwd(geom, x[B,Hi,Wi,Ci], ..., res_up=True) run?  The bilinear x2 of a half-resolution residual is blended in
     by the Winograd kernel's epilogue (and its split-K second stage) only: True iff the automatic choice for this launch
-    is that kernel (tile_cfg 9); otherwise the caller up-samples the residual itself (diagan_upsample2x)."""
+    is that kernel (tile_cfg 9); otherwise the caller up-samples the residual itself (diagan_upsample2x).
+    group_imgs: images per prologue group of the launch (0: ungrouped) -- part of the choice, see
+    diagan_conv_gemm_pick_cfg_grouped."""
     Ho, Wo = geom.out_hw(Hi, Wi)
     sy, dr, off, up = geom.fwd_params()
     ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
-    return 9 == nat.fn("diagan_conv_gemm_pick_cfg_geom")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up,
-                                                         geom.Kp, 0 if want_stats else 1, ws.numel())
+    return 9 == nat.fn("diagan_conv_gemm_pick_cfg_grouped")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off,
+                                                            up, geom.Kp, 0 if want_stats else 1, ws.numel(),
+                                                            group_imgs * Ho * Wo)
 
 
 def pool_fused(geom, B, Hi, Wi, pro=None):

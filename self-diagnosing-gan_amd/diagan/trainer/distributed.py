@@ -13,16 +13,27 @@ import torch.distributed as dist
 
 
 # ---- native exchange: RCCL behind the C ABI (csrc/comm.hip) ---------------------------------------------------------
-# DIAGAN_COMM=rccl: the gradient all-reduce and the logit all-gather go through diagan_allreduce_grads /
-# diagan_allgather_logits on an explicit diagan_ctx (stream-ordered launches on torch's current stream: no host wait,
-# capturable in a hipGraph) instead of torch.distributed's process group, which then only carries the 128-byte
-# unique id and the barriers.  Default: torch.distributed ('nccl' = RCCL on ROCm) -- the native path cannot be
-# exercised with more than one rank on the single-GPU test box (RCCL refuses two ranks on one device).
-_NATIVE = {'ctx': None}
+# The gradient all-reduce and the logit all-gather go through diagan_allreduce_grads / diagan_allgather_logits on an
+# explicit diagan_ctx (stream-ordered launches: no host wait, capturable in a hipGraph) instead of torch.distributed's
+# process group, which then only carries the 128-byte unique id, the barriers and the start-up broadcast.
+# Policy (DIAGAN_COMM): "rccl" = native or fail; "torch" = process group only; unset / "auto" = native whenever every
+# rank has a device of its own (backend nccl and device_count() >= ranks on this node) AND the context passes a
+# start-up self-test against the process group's all-reduce on every rank -- otherwise the process group, with the
+# reason on stderr (RCCL refuses two ranks on one device, so single-GPU test boxes always take the process group).
+_NATIVE = {'ctx': None, 'side': None, 'why': 'single process'}
 
 
 def native_ctx():
     return _NATIVE['ctx']
+
+
+def comm_description():
+    """what carries the gradient exchange of this process (bench.py's config.comm)"""
+    if get_world_size() == 1:
+        return "none (single process)"
+    if _NATIVE['ctx'] is not None:
+        return "rccl-native"
+    return f"torch.distributed/{dist.get_backend()} ({_NATIVE['why']})"
 
 
 def _register_native():
@@ -37,7 +48,9 @@ def _register_native():
 
 def init_native_comm(rank, world, device_index):
     """Create the process's diagan_ctx: rank 0 draws the unique id, every rank receives it (torch.distributed object
-    broadcast when a process group exists, else world must be 1), all ranks enter ncclCommInitRank together."""
+    broadcast when a process group exists, else world must be 1), all ranks enter ncclCommInitRank together.
+    The context is destroyed at interpreter exit (`destroy_native_comm`, atexit)."""
+    import atexit
     import ctypes
     nat = _register_native()
     ident = ctypes.create_string_buffer(128)
@@ -50,15 +63,115 @@ def init_native_comm(rank, world, device_index):
     handle = ctypes.c_void_p()
     nat.call("diagan_ctx_create", ctypes.cast(ctypes.pointer(handle), ctypes.c_void_p), ctypes.cast(ident, ctypes.c_void_p),
              rank, world, device_index)
+    if _NATIVE['ctx'] is None:
+        atexit.register(destroy_native_comm)
     _NATIVE['ctx'] = handle
+    _NATIVE['why'] = 'native'
     return handle
 
 
 def destroy_native_comm():
     if _NATIVE['ctx'] is not None:
         nat = _register_native()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()        # nothing of ours may still be queued on the communicator
         nat.call("diagan_ctx_destroy", _NATIVE['ctx'])
         _NATIVE['ctx'] = None
+        _NATIVE['side'] = None
+
+
+def _all_ranks_agree(ok):
+    """True iff `ok` on every rank (one tiny MIN all-reduce on the process group)"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def _native_selftest(rank, world):
+    """The native context against the process group on the same data: a 1 Mi-element SUM all-reduce (values that sum
+    exactly in any order) and a float64 all-gather.  Returns an error string or None."""
+    try:
+        from diagan import _native as nat
+        n = 1 << 20
+        a = (torch.arange(n, device='cuda', dtype=torch.float32) % 1024) + rank
+        b = a.clone()
+        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], a.data_ptr(), a.numel(), nat.current_stream())
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        row = torch.full((4096,), float(rank), dtype=torch.float64, device='cuda')
+        out = torch.empty(world * 4096, dtype=torch.float64, device='cuda')
+        nat.call("diagan_allgather_logits", _NATIVE['ctx'], row.data_ptr(), out.data_ptr(), row.numel(), 8,
+                 nat.current_stream())
+        torch.cuda.synchronize()
+        want = torch.arange(world, device='cuda', dtype=torch.float64).repeat_interleave(4096)
+        if not torch.equal(a, b):
+            return "native all-reduce disagrees with the process group's"
+        if not torch.equal(out, want):
+            return "native all-gather returned the wrong rows"
+        return None
+    except Exception as e:      # noqa: BLE001 -- any failure here means: use the process group
+        return repr(e)
+
+
+def _maybe_init_native(rank, world, local_rank, backend):
+    import sys
+    policy = (os.environ.get("DIAGAN_COMM") or "auto").lower()
+    if policy == "torch" or not torch.cuda.is_available():
+        _NATIVE['why'] = "DIAGAN_COMM=torch" if policy == "torch" else "no GPU"
+        return
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    own_device = torch.cuda.device_count() >= local_world
+    if policy == "auto" and (backend != "nccl" or not own_device):
+        _NATIVE['why'] = ("ranks share a device" if not own_device else f"backend {backend}")
+        return
+    err = None
+    try:
+        init_native_comm(rank, world, local_rank % max(torch.cuda.device_count(), 1))
+    except Exception as e:      # noqa: BLE001
+        err = repr(e)
+    if policy == "rccl":
+        if err:
+            raise RuntimeError(f"DIAGAN_COMM=rccl: {err}")
+        return
+    if err is None:
+        err = _native_selftest(rank, world)
+    if not _all_ranks_agree(err is None):
+        if _NATIVE['ctx'] is not None:
+            try:
+                destroy_native_comm()
+            except Exception:   # noqa: BLE001
+                _NATIVE['ctx'] = None
+        _NATIVE['why'] = "native context failed its self-test: " + (err or "on another rank")
+        if rank == 0:
+            print(f"WARNING: native RCCL exchange disabled ({_NATIVE['why']}); using torch.distributed", file=sys.stderr)
+
+
+class _NativeWork:
+    """handle of a native collective issued on the side stream: wait() orders torch's current stream behind it"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
+def _native_allreduce(flat, async_op):
+    from diagan import _native as nat
+    if not async_op:
+        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], flat.data_ptr(), flat.numel(), nat.current_stream())
+        return None                              # ordered on the current stream: nothing to wait for
+    # in flight beside the compute stream: the side stream picks up behind everything queued so far
+    # (fork / join by events, so the pattern is also legal inside a stream capture)
+    if _NATIVE['side'] is None:
+        _NATIVE['side'] = torch.cuda.Stream()
+    side = _NATIVE['side']
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], flat.data_ptr(), flat.numel(), side.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(side)
+    return _NativeWork(done)
 
 
 def is_dist():
@@ -88,8 +201,7 @@ def init_from_env(backend=None):
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
         synchronize()
-        if os.environ.get("DIAGAN_COMM") == "rccl" and torch.cuda.is_available():
-            init_native_comm(rank, world, local_rank % max(torch.cuda.device_count(), 1))
+        _maybe_init_native(rank, world, local_rank, backend)
     return rank, local_rank, world
 
 
@@ -115,9 +227,7 @@ def all_reduce_sum_(flat, async_op=False):
     if get_world_size() == 1:
         return None
     if _NATIVE['ctx'] is not None and flat.is_cuda:
-        from diagan import _native as nat
-        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], flat.data_ptr(), flat.numel(), nat.current_stream())
-        return None                              # ordered on the current stream: nothing to wait for
+        return _native_allreduce(flat, async_op)
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
 
@@ -168,13 +278,18 @@ def all_gather(data):
 
 
 def all_gather_cat(tensor):
-    """Rank-major concatenation of equally shaped per-rank tensors."""
+    """Rank-major concatenation of equally shaped per-rank tensors (the shapes are checked: one MAX / MIN all-reduce of
+    the element count -- this runs once per logit snapshot, not per step)."""
     world = get_world_size()
     if world == 1:
         return tensor
     if _NATIVE['ctx'] is not None and tensor.is_cuda and tensor.element_size() in (1, 4, 8):
         from diagan import _native as nat
         send = tensor.contiguous()
+        n = torch.tensor([send.numel(), -send.numel()], dtype=torch.int64, device=send.device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        if int(n[0]) != -int(n[1]):
+            raise RuntimeError(f"all_gather_cat: per-rank element counts differ ({-int(n[1])} .. {int(n[0])})")
         recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
         nat.call("diagan_allgather_logits", _NATIVE['ctx'], send.data_ptr(), recv.data_ptr(), send.numel(),
                  send.element_size(), nat.current_stream())

@@ -180,3 +180,27 @@ def test_bench_two_ranks_prints_one_json_line():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["config"]["global_batch"] == 128
     assert rec["scaling"] == "weak" and rec["value"] > 0 and "roofline" in rec and "cpu_baseline" not in rec
+
+
+@pytest.mark.timeout(900)
+def test_bare_bench_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2` with NO torch.distributed.run around it and no WORLD_SIZE in the environment (the shape
+    of the driver's N = 1 command with another N): the script must start the two ranks itself as a child process group
+    and relay rank 0's line -- n_gpus 2, not a silent one-GPU number.  On this one-GPU box the launcher puts both ranks
+    on device 0 over gloo and says so in config."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DIAGAN_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no_cpu_baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks"] == 2 and rec["config"]["global_batch"] == 128
+    assert len(rec["config"]["devices"]) == 2
+    if torch.cuda.device_count() < 2:
+        assert "gloo" in rec["config"]["comm"] and "share" in rec["config"]["comm"]

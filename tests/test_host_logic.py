@@ -267,3 +267,22 @@ def test_color_mnist_front_ends_keep_the_reference_flags():
     mean, var = w.mean(), w.var()
     expect = np.clip(w, max(mean - 2 * var, 0.1), mean + 2 * var)
     np.testing.assert_allclose(cli.floor_or_clip_weights(w, clip=True), expect)
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    """bench.py --gpus N inside a job of another size: non-zero exit and NO JSON line (a line that silently reports a
+    different job size than the one asked for is worse than none); decided before any rendezvous or GPU access."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "WORLD_SIZE=2" in out.stderr
+    env = dict(env, WORLD_SIZE="2")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

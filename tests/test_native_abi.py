@@ -68,3 +68,29 @@ def test_launch_selection_queries_are_host_logic():
     assert unpool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, ws) == 1             # its data gradient: tile_cfg 12
     assert unpool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, ws) == 0             # (a forward geometry)
     assert nat.fn("diagan_conv_gemm_tile_rows")(11) == 256 and nat.fn("diagan_conv_gemm_tile_cols")(12) == 128
+
+
+def test_grouped_prologue_never_gets_a_tile_that_straddles_two_groups():
+    """The stacked generator forward (BaseGenerator.prefetch_fakes) gives the conv kernels one BatchNorm row per group of
+    batch*Ho*Wo GEMM rows.  A batch size that is not a multiple of 4 makes a group at 8x8 a non-multiple of the Winograd
+    kernel's 256-row tile (--batch_size 50, n_dis 5: 6 groups of 3200 rows): the automatic choice must then be a kernel
+    whose tile divides the group -- what diagan_conv_gemm itself launches -- instead of an error at launch time."""
+    from diagan import _native as nat
+    import diagan.ops  # noqa: F401
+    pick, grouped = nat.fn("diagan_conv_gemm_pick_cfg_geom"), nat.fn("diagan_conv_gemm_pick_cfg_grouped")
+    rows = nat.fn("diagan_conv_gemm_tile_rows")
+    ws = 64 << 20
+    for batch in (64, 50, 30, 25, 7):
+        for (H, C) in ((8, 256), (16, 256), (32, 256), (8, 1024), (64, 64)):
+            B = 6 * batch
+            geo = (B, H, H, C, H, H, C, 3, 3, 1, 1, -1, 1, 9 * C)
+            group = batch * H * H
+            for allow in (0, 1):
+                cfg = grouped(*geo, allow, ws, group)
+                assert rows(cfg) > 0 and group % rows(cfg) == 0, (batch, H, C, cfg)
+                if group % rows(pick(*geo, allow, ws)) == 0:
+                    assert cfg == pick(*geo, allow, ws)              # untouched where the first choice already fits
+                assert grouped(*geo, allow, ws, 0) == pick(*geo, allow, ws)
+    # the ADVICE r2 example: batch 50 at 8x8, six stacked batches -> Winograd would be picked, 3200 % 256 != 0
+    geo = (300, 8, 8, 256, 8, 8, 256, 3, 3, 1, 1, -1, 1, 2304)
+    assert pick(*geo, 1, ws) == 9 and grouped(*geo, 1, ws, 3200) != 9
