@@ -194,6 +194,8 @@ def executed_flop(name, flop):
     """FLOP the matrix pipe actually executes for `flop` algorithmic (direct-convolution, 2*M*Co*R*S*Ci) FLOP"""
     if name.startswith("conv_wino_pool_kernel"):
         return flop * WINO_POOL_MAC_RATIO
+    if name.startswith("conv_wino4_kernel"):     # Winograd F(4x4,3x3): 36 products per 4x4 output tile instead of 144
+        return flop * 0.25
     if name.endswith("[pooled gradient]"):     # weight gradient through the average pool as a strided convolution over box sums
         return flop * 0.25
     return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wino_s_kernel", "conv_wgrad_wino_kernel")) else flop

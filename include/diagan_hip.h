@@ -167,6 +167,11 @@ int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, int Ho, int
  * Winograd off. */
 int diagan_conv_gemm_set_wino(int mode);   /* run-time form of DIAGAN_WINO: 0 off, 1 on, -1 environment / default (on) */
 int diagan_conv_gemm_get_wino(void);
+/* Winograd F(4x4,3x3) (tile_cfg 13, csrc/conv_wino4.hip; round 3): same reference ops and arguments as tile_cfg 9 for 3x3 /
+ * stride 1 / pad 1 layers with H and W multiples of 4 -- 36 products per 4x4 output tile instead of 144 (F(2x2): 64), fp32,
+ * error ~1e-5 of the output scale (cuDNN's non-fused Winograd for the reference's F.conv2d is the same F(4x4,3x3)).  The
+ * automatic choice takes it for launches of >= 512 workgroups (32 tiles x 64 channels each).  0 = never, 1 / -1 = default. */
+int diagan_conv_gemm_set_wino4(int mode);
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* The same choice for a launch with a GROUPED prologue (pro_group_rows > 0: one affine row per group of that many GEMM

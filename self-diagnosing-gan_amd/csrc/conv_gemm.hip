@@ -40,6 +40,9 @@ namespace diagan {
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
 long wino_ws_floats(int Co, int Ci);
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
+int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st);     // conv_wino4.hip: F(4x4,3x3)
+long wino4_ws_floats(int Co, int Ci);
+bool wino4_geom_ok(int Ho, int Wo, int Ci);
 int launch_wino_s(ConvGemmArgs a, float* ws, hipStream_t st);    // conv_wino_s.hip
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
@@ -728,6 +731,7 @@ static int g_force_ksplit = 0;                    // tuning sweeps only (diagan_
 static int g_tune_flags = -1;                     // -1: production default (see kDefaultTune)
 static long g_lds_delta = 0;
 static int g_wino = -1;                           // -1: DIAGAN_WINO / default (on); 0 / 1: diagan_conv_gemm_set_wino
+static int g_wino4 = -1;                          // -1: DIAGAN_WINO4 / default (on); 0 / 1: diagan_conv_gemm_set_wino4
 constexpr int kDefaultTune = 0;
 
 template <int BM, int BN, int WM, int WN, int BK, int PRO, bool X6 = false, bool STAMP = false, bool FP = false>
@@ -996,6 +1000,26 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     }
     return rc;
   }
+  if (cfg == 13) {
+    // Winograd F(4x4,3x3) (conv_wino4.hip): 32 tiles of 4x4 outputs x 64 channels per workgroup
+    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && wino4_geom_ok(Ho, Wo, Ci),
+               "conv_gemm: tile_cfg 13 (Winograd F(4x4,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, H and W multiples of 4, Ci %% 8 == 0");
+    const long wfl = wino4_ws_floats(Co, Ci);
+    DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 13 needs %ld floats of workspace for the transformed weights", wfl);
+    int ks = 1;
+    if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats && Ci / 8 / g_force_ksplit >= 1)
+      ks = g_force_ksplit;
+    a.ksplit = ks;
+    a.slab = splitk_ws + wfl;
+    int rc = launch_wino4(a, splitk_ws, st);
+    if (rc == DIAGAN_OK && ks > 1) {
+      long blocks = ((long)a.M * (Co / 4) + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+      rc = check_launch("conv_wino4 split-K epilogue");
+    }
+    return rc;
+  }
   if (cfg == 9 || cfg == 10) {
     DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up),
                "conv_gemm: tile_cfg %d (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0", cfg);
@@ -1046,10 +1070,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: case 10: return 128; case 3: case 7: return 64; case 5: case 9: case 11: case 12: return 256; default: return 0; }
+  switch (cfg) { case 1: case 8: case 10: return 128; case 3: case 7: return 64; case 5: case 9: case 11: case 12: return 256; case 13: return 512; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 10: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 10: case 13: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -1105,6 +1129,14 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
     // the staged kernel (32-tile blocks, two workgroups per CU) where its blocks tile the batch
     static const int staged_env = getenv("DIAGAN_WINO_STAGED") ? atoi(getenv("DIAGAN_WINO_STAGED")) : 0;
     static const int min_wgs_s = getenv("DIAGAN_WINO_S_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_S_MIN_WGS")) : 256;
+    // F(4x4,3x3) (conv_wino4.hip, 32 tiles of 4x4 outputs x 64 channels per workgroup, ONE resident workgroup per CU): where the
+    // launch fills the chip at least twice (measured r3: 1.2-1.3x the F(2x2) kernel from 512 workgroups up, 0.67x at 128)
+    static const int w4_env = getenv("DIAGAN_WINO4") ? atoi(getenv("DIAGAN_WINO4")) : 1;
+    static const int w4_min = getenv("DIAGAN_WINO4_MIN_WGS") ? atoi(getenv("DIAGAN_WINO4_MIN_WGS")) : 512;
+    static const int w4_min_ci = getenv("DIAGAN_WINO4_MIN_CI") ? atoi(getenv("DIAGAN_WINO4_MIN_CI")) : 64;
+    if (w4_env && g_wino4 != 0 && wino4_geom_ok(Ho, Wo, Ci) && Ci >= w4_min_ci && ws_floats >= wino4_ws_floats(Co, Ci) &&
+        (long)cdiv((long)B * (Ho >> 2) * (Wo >> 2), 32) * cdiv(Co, 64) >= w4_min)
+      return 13;
     if (staged_env && wino_s_block(B, Ho, Wo, Ci, 0) &&
         wino_s_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs_s) > 0)
       return 10;
@@ -1142,6 +1174,14 @@ DIAGAN_API int diagan_conv_gemm_get_wino(void) { return g_wino; }
 DIAGAN_API int diagan_conv_gemm_set_wino(int mode) {
   DG_REQUIRE(mode >= -1 && mode <= 1, "set_wino: -1, 0 or 1");
   g_wino = mode;
+  return DIAGAN_OK;
+}
+
+// Run-time form of DIAGAN_WINO4: 0 = the automatic choice never takes the F(4x4,3x3) kernel (tile_cfg 13), 1 / -1 = where it
+// qualifies (like-with-like tests, A/B runs)
+DIAGAN_API int diagan_conv_gemm_set_wino4(int mode) {
+  DG_REQUIRE(mode >= -1 && mode <= 1, "set_wino4: -1, 0 or 1");
+  g_wino4 = mode;
   return DIAGAN_OK;
 }
 

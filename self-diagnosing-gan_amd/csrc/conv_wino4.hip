@@ -1,0 +1,537 @@
+// Winograd F(4x4, 3x3) forward / data-gradient convolution on the fp32 matrix cores (round 3).
+//
+// Replaces the same reference ops as conv_wino.hip (F.conv2d and its input gradient in mimicry's GBlock / DBlock,
+// selected at diagan-pkg/diagan/models/predefined_models.py:19-21,38-40,57-59,76-78) for the large 3x3 / stride 1 / pad 1
+// launches:  Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A  per 4x4 output tile with the 6x6 transforms of Lavin & Gray
+// (interpolation points 0, +-1, +-2, inf) -- 36 multiply-accumulates per tile, output and input channel instead of 144,
+// i.e. 4x fewer MFMA cycles than the implicit GEMM and 1.78x fewer than F(2x2,3x3).  fp32 throughout; rounding error
+// against float64 ~1e-5 of the output scale (tools/micro/wino_f4_error.py; F(2x2): 5e-7, direct fp32: 3e-7).  cuDNN --
+// what the reference's F.conv2d runs -- uses the same F(4x4,3x3) for these layers in its non-fused Winograd algorithm.
+//
+// One workgroup = 512 threads = 8 waves = 32 tiles (512 output pixels) x 64 output channels, one per CU (146 KB of LDS).
+//   * K loop over input channels in steps of 8.  Per step the 36 "frequency" GEMMs  M_f[32 x 64] += V_f[32 x 8] U_f[64 x 8]^T
+//     run as v_mfma_f32_32x32x2_f32: wave w owns the 9 frequencies f = 9 (w >> 1) .. + 8 on column half w & 1
+//     (9 accumulator tiles = 144 registers).
+//   * U (transformed weights, written once per launch by wino4_weight_kernel in the order the waves consume it): every U
+//     element is used by exactly ONE wave, so a wave fetches its own nine 1 KB units per step by LDS-DMA into wave-private
+//     LDS slots (no registers held across the step, no barrier for them); the unit of slot s is re-filled for the next
+//     step as soon as this step's fragment of it has been read.
+//   * V (transformed input): thread (tile, channel quad, patch row r < 6) loads its 6 pixels x 4 channels (prologue
+//     applied here), transforms along the row and parks the result in the V planes; thread (tile, quad, column j) of the
+//     same 16-lane group then transforms its column in place (LDS operations of one wave execute in order: no barrier).
+//     Planes are [f][quad][tile][4 channels] with a 132-float stride: a quarter wave's 16 ds_write_b128 hit 64 banks once;
+//     an MFMA fragment (lane = tile, k half = quad) is ONE conflict-free ds_read_b128 per frequency and step.
+//   * epilogue: the 36 products of a (tile, channel) meet in LDS ([f][tile][32 channels] = 144 KB, one column half at a
+//     time); thread (tile, channel quad, row pair) applies A^T . A and the usual epilogue (per-half 1/sigma, bias, residual
+//     (also the bilinear x2 of a half-resolution one), ReLU-backward mask, BatchNorm statistics), 16-byte stores.
+//
+// Roofline: MFMA fp32; the kernel executes 36/144 of the direct convolution's multiply-accumulates.
+#include "conv_common.h"
+#include <type_traits>
+
+namespace diagan {
+
+constexpr int W4T = 32;                 // 4x4-output tiles per workgroup
+constexpr int W4N = 64;                 // output channels per workgroup
+constexpr int W4K = 8;                  // input channels per K-step
+constexpr int W4_PS = 132;              // floats between consecutive V planes (32 tiles x 4 channels + 4 of padding)
+constexpr int W4_VSTAGE = 72 * W4_PS;   // V planes of one stage: 36 frequencies x 2 channel quads
+constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency, column half) of 64 lanes x 4 floats
+#ifndef W4_ROW_AT
+#define W4_ROW_AT 3
+#endif
+#ifndef W4_COL_AT
+#define W4_COL_AT 5
+#endif
+#ifndef W4_STAGGER            // the two waves of a SIMD (w, w + 4) transform at different slots of the step
+#define W4_STAGGER 0
+#endif
+#ifndef W4_ROW_LATE
+#define W4_ROW_LATE 5
+#endif
+#ifndef W4_COL_LATE
+#define W4_COL_LATE 7
+#endif
+#ifndef W4_PAIR               // MFMAs of two slots interleaved (no back-to-back dependent accumulators)
+#define W4_PAIR 0
+#endif
+constexpr int W4_LDS_FLOATS = 2 * W4_VSTAGE + W4_U;      // 149 760 bytes (the epilogue's 36 x 32 x 32 floats fit inside)
+
+// U[f][co][ci] = (G g G^T)[i][j], f = 6 i + j, in the order the main kernel's waves consume it:
+// [64-column block][K-step][unit = wave * 9 + slot][lane = k half * 32 + column][4 channels], wave = (f / 9) * 2 + column half.
+// flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
+__global__ __launch_bounds__(64) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                          int Kp, int flip) {
+  const int c = blockIdx.x * 4, nb = blockIdx.y, col = threadIdx.x, co = nb * 64 + col;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
+      g[r][s] = co < Co ? *reinterpret_cast<const f32x4*>(w + (long)co * Kp + (rr * 3 + ss) * Ci + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  constexpr float k4 = 0.25f, k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
+  auto gt = [&](const f32x4& g0, const f32x4& g1, const f32x4& g2, f32x4* o) {
+    o[0] = k4 * g0;
+    o[1] = -k6 * (g0 + g1 + g2);
+    o[2] = -k6 * (g0 - g1 + g2);
+    o[3] = k24 * g0 + k12 * g1 + k6 * g2;
+    o[4] = k24 * g0 - k12 * g1 + k6 * g2;
+    o[5] = g2;
+  };
+  f32x4 t[3][6];                                        // t[s][i] = (G g)[i][s]
+#pragma unroll
+  for (int s = 0; s < 3; ++s) gt(g[0][s], g[1][s], g[2][s], t[s]);
+  const int nk = Ci >> 3, ks = c >> 3, kh = (c >> 2) & 1, nh = col >> 5, n = col & 31;
+  float* base = ug + ((long)nb * nk + ks) * W4_U + (kh * 32 + n) * 4;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    f32x4 u[6];
+    gt(t[0][i], t[1][i], t[2][i], u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int f = i * 6 + j, unit = ((f / 9) * 2 + nh) * 9 + f % 9;
+      *reinterpret_cast<f32x4*>(base + unit * 256) = u[j];
+    }
+  }
+}
+
+// 1-D input transform B^T (6 -> 6), in place
+__device__ __forceinline__ void w4_bt(f32x4* d) {
+  const f32x4 t0 = 4.f * d[0] - 5.f * d[2] + d[4];
+  const f32x4 t5 = 4.f * d[1] - 5.f * d[3] + d[5];
+  const f32x4 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = d[3] - d[1];
+  d[0] = t0;
+  d[1] = a + b;
+  d[2] = a - b;
+  d[3] = c + 2.f * e;
+  d[4] = c - 2.f * e;
+  d[5] = t5;
+}
+
+// Diagnostic build only (make EXTRA=-DDIAGAN_WINO_ABLATE; tools/wino4_ablate.py): ConvGemmArgs::tune bits switch parts of the K
+// loop off (16 row pass, 4096 column pass, 32 input loads, 64 weight DMA, 128 barrier, 256 MFMAs, 2048 fragment reads: the
+// results are then garbage) so that their cost can be read off the launch time.
+#ifdef DIAGAN_WINO_ABLATE
+#define W4_ON(bit) (!(a.tune & (bit)))
+#else
+#define W4_ON(bit) true
+#endif
+
+template <int PRO>
+__global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 V stages | U] = 146 KB
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.Co + W4N - 1) / W4N;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int t0 = (tile / tiles_n) * W4T, nb = tile % tiles_n, n0 = nb * W4N;
+  const int TW = g.Wo >> 2, TH = g.Ho >> 2;
+  const int MT = g.B * TH * TW;                         // 4x4 output tiles in all
+  const int nk = g.Ci / W4K;
+  const int k_per = (nk + a.ksplit - 1) / a.ksplit;
+  const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk);
+  constexpr bool affine = PRO == PRO_AFFINE_RELU || PRO == PRO_AFFINE;
+
+  // ---- loader role: (tile lt, channel quad lq, patch row / column lr < 6); a 16-lane group holds one tile ----
+  const int lr = tid & 7, lq = (tid >> 3) & 1, lt = tid >> 4;
+  const bool lact = lr < 6;
+  unsigned off[6];                                       // byte offsets of this row's 6 patch pixels, bit 31 set if outside
+  int kbound[6];                                         // upper clamp of the activation: 0 on padding pixels
+  {
+    const int gt = t0 + lt;
+    const bool tv = gt < MT && lact;
+    const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);          // dWo: divisor TW
+    const int tx = (tv ? gt : 0) - (int)q1 * TW;
+    const unsigned b = fdiv(q1, a.dHo);                                // dHo: divisor TH
+    const int ty = (int)q1 - (int)b * TH;
+    const int iy = 4 * ty - 1 + lr, ix0 = 4 * tx - 1;
+    const bool rv = tv && iy >= 0 && iy < g.Hi;
+    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + lq * 16;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
+      off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0x80000000u;  // beyond num_records: the hardware returns zeros
+      kbound[c] = ok ? 0x7fffffff : 0;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  const int pro_group_off = a.pro_group_rows > 0 ? ((t0 * 16) / a.pro_group_rows) * g.Ci : 0;
+  // this thread's V slots: row pass writes planes (lr, j), column pass reads / writes planes (i, lr); plane = (6 i + j) * 2 + quad
+  float* const vrow = smem + ((6 * lr) * 2 + lq) * W4_PS + lt * 4;     // + j * 2 * W4_PS
+  float* const vcol = smem + (lr * 2 + lq) * W4_PS + lt * 4;           // + i * 12 * W4_PS
+
+  float* const ulds = smem + 2 * W4_VSTAGE;
+  const float* ublock = ug + (long)nb * nk * W4_U + wave * 9 * 256;
+  float* const uslot = ulds + wave * 9 * 256;                          // this wave's nine private units
+
+  auto issue_u = [&](int kk, int s) {
+    const unsigned long long ub = (unsigned long long)(ublock + (long)kk * W4_U + s * 256);
+    const unsigned long long us64 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32;
+    const float* up = reinterpret_cast<const float*>(us64) + (unsigned)(lane * 4);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)up,
+                                     (__attribute__((address_space(3))) void*)(uslot + s * 256), 16, 0, 0);
+  };
+  f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  auto issue_x = [&](int kk) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off[c], kk * (W4K * 4), 0));
+    if (affine) {
+      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + pro_group_off + kk * W4K + lq * 4);
+      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + kk * W4K + lq * 4);
+    }
+  };
+  // prologue on the loaded pixels + row transform + park in the V planes of `stage`
+  auto row_pass = [&](int stage) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      f32x4 v = ra[c];
+      if (PRO != PRO_NONE) {
+        if (affine) v = v * psc + psh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float q = v[e];
+          float r;
+          if (PRO == PRO_LRELU) {
+            const float q2 = 0.2f * q;
+            asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(q2));
+          } else if (PRO == PRO_RELU) {
+            r = __int_as_float(max(__float_as_int(q), 0));
+          } else if (PRO == PRO_AFFINE_RELU) {
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(q), "v"(kbound[c]));     // ReLU and "padding is zero" in one
+          } else {
+            r = kbound[c] ? q : 0.f;                    // PRO_AFFINE: padding is zero AFTER the affine map
+          }
+          v[e] = r;
+        }
+      }
+      ra[c] = v;
+    }
+    w4_bt(ra);
+    if (lact) {
+      float* vs = vrow + stage * W4_VSTAGE;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vs + j * 2 * W4_PS) = ra[j];
+    }
+  };
+  // column transform of column lr, in place (reads what the row pass of this 16-lane group parked)
+  auto col_pass = [&](int stage) {
+    float* vs = vcol + stage * W4_VSTAGE;
+    f32x4 d[6];
+    if (lact) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * 12 * W4_PS);
+    }
+    w4_bt(d);
+    if (lact) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vs + i * 12 * W4_PS) = d[i];
+    }
+  };
+
+  // wave w owns frequencies f = 9 (w >> 1) + s, s < 9, on column half w & 1
+  const int grp = wave >> 1, nh = wave & 1;
+  f32x16 acc[9];
+#pragma unroll
+  for (int s = 0; s < 9; ++s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
+  const int fi = lane & 31, kh = lane >> 5;
+
+  if (k_begin < k_end) {
+#pragma unroll
+    for (int s = 0; s < 9; ++s) issue_u(k_begin, s);
+    issue_x(k_begin);
+    row_pass(0);
+    col_pass(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float* const fa_base = smem + ((9 * grp) * 2 + kh) * W4_PS + fi * 4;
+  const float* const fb_base = uslot + lane * 4;
+  // vm-counter bookkeeping: a wave's DMA unit of slot s for step kk + 1 is issued right after slot s of step kk has been
+  // consumed and gets a WHOLE step to land -- the wait sits in front of the fragment read of step kk + 1, not at the end
+  // of step kk.  Operations younger than D(kk, s + 1) when fragment s + 1 is about to be read: D(kk, s + 2 .. 8), the NI
+  // input loads of step kk + 1 and D(kk + 1, 0 .. s - 1): 7 + NI in every slot.
+#define W4_WAIT_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+  auto wait_vm = [&](int n) {          // n is a compile-time constant after unrolling: the switch folds to one s_waitcnt
+    switch (n) {
+      W4_WAIT_VM(0) W4_WAIT_VM(1) W4_WAIT_VM(2) W4_WAIT_VM(3) W4_WAIT_VM(4) W4_WAIT_VM(5) W4_WAIT_VM(6) W4_WAIT_VM(7)
+      W4_WAIT_VM(8) W4_WAIT_VM(9) W4_WAIT_VM(10) W4_WAIT_VM(11) W4_WAIT_VM(12) W4_WAIT_VM(13) W4_WAIT_VM(14) W4_WAIT_VM(15)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+#undef W4_WAIT_VM
+  auto kstep = [&](int kk, auto has_next) {
+    constexpr bool HN = decltype(has_next)::value;
+    const int cur = (kk - k_begin) & 1;
+    if (HN) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // D(kk, 0) has landed (D(kk, 1 .. 8) may still fly)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const bool late = W4_STAGGER && (wave >> 2);
+    // s: slot (group in the W4_PAIR variant) whose MFMAs have just been issued; issued: DMA units of the next step issued so
+    // far in this step = operations younger than the input loads
+    auto transform_at = [&](int s, int issued) {
+      const bool row_now = W4_STAGGER ? ((s == W4_ROW_AT && !late) || (s == W4_ROW_LATE && late)) : s == W4_ROW_AT;
+      const bool col_now = W4_STAGGER ? ((s == W4_COL_AT && !late) || (s == W4_COL_LATE && late)) : s == W4_COL_AT;
+      if (row_now) {
+        wait_vm(issued);                                  // the input loads have landed (the younger DMAs may still fly)
+        if (W4_ON(16)) row_pass(cur ^ 1);
+      } else if (col_now) {
+        if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
+      }
+    };
+#if !W4_PAIR
+    f32x4 fa[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, fb[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    if (W4_ON(2048)) {
+      fa[0] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE);
+      fb[0] = *reinterpret_cast<const f32x4*>(fb_base);
+    }
+    if (HN && W4_ON(32)) issue_x(kk + 1);
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+      if (s + 1 < 9) {
+        if (HN) {
+          if (affine) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        }
+        if (W4_ON(2048)) {
+          fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (s + 1) * 2 * W4_PS);
+          fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
+        }
+      }
+      if (W4_ON(256))
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][e], fb[s & 1][e], acc[s], 0, 0, 0);
+      if (HN) {
+        // slot s has been read into registers (the MFMAs above needed it): re-fill it for the next step
+        __builtin_amdgcn_sched_barrier(0);
+        if (W4_ON(64)) issue_u(kk + 1, s);
+        transform_at(s, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#else
+    // slots in groups (0,1) (2,3) (4,5) (6,7) (8): the MFMAs of a pair alternate between its two accumulators; the
+    // fragments of the next group are read before the MFMAs of this one
+    f32x4 fa[2][2], fb[2][2];
+    fa[0][0] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE);
+    fb[0][0] = *reinterpret_cast<const f32x4*>(fb_base);
+    // (D(kk, 1): one more unit must have landed than the top-of-step wait guarantees)
+    if (HN) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    fa[0][1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + 2 * W4_PS);
+    fb[0][1] = *reinterpret_cast<const f32x4*>(fb_base + 256);
+    if (HN && W4_ON(32)) issue_x(kk + 1);
+#pragma unroll
+    for (int gq = 0; gq < 5; ++gq) {
+      const int s0 = 2 * gq, ns = gq < 4 ? 2 : 1;
+      if (gq < 4) {
+        // next group: slots s0 + 2 (, s0 + 3).  Younger than D(kk, s0 + 3): D(kk, s0 + 4 .. 8) = 5 - s0, NI, D(kk + 1, 0 .. s0 - 1) = s0
+        if (HN) {
+          if (affine) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (s0 + 2 + u < 9) {
+            fa[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (s0 + 2 + u) * 2 * W4_PS);
+            fb[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fb_base + (s0 + 2 + u) * 256);
+          }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (u < ns)
+            acc[s0 + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gq & 1][u][e], fb[gq & 1][u][e], acc[s0 + u], 0, 0, 0);
+      if (HN) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (u < ns) issue_u(kk + 1, s0 + u);
+        transform_at(gq, gq < 4 ? 2 * (gq + 1) : 9);      // (group index: W4_ROW_AT / W4_COL_AT count groups in this variant)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#endif
+    if (W4_ON(128)) __syncthreads();                       // V of the next step is complete (U is wave-private)
+  };
+  for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+  if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+
+#ifdef DIAGAN_WINO_ABLATE
+  if (a.tune & 512) {
+    if (acc[0][0] == 123.456f) a.y[0] = acc[1][3] + acc[5][5] + acc[8][7];
+    return;
+  }
+#endif
+  // ---- epilogue ----
+  const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
+  const int split = a.scale0 ? a.scale_split : 0x7fffffff;            // pixel-row index where the second sigma starts
+  const bool raw = a.ksplit > 1;                                       // split-K: un-scaled partial sums to the slab
+  const bool hr = !raw && a.residual != nullptr, hm = !raw && a.mask_src != nullptr, hs = !raw && a.stat_partials != nullptr;
+  float* ydst = raw ? a.slab + (long)blockIdx.y * a.M * g.Co : a.y;
+  const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
+  const int et = tid >> 4, eq = (tid >> 1) & 7, eh = tid & 1;         // tile, channel quad (of a 32-column half), row pair
+  // this thread's tile
+  const int gt = t0 + et;
+  const bool tv = gt < MT;
+  const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);
+  const int tx = (tv ? gt : 0) - (int)q1 * TW;
+  const unsigned eb = fdiv(q1, a.dHo);
+  const int ty = (int)q1 - (int)eb * TH;
+  float* ss = smem;
+  f32x4 cs1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, cs2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (nh == p) {
+#pragma unroll
+      for (int s = 0; s < 9; ++s)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = 8 * (e >> 2) + 4 * kh + (e & 3);
+          ss[((9 * grp + s) * 32 + m) * 32 + fi] = acc[s][e];
+        }
+    }
+    __syncthreads();
+    const int n = n0 + p * 32 + eq * 4;
+    const bool ok = tv && n < g.Co;
+    // s[a][j] = sum_i A^T[a][i] M[i][j] for this thread's two rows a = 2 eh, 2 eh + 1
+    f32x4 sr[2][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      f32x4 m[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(ss + ((i * 6 + j) * 32 + et) * 32 + eq * 4);
+      const f32x4 pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], tt = m[3] - m[4];
+      if (eh == 0) {
+        sr[0][j] = m[0] + pp + rr;
+        sr[1][j] = qq + 2.f * tt;
+      } else {
+        sr[0][j] = pp + 4.f * rr;
+        sr[1][j] = qq + 8.f * tt + m[5];
+      }
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (!raw && a.bias && ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (ok) {
+#pragma unroll
+      for (int ar = 0; ar < 2; ++ar) {
+        const f32x4* s6 = sr[ar];
+        const f32x4 pp = s6[1] + s6[2], qq = s6[1] - s6[2], rr = s6[3] + s6[4], tt = s6[3] - s6[4];
+        f32x4 y4[4];
+        y4[0] = s6[0] + pp + rr;
+        y4[1] = qq + 2.f * tt;
+        y4[2] = pp + 4.f * rr;
+        y4[3] = qq + 8.f * tt + s6[5];
+        const int oy = 4 * ty + 2 * eh + ar;
+#pragma unroll
+        for (int bc = 0; bc < 4; ++bc) {
+          const int ox = 4 * tx + bc;
+          const int prow = ((int)eb * g.Ho + oy) * g.Wo + ox;           // pixel (GEMM row) index
+          const long o = (long)prow * g.Co + n;
+          f32x4 y = raw ? y4[bc] : y4[bc] * (prow < split ? sc0 : sc1) + bv;
+          if (hr) {
+            f32x4 r;
+            if (a.res_up) {
+              r = residual_up2(a.residual, (int)eb, oy, ox, g.Ho >> 1, g.Wo >> 1, g.Co, n);
+            } else {
+              r = *reinterpret_cast<const f32x4*>(a.residual + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+            }
+            y += r;
+          }
+          if (hm) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : y[e] * a.mask_slope;
+          }
+          if (W4_ON(1024)) *reinterpret_cast<f32x4*>(ydst + o) = y;
+          else if (y[0] == 123.456f) ydst[o] = y[1];
+          if (hs) {
+            cs1[p] += y;
+            cs2[p] += y * y;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (hs) {
+    // column sums over the workgroup's 512 pixels: lanes that differ in bit 0 (row pair) and bits 4, 5 (tile) hold the
+    // same channels; then the eight waves meet in LDS, fixed order
+    float* red = smem;                                                 // [8 waves][2 halves][2][32]
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v1 = cs1[p][e], v2 = cs2[p][e];
+        v1 += __shfl_xor(v1, 1, 64);
+        v2 += __shfl_xor(v2, 1, 64);
+        v1 += __shfl_xor(v1, 16, 64);
+        v2 += __shfl_xor(v2, 16, 64);
+        v1 += __shfl_xor(v1, 32, 64);
+        v2 += __shfl_xor(v2, 32, 64);
+        cs1[p][e] = v1;
+        cs2[p][e] = v2;
+      }
+      if ((lane & 0x31) == 0) {
+        *reinterpret_cast<f32x4*>(red + ((wave * 2 + p) * 2 + 0) * 32 + eq * 4) = cs1[p];
+        *reinterpret_cast<f32x4*>(red + ((wave * 2 + p) * 2 + 1) * 32 + eq * 4) = cs2[p];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, col = tid & 63, p = col >> 5, c32 = col & 31;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[((w * 2 + p) * 2 + which) * 32 + c32];
+      if (n0 + col < g.Co) a.stat_partials[(long)(tile / tiles_n) * 2 * g.Co + which * g.Co + n0 + col] = t;
+    }
+  }
+}
+
+template <int PRO>
+static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
+  const int MT = a.g.B * (a.g.Ho >> 2) * (a.g.Wo >> 2);
+  const int wgs = cdiv(MT, W4T) * cdiv(a.g.Co, W4N);
+  const size_t lds = (size_t)W4_LDS_FLOATS * sizeof(float);
+  auto kern = conv_wino4_kernel<PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs, a.ksplit), dim3(512), lds, st, a, ug);
+  return check_launch("conv_wino4");
+}
+
+// floats of workspace the transformed weights need
+long wino4_ws_floats(int Co, int Ci) { return (long)cdiv(Co, W4N) * W4N * Ci * 36; }
+
+// geometry the F(4x4,3x3) kernel takes on top of diagan_conv_wino_supported: H and W multiples of 4
+bool wino4_geom_ok(int Ho, int Wo, int Ci) { return !(Ho & 3) && !(Wo & 3) && (Ci & 7) == 0; }
+
+// `a` as prepared by diagan_conv_gemm (dWo / dHo re-made here for the TILE grid); ws: wino4_ws_floats(Co, Ci) floats
+int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
+  hipLaunchKernelGGL(wino4_weight_kernel, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
+                     g.dr < 0 ? 1 : 0);
+  switch (a.pro_mode) {
+    case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ws, st);
+    case PRO_RELU: return launch_wino4_pro<PRO_RELU>(a, ws, st);
+    case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU>(a, ws, st);
+    case PRO_LRELU: return launch_wino4_pro<PRO_LRELU>(a, ws, st);
+    default: return launch_wino4_pro<PRO_AFFINE>(a, ws, st);
+  }
+}
+
+}  // namespace diagan

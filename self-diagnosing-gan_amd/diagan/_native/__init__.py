@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdiagan_hip.so")
+# DIAGAN_LIB_PATH: another build of the same library (kernel A/B runs of the tuning tools); default: the in-tree build
+LIB_PATH = os.environ.get("DIAGAN_LIB_PATH") or os.path.join(_HERE, "libdiagan_hip.so")
 
 _lib = None
 

@@ -153,7 +153,7 @@ class ConvLayer(nn.Module):
         if not res_up:
             return residual, False
         group_imgs = pro[3] if (pro is not None and len(pro) > 3) else 0
-        fused = tile_cfg == 9 or (tile_cfg == 0 and C.res_up_fused(self.geom, x.shape[0], x.shape[1], x.shape[2],
+        fused = tile_cfg in (9, 13) or (tile_cfg == 0 and C.res_up_fused(self.geom, x.shape[0], x.shape[1], x.shape[2],
                                                                   want_stats=want_stats, group_imgs=group_imgs))
         return (residual, True) if fused else (E.upsample2x(residual), False)
 

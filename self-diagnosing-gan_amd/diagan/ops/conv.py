@@ -14,6 +14,7 @@ nat.register("diagan_conv_gemm_pick_cfg", [I, I, I, I])
 nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
+nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
@@ -55,6 +56,8 @@ def gemm_kernel_name(cfg, mode, Co=128):
         return f"conv_wino_kernel<{mode}>"
     if cfg == 10:
         return f"conv_wino_s_kernel<{mode}>"
+    if cfg == 13:
+        return f"conv_wino4_kernel<{mode}>"
     if cfg == 11:
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
@@ -124,6 +127,12 @@ def set_winograd(mode):
     """True / False: allow / forbid the Winograd kernel for auto-selected tile configurations; None: the default
     (on, or what DIAGAN_WINO says)"""
     nat.call("diagan_conv_gemm_set_wino", -1 if mode is None else (1 if mode else 0))
+
+
+def set_winograd4(mode):
+    """True / False: allow / forbid the F(4x4,3x3) kernel (tile_cfg 13) for auto-selected launches; None: the default (on, or
+    what DIAGAN_WINO4 says)"""
+    nat.call("diagan_conv_gemm_set_wino4", -1 if mode is None else (1 if mode else 0))
 
 
 def get_mfma_mode():
@@ -279,9 +288,9 @@ def res_up_fused(geom, B, Hi, Wi, want_stats=False, group_imgs=0):
     Ho, Wo = geom.out_hw(Hi, Wi)
     sy, dr, off, up = geom.fwd_params()
     ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
-    return 9 == nat.fn("diagan_conv_gemm_pick_cfg_grouped")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off,
-                                                            up, geom.Kp, 0 if want_stats else 1, ws.numel(),
-                                                            group_imgs * Ho * Wo)
+    return nat.fn("diagan_conv_gemm_pick_cfg_grouped")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off,
+                                                       up, geom.Kp, 0 if want_stats else 1, ws.numel(),
+                                                       group_imgs * Ho * Wo) in (9, 13)
 
 
 def pool_fused(geom, B, Hi, Wi, pro=None):

@@ -58,7 +58,14 @@ def test_launch_selection_queries_are_host_logic():
     pool, unpool = nat.fn("diagan_conv_wino_pool_supported"), nat.fn("diagan_conv_wino_unpool_supported")
     ws = 64 << 20
     assert nat.fn("diagan_get_mfma_mode")() == 0
-    assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9      # D-32 block1.c2, pair pass
+    assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 13     # D-32 block1.c2, pair pass: 512 workgroups of F(4x4,3x3)
+    nat.call("diagan_conv_gemm_set_wino4", 0)
+    try:
+        assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9  # ... F(2x2,3x3) when that kernel is off
+    finally:
+        nat.call("diagan_conv_gemm_set_wino4", -1)
+    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 9       # 128 workgroups of F(4x4): too few
+    assert pick(64, 6, 6, 256, 6, 6, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) not in (13,)   # H, W not multiples of 4
     assert pick(128, 8, 8, 128, 8, 8, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) != 9          # 8x8 / 128 channels: implicit GEMM
     assert pick(64, 16, 16, 128, 8, 8, 128, 3, 3, 2, 1, -1, 1, 1152, 1, ws) != 9         # stride 2
     assert pool(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1, ws) == 1            # ... + average pool: tile_cfg 11

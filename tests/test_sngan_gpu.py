@@ -397,7 +397,7 @@ def test_stacked_forward_with_a_batch_size_not_divisible_by_four():
     """--batch_size 50, n_dis 5 (+ the generator's own batch): six groups of 50 images.  At 8x8 a group is 3200 GEMM rows,
     not a multiple of the Winograd kernel's 256-row tile although the launch is large enough to be given that kernel:
     the launch must fall back to a tile that divides the group (diagan_conv_gemm_pick_cfg_grouped), not raise."""
-    _stacked_forward_check('cifar10', 1e-5, B=50, n=6, short=True)
+    _stacked_forward_check('cifar10', 2e-5, B=50, n=6, short=True)
 
 
 def _stacked_forward_check(dataset, tol, B=8, n=3, short=False):

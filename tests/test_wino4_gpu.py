@@ -1,0 +1,134 @@
+"""GPU: the Winograd F(4x4,3x3) kernel (tile_cfg 13, csrc/conv_wino4.hip) against float64 PyTorch references of the same
+convolution (F.conv2d and its input gradient, as used by mimicry's GBlock / DBlock: predefined_models.py:19-21,38-40,
+57-59,76-78) with every fused prologue and epilogue, against the F(2x2,3x3) kernel, and the automatic selection.
+Tolerance: 1e-4 of the output scale -- the 6x6 transforms (interpolation points 0, +-1, +-2, inf) put the kernel at
+~1e-5 (tools/micro/wino_f4_error.py: fp32 F(4x4) against float64 on CPU gives the same figure), against ~6e-7 for F(2x2)
+and ~1e-6 for the implicit GEMM; north_star's bar is 1e-3 on losses."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_conv_gpu import close, nchw, nhwc, ref_pro
+from test_wino_gpu import _fp32_mode, make
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _fp32_mode(), reason="Winograd kernels belong to the fp32 MFMA mode")]
+
+TOL = 1e-4
+# B, H, W, Ci, Co: ragged tile counts (tiles % 32 != 0), non-square images, Co not a multiple of 64, SNGAN block shapes
+CASES = [(4, 8, 8, 64, 64), (3, 4, 12, 16, 24), (5, 16, 16, 128, 72), (2, 32, 32, 256, 256), (8, 64, 64, 64, 64),
+         (16, 4, 4, 512, 256), (1, 4, 4, 8, 4)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("pro", [0, 1, 2, 3, 4])
+def test_forward_all_prologues_with_bias_and_residual(case, pro):
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(1)
+    bias, scale, shift = torch.randn(Co, generator=g), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    ref = F.conv2d(ref_pro(x.double(), pro, scale.double(), shift.double()), w.double(), bias.double(), padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(),
+                   pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=13)
+    close(nchw(y), ref + res.double(), tol=TOL)
+
+
+@pytest.mark.parametrize("case", CASES[:6])
+def test_data_gradient_with_mask_and_residual(case):
+    """dx = conv^T(dy) (+ residual) * relu'(mask): the backward of DBlock's / GBlock's c1, c2 (taps reversed in U)"""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(2)
+    dy = torch.randn(B, Co, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double(), padding=1).backward(dy.double())
+    msk, res = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Ci, H, W, generator=g)
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), residual=nhwc(res).cuda(), mask_src=nhwc(msk).cuda(), tile_cfg=13)
+    close(nchw(dx), (xr.grad + res.double()) * (msk > 0).double(), tol=TOL)
+    dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), mask_src=nhwc(msk).cuda(), mask_slope=0.2, tile_cfg=13)
+    close(nchw(dx), torch.where(msk > 0, xr.grad, 0.2 * xr.grad), tol=TOL)
+
+
+def test_pair_scales_res_relu_statistics_and_groups():
+    """the epilogue / prologue variants the networks use: per-half 1/sigma of a paired D(real) | D(fake) pass, DBlock's
+    relu(shortcut), BatchNorm statistics from the epilogue, one BatchNorm row per stacked batch (grouped prologue)"""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = 8, 16, 16, 64, 128
+    geom, x, w, wp = make(B, H, W, Ci, Co, seed=3)
+    g = torch.Generator().manual_seed(4)
+    xg = nhwc(x).cuda()
+    ref = F.conv2d(F.relu(x.double()), w.double(), padding=1)
+    s0, s1 = torch.tensor([0.7]), torch.tensor([1.9])
+    y = C.conv_fwd(geom, xg, wp, pro=(C.PRO_RELU, None, None), row_scale=(s0.cuda(), s1.cuda()), tile_cfg=13)
+    half = torch.cat([ref[: B // 2] * 0.7, ref[B // 2:] * 1.9])
+    close(nchw(y), half, tol=TOL)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, xg, wp, pro=(C.PRO_RELU, None, None), residual=nhwc(res).cuda(), res_relu=True, tile_cfg=13)
+    close(nchw(y), ref + F.relu(res.double()), tol=TOL)
+    bias = torch.randn(Co, generator=g)
+    y, st = C.conv_fwd(geom, xg, wp, bias=bias.cuda(), tile_cfg=13, want_stats=True)
+    full = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    assert st[1] == B * H * W // 512 and st[0].shape == (st[1], 2, Co)
+    close(st[0][:, 0].sum(0), full.sum((0, 2, 3)), tol=TOL)
+    close(st[0][:, 1].sum(0), (full * full).sum((0, 2, 3)), tol=TOL)
+    close(st[0][:, 0].sum(0), y.double().sum((0, 1, 2)), tol=1e-5)       # the sums are of the kernel's own outputs
+    groups = 4
+    sc, sh = torch.rand(groups, Ci, generator=g) + 0.5, torch.randn(groups, Ci, generator=g) * 0.3
+    y = C.conv_fwd(geom, xg, wp, pro=(C.PRO_AFFINE_RELU, sc.cuda(), sh.cuda(), B // groups), tile_cfg=13)
+    parts = [F.conv2d(ref_pro(x[i * 2: i * 2 + 2].double(), 2, sc[i].double(), sh[i].double()), w.double(), padding=1)
+             for i in range(groups)]
+    close(nchw(y), torch.cat(parts), tol=TOL)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (3, 4, 12, 16, 24), (5, 16, 16, 128, 72)])
+def test_half_resolution_residual_is_upsampled_in_the_epilogue(case):
+    """GBlock: c2's output + bilinear x2 of the low-resolution shortcut conv (mimicry GBlock._upsample_conv on the
+    shortcut, align_corners=False), blended in the epilogue from the half-resolution tensor"""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=5)
+    g = torch.Generator().manual_seed(6)
+    bias = torch.randn(Co, generator=g)
+    lo = torch.randn(B, Co, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1) + \
+        F.interpolate(lo.double(), scale_factor=2, mode='bilinear', align_corners=False)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(lo).cuda(), res_up=True, tile_cfg=13)
+    close(nchw(y), ref, tol=TOL)
+
+
+def test_auto_selection_split_k_and_refusals():
+    """tile_cfg 0 takes the F(4x4) kernel for a qualifying launch of >= 512 workgroups (diagan_conv_gemm_pick_cfg_geom), F(2x2)
+    or the implicit GEMM otherwise; DIAGAN_WINO4 / set_winograd4(False) keeps it out; a forced split over the input channels
+    goes through the shared second stage; geometries the kernel cannot take are refused with the reason"""
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    pick = nat.fn("diagan_conv_gemm_pick_cfg_geom")
+    ws = C._splitk_ws(torch.device('cuda', 0)).numel()
+    assert pick(64, 32, 32, 256, 32, 32, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 13
+    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 9
+    C.set_winograd4(False)
+    try:
+        assert pick(64, 32, 32, 256, 32, 32, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 9
+    finally:
+        C.set_winograd4(None)
+    geom, x, w, wp = make(64, 32, 32, 64, 128, seed=7)
+    ref = F.conv2d(x[:4].double(), w.double(), padding=1)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp)                     # automatic: 1024 workgroups of F(4x4)
+    close(nchw(y[:4]), ref, tol=TOL)
+    a = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=13)
+    assert torch.equal(a, y)
+    b = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=9)
+    close(a, b, tol=TOL)
+    nat.call("diagan_conv_gemm_tune", 2, -1, 0)                 # forced split-K (tuning entry point)
+    try:
+        s = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=13)
+    finally:
+        nat.call("diagan_conv_gemm_tune", 0, -1, 0)
+    close(s, a, tol=1e-5)
+    g2, x2, w2, wp2 = make(2, 6, 10, 16, 24)                     # H, W not multiples of 4
+    with pytest.raises(RuntimeError, match="tile_cfg 13"):
+        C.conv_fwd(g2, nhwc(x2).cuda(), wp2, tile_cfg=13)
