@@ -43,6 +43,7 @@ int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_
 int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st);     // conv_wino4.hip: F(4x4,3x3)
 long wino4_ws_floats(int Co, int Ci);
 bool wino4_geom_ok(int Ho, int Wo, int Ci);
+int wino4_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats);
 int launch_wino_s(ConvGemmArgs a, float* ws, hipStream_t st);    // conv_wino_s.hip
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
@@ -1007,8 +1008,12 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     const long wfl = wino4_ws_floats(Co, Ci);
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 13 needs %ld floats of workspace for the transformed weights", wfl);
     int ks = 1;
-    if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats && Ci / 8 / g_force_ksplit >= 1)
+    if (tile_cfg == 0 && !stat_partials) {
+      ks = wino4_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats);
+      if (ks < 1) ks = 1;
+    } else if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats && Ci / 8 / g_force_ksplit >= 1) {
       ks = g_force_ksplit;
+    }
     a.ksplit = ks;
     a.slab = splitk_ws + wfl;
     int rc = launch_wino4(a, splitk_ws, st);
@@ -1116,8 +1121,14 @@ DIAGAN_API int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, 
 // Tile configuration for a full geometry (what diagan_conv_gemm does when tile_cfg == 0): Winograd (9) where the layer
 // qualifies, the workspace holds the transformed weights and the launch has enough workgroups; otherwise the
 // implicit-GEMM choice of diagan_conv_gemm_pick_cfg.  DIAGAN_WINO=0 disables Winograd (A/B runs).
+static int pick_cfg_geom_impl(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                              int up, int Kp, int allow_split, int64_t ws_floats, bool allow_w4);
 DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                               int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats) {
+  return pick_cfg_geom_impl(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow_split, ws_floats, true);
+}
+static int pick_cfg_geom_impl(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                              int up, int Kp, int allow_split, int64_t ws_floats, bool allow_w4) {
   static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
   const int wino = g_wino >= 0 ? g_wino : wino_env;
   // one 512-thread workgroup per CU: below ~3/4 of the chip the implicit GEMM's smaller tiles win (8x8 / 4x4 blocks at
@@ -1129,13 +1140,12 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
     // the staged kernel (32-tile blocks, two workgroups per CU) where its blocks tile the batch
     static const int staged_env = getenv("DIAGAN_WINO_STAGED") ? atoi(getenv("DIAGAN_WINO_STAGED")) : 0;
     static const int min_wgs_s = getenv("DIAGAN_WINO_S_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_S_MIN_WGS")) : 256;
-    // F(4x4,3x3) (conv_wino4.hip, 32 tiles of 4x4 outputs x 64 channels per workgroup, ONE resident workgroup per CU): where the
-    // launch fills the chip at least twice (measured r3: 1.2-1.3x the F(2x2) kernel from 512 workgroups up, 0.67x at 128)
+    // F(4x4,3x3) (conv_wino4.hip, 32 tiles of 4x4 outputs x 64 channels per workgroup, ONE resident workgroup per CU): where its
+    // launch-size policy (wino4_ksplit) expects it ahead of the F(2x2) kernel
     static const int w4_env = getenv("DIAGAN_WINO4") ? atoi(getenv("DIAGAN_WINO4")) : 1;
-    static const int w4_min = getenv("DIAGAN_WINO4_MIN_WGS") ? atoi(getenv("DIAGAN_WINO4_MIN_WGS")) : 512;
     static const int w4_min_ci = getenv("DIAGAN_WINO4_MIN_CI") ? atoi(getenv("DIAGAN_WINO4_MIN_CI")) : 64;
-    if (w4_env && g_wino4 != 0 && wino4_geom_ok(Ho, Wo, Ci) && Ci >= w4_min_ci && ws_floats >= wino4_ws_floats(Co, Ci) &&
-        (long)cdiv((long)B * (Ho >> 2) * (Wo >> 2), 32) * cdiv(Co, 64) >= w4_min)
+    if (allow_w4 && w4_env && g_wino4 != 0 && wino4_geom_ok(Ho, Wo, Ci) && Ci >= w4_min_ci && ws_floats >= wino4_ws_floats(Co, Ci) &&
+        wino4_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats) > 0)
       return 13;
     if (staged_env && wino_s_block(B, Ho, Wo, Ci, 0) &&
         wino_s_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs_s) > 0)
@@ -1155,6 +1165,8 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_grouped(int B, int Hi, int Wi, int Ci, 
                                                  int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats,
                                                  int pro_group_rows) {
   int cfg = diagan_conv_gemm_pick_cfg_geom(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow_split, ws_floats);
+  if (cfg == 13 && pro_group_rows > 0 && pro_group_rows % 512 != 0)       // F(4x4): 512-row tiles; next the F(2x2) kernel's 256
+    cfg = pick_cfg_geom_impl(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow_split, ws_floats, false);
   if (pro_group_rows > 0 && pro_group_rows % diagan_conv_gemm_tile_rows(cfg) != 0) {
     cfg = diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
     if (pro_group_rows % diagan_conv_gemm_tile_rows(cfg) != 0) cfg = 3;

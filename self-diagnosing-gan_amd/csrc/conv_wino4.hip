@@ -52,6 +52,9 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_COL_LATE
 #define W4_COL_LATE 7
 #endif
+#ifndef W4_NT_STORE           // non-temporal output stores
+#define W4_NT_STORE 0
+#endif
 #ifndef W4_PAIR               // MFMAs of two slots interleaved (no back-to-back dependent accumulators)
 #define W4_PAIR 0
 #endif
@@ -156,35 +159,72 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       kbound[c] = ok ? 0x7fffffff : 0;
     }
   }
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+  // raw buffer descriptor {base, stride 0, num_records, flags}.  The six input loads of a step are issued through inline
+  // assembly: the compiler's wait-count pass assumes that LDS-DMA units and ordinary loads return out of order and puts
+  // vmcnt(0) in front of the first use of a loaded register, i.e. it would wait for every weight unit in flight; this way
+  // the ONLY wait is the explicit vmcnt(n) of wait_inputs (vector memory operations of a wave do return in order).
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 xsrc;
+  {
+    const unsigned long long xb = (unsigned long long)a.x;
+    xsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+    xsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffffu));
+    xsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u));
+    xsrc[3] = 0x00020000;
+  }
   const int pro_group_off = a.pro_group_rows > 0 ? ((t0 * 16) / a.pro_group_rows) * g.Ci : 0;
+  i32x4 scsrc = xsrc, shsrc = xsrc;
+  const unsigned poff = (unsigned)(pro_group_off + lq * 4) * 4u;
+  if (affine) {
+    const unsigned long long sb = (unsigned long long)a.pro_scale, hb = (unsigned long long)a.pro_shift;
+    scsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)sb);
+    scsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(sb >> 32) & 0xffffu));
+    shsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)hb);
+    shsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(hb >> 32) & 0xffffu));
+    scsrc[2] = shsrc[2] = 0x7fffffff;       // (the rows are sized by the caller: [groups][Ci])
+  }
   // this thread's V slots: row pass writes planes (lr, j), column pass reads / writes planes (i, lr); plane = (6 i + j) * 2 + quad
-  float* const vrow = smem + ((6 * lr) * 2 + lq) * W4_PS + lt * 4;     // + j * 2 * W4_PS
-  float* const vcol = smem + (lr * 2 + lq) * W4_PS + lt * 4;           // + i * 12 * W4_PS
+  // (the idle lanes lr = 6, 7 of a group point far outside the LDS allocation: the hardware drops such writes and returns
+  //  zeros for such reads -- no branch around the passes, which keeps the K loop one basic block: behind a join the
+  //  compiler's wait-count pass loses track of the in-flight LDS-DMA units and waits for ALL of them before any ds_read)
+  float* const vrow = smem + (lact ? ((6 * lr) * 2 + lq) * W4_PS + lt * 4 : (1 << 22));     // + j * 2 * W4_PS
+  float* const vcol = smem + (lact ? (lr * 2 + lq) * W4_PS + lt * 4 : (1 << 22));           // + i * 12 * W4_PS
 
   float* const ulds = smem + 2 * W4_VSTAGE;
   const float* ublock = ug + (long)nb * nk * W4_U + wave * 9 * 256;
   float* const uslot = ulds + wave * 9 * 256;                          // this wave's nine private units
 
+  // wave-uniform unit address (kernel argument + block / wave / step indices: scalar registers) + the lane's 16 bytes
   auto issue_u = [&](int kk, int s) {
-    const unsigned long long ub = (unsigned long long)(ublock + (long)kk * W4_U + s * 256);
-    const unsigned long long us64 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)ub) |
-                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(ub >> 32)) << 32;
-    const float* up = reinterpret_cast<const float*>(us64) + (unsigned)(lane * 4);
+    const float* up = ublock + (long)kk * W4_U + s * 256 + lane * 4;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)up,
                                      (__attribute__((address_space(3))) void*)(uslot + s * 256), 16, 0, 0);
   };
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   auto issue_x = [&](int kk) {
+    const int soff = kk * (W4K * 4);
 #pragma unroll
     for (int c = 0; c < 6; ++c)
-      ra[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off[c], kk * (W4K * 4), 0));
-    if (affine) {
-      psc = *reinterpret_cast<const f32x4*>(a.pro_scale + pro_group_off + kk * W4K + lq * 4);
-      psh = *reinterpret_cast<const f32x4*>(a.pro_shift + pro_group_off + kk * W4K + lq * 4);
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
+    if (affine) {                     // BatchNorm scale / shift of this lane's channel quad, same mechanism
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(psc) : "v"(poff), "s"(scsrc), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(psh) : "v"(poff), "s"(shsrc), "s"(soff) : "memory");
     }
   };
+#define W4_WAIT_IN(n)                                                                                            \
+  case n:                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(" #n ")"                                                                       \
+                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)::"memory"); \
+    break;
+  // the input loads have landed when at most n younger operations (weight units of the next step) are still in flight
+  auto wait_inputs = [&](int n) {
+    switch (n) {
+      W4_WAIT_IN(0) W4_WAIT_IN(1) W4_WAIT_IN(2) W4_WAIT_IN(3) W4_WAIT_IN(4) W4_WAIT_IN(5) W4_WAIT_IN(6) W4_WAIT_IN(7) W4_WAIT_IN(8)
+      W4_WAIT_IN(9)
+      default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)::"memory");
+    }
+  };
+#undef W4_WAIT_IN
   // prologue on the loaded pixels + row transform + park in the V planes of `stage`
   auto row_pass = [&](int stage) {
 #pragma unroll
@@ -212,25 +252,19 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       ra[c] = v;
     }
     w4_bt(ra);
-    if (lact) {
-      float* vs = vrow + stage * W4_VSTAGE;
+    float* vs = vrow + stage * W4_VSTAGE;
 #pragma unroll
-      for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vs + j * 2 * W4_PS) = ra[j];
-    }
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vs + j * 2 * W4_PS) = ra[j];
   };
   // column transform of column lr, in place (reads what the row pass of this 16-lane group parked)
   auto col_pass = [&](int stage) {
     float* vs = vcol + stage * W4_VSTAGE;
     f32x4 d[6];
-    if (lact) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * 12 * W4_PS);
-    }
+    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * 12 * W4_PS);
     w4_bt(d);
-    if (lact) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vs + i * 12 * W4_PS) = d[i];
-    }
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vs + i * 12 * W4_PS) = d[i];
   };
 
   // wave w owns frequencies f = 9 (w >> 1) + s, s < 9, on column half w & 1
@@ -246,6 +280,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
     for (int s = 0; s < 9; ++s) issue_u(k_begin, s);
     issue_x(k_begin);
+    wait_inputs(0);
     row_pass(0);
     col_pass(0);
   }
@@ -256,8 +291,8 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   const float* const fb_base = uslot + lane * 4;
   // vm-counter bookkeeping: a wave's DMA unit of slot s for step kk + 1 is issued right after slot s of step kk has been
   // consumed and gets a WHOLE step to land -- the wait sits in front of the fragment read of step kk + 1, not at the end
-  // of step kk.  Operations younger than D(kk, s + 1) when fragment s + 1 is about to be read: D(kk, s + 2 .. 8), the NI
-  // input loads of step kk + 1 and D(kk + 1, 0 .. s - 1): 7 + NI in every slot.
+  // of step kk.  Operations younger than D(kk, s + 1) when fragment s + 1 is about to be read: D(kk, s + 2 .. 8), the six
+  // input loads of step kk + 1 (eight with the BatchNorm rows) and D(kk + 1, 0 .. s - 1): 13 (15) in every slot.
 #define W4_WAIT_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
   auto wait_vm = [&](int n) {          // n is a compile-time constant after unrolling: the switch folds to one s_waitcnt
     switch (n) {
@@ -279,7 +314,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       const bool row_now = W4_STAGGER ? ((s == W4_ROW_AT && !late) || (s == W4_ROW_LATE && late)) : s == W4_ROW_AT;
       const bool col_now = W4_STAGGER ? ((s == W4_COL_AT && !late) || (s == W4_COL_LATE && late)) : s == W4_COL_AT;
       if (row_now) {
-        wait_vm(issued);                                  // the input loads have landed (the younger DMAs may still fly)
+        wait_inputs(issued);                              // the input loads have landed (the younger DMAs may still fly)
         if (W4_ON(16)) row_pass(cur ^ 1);
       } else if (col_now) {
         if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
@@ -295,10 +330,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
     for (int s = 0; s < 9; ++s) {
       if (s + 1 < 9) {
-        if (HN) {
-          if (affine) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-        }
+        if (HN) wait_vm(affine ? 15 : 13);
         if (W4_ON(2048)) {
           fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (s + 1) * 2 * W4_PS);
           fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
@@ -332,10 +364,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       const int s0 = 2 * gq, ns = gq < 4 ? 2 : 1;
       if (gq < 4) {
         // next group: slots s0 + 2 (, s0 + 3).  Younger than D(kk, s0 + 3): D(kk, s0 + 4 .. 8) = 5 - s0, NI, D(kk + 1, 0 .. s0 - 1) = s0
-        if (HN) {
-          if (affine) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-        }
+        if (HN) wait_vm(affine ? 13 : 11);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           if (s0 + 2 + u < 9) {
@@ -359,7 +388,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       }
     }
 #endif
-    if (W4_ON(128)) __syncthreads();                       // V of the next step is complete (U is wave-private)
+    // V of the next step is complete (LDS writes: lgkmcnt; U is wave-private and waited for where it is read).  NOT
+    // __syncthreads(): its fence would make the compiler wait for every DMA unit in flight
+    if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
   if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
@@ -452,7 +483,11 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : y[e] * a.mask_slope;
           }
+#if W4_NT_STORE
+          if (W4_ON(1024)) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(ydst + o));
+#else
           if (W4_ON(1024)) *reinterpret_cast<f32x4*>(ydst + o) = y;
+#endif
           else if (y[0] == 123.456f) ydst[o] = y[1];
           if (hs) {
             cs1[p] += y;
@@ -517,6 +552,21 @@ long wino4_ws_floats(int Co, int Ci) { return (long)cdiv(Co, W4N) * W4N * Ci * 3
 
 // geometry the F(4x4,3x3) kernel takes on top of diagan_conv_wino_supported: H and W multiples of 4
 bool wino4_geom_ok(int Ho, int Wo, int Ci) { return !(Ho & 3) && !(Wo & 3) && (Ci & 7) == 0; }
+
+// Launch-size policy (tools/wino4_policy.py on the SNGAN-32 / SNGAN-64 layer shapes, r3): channel splits for this launch, 0 =
+// leave it to the F(2x2) kernel / the implicit GEMM.  One 512-thread workgroup per CU, so what counts is how well the
+// workgroup count fills rounds of 256: >= 192 workgroups run 1.15-1.30x the F(2x2) kernel when both fill their last round
+// equally well (measured 1.27 x the ratio of the two fill factors: 384 workgroups = 1.5 rounds against F(2x2)'s exact 3
+// rounds came out at 0.96x); 96-191 workgroups with >= 32 K-steps split two ways (1.04-1.14x); below that the split-K
+// F(2x2) / implicit-GEMM launches win.
+int wino4_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats) {
+  const long wgs4 = (long)cdiv((long)B * (Ho >> 2) * (Wo >> 2), W4T) * cdiv(Co, W4N);
+  const long wgs2 = (long)cdiv((long)B * (Ho >> 1) * (Wo >> 1), 64) * cdiv(Co, 64);
+  auto fill = [](long w) { return (double)w / (256.0 * ((w + 255) / 256)); };
+  if (wgs4 >= 192) return 1.27 * fill(wgs4) / (wgs2 >= 192 ? fill(wgs2) : 1.0) >= 1.05 ? 1 : 0;
+  if (allow_split && wgs4 * 2 >= 192 && Ci >= 256 && wino4_ws_floats(Co, Ci) + 2L * B * Ho * Wo * Co <= ws_floats) return 2;
+  return 0;
+}
 
 // `a` as prepared by diagan_conv_gemm (dWo / dHo re-made here for the TILE grid); ws: wino4_ws_floats(Co, Ci) floats
 int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {

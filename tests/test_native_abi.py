@@ -64,7 +64,10 @@ def test_launch_selection_queries_are_host_logic():
         assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9  # ... F(2x2,3x3) when that kernel is off
     finally:
         nat.call("diagan_conv_gemm_set_wino4", -1)
-    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 9       # 128 workgroups of F(4x4): too few
+    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 13      # 128 workgroups of F(4x4): split two ways
+    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 0, ws) == 9       # ... not where the epilogue must write statistics
+    assert pick(64, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9       # 64 workgroups: F(2x2) with its own split
+    assert pick(384, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9      # 1.5 rounds against F(2x2)'s exact 3
     assert pick(64, 6, 6, 256, 6, 6, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) not in (13,)   # H, W not multiples of 4
     assert pick(128, 8, 8, 128, 8, 8, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) != 9          # 8x8 / 128 channels: implicit GEMM
     assert pick(64, 16, 16, 128, 8, 8, 128, 3, 3, 2, 1, -1, 1, 1152, 1, ws) != 9         # stride 2
@@ -100,4 +103,7 @@ def test_grouped_prologue_never_gets_a_tile_that_straddles_two_groups():
                 assert grouped(*geo, allow, ws, 0) == pick(*geo, allow, ws)
     # the ADVICE r2 example: batch 50 at 8x8, six stacked batches -> Winograd would be picked, 3200 % 256 != 0
     geo = (300, 8, 8, 256, 8, 8, 256, 3, 3, 1, 1, -1, 1, 2304)
-    assert pick(*geo, 1, ws) == 9 and grouped(*geo, 1, ws, 3200) != 9
+    assert pick(*geo, 1, ws) in (9, 13) and grouped(*geo, 1, ws, 3200) not in (9, 13)
+    # a group that the F(4x4) kernel's 512-row tile does not divide but the F(2x2) kernel's 256 does: batch 12 at 8x8 = 768 rows
+    geo = (24 * 12, 8, 8, 256, 8, 8, 256, 3, 3, 1, 1, -1, 1, 2304)
+    assert pick(*geo, 1, ws) == 13 and grouped(*geo, 1, ws, 768) == 9

@@ -109,7 +109,8 @@ def test_auto_selection_split_k_and_refusals():
     pick = nat.fn("diagan_conv_gemm_pick_cfg_geom")
     ws = C._splitk_ws(torch.device('cuda', 0)).numel()
     assert pick(64, 32, 32, 256, 32, 32, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 13
-    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 9
+    assert pick(64, 16, 16, 256, 16, 16, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 13        # 128 workgroups, split two ways
+    assert pick(64, 16, 16, 128, 16, 16, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9
     C.set_winograd4(False)
     try:
         assert pick(64, 32, 32, 256, 32, 32, 256, 3, 3, 1, 1, -1, 1, 2304, 1, ws) == 9
@@ -117,7 +118,7 @@ def test_auto_selection_split_k_and_refusals():
         C.set_winograd4(None)
     geom, x, w, wp = make(64, 32, 32, 64, 128, seed=7)
     ref = F.conv2d(x[:4].double(), w.double(), padding=1)
-    y = C.conv_fwd(geom, nhwc(x).cuda(), wp)                     # automatic: 1024 workgroups of F(4x4)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp)                     # automatic: 256 workgroups of F(4x4)
     close(nchw(y[:4]), ref, tol=TOL)
     a = C.conv_fwd(geom, nhwc(x).cuda(), wp, tile_cfg=13)
     assert torch.equal(a, y)
@@ -129,6 +130,10 @@ def test_auto_selection_split_k_and_refusals():
     finally:
         nat.call("diagan_conv_gemm_tune", 0, -1, 0)
     close(s, a, tol=1e-5)
+    # a launch the policy splits two ways over the input channels (128 workgroups, 32 K-steps): same result as unsplit
+    geom, x, w, wp = make(64, 16, 16, 256, 256, seed=8)
+    auto = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'))
+    close(auto, C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'), tile_cfg=13), tol=1e-5)
     g2, x2, w2, wp2 = make(2, 6, 10, 16, 24)                     # H, W not multiples of 4
     with pytest.raises(RuntimeError, match="tile_cfg 13"):
         C.conv_fwd(g2, nhwc(x2).cuda(), wp2, tile_cfg=13)
