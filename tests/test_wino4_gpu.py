@@ -133,7 +133,7 @@ def test_auto_selection_split_k_and_refusals():
     # a launch the policy splits two ways over the input channels (128 workgroups, 32 K-steps): same result as unsplit
     geom, x, w, wp = make(64, 16, 16, 256, 256, seed=8)
     auto = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'))
-    close(auto, C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'), tile_cfg=13), tol=1e-5)
+    close(auto, C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'), tile_cfg=13), tol=TOL / 2)
     g2, x2, w2, wp2 = make(2, 6, 10, 16, 24)                     # H, W not multiples of 4
     with pytest.raises(RuntimeError, match="tile_cfg 13"):
         C.conv_fwd(g2, nhwc(x2).cuda(), wp2, tile_cfg=13)

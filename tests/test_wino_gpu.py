@@ -159,7 +159,14 @@ def test_auto_selection_and_agreement_with_the_implicit_gemm():
     kernels agree to rounding on the same inputs"""
     from diagan import _native as nat
     from diagan.ops import conv as C
-    pick = nat.fn("diagan_conv_gemm_pick_cfg_geom")
+    pick_any = nat.fn("diagan_conv_gemm_pick_cfg_geom")
+
+    def pick(*a):                    # the choice between THIS kernel and the implicit GEMM (F(4x4), tile_cfg 13, set aside)
+        C.set_winograd4(False)
+        try:
+            return pick_any(*a)
+        finally:
+            C.set_winograd4(None)
     ws = 16 << 20
     assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 9          # D32 block1.c2 (pair pass)
     assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, -1, 1, 1, 1152, 1, ws) == 9          # its data-gradient
