@@ -20,6 +20,11 @@ PREFETCH_FAKES = os.environ.get("DIAGAN_PREFETCH_FAKES", "1") != "0"
 STACK_G_STEP = os.environ.get("DIAGAN_STACK_G_STEP", "1") != "0"
 
 
+def _world_size():
+    from diagan.trainer import distributed as dist
+    return dist.get_world_size()
+
+
 class BaseModel(FlatNet):
     """Checkpoint I/O with mimicry's file layout: {model_state_dict, optimizer_state_dict,
     global_step} at <directory>/<basename(directory)>_<step>_steps.pth (consumers:
@@ -150,6 +155,7 @@ class BaseGenerator(BaseModel):
         if scaler is not None:
             raise NotImplementedError("amp/GradScaler is not part of the fp32 MI355X path")
         self.zero_grad()
+        self.wgrad_batch.hold = _world_size() > 1      # the weight-gradient reduction overlaps the exchange (sync_grads)
         batch_size = real_batch[0].shape[0]
         fake, gctx = self.generate_images_nhwc(batch_size, device=device, noise=noise, save=True)
         output, dctx = netD.forward_nhwc(fake, netD.training, save=True, need_dgrad=True, need_in_dgrad=True)
@@ -199,6 +205,7 @@ class BaseDiscriminator(BaseModel):
         if scaler is not None:
             raise NotImplementedError("amp/GradScaler is not part of the fp32 MI355X path")
         self.zero_grad()
+        self.wgrad_batch.hold = _world_size() > 1      # the weight-gradient reduction overlaps the exchange (sync_grads)
         real_images = real_batch[0]
         batch_size = real_images.shape[0]
         if getattr(self, 'pair_forward', False) and self.training:

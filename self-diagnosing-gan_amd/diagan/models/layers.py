@@ -537,6 +537,12 @@ class WgradBatch:
         self.launched = {}       # slot -> list of layers launched in the current pass
         self.tables = {}         # (slot, tuple(layer ids)) -> (table tensor, n, total_blocks, any_sn)
         self.slab_generation = None
+        # data parallelism (FlatNet.sync_grads): while `hold` is set, finish() only notes the slot; the reduction then
+        # runs in two halves -- late layers first -- so that the exchange of the first half's slab range is in flight
+        # under the second half's reduction (DDP's bucketed overlap, stylegan2/train_ffhq.py:572-585, for a flat slab)
+        self.hold = False
+        self.pending = []
+        self.overlapped = 0      # updates whose reduction was split (tests)
 
     def _entry(self, layer, slot, M, segments=1, dy_shape=None, x_shape=None, geom=None):
         self.net.flat_grads
@@ -580,9 +586,36 @@ class WgradBatch:
         self.launched.setdefault(slot, []).append(layer)
 
     def finish(self, slot):
+        if self.hold:
+            self.pending.append(slot)
+            return
+        self._finish_layers(slot, self.launched.pop(slot, []))
+
+    def split_for_overlap(self, slot):
+        """(late layers, early layers, cut) of the layers launched in `slot` -- in launch order the backward pass reaches
+        the LAST layers of the network first -- such that every late layer's gradient lies in flat_grads[cut:], every early
+        one's in flat_grads[:cut], and the late part holds about half of the weight-gradient elements; None when the
+        launch order does not partition the slab that way (then the reduction stays in one piece)."""
+        layers = self.launched.get(slot, [])
+        if len(layers) < 2:
+            return None
+        base = self.net.flat_grads.data_ptr()
+        lo = [(l.weight.grad.data_ptr() - base) // 4 for l in layers]
+        hi = [o + self.entries[(l, slot)]['n_elem'] for o, l in zip(lo, layers)]
+        total, acc, h = sum(b - a for a, b in zip(lo, hi)), 0, 0
+        for i in range(len(layers) - 1):
+            acc += hi[i] - lo[i]
+            h = i + 1
+            if 2 * acc >= total:
+                break
+        cut = min(lo[:h])
+        if cut % 4 or any(b > cut for b in hi[h:]) or any(a < cut for a in lo[:h]):
+            return None
+        return layers[:h], layers[h:], cut
+
+    def _finish_layers(self, slot, layers):
         import numpy as np
         from diagan import _native as nat
-        layers = self.launched.pop(slot, [])
         if not layers:
             return
         key = (slot, tuple(id(l) for l in layers))
@@ -668,6 +701,7 @@ class FlatNet(nn.Module):
         if self._flat_grad is None:
             self._build_flat()
         self._flat_grad.zero_()
+        self.wgrad_batch.hold, self.wgrad_batch.pending = False, []
 
     @property
     def flat_params(self):
@@ -690,17 +724,44 @@ class FlatNet(nn.Module):
         (pattern: DistributedDataParallel in stylegan2/train_ffhq.py:572-585).  With the network's FusedAdam given, the
         ranks exchange the SUM and the optimiser applies 1/W as it reads the gradient (no extra pass over the slab);
         async_op leaves the collective in flight on the backend's stream until `optimizer.step()` waits for it, so the
-        next update's forward / backward (phase 2: D_drs after D) runs beside it."""
+        next update's forward / backward (phase 2: D_drs after D) runs beside it.
+        When the train step held back the deferred weight-gradient reduction (`wgrad_batch.hold`), it runs here in two
+        halves, late layers first, and the first half's slab range is exchanged while the second half is reduced."""
         from diagan.trainer import distributed as dist
         world = dist.get_world_size()
-        if world == 1:
+        wb = self.wgrad_batch
+        held, wb.hold, wb.pending = wb.pending, False, []
+        for slot in held[:-1]:
+            wb.finish(slot)
+        last = held[-1] if held else None
+        if world == 1 or optimizer is None or not hasattr(optimizer, 'grad_scale'):
+            if last is not None:
+                wb.finish(last)
+            if world > 1:
+                dist.all_reduce_mean_(self.flat_grads)
             return
-        if optimizer is not None and hasattr(optimizer, 'grad_scale'):
-            optimizer.grad_scale = 1.0 / world
-            work = dist.all_reduce_sum_(self.flat_grads, async_op=async_op)
-            optimizer.pending = work if async_op else None
+        optimizer.grad_scale = 1.0 / world
+        parts = wb.split_for_overlap(last) if last is not None else None
+        if parts is None:
+            if last is not None:
+                wb.finish(last)
+            works = [dist.all_reduce_sum_(self.flat_grads, async_op=async_op)]
         else:
-            dist.all_reduce_mean_(self.flat_grads)
+            # late layers reduced first; their slab range travels while the early layers are reduced
+            late, early, cut = parts
+            wb.launched.pop(last, None)
+            flat = self.flat_grads
+            wb._finish_layers(last, late)
+            works = [dist.all_reduce_sum_(flat[cut:], async_op=True)]
+            wb._finish_layers(last, early)
+            works.append(dist.all_reduce_sum_(flat[:cut], async_op=True))
+            wb.overlapped += 1
+            if not async_op:
+                for w in works:
+                    if w is not None:
+                        w.wait()
+                works = []
+        optimizer.pending = [w for w in works if w is not None] if async_op else None
 
     def export_grads(self):
         """Gradients in the reference's tensor shapes, keyed like state_dict() (tests, debugging)."""

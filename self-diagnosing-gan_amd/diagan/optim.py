@@ -41,8 +41,9 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         self._ensure_state()
         g = self.param_groups[0]
-        if self.pending is not None:         # the gradient exchange issued asynchronously by BaseModel.sync_grads
-            self.pending.wait()
+        if self.pending is not None:         # the gradient exchange(s) issued asynchronously by FlatNet.sync_grads
+            for w in (self.pending if isinstance(self.pending, (list, tuple)) else [self.pending]):
+                w.wait()
             self.pending = None
         if self._capturing:
             # stream capture: the launch reads its hyper-parameters from device row `cursor`, which

@@ -50,7 +50,8 @@ def _worker(rank, world, port, out_dir):
     netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=zd.cuda())
     netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda', noise=zg.cuda())
     torch.cuda.synchronize()
-    torch.save({'D': netD.flat_params.cpu(), 'G': netG.flat_params.cpu()}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.save({'D': netD.flat_params.cpu(), 'G': netG.flat_params.cpu(),
+                'overlapped': (netD.wgrad_batch.overlapped, netG.wgrad_batch.overlapped)}, os.path.join(out_dir, f"r{rank}.pt"))
     torch.distributed.destroy_process_group()
 
 
@@ -60,6 +61,8 @@ def test_two_rank_step_equals_microbatch_emulation(tmp_path):
     mp.spawn(_worker, args=(world, _port(), str(tmp_path)), nprocs=world, join=True)
     r = [torch.load(tmp_path / f"r{k}.pt") for k in range(world)]
     assert torch.equal(r[0]['D'], r[1]['D']) and torch.equal(r[0]['G'], r[1]['G'])   # replicas stay in lock-step
+    # both updates took the two-half reduction: the late layers' slab range was exchanged under the early layers' reduction
+    assert r[0]['overlapped'] == (1, 1) and r[1]['overlapped'] == (1, 1), r[0]['overlapped']
 
     # single-process emulation: per-rank micro-batches, gradients averaged, one optimiser step
     from diagan.models.predefined_models import get_gan_model
