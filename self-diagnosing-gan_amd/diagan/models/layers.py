@@ -602,15 +602,17 @@ class WgradBatch:
         base = self.net.flat_grads.data_ptr()
         lo = [(l.weight.grad.data_ptr() - base) // 4 for l in layers]
         hi = [o + self.entries[(l, slot)]['n_elem'] for o, l in zip(lo, layers)]
-        total, acc, h = sum(b - a for a, b in zip(lo, hi)), 0, 0
-        for i in range(len(layers) - 1):
-            acc += hi[i] - lo[i]
-            h = i + 1
-            if 2 * acc >= total:
-                break
-        cut = min(lo[:h])
-        if cut % 4 or any(b > cut for b in hi[h:]) or any(a < cut for a in lo[:h]):
+        total, acc, best = sum(b - a for a, b in zip(lo, hi)), 0, None
+        for h in range(1, len(layers)):            # late = layers[:h]: a valid cut leaves every early layer below it
+            acc += hi[h - 1] - lo[h - 1]
+            cut = min(lo[:h])
+            if cut % 4 == 0 and all(b <= cut for b in hi[h:]):
+                score = abs(2 * acc - total)
+                if best is None or score < best[0]:
+                    best = (score, h, cut)
+        if best is None:
             return None
+        _, h, cut = best
         return layers[:h], layers[h:], cut
 
     def _finish_layers(self, slot, layers):
