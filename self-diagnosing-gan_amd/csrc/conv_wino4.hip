@@ -10,7 +10,7 @@
 //
 // One workgroup = 512 threads = 8 waves = 32 tiles (512 output pixels) x 64 output channels, one per CU (146 KB of LDS).
 //   * K loop over input channels in steps of 8.  Per step the 36 "frequency" GEMMs  M_f[32 x 64] += V_f[32 x 8] U_f[64 x 8]^T
-//     run as v_mfma_f32_32x32x2_f32: wave w owns the 9 frequencies f = 9 (w >> 1) .. + 8 on column half w & 1
+//     run as v_mfma_f32_32x32x2_f32: wave w owns a 3 x 3 block of the 6 x 6 frequencies (group w & 3) on column half w >> 2
 //     (9 accumulator tiles = 144 registers).
 //   * U (transformed weights, written once per launch by wino4_weight_kernel in the order the waves consume it): every U
 //     element is used by exactly ONE wave, so a wave fetches its own nine 1 KB units per step by LDS-DMA into wave-private
@@ -19,7 +19,7 @@
 //   * V (transformed input): thread (tile, channel quad, patch row r < 6) loads its 6 pixels x 4 channels (prologue
 //     applied here), transforms along the row and parks the result in the V planes; thread (tile, quad, column j) of the
 //     same 16-lane group then transforms its column in place (LDS operations of one wave execute in order: no barrier).
-//     Planes are [f][quad][tile][4 channels] with a 132-float stride: a quarter wave's 16 ds_write_b128 hit 64 banks once;
+//     Planes are [quad][j][i (+ 1 dummy)][tile][4 channels] with a 132-float stride: conflict-free ds_write_b128 in both passes;
 //     an MFMA fragment (lane = tile, k half = quad) is ONE conflict-free ds_read_b128 per frequency and step.
 //   * epilogue: the 36 products of a (tile, channel) meet in LDS ([f][tile][32 channels] = 144 KB, one column half at a
 //     time); thread (tile, channel quad, row pair) applies A^T . A and the usual epilogue (per-half 1/sigma, bias, residual
@@ -35,7 +35,11 @@ constexpr int W4T = 32;                 // 4x4-output tiles per workgroup
 constexpr int W4N = 64;                 // output channels per workgroup
 constexpr int W4K = 8;                  // input channels per K-step
 constexpr int W4_PS = 132;              // floats between consecutive V planes (32 tiles x 4 channels + 4 of padding)
-constexpr int W4_VSTAGE = 72 * W4_PS;   // V planes of one stage: 36 frequencies x 2 channel quads
+// V plane of frequency (i, j) and channel quad q: q * 42 + 7 j + i.  Row stride 1 plane and column stride 7 planes (one
+// dummy plane per column) are both odd multiples of 4 banks with the 132-float plane stride, so the six lanes of a group hit
+// six different bank quads in the row pass (lanes differ in i) AND in the column pass (lanes differ in j): the 13-cycle
+// ds_write_b128 stays at its conflict-free cost (a 12-plane row stride put lanes i and i + 2 on the same banks: 3-way).
+constexpr int W4_VSTAGE = 84 * W4_PS;   // V planes of one stage: 2 channel quads x 42
 constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency, column half) of 64 lanes x 4 floats
 #ifndef W4_ROW_AT
 #define W4_ROW_AT 3
@@ -58,10 +62,11 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_PAIR               // MFMAs of two slots interleaved (no back-to-back dependent accumulators)
 #define W4_PAIR 0
 #endif
-constexpr int W4_LDS_FLOATS = 2 * W4_VSTAGE + W4_U;      // 149 760 bytes (the epilogue's 36 x 32 x 32 floats fit inside)
+constexpr int W4_LDS_FLOATS = 2 * W4_VSTAGE + W4_U;      // 162 432 bytes of the 163 840 (the epilogue's 36 x 32 x 32 floats fit inside)
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 6 i + j, in the order the main kernel's waves consume it:
-// [64-column block][K-step][unit = wave * 9 + slot][lane = k half * 32 + column][4 channels], wave = (f / 9) * 2 + column half.
+// [64-column block][K-step][unit = wave * 9 + slot][lane = k half * 32 + column][4 channels], wave = group * 2 + column half,
+// group = (i / 3) * 2 + j / 3 (a 3 x 3 block of the 6 x 6 frequencies), slot = 3 (i % 3) + j % 3.
 // flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
 __global__ __launch_bounds__(64) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
                                                           int Kp, int flip) {
@@ -94,22 +99,34 @@ __global__ __launch_bounds__(64) void wino4_weight_kernel(const float* __restric
     gt(t[0][i], t[1][i], t[2][i], u);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const int f = i * 6 + j, unit = ((f / 9) * 2 + nh) * 9 + f % 9;
+      // wave group g owns the 3 x 3 block of frequencies i in 3 (g >> 1) .. + 2, j in 3 (g & 1) .. + 2; slot 3 (i % 3) + j % 3
+      const int unit = ((((i / 3) * 2 + j / 3) * 2 + nh) * 9) + (i % 3) * 3 + j % 3;
       *reinterpret_cast<f32x4*>(base + unit * 256) = u[j];
     }
   }
 }
 
-// 1-D input transform B^T (6 -> 6), in place
-__device__ __forceinline__ void w4_bt(f32x4* d) {
-  const f32x4 t0 = 4.f * d[0] - 5.f * d[2] + d[4];
-  const f32x4 t5 = 4.f * d[1] - 5.f * d[3] + d[5];
-  const f32x4 a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = d[3] - d[1];
+// 1-D input transform B^T (6 -> 6), in place.  Every line is a * K + b with a SCALAR K the compiler cannot see through
+// (W4Consts: values parked in scalar registers behind an empty asm), so each becomes one v_pk_fma_f32 per channel pair --
+// 12 per pair, 24 per call; written with literal constants the compiler turns the +-1 / +-2 products back into
+// subtractions and sign flips that it does not pack (24 v_sub_f32 + 20 v_xor_b32 per call on top of the packed ones).
+struct W4Consts {
+  float m1, p1, m2, p2, m4, p4, m5;
+};
+__device__ __forceinline__ W4Consts w4_consts() {
+  W4Consts k = {-1.f, 1.f, -2.f, 2.f, -4.f, 4.f, -5.f};
+  asm volatile("" : "+s"(k.m1), "+s"(k.p1), "+s"(k.m2), "+s"(k.p2), "+s"(k.m4), "+s"(k.p4), "+s"(k.m5));
+  return k;
+}
+__device__ __forceinline__ void w4_bt(f32x4* d, const W4Consts& k) {
+  const f32x4 t0 = d[0] * k.p4 + (d[2] * k.m5 + d[4]);
+  const f32x4 t5 = d[1] * k.p4 + (d[3] * k.m5 + d[5]);
+  const f32x4 a = d[2] * k.m4 + d[4], b = d[1] * k.m4 + d[3], c = d[2] * k.m1 + d[4], e = d[1] * k.m1 + d[3];
   d[0] = t0;
-  d[1] = a + b;
-  d[2] = a - b;
-  d[3] = c + 2.f * e;
-  d[4] = c - 2.f * e;
+  d[1] = b * k.p1 + a;
+  d[2] = b * k.m1 + a;
+  d[3] = e * k.p2 + c;
+  d[4] = e * k.m2 + c;
   d[5] = t5;
 }
 
@@ -187,11 +204,12 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   // (the idle lanes lr = 6, 7 of a group point far outside the LDS allocation: the hardware drops such writes and returns
   //  zeros for such reads -- no branch around the passes, which keeps the K loop one basic block: behind a join the
   //  compiler's wait-count pass loses track of the in-flight LDS-DMA units and waits for ALL of them before any ds_read)
-  float* const vrow = smem + (lact ? ((6 * lr) * 2 + lq) * W4_PS + lt * 4 : (1 << 22));     // + j * 2 * W4_PS
-  float* const vcol = smem + (lact ? (lr * 2 + lq) * W4_PS + lt * 4 : (1 << 22));           // + i * 12 * W4_PS
+  float* const vrow = smem + (lact ? (lq * 42 + lr) * W4_PS + lt * 4 : (1 << 22));          // + j * 7 * W4_PS
+  float* const vcol = smem + (lact ? (lq * 42 + 7 * lr) * W4_PS + lt * 4 : (1 << 22));      // + i * W4_PS
 
   float* const ulds = smem + 2 * W4_VSTAGE;
-  const float* ublock = ug + (long)nb * nk * W4_U + wave * 9 * 256;
+  // (weight units are stored [group][column half]: this wave's nine are unit block (wave & 3) * 2 + (wave >> 2))
+  const float* ublock = ug + (long)nb * nk * W4_U + ((wave & 3) * 2 + (wave >> 2)) * 9 * 256;
   float* const uslot = ulds + wave * 9 * 256;                          // this wave's nine private units
 
   // wave-uniform unit address (kernel argument + block / wave / step indices: scalar registers) + the lane's 16 bytes
@@ -200,9 +218,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)up,
                                      (__attribute__((address_space(3))) void*)(uslot + s * 256), 16, 0, 0);
   };
+  const W4Consts kc = w4_consts();
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   auto issue_x = [&](int kk) {
-    const int soff = kk * (W4K * 4);
+    const int soff = __builtin_amdgcn_readfirstlane(kk * (W4K * 4));
 #pragma unroll
     for (int c = 0; c < 6; ++c)
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
@@ -251,24 +270,26 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       }
       ra[c] = v;
     }
-    w4_bt(ra);
+    w4_bt(ra, kc);
     float* vs = vrow + stage * W4_VSTAGE;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vs + j * 2 * W4_PS) = ra[j];
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vs + j * 7 * W4_PS) = ra[j];
   };
   // column transform of column lr, in place (reads what the row pass of this 16-lane group parked)
   auto col_pass = [&](int stage) {
     float* vs = vcol + stage * W4_VSTAGE;
     f32x4 d[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * 12 * W4_PS);
-    w4_bt(d);
+    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * W4_PS);
+    w4_bt(d, kc);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vs + i * 12 * W4_PS) = d[i];
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vs + i * W4_PS) = d[i];
   };
 
-  // wave w owns frequencies f = 9 (w >> 1) + s, s < 9, on column half w & 1
-  const int grp = wave >> 1, nh = wave & 1;
+  // wave w owns the 3 x 3 frequency block of group w & 3 on column half w >> 2
+  // (column half = wave >> 2: the two waves of a SIMD, w and w + 4, then sit in different halves, and each epilogue phase
+  //  below keeps one wave per SIMD busy)
+  const int grp = wave & 3, nh = wave >> 2;
   f32x16 acc[9];
 #pragma unroll
   for (int s = 0; s < 9; ++s)
@@ -287,7 +308,8 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const float* const fa_base = smem + ((9 * grp) * 2 + kh) * W4_PS + fi * 4;
+  const int fi0 = 3 * (grp >> 1), fj0 = 3 * (grp & 1);      // this wave's block of frequencies
+  const float* const fa_base = smem + (kh * 42 + 7 * fj0 + fi0) * W4_PS + fi * 4;     // slot s = 3 di + dj: + (7 dj + di) planes
   const float* const fb_base = uslot + lane * 4;
   // vm-counter bookkeeping: a wave's DMA unit of slot s for step kk + 1 is issued right after slot s of step kk has been
   // consumed and gets a WHOLE step to land -- the wait sits in front of the fragment read of step kk + 1, not at the end
@@ -332,7 +354,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       if (s + 1 < 9) {
         if (HN) wait_vm(affine ? 15 : 13);
         if (W4_ON(2048)) {
-          fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (s + 1) * 2 * W4_PS);
+          fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (7 * ((s + 1) % 3) + (s + 1) / 3) * W4_PS);
           fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
         }
       }
@@ -356,7 +378,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     fb[0][0] = *reinterpret_cast<const f32x4*>(fb_base);
     // (D(kk, 1): one more unit must have landed than the top-of-step wait guarantees)
     if (HN) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    fa[0][1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + 2 * W4_PS);
+    fa[0][1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + 7 * W4_PS);
     fb[0][1] = *reinterpret_cast<const f32x4*>(fb_base + 256);
     if (HN && W4_ON(32)) issue_x(kk + 1);
 #pragma unroll
@@ -368,7 +390,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           if (s0 + 2 + u < 9) {
-            fa[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (s0 + 2 + u) * 2 * W4_PS);
+            fa[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (7 * ((s0 + 2 + u) % 3) + (s0 + 2 + u) / 3) * W4_PS);
             fb[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fb_base + (s0 + 2 + u) * 256);
           }
       }
@@ -409,13 +431,23 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   float* ydst = raw ? a.slab + (long)blockIdx.y * a.M * g.Co : a.y;
   const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
   const int et = tid >> 4, eq = (tid >> 1) & 7, eh = tid & 1;         // tile, channel quad (of a 32-column half), row pair
-  // this thread's tile
+  // this thread's tile and its 2 x 4 output pixels: ONE 32-bit byte offset per pass, the pixels' distances are wave-uniform
+  // (scalar offsets of raw buffer loads / stores)
   const int gt = t0 + et;
   const bool tv = gt < MT;
   const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);
   const int tx = (tv ? gt : 0) - (int)q1 * TW;
   const unsigned eb = fdiv(q1, a.dHo);
   const int ty = (int)q1 - (int)eb * TH;
+  const int oy0 = 4 * ty + 2 * eh, ox0 = 4 * tx;
+  const int prow0 = ((int)eb * g.Ho + oy0) * g.Wo + ox0;              // pixel (GEMM row) index of the first of them
+  const float scv = prow0 < split ? sc0 : sc1;                        // (the halves of a paired pass are whole images)
+  const int ybytes = (int)((unsigned)a.M * (unsigned)g.Co * 4u);
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(ydst, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0, hr && !a.res_up ? ybytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask_src), 0, hm ? ybytes : 0, 0x00020000);
+  const int pixb = g.Co * 4, rowb = g.Wo * pixb;                      // bytes to the next pixel / the next image row
   float* ss = smem;
   f32x4 cs1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, cs2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -426,13 +458,16 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = 8 * (e >> 2) + 4 * kh + (e & 3);
-          ss[((9 * grp + s) * 32 + m) * 32 + fi] = acc[s][e];
+          ss[((6 * (fi0 + s / 3) + fj0 + s % 3) * 32 + m) * 32 + fi] = acc[s][e];
         }
     }
     __syncthreads();
     const int n = n0 + p * 32 + eq * 4;
     const bool ok = tv && n < g.Co;
-    // s[a][j] = sum_i A^T[a][i] M[i][j] for this thread's two rows a = 2 eh, 2 eh + 1
+    const unsigned voff = ok ? (unsigned)(prow0 * g.Co + n) * 4u : 0x80000000u;   // (nothing to store: beyond the descriptor)
+    // s[a][j] = sum_i A^T[a][i] M[i][j] for this thread's two rows a = 2 eh, 2 eh + 1:
+    //   a = 0: m0 + (m1 + m2) + (m3 + m4)        a = 1: (m1 - m2) + 2 (m3 - m4)
+    //   a = 2: (m1 + m2) + 4 (m3 + m4)           a = 3: (m1 - m2) + 8 (m3 - m4) + m5
     f32x4 sr[2][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -450,49 +485,44 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (!raw && a.bias && ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
-    if (ok) {
 #pragma unroll
-      for (int ar = 0; ar < 2; ++ar) {
-        const f32x4* s6 = sr[ar];
-        const f32x4 pp = s6[1] + s6[2], qq = s6[1] - s6[2], rr = s6[3] + s6[4], tt = s6[3] - s6[4];
-        f32x4 y4[4];
-        y4[0] = s6[0] + pp + rr;
-        y4[1] = qq + 2.f * tt;
-        y4[2] = pp + 4.f * rr;
-        y4[3] = qq + 8.f * tt + s6[5];
-        const int oy = 4 * ty + 2 * eh + ar;
+    for (int ar = 0; ar < 2; ++ar) {
+      const f32x4* s6 = sr[ar];
+      const f32x4 pp = s6[1] + s6[2], qq = s6[1] - s6[2], rr = s6[3] + s6[4], tt = s6[3] - s6[4];
+      f32x4 y4[4];
+      y4[0] = s6[0] + pp + rr;
+      y4[1] = qq + 2.f * tt;
+      y4[2] = pp + 4.f * rr;
+      y4[3] = qq + 8.f * tt + s6[5];
 #pragma unroll
-        for (int bc = 0; bc < 4; ++bc) {
-          const int ox = 4 * tx + bc;
-          const int prow = ((int)eb * g.Ho + oy) * g.Wo + ox;           // pixel (GEMM row) index
-          const long o = (long)prow * g.Co + n;
-          f32x4 y = raw ? y4[bc] : y4[bc] * (prow < split ? sc0 : sc1) + bv;
-          if (hr) {
-            f32x4 r;
-            if (a.res_up) {
-              r = residual_up2(a.residual, (int)eb, oy, ox, g.Ho >> 1, g.Wo >> 1, g.Co, n);
-            } else {
-              r = *reinterpret_cast<const f32x4*>(a.residual + o);
+      for (int bc = 0; bc < 4; ++bc) {
+        const int soff = ar * rowb + bc * pixb;
+        f32x4 y = raw ? y4[bc] : y4[bc] * scv + bv;
+        if (hr) {
+          f32x4 r;
+          if (a.res_up) {
+            r = ok ? residual_up2(a.residual, (int)eb, oy0 + ar, ox0 + bc, g.Ho >> 1, g.Wo >> 1, g.Co, n) : f32x4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 #pragma unroll
-              for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
-            }
-            y += r;
+            for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
           }
-          if (hm) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask_src + o);
+          y += r;
+        }
+        if (hm) {
+          const f32x4 mk = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(msrc, voff, soff, 0));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : y[e] * a.mask_slope;
-          }
-#if W4_NT_STORE
-          if (W4_ON(1024)) __builtin_nontemporal_store(y, reinterpret_cast<f32x4*>(ydst + o));
-#else
-          if (W4_ON(1024)) *reinterpret_cast<f32x4*>(ydst + o) = y;
+          for (int e = 0; e < 4; ++e) y[e] = mk[e] > 0.f ? y[e] : y[e] * a.mask_slope;
+        }
+#ifdef DIAGAN_WINO_ABLATE
+        if (!W4_ON(1024)) {
+          if (y[0] == 123.456f) ydst[0] = y[1];
+        } else
 #endif
-          else if (y[0] == 123.456f) ydst[o] = y[1];
-          if (hs) {
-            cs1[p] += y;
-            cs2[p] += y * y;
-          }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), ysrc, voff, soff, 0);
+        if (hs && ok) {
+          cs1[p] += y;
+          cs2[p] += y * y;
         }
       }
     }
