@@ -37,7 +37,6 @@ sys.path.insert(0, os.path.join(ROOT, "self-diagnosing-gan_amd"))
 import torch
 
 MFMA_F32_PEAK = 157.3e12      # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK = 2500e12      # same guide: dense bf16 MFMA peak; the bf16x6 mode spends 6 bf16 products per fp32 product
 HBM_PEAK = 8.0e12
 
 WORKLOADS = {
@@ -198,7 +197,7 @@ def executed_flop(name, flop):
         return flop * 0.25
     if name.endswith("[pooled gradient]"):     # weight gradient through the average pool as a strided convolution over box sums
         return flop * 0.25
-    return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wino_s_kernel", "conv_wgrad_wino_kernel")) else flop
+    return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel")) else flop
 
 
 def conv_block_excluded(name, shape):
@@ -359,8 +358,7 @@ def main():
     ap.add_argument("--n_dis", type=int, default=5)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timer", action="store_true")
-    ap.add_argument("--no_x6_leg", action="store_true",
-                    help="skip the extra (un-scored) measurement of the same steps in the experimental bf16x6 MFMA mode")
+    ap.add_argument("--no_x6_leg", action="store_true", help="(no effect: the bf16x6 mode and its bench leg were retired in round 3)")
     ap.add_argument("--no_sngan64_leg", action="store_true",
                     help="skip the extra (un-scored) SNGAN-64 conv-block roofline leg of the default sngan32 run")
     ap.add_argument("--graph", action="store_true",
@@ -475,29 +473,10 @@ def main():
         if dominant_outside:
             timer = full
         dist.synchronize()
-    # Extra leg, reported beside the scored number and never mixed into it: the same steps with the conv GEMMs in the
-    # experimental "bf16x6" mode (every fp32 operand split exactly into three bf16 pieces, six exact piece products
-    # accumulated in fp32 on the bf16 matrix pipe; error against float64 at or below the fp32 MFMA's).
-    x6, x6_error = None, None
-    if world == 1 and not args.no_x6_leg and not args.graph and C.get_mfma_mode() == 0:
-        try:
-            C.set_mfma_mode('bf16x6')
-            for _ in range(max(args.warmup, 2)):
-                eager_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                eager_step()
-            torch.cuda.synchronize()
-            x6 = time.perf_counter() - t1
-        except Exception as e:          # the extra leg must never cost the scored line
-            x6, x6_error = None, repr(e)
-        finally:
-            C.set_mfma_mode(0)
     # Extra leg: north_star's >= 60 % MFMA-roofline target on the SNGAN-64 conv blocks (default workload, one GPU only)
     s64, s64_error = None, None
     if (world == 1 and args.workload == 'sngan32' and args.phase == 1 and not args.no_sngan64_leg and not args.graph
-            and not args.no_kernel_timer and C.get_mfma_mode() == 0):
+            and not args.no_kernel_timer):
         try:
             s64 = sngan64_leg(args, device)
         except Exception as e:          # the extra leg must never cost the scored line
@@ -519,7 +498,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if C.get_mfma_mode() == 0 else "f32 (exact 3-way bf16 operand split, 6 products, f32 accumulate)",
+        "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": desc + (" + D_drs (phase 2)" if args.phase == 2 else ""),
                    "global_batch": args.batch_size * world, "n_dis": args.n_dis, "loss_type": args.loss_type,
@@ -541,8 +520,7 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
             except Exception:
                 traffic = None
-        x6_run = C.get_mfma_mode() == 1      # whole run in the experimental mode (DIAGAN_MFMA=bf16x6): price it as such
-        peak = MFMA_BF16_PEAK / 6 if x6_run else MFMA_F32_PEAK
+        peak = MFMA_F32_PEAK
         line["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak / 1e12, 1),
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4), "frac_executed": round(achieved * 1e12 / peak, 4),
@@ -567,14 +545,6 @@ def main():
         line["sngan64_conv_blocks"] = s64
     elif s64_error:
         line["sngan64_conv_blocks"] = {"error": s64_error}
-    if x6_error:
-        line["bf16x6_mode"] = {"error": x6_error}
-    if x6 is not None:
-        line["bf16x6_mode"] = {
-            "value": round(args.batch_size * args.steps / x6, 2), "unit": "images/s",
-            "ms_per_step": round(x6 / args.steps * 1e3, 3),
-            "note": "NOT the scored value: same steps, conv GEMMs via exact 3-way bf16 operand split + 6 piece products "
-                    "(fp32 accumulate) on the bf16 matrix pipe; opt-in (DIAGAN_MFMA=bf16x6); parity suite passes in this mode"}
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dataset, res, args.loss_type, args.batch_size, args.n_dis)
         line["ldr_scorer"] = scorer_leg(device)

@@ -105,12 +105,6 @@ int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bi
                        const float* pro_scale, const float* pro_shift, int pro_mode, int B, int H, int W, int Ci,
                        int dr, int off, int Kp, int group_imgs, void* stream);
 /* group_imgs > 0: image b reads the affine prologue of group b / group_imgs (see diagan_conv_gemm pro_group_rows). */
-/* Arithmetic of diagan_conv_gemm: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32, the default, what every parity claim is
- * made with); 1 = "bf16x6", experimental: every fp32 operand split exactly into three bf16 pieces, six exact piece
- * products per element accumulated in fp32 on the bf16 matrix pipe (error at or below the fp32 MFMA's).  Also
- * selectable with DIAGAN_MFMA=bf16x6 in the environment.  (No reference counterpart: cuDNN's math-mode switch.) */
-int diagan_set_mfma_mode(int mode);
-int diagan_get_mfma_mode(void);
 
 /* Weight (+ bias) gradient of the same layer, Ci in {64,128,256}, Kp == 9*Ci: the whole [4][Kp] gradient lives in
  * each wave's accumulators; writes diagan_conv3x3_co4_wgrad_splits(B, H) partial slabs
@@ -126,7 +120,8 @@ int diagan_conv3x3_co4_wgrad(const float* dy, const float* x, float* slab, int64
  * no stat_partials) */
 int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split);
 /* Tile configurations: 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 / 8 = 64x64 / 128x64 with double-buffered MFMA fragments
- * (2, 4 and 6 -- other 128x64 wave layouts, 64-wide K-steps -- were retired after the round-2 sweeps); rows / columns of a
+ * (2, 4, 6 -- other 128x64 wave layouts, 64-wide K-steps -- and 10 -- a staged-input Winograd kernel, 10 % slower than 9 -- were
+ * retired: profiles/r02_wino_ablation.md); rows / columns of a
  * configuration (0 for an unknown one): */
 int diagan_conv_gemm_tile_rows(int cfg);
 int diagan_conv_gemm_tile_cols(int cfg);
@@ -137,12 +132,6 @@ int diagan_conv_gemm_tile_cols(int cfg);
  * per workgroup (stat_partials / pro_group_rows granularity).  Returns 1 when the geometry qualifies. */
 int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
                                int up);
-/* tile_cfg 10: the same Winograd kernel with a staged input (csrc/conv_wino_s.hip): 256-thread workgroups of 32 tiles
- * (8x4 tiles of one image, 4x4 of two, ...) x 64 columns, two per CU; the block's input region goes global -> LDS once
- * (LDS-DMA, 16 channels per request) instead of once per tile.  Needs, on top of diagan_conv_wino_supported, Ci % 16 == 0
- * and blocks that tile the batch (and the prologue groups) exactly -- this query; 128 pixel rows x 64 columns per
- * workgroup (stat_partials granularity).  Measured 10 % slower than tile_cfg 9 (profiles/r02_wino_ablation.md): tile_cfg 0 picks it only with DIAGAN_WINO_STAGED=1. */
-int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
 /* tile_cfg 11: Winograd F(2x2,3x3) FOLLOWED BY F.avg_pool2d(., 2) in one launch (csrc/conv_wino_pool.hip) -- the end of
  * mimicry's DBlock / DBlockOptimized with downsample=True (predefined_models.py:38-40,76-78).  A Winograd tile is one
  * pooling window and the window's sum needs only 9 of the 16 transform-domain products (c = (1,2,0,-1): frequency row /

@@ -153,24 +153,3 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 }  // namespace diagan
-
-// ---- exact 3-way bf16 split of fp32 values (bf16x6 kernels) ---------------------------------------------------------
-// x = p0 + p1 + p2 exactly (8 + 8 + 8 significant bits), each piece the round-to-nearest bf16 of what is left.  Two values
-// are converted by ONE v_cvt_pk_bf16_f32 and the pieces are widened back from the PACKED word (shift / mask), so a pair
-// costs 3 conversions + 4 unpacks + 4 subtractions; written element by element the compiler converts every value twice
-// (once alone for the subtraction, once more to pack the stored word).
-typedef float x6_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 x6_bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned x6_pack2(float a, float b) {
-  const x6_f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, x6_bf16x2));
-}
-
-// pieces of (a, b): w0 / w1 / w2 hold the bf16 pair (a in the low half) of plane 0 / 1 / 2
-__device__ __forceinline__ void x6_split_pair(float a, float b, unsigned& w0, unsigned& w1, unsigned& w2) {
-  w0 = x6_pack2(a, b);
-  const float ra = a - __uint_as_float(w0 << 16), rb = b - __uint_as_float(w0 & 0xffff0000u);        // exact
-  w1 = x6_pack2(ra, rb);
-  w2 = x6_pack2(ra - __uint_as_float(w1 << 16), rb - __uint_as_float(w1 & 0xffff0000u));              // exact differences
-}

@@ -23,13 +23,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-extern "C" int diagan_get_mfma_mode(void);
 extern "C" int diagan_conv_gemm_tile_rows(int cfg);
 extern "C" int diagan_conv_gemm_tile_cols(int cfg);
 extern "C" int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg);
 extern "C" int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                               int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats);
-extern "C" int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows);
 extern "C" int diagan_conv_gemm_pick_cfg_grouped(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                                  int dr, int off, int up, int Kp, int allow_split, int64_t ws_floats,
                                                  int pro_group_rows);
@@ -44,24 +42,12 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st);     // conv_wino4.h
 long wino4_ws_floats(int Co, int Ci);
 bool wino4_geom_ok(int Ho, int Wo, int Ci);
 int wino4_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats);
-int launch_wino_s(ConvGemmArgs a, float* ws, hipStream_t st);    // conv_wino_s.hip
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs);
-int wino_s_block(int B, int Ho, int Wo, int Ci, int pro_group_rows);
-int wino_s_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
 
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-// X6 ("bf16x6", opt-in): the same kernel on the bf16 matrix pipe with fp32 accuracy.  Every fp32 operand is
-// split EXACTLY into three bf16 pieces (8 + 8 + 8 significant bits) on its way into LDS; a product is the sum of the six
-// piece products that are not below 2^-24 relative (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0), each exact in fp32, accumulated
-// in fp32: six v_mfma_f32_32x32x16_bf16 (6 x 32 cycles) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles) per
-// 32x32x16 block.  Measured error against double is at or below the fp32 MFMA's (tools/probe/bf16x6.hip).
-template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool X6 = false, bool STAMP = false, bool FP = false>
+template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool STAMP = false, bool FP = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int CH = BK / 4;                           // 16-byte chunks per tile row
   constexpr int RP = 256 / CH;                         // tile rows covered by one pass of the 256 loaders
@@ -76,22 +62,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                  // [2][BM*32]
   float* Bs = smem + 2 * BM * BK;    // [2][BN*32]
-  // X6: per buffer three bf16 planes per operand, rows of BK bf16 (64 B), 16-byte slots swizzled by (row >> 2) & 3
-  __bf16* Ax = reinterpret_cast<__bf16*>(smem);       // [2][3][BM][BK]
-  __bf16* Bx = Ax + 2 * 3 * BM * BK;                  // [2][3][BN][BK]
-  static_assert(!X6 || BK == 32 || BK == 16, "the bf16x6 variant is written for 16- or 32-wide K-steps");
-  // conflict-free ds_read_b128 of a lane's 8 k: rows are BK bf16 = 64 (32) bytes, 4 (2) slots of 16 B
-  auto xslot = [](int row, int q) { return BK == 32 ? (q ^ ((row >> 2) & 3)) : (q ^ ((row >> 3) & 1)); };
-  auto store_x6 = [&](__bf16* tile, int rows, int row, int lq_, f32x4 v) {
-    unsigned a0, a1, a2, b0, b1, b2;
-    x6_split_pair(v[0], v[1], a0, a1, a2);
-    x6_split_pair(v[2], v[3], b0, b1, b2);
-    const u32x2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2};
-    const int off = row * BK + (xslot(row, lq_ >> 1) << 3) + ((lq_ & 1) << 2);
-    *reinterpret_cast<u32x2*>(tile + off) = p0;
-    *reinterpret_cast<u32x2*>(tile + rows * BK + off) = p1;
-    *reinterpret_cast<u32x2*>(tile + 2 * rows * BK + off) = p2;
-  };
 
   // Diagnostic build (STAMP, reached only through diagan_conv_gemm_set_stamp_buffer): lane 0 of wave 0 records the
   // shader clock at the phase boundaries of the workgroup plus the constant 100 MHz real-time counter at entry and
@@ -191,12 +161,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   f32x4 ra[AJ], rb[BJ], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   unsigned a_ok = 0;
 
-  // Uniform-tap path (Ci % BK == 0, the bf16x6 kernels excepted): a K-step then lies inside ONE tap for every lane, so the
+  // Uniform-tap path (Ci % BK == 0): a K-step then lies inside ONE tap for every lane, so the
   // tap walk (ukr, uks, ukc) is wave-uniform scalar work, a row's gather offset avo[j] (bit 31 = outside the image) changes
   // only when the tap does, and the K-step's channel / weight-column offsets ride in the loads' scalar offset.  Vector
   // instructions do not hide behind MFMAs on this hardware (profiles/r02_wino_ablation.md): the general walk below costs
   // ~45 of them per K-step, this one none between tap changes.
-  const bool ut = !X6 && (g.Ci % BK) == 0;
+  const bool ut = (g.Ci % BK) == 0;
   int ukr = 0, uks = 0, ukc = 0;
   unsigned avo[AJ], tap_ok = 0;
   auto tap_setup = [&]() {
@@ -317,13 +287,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
           v *= keep;
         }
       }
-      if constexpr (X6) store_x6(Ax + buf * 3 * BM * BK, BM, row, lq, v);
-      else *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK + (swz(row, lq) << 2)) = v;
+      *reinterpret_cast<f32x4*>(As + buf * BM * BK + row * BK + (swz(row, lq) << 2)) = v;
     } else {
       const int j = p - AJ;
       const int row = lrow + RP * j;
-      if constexpr (X6) store_x6(Bx + buf * 3 * BN * BK, BN, row, lq, rb[j]);
-      else *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK + (swz(row, lq) << 2)) = rb[j];
+      *reinterpret_cast<f32x4*>(Bs + buf * BN * BK + row * BK + (swz(row, lq) << 2)) = rb[j];
     }
   };
   auto store_tiles = [&](int buf) {
@@ -356,9 +324,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   if (k_begin < k_end) {
     load_tiles(k_begin);
     store_tiles(0);
-    if constexpr (X6) {
-      if (k_begin + 1 < k_end) load_tiles(k_begin + 1);     // bf16x6 keeps one tile in flight in the staging registers
-    }
   }
   __syncthreads();
 
@@ -488,86 +453,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
     __syncthreads();
   };
-  // bf16x6 K-step: its MFMA phase is 2.67x shorter than the fp32 one, so a tile's global loads get a WHOLE K-step to
-  // land: during step kk the pieces of tile kk+1 (loaded during step kk-1) are written to the other LDS buffer in the
-  // first slots, and the freed staging registers are re-loaded with tile kk+2 in the last slots.
-  auto kstep_x6 = [&](int kk, auto has1, auto has2) {
-    const int cur = (kk - k_begin) & 1;
-    const __bf16* Ac = Ax + cur * 3 * BM * BK;
-    const __bf16* Bc = Bx + cur * 3 * BN * BK;
-    constexpr int NS = (BK / 16) * 6;            // (16-wide K chunks) x (six piece products)
-    constexpr int LS = (NP + 1) / 2;             // slots that carry two loads each
-    static_assert(NP + LS <= NS, "piece schedule of the bf16x6 step");
-#pragma unroll
-    for (int u = 0; u < BK / 16; ++u) {
-      const int q = 2 * u + fh;                  // lane half h takes k = 8h .. 8h+7 of the chunk
-      bf16x8 fa[TM][3], fb[TN][3];
-      // planes in the order the products consume them (a2, b0, a0, b2, a1, b1): the first MFMAs wait for a third of the
-      // LDS reads, not for all of them
-      constexpr int ORD[3] = {2, 0, 1}, ORDB[3] = {0, 2, 1};
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int row = wm * (TM * 32) + i * 32 + fi;
-          fa[i][ORD[t]] = *reinterpret_cast<const bf16x8*>(Ac + ORD[t] * BM * BK + row * BK + (xslot(row, q) << 3));
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int row = wn * (TN * 32) + j * 32 + fi;
-          fb[j][ORDB[t]] = *reinterpret_cast<const bf16x8*>(Bc + ORDB[t] * BN * BK + row * BK + (xslot(row, q) << 3));
-        }
-      }
-#pragma unroll
-      for (int sidx = 0; sidx < 6; ++sidx) {
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
-        const int es = u * 6 + sidx;
-        if (decltype(has1)::value && es < NP) {
-          __builtin_amdgcn_sched_barrier(0);
-          store_piece(cur ^ 1, es);
-        }
-        if (decltype(has2)::value && es >= NS - LS) {
-          const int p0 = 2 * (es - (NS - LS));
-          load_piece(kk + 2, p0, std::false_type{});
-          if (p0 + 1 < NP) load_piece(kk + 2, p0 + 1, std::false_type{});
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[sidx]], fb[j][PB[sidx]], acc[i][j], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  };
   if (a.tune & 1) __builtin_amdgcn_s_setprio(0);
   stamp(2);
-  if constexpr (X6) {
-    using T = std::true_type;
-    using F = std::false_type;
+  if (ut) {
+    const std::integral_constant<int, 0> b0;
+    const std::integral_constant<int, 1> b1;
     int kk = k_begin;
-    for (; kk + 2 < k_end; ++kk) kstep_x6(kk, T{}, T{});
-    if (kk + 1 < k_end) { kstep_x6(kk, T{}, F{}); ++kk; }
-    if (kk < k_end) kstep_x6(kk, F{}, F{});
-  } else {
-    if (ut) {
-      const std::integral_constant<int, 0> b0;
-      const std::integral_constant<int, 1> b1;
-      int kk = k_begin;
-      for (; kk + 2 < k_end; kk += 2) {
-        kstep_u(kk, b0, std::true_type{});
-        kstep_u(kk + 1, b1, std::true_type{});
-      }
-      if (kk + 1 < k_end) {
-        kstep_u(kk, b0, std::true_type{});
-        kstep_u(kk + 1, b1, std::false_type{});
-      } else if (kk < k_end) {
-        kstep_u(kk, b0, std::false_type{});
-      }
-    } else {
-      for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
-      if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+    for (; kk + 2 < k_end; kk += 2) {
+      kstep_u(kk, b0, std::true_type{});
+      kstep_u(kk + 1, b1, std::true_type{});
     }
+    if (kk + 1 < k_end) {
+      kstep_u(kk, b0, std::true_type{});
+      kstep_u(kk + 1, b1, std::false_type{});
+    } else if (kk < k_end) {
+      kstep_u(kk, b0, std::false_type{});
+    }
+  } else {
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
+    if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
   }
   stamp(3);
   if (a.tune & 2) __builtin_amdgcn_s_setprio(3);
@@ -725,7 +629,6 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
   }
 }
 
-static int g_mfma_x6 = -1;       // -1: read DIAGAN_MFMA on first use; 0: fp32 MFMA (default); 1: bf16x6
 static unsigned long long* g_stamps = nullptr;   // diagnostic: stamp buffer of the STAMP kernels (null in production)
 static long g_stamp_slots = 0;
 static int g_force_ksplit = 0;                    // tuning sweeps only (diagan_conv_gemm_tune)
@@ -735,13 +638,13 @@ static int g_wino = -1;                           // -1: DIAGAN_WINO / default (
 static int g_wino4 = -1;                          // -1: DIAGAN_WINO4 / default (on); 0 / 1: diagan_conv_gemm_set_wino4
 constexpr int kDefaultTune = 0;
 
-template <int BM, int BN, int WM, int WN, int BK, int PRO, bool X6 = false, bool STAMP = false, bool FP = false>
+template <int BM, int BN, int WM, int WN, int BK, int PRO, bool STAMP = false, bool FP = false>
 static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
   // (g_lds_delta: occupancy probe of the tuning sweeps, timing only -- a negative value leaves part of the tile outside
   //  the allocation, where LDS accesses are dropped by the hardware's range check)
-  const size_t lds = (size_t)((long)(X6 ? (size_t)2 * 3 * (BM + BN) * BK * 2 : (size_t)2 * (BM + BN) * BK * sizeof(float)) + g_lds_delta);
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, X6, STAMP, FP>;
+  const size_t lds = (size_t)((long)((size_t)2 * (BM + BN) * BK * sizeof(float)) + g_lds_delta);
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, STAMP, FP>;
   static size_t attr_set = 0;
   if (attr_set < lds) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -757,59 +660,28 @@ static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
 }
 
 // SPEC: one kernel per prologue mode (the production tiles); otherwise the mode is a run-time argument.
-// X6OK: the tile has a bf16x6 twin (the two square tiles).
-template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false, bool X6OK = false, bool FP = false>
+template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false, bool FP = false>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
-  if constexpr (X6OK) {
-    if (diagan_get_mfma_mode() == 1) {        // bf16x6: 16-wide K-steps (48 KB of LDS: two workgroups per CU)
-      static const int xbk = getenv("DIAGAN_X6_BK") ? atoi(getenv("DIAGAN_X6_BK")) : 16;
-      if (xbk == 32) return launch_one<BM, BN, WM, WN, 32, -1, true>(a, st);
-      if (SPEC) {
-        switch (a.pro_mode) {
-          case PRO_NONE: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_NONE : -1, true>(a, st);
-          case PRO_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_RELU : -1, true>(a, st);
-          case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, 16, SPEC ? PRO_AFFINE_RELU : -1, true>(a, st);
-          default: break;
-        }
-      }
-      return launch_one<BM, BN, WM, WN, 16, -1, true>(a, st);
-    }
-  }
   if (a.stamps) {                             // diagnostic build: the two most common prologue modes only
-    if (a.pro_mode == PRO_NONE) return launch_one<BM, BN, WM, WN, BK, PRO_NONE, false, true, FP>(a, st);
-    if (a.pro_mode == PRO_RELU) return launch_one<BM, BN, WM, WN, BK, PRO_RELU, false, true, FP>(a, st);
+    if (a.pro_mode == PRO_NONE) return launch_one<BM, BN, WM, WN, BK, PRO_NONE, true, FP>(a, st);
+    if (a.pro_mode == PRO_RELU) return launch_one<BM, BN, WM, WN, BK, PRO_RELU, true, FP>(a, st);
     return set_err(DIAGAN_EUNSUP, "conv_gemm: the stamped diagnostic kernels exist for prologue modes 0 and 1");
   }
   if (SPEC) {
     switch (a.pro_mode) {
-      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1, false, false, FP>(a, st);
-      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1, false, false, FP>(a, st);
-      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1, false, false, FP>(a, st);
-      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1, false, false, FP>(a, st);
-      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1, false, false, FP>(a, st);
+      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1, false, FP>(a, st);
+      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1, false, FP>(a, st);
+      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1, false, FP>(a, st);
+      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1, false, FP>(a, st);
+      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1, false, FP>(a, st);
     }
   }
-  return launch_one<BM, BN, WM, WN, BK, -1, false, false, FP>(a, st);
+  return launch_one<BM, BN, WM, WN, BK, -1, false, FP>(a, st);
 }
 
 }  // namespace diagan
 
 using namespace diagan;
-
-// 0: exact fp32 MFMA (default); 1: bf16x6 (fp32-accurate on the bf16 matrix pipe, experimental)
-DIAGAN_API int diagan_set_mfma_mode(int mode) {
-  DG_REQUIRE(mode == 0 || mode == 1, "set_mfma_mode: 0 (fp32 MFMA) or 1 (bf16x6)");
-  g_mfma_x6 = mode;
-  return DIAGAN_OK;
-}
-
-DIAGAN_API int diagan_get_mfma_mode(void) {
-  if (g_mfma_x6 < 0) {
-    const char* m = getenv("DIAGAN_MFMA");
-    g_mfma_x6 = (m && !strcmp(m, "bf16x6")) ? 1 : 0;
-  }
-  return g_mfma_x6;
-}
 
 static bool split128_enabled() {
   static const bool on = getenv("DIAGAN_SPLIT128") && atoi(getenv("DIAGAN_SPLIT128")) > 0;
@@ -826,29 +698,24 @@ static bool split128_enabled() {
 //    workgroups per CU (the stamped build shows 4, not the 5 that 160 KB / 32 KB suggests).
 // allow_split: the caller can take the split-K path (workspace present, no fused BatchNorm statistics).
 DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split) {
-  const bool x6 = diagan_get_mfma_mode() == 1;
-  const int small = x6 ? 3 : 7;            // 64x64 (the fp32 kernel with double-buffered fragments)
+  const int small = 7;                     // 64x64 (with double-buffered fragments)
   // short K loops (first conv of D on RGB, 1x1 shortcuts) are bound by the output stream, not the MFMAs: more,
   // smaller workgroups in flight win (measured 52 -> 46 us at M=131072,N=128,K=36; 27 -> 19 us at K=128; round 2, fp32:
   // K = 256 at N = 256: 45.6 -> 33.4 us at M=20480, 118.8 -> 110.5 at M=81920, 27.2 -> 25.0 at M=16384)
-  if (Kp <= (x6 ? 128 : 256)) return small;
+  if (Kp <= 256) return small;
   const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128), t64 = (long)cdiv(M, 64) * cdiv(Co, 64);
-  if (!x6) {
-    // (in a training step this is within box-to-box noise of the 64x64 tile -- tools/layer_report.py, 32.8 vs 33.2 ms of
-    //  GEMM time per SNGAN-64 step -- so it stays opt-in: DIAGAN_SPLIT128=1)
-    if (split128_enabled() && allow_split && (Co & 127) == 0 && t128 <= 256 && diagan_conv_gemm_pick_ksplit(M, Co, Kp, 1) > 1) return 1;
-    if (Co <= 64 && Kp >= 256) return M >= 65536 ? 5 : (M >= 32768 ? 8 : 7);
-  }
+  // (in a training step this is within box-to-box noise of the 64x64 tile -- tools/layer_report.py, 32.8 vs 33.2 ms of
+  //  GEMM time per SNGAN-64 step -- so it stays opt-in: DIAGAN_SPLIT128=1)
+  if (split128_enabled() && allow_split && (Co & 127) == 0 && t128 <= 256 && diagan_conv_gemm_pick_ksplit(M, Co, Kp, 1) > 1) return 1;
+  if (Co <= 64 && Kp >= 256) return M >= 65536 ? 5 : (M >= 32768 ? 8 : 7);
   // Blocks run a whole K loop, so a partially filled last round of blocks costs a full round
   // ("wave quantisation"): weigh each tile shape by tiles / (rounds * resident slots).
-  const long s128 = 256 * 2, s64 = x6 ? 256 * 3 : 256 * 4;     // resident workgroups
+  const long s128 = 256 * 2, s64 = 256 * 4;     // resident workgroups
   const double q128 = (double)t128 / (double)(cdiv(t128, s128) * s128);
   const double q64 = (double)t64 / (double)(cdiv(t64, s64) * s64);
   const double waste128 = (double)M * Co / ((double)t128 * 128 * 128);
   const double waste64 = (double)M * Co / ((double)t64 * 64 * 64);
-  // (bf16x6 mode: the 128x128 variant gains 1.4-1.6x over its fp32 twin, the latency-bound 64x64 one 1.2x)
-  static const double x6_bias = getenv("DIAGAN_X6_TILE_BIAS") ? atof(getenv("DIAGAN_X6_TILE_BIAS")) : 1.3;
-  const double bias = x6 ? x6_bias : 1.08;
+  const double bias = 1.08;
   return bias * q128 * waste128 > q64 * waste64 ? 1 : small;
 }
 
@@ -869,7 +736,7 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   if (cfg == 1) {                      // 128x128 tiles on problems with at most one tile per CU and a long K loop (opt-in)
     if (!split128_enabled()) return 1;
     const long t128 = (long)cdiv(M, 128) * cdiv(Co, 128);
-    if (diagan_get_mfma_mode() == 1 || t128 > 256 || nk < 64) return 1;
+    if (t128 > 256 || nk < 64) return 1;
     int s = t128 <= 128 ? 4 : 2;
     while (s > 1 && nk / s < 16) --s;
     return s;
@@ -878,12 +745,6 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   const long tiles = (long)cdiv(M, 64) * cdiv(Co, 64);
   if (nk < 16) return 1;
   if (tiles <= 320) {
-    // bf16x6: the MFMA phases are 2.67x shorter, so a lone workgroup per CU is even more latency-bound: split sooner
-    static const int x6_div = getenv("DIAGAN_X6_SPLIT_DIV") ? atoi(getenv("DIAGAN_X6_SPLIT_DIV")) : 8;
-    if (x6_div > 0 && diagan_get_mfma_mode() == 1) {
-      const int s6 = nk / x6_div;
-      return s6 < 2 ? 1 : (s6 > 4 ? 4 : s6);
-    }
     if (nk < 64) return 1;
     int s = nk / 24;
     return s > 4 ? 4 : s;
@@ -937,7 +798,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 = 64x64 with fragment "
-             "prefetch, 8 = 128x64 with fragment prefetch, 9 / 10 = Winograd, 11 / 12 = Winograd + average pool and its data-gradient; 2, 4, 6 were retired after the round-2 sweeps)", tile_cfg);
+             "prefetch, 8 = 128x64 with fragment prefetch, 9 = Winograd F(2x2,3x3), 11 / 12 = Winograd + average pool and its data-gradient, 13 = Winograd F(4x4,3x3); 2, 4, 6, 10 were retired)", tile_cfg);
   DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % bm == 0 && a.M % pro_group_rows == 0)),
              "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, bm, a.M);
   a.slab = splitk_ws;
@@ -1025,26 +886,16 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     }
     return rc;
   }
-  if (cfg == 9 || cfg == 10) {
+  if (cfg == 9) {
     DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up),
-               "conv_gemm: tile_cfg %d (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0", cfg);
+               "conv_gemm: tile_cfg 9 (Winograd F(2x2,3x3)) needs a 3x3 / stride 1 / pad 1 geometry, even H and W, Ci %% 8 == 0");
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wino_ws_floats(Co, Ci),
-               "conv_gemm: tile_cfg %d needs %ld floats of workspace for the transformed weights", cfg, wino_ws_floats(Co, Ci));
-    // the staged kernel (10) wants blocks that tile the batch and the prologue groups; the automatic choice falls back
-    bool staged = cfg == 10;
-    DG_REQUIRE(!(a.res_up && staged && tile_cfg != 0), "conv_gemm: tile_cfg 10 takes no half-resolution residual");
-    if (staged && a.res_up) staged = false;
-    if (staged && !wino_s_block(B, Ho, Wo, Ci, pro_group_rows)) {
-      DG_REQUIRE(tile_cfg == 0, "conv_gemm: tile_cfg 10 (staged Winograd) needs Ci %% 16 == 0 and 32-tile blocks (8x4 tiles of one "
-                 "image, 4x4 of two, ...) that tile the batch and the prologue groups exactly");
-      staged = false;
-    }
+               "conv_gemm: tile_cfg 9 needs %ld floats of workspace for the transformed weights", wino_ws_floats(Co, Ci));
     // transformed weights first, split-K slab (if any) behind them
     const long wfl = wino_ws_floats(Co, Ci);
     int ks = 1;
     if (tile_cfg == 0 && !stat_partials) {
-      ks = staged ? wino_s_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 256)
-                  : wino_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 192);
+      ks = wino_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 192);
       if (ks < 1) ks = 1;
     } else if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats &&
                Ci / 16 / g_force_ksplit >= 1) {
@@ -1052,7 +903,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     }
     a.ksplit = ks;
     a.slab = splitk_ws + wfl;
-    int rc = staged ? launch_wino_s(a, splitk_ws, st) : launch_wino(a, splitk_ws, st);
+    int rc = launch_wino(a, splitk_ws, st);
     if (rc == DIAGAN_OK && ks > 1) {
       long blocks = ((long)a.M * (Co / 4) + 255) / 256;
       if (blocks > 4096) blocks = 4096;
@@ -1064,21 +915,21 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   DG_REQUIRE(!a.res_up, "conv_gemm: a half-resolution residual is added by the Winograd kernel only (tile_cfg 9; ask "
              "diagan_conv_gemm_pick_cfg_geom first)");
   switch (cfg) {
-    case 1: return launch_cfg<128, 128, 2, 2, 32, true, true>(a, st);
-    case 3: return launch_cfg<64, 64, 2, 2, 32, true, true>(a, st);
+    case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);
+    case 3: return launch_cfg<64, 64, 2, 2, 32, true>(a, st);
     case 5: return launch_cfg<256, 64, 4, 1, 32, true>(a, st);
-    case 7: return launch_cfg<64, 64, 2, 2, 32, true, false, true>(a, st);
-    case 8: return launch_cfg<128, 64, 2, 2, 32, true, false, true>(a, st);
+    case 7: return launch_cfg<64, 64, 2, 2, 32, true, true>(a, st);
+    case 8: return launch_cfg<128, 64, 2, 2, 32, true, true>(a, st);
     default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
   }
 }
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: case 10: return 128; case 3: case 7: return 64; case 5: case 9: case 11: case 12: return 256; case 13: return 512; default: return 0; }
+  switch (cfg) { case 1: case 8: return 128; case 3: case 7: return 64; case 5: case 9: case 11: case 12: return 256; case 13: return 512; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 10: case 13: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -1086,7 +937,7 @@ DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
 DIAGAN_API int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                           int off, int up) {
   return R == 3 && S == 3 && sy == 1 && up == 1 && ((dr == 1 && off == -1) || (dr == -1 && off == 1)) && Hi == Ho &&
-         Wi == Wo && !(Ho & 1) && !(Wo & 1) && (Ci & 7) == 0 && (Co & 3) == 0 && diagan_get_mfma_mode() == 0;
+         Wi == Wo && !(Ho & 1) && !(Wo & 1) && (Ci & 7) == 0 && (Co & 3) == 0;
 }
 
 // Winograd + 2x2 average pool (tile_cfg 11, conv_wino_pool.hip): does F.avg_pool2d(conv3x3(pro(x)), 2) of this layer run
@@ -1137,9 +988,6 @@ static int pick_cfg_geom_impl(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int
   if (wino && diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) &&
       ws_floats >= wino_ws_floats(Co, Ci) && Ci >= 16) {
     static const int wsplit = getenv("DIAGAN_WINO_SPLIT") ? atoi(getenv("DIAGAN_WINO_SPLIT")) : 1;
-    // the staged kernel (32-tile blocks, two workgroups per CU) where its blocks tile the batch
-    static const int staged_env = getenv("DIAGAN_WINO_STAGED") ? atoi(getenv("DIAGAN_WINO_STAGED")) : 0;
-    static const int min_wgs_s = getenv("DIAGAN_WINO_S_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_S_MIN_WGS")) : 256;
     // F(4x4,3x3) (conv_wino4.hip, 32 tiles of 4x4 outputs x 64 channels per workgroup, ONE resident workgroup per CU): where its
     // launch-size policy (wino4_ksplit) expects it ahead of the F(2x2) kernel
     static const int w4_env = getenv("DIAGAN_WINO4") ? atoi(getenv("DIAGAN_WINO4")) : 1;
@@ -1147,9 +995,6 @@ static int pick_cfg_geom_impl(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int
     if (allow_w4 && w4_env && g_wino4 != 0 && wino4_geom_ok(Ho, Wo, Ci) && Ci >= w4_min_ci && ws_floats >= wino4_ws_floats(Co, Ci) &&
         wino4_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats) > 0)
       return 13;
-    if (staged_env && wino_s_block(B, Ho, Wo, Ci, 0) &&
-        wino_s_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs_s) > 0)
-      return 10;
     if (wino_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs) > 0) return 9;
   }
   return diagan_conv_gemm_pick_cfg(B * Ho * Wo, Co, Kp, allow_split);
@@ -1172,12 +1017,6 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_grouped(int B, int Hi, int Wi, int Ci, 
     if (pro_group_rows % diagan_conv_gemm_tile_rows(cfg) != 0) cfg = 3;
   }
   return cfg;
-}
-
-// whether the staged Winograd kernel (tile_cfg 10) takes a batch / prologue-group shape (the geometry itself must pass
-// diagan_conv_wino_supported)
-DIAGAN_API int diagan_conv_wino_staged_supported(int B, int Ho, int Wo, int Ci, int pro_group_rows) {
-  return wino_s_block(B, Ho, Wo, Ci, pro_group_rows) ? 1 : 0;
 }
 
 // Run-time form of DIAGAN_WINO (A/B runs and the tests that compare kernels like with like): 0 = implicit GEMM only,

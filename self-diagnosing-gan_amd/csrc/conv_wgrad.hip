@@ -17,7 +17,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-extern "C" int diagan_get_mfma_mode(void);
 
 namespace diagan {
 bool wgrad_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up,
@@ -277,527 +276,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// ---- bf16x6 variant (opt-in, see conv_gemm.hip): the same weight gradient on the bf16 matrix pipe, fp32-accurate ----
-// Both operand tiles stay PIXEL-major in LDS, as three bf16 planes each ([16 pixels][128 columns], 8-byte chunks
-// XOR-swizzled by the pixel row so that every access is bank-conflict free); the MFMA operands need 8 consecutive
-// PIXELS of one column per lane, which gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-row x 16-column block of
-// 16-bit elements per 16 lanes, delivered column-major) supplies without any shuffle.  A 32-pixel K-step is processed
-// as two 16-pixel halves with the LDS double buffer at half-step granularity (48 KB: two workgroups per CU); the
-// staging registers of one half are stored while the other half's MFMAs run and re-loaded two half-steps ahead.
-typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
-typedef short ws16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned wu32x2 __attribute__((ext_vector_type(2)));
-
-template <int BNn = 128, int PRO = -1, bool P2 = false>
-__global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(const WgradArgs a) {
-  constexpr int BNk = 128, BK = 32, HK = 16;
-  constexpr int TM = BNn / 64, TN = 2, AC = BNn / 4, BC = 32, APR = 256 / AC, BPR = 8, AJ = BK / APR, BJ = 4;
-  constexpr int AH = AJ / 2;      // dy pieces per 16-pixel half (2 for 128 columns, 1 for 64)
-  static_assert(BNn == 128 || BNn == 64, "dy tile of 128 or 64 columns");
-  __shared__ __attribute__((aligned(16))) __bf16 Ax[2][3][HK * BNn];
-  __shared__ __attribute__((aligned(16))) __bf16 Bx[2][3][HK * BNk];
-
-  const ConvGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_k = (g.Kp + BNk - 1) / BNk;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = logical / a.tiles, tile = logical - split * a.tiles;
-  const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
-  const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
-  const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
-  const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
-
-  const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;
-  const int ac = tid % AC, ap = tid / AC;
-  const int an = n0 + ac * 4;
-  const unsigned a_kill = an < g.Co ? 0u : 0x80000000u;
-  const int bc = tid % BC, bp = tid / BC;
-  const int kf = k0 + bc * 4;
-  const int tap = kf / g.Ci, kc = kf - tap * g.Ci;
-  const int kr = tap / g.S, ks = tap - kr * g.S;
-  const bool b_ok = kf < g.K;
-  const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
-  const int upm = g.up - 1, ush = g.up >> 1;
-  const int pstep = (g.Ci * 4) >> ush;
-  const int img_bytes = g.Hi * g.Wi * g.Ci * 4;
-  const unsigned ylim = (unsigned)g.Hi << ush, xlim = (unsigned)g.Wi << ush;
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
-  const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
-  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-  if (affine && b_ok) {
-    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
-    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
-  }
-  // every piece j advances on its own (pieces 0,1 and 2,3 of a K-step are loaded at different times)
-  int pb[BJ], py[BJ], px[BJ], mst[BJ];
-  unsigned xoff[BJ], aoff[AJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    const int m = step0 * BK + bp + BPR * j;
-    const unsigned t = fdiv((unsigned)m, a.dWo);
-    px[j] = m - (int)t * g.Wo;
-    const unsigned b = fdiv(t, a.dHo);
-    py[j] = (int)t - (int)b * g.Ho;
-    pb[j] = (int)b;
-    mst[j] = step0 * BK;
-    xoff[j] = (unsigned)((m + dyo * g.Wi + dxo) * g.Ci * 4 + kc * 4);
-  }
-  const unsigned xstep = (unsigned)BK * g.Ci * 4u, astep = (unsigned)BK * g.Co * 4u;
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
-  f32x4 ra[AJ], rb[BJ];
-  unsigned bmask = 0;
-  const bool bias_tile = a.bias_off >= 0 && k0 == 0;
-  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
-
-  auto load_a = [&](int j) {
-    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[j] | a_kill, 0, 0));
-    aoff[j] += astep;
-  };
-  auto load_b = [&](int j) {
-    unsigned okb;
-    if (P2 && a.same) {
-      const int m = mst[j] + bp + BPR * j;
-      const int yn = ((m >> a.lgW) & (g.Ho - 1)) + dyo, xn = (m & (g.Wo - 1)) + dxo;
-      okb = (b_ok && m < a.M && (unsigned)yn < (unsigned)g.Hi && (unsigned)xn < (unsigned)g.Wi) ? 1u : 0u;
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[j] | ((okb ^ 1u) << 31), 0, 0));
-      xoff[j] += xstep;
-    } else {
-      int pbj, pyj, pxj;
-      if (P2) {
-        const int m = mst[j] + bp + BPR * j;
-        pxj = m & (g.Wo - 1);
-        pyj = (m >> a.lgW) & (g.Ho - 1);
-        pbj = m >> a.lgHW;
-      } else {
-        pbj = pb[j]; pyj = py[j]; pxj = px[j];
-      }
-      const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
-      okb = (b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0) ? 1u : 0u;
-      const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
-      if (!P2) {
-        int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
-        const int cx = x >= g.Wo ? 1 : 0;
-        x -= cx ? g.Wo : 0;
-        y += cx;
-        const int cy = y >= g.Ho ? 1 : 0;
-        y -= cy ? g.Ho : 0;
-        b += cy;
-        px[j] = x; py[j] = y; pb[j] = b;
-      }
-    }
-    bmask = (bmask & ~(1u << j)) | (okb << j);
-    mst[j] += BK;
-  };
-  // exact 3-way bf16 split of four values into the three planes of an LDS tile
-  // 8-byte chunk swizzle by the pixel row: 256-byte rows (128 columns) take the two low pixel bits into chunk bits
-  // 3-4, 128-byte rows (64 columns; two pixel rows share a 256-byte bank row) take pixel bit 1 into chunk bit 3
-  auto swz = [](int pitch, int ph, int chunk) { return pitch == 128 ? (chunk ^ ((ph & 3) << 3)) : (chunk ^ (((ph >> 1) & 1) << 3)); };
-  auto store3 = [&](__bf16* t0, __bf16* t1, __bf16* t2, int pitch, int prow, int chunk, f32x4 v) {
-    unsigned a0, a1, a2, b0, b1, b2;
-    x6_split_pair(v[0], v[1], a0, a1, a2);
-    x6_split_pair(v[2], v[3], b0, b1, b2);
-    const wu32x2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2};
-    const int ph = prow & (HK - 1);
-    const int off = ph * pitch + (swz(pitch, ph, chunk) << 2);
-    *reinterpret_cast<wu32x2*>(t0 + off) = p0;
-    *reinterpret_cast<wu32x2*>(t1 + off) = p1;
-    *reinterpret_cast<wu32x2*>(t2 + off) = p2;
-  };
-  auto store_a = [&](int buf, int j) {
-    store3(Ax[buf][0], Ax[buf][1], Ax[buf][2], BNn, ap + APR * j, ac, ra[j]);
-    if (bias_tile) bacc += ra[j];
-  };
-  auto store_b = [&](int buf, int j) {
-    f32x4 v = rb[j];
-    if (pro_mode != PRO_NONE) {
-      if (affine) v = v * psc + psh;
-      if (pro_mode == PRO_LRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-      } else if (pro_mode != PRO_AFFINE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (affine) v *= (float)((bmask >> j) & 1u);
-    }
-    store3(Bx[buf][0], Bx[buf][1], Bx[buf][2], BNk, bp + BPR * j, bc, v);
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int fi = lane & 31, fh = lane >> 5;
-  const int li = lane & 15, g1 = (lane >> 4) & 1;
-  // transposing read of one operand block: lane (4q+p) of a 16-lane group supplies row q (a pixel), columns 4p..4p+3;
-  // two reads give the lane's 8 pixels k = 8*fh .. 8*fh+7 of column (lane & 31)
-  auto read_frag = [&](const __bf16* plane, int pitch, int col0) {
-    const int q = li >> 2, chunk = (col0 >> 2) + 4 * g1 + (li & 3);
-    // rows 8*fh + q and 8*fh + 4 + q have the same low pixel bits, hence the same swizzle
-    const int off = (8 * fh + q) * pitch + (swz(pitch, q, chunk) << 2);
-    typedef __attribute__((address_space(3))) ws16x4* lds_p;
-    const ws16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off));
-    const ws16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(plane + off + 4 * pitch));
-    ws16x4 both[2] = {lo, hi};
-    return __builtin_bit_cast(wbf16x8, both);
-  };
-  auto mfma_half = [&](int buf, auto&& slot_work) {
-    wbf16x8 fa[TM][3], fb[TN][3];
-    // planes in the order the products consume them (a2, b0, a0, b2, a1, b1): the first MFMAs wait for a third of the
-    // LDS reads, not for all of them
-    constexpr int ORD[3] = {2, 0, 1}, ORDB[3] = {0, 2, 1};
-#pragma unroll
-    for (int t = 0; t < 3; ++t) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i][ORD[t]] = read_frag(Ax[buf][ORD[t]], BNn, wm * (TM * 32) + i * 32);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j][ORDB[t]] = read_frag(Bx[buf][ORDB[t]], BNk, wn * 64 + j * 32);
-    }
-#pragma unroll
-    for (int sidx = 0; sidx < 6; ++sidx) {
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-      slot_work(sidx);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[sidx]], fb[j][PB[sidx]], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // prologue: the whole first K-step is loaded; its first half goes to buffer 0, and the registers of that half are
-  // re-loaded for the next K-step right away
-  if (step0 < step1) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) load_a(j);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) load_b(j);
-#pragma unroll
-    for (int t = 0; t < AH; ++t) store_a(0, t);
-    store_b(0, 0); store_b(0, 1);
-    if (step0 + 1 < step1) {
-#pragma unroll
-      for (int t = 0; t < AH; ++t) load_a(t);
-      load_b(0); load_b(1);
-    }
-  }
-  __syncthreads();
-  // slots 0 .. AH+1 of a half-step carry the stores of the OTHER half's pieces (AH dy pieces, 2 gathered pieces), slots
-  // 4 and 5 the re-loads of the registers just freed
-  for (int step = step0; step < step1; ++step) {
-    const bool next1 = step + 1 < step1, next2 = step + 2 < step1;
-    mfma_half(0, [&](int sidx) {
-      if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
-      if (sidx < AH) store_a(1, AH + sidx);
-      if (sidx == AH) store_b(1, 2);
-      if (sidx == AH + 1) store_b(1, 3);
-      if (next1 && sidx == 4) {
-#pragma unroll
-        for (int t = 0; t < AH; ++t) load_a(AH + t);
-      }
-      if (next1 && sidx == 5) { load_b(2); load_b(3); }
-    });
-    __syncthreads();
-    mfma_half(1, [&](int sidx) {
-      if (next1) {
-        if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
-        if (sidx < AH) store_a(0, sidx);
-        if (sidx == AH) store_b(0, 0);
-        if (sidx == AH + 1) store_b(0, 1);
-      }
-      if (next2 && sidx == 4) {
-#pragma unroll
-        for (int t = 0; t < AH; ++t) load_a(t);
-      }
-      if (next2 && sidx == 5) { load_b(0); load_b(1); }
-    });
-    __syncthreads();
-  }
-
-  float* out = a.slab + (long)split * a.slab_stride;
-  if (bias_tile) {
-    float* red = reinterpret_cast<float*>(&Ax[0][0][0]);      // tiles are done with: [APR][BNn] partial rows
-    __syncthreads();
-    *reinterpret_cast<f32x4*>(red + ap * BNn + ac * 4) = bacc;
-    __syncthreads();
-    if (tid < BNn && n0 + tid < g.Co) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < APR; ++r) t += red[r * BNn + tid];
-      out[a.bias_off + n0 + tid] = t;
-    }
-  }
-  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
-  const unsigned rowbytes = (unsigned)g.Kp * 4u;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int k = k0 + wn * (TN * 32) + j * 32 + fi;
-      const int nrow = n0 + wm * (TM * 32) + i * 32 + 4 * fh;
-      const unsigned vbase = k < g.Kp ? ((unsigned)nrow * g.Kp + k) * 4u : 0x80000000u;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float av = acc[i][j][e];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), osrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0);
-      }
-    }
-}
-
-// ---- fp32 weight gradient with the LDS double buffer at HALF-step granularity (16 pixels) -------------------------------
-// Same arithmetic and the same 32-pixel K-steps as conv_wgrad_kernel (exact fp32 MFMA), but the operand tiles live in
-// 2 x 16-pixel buffers (32 KB instead of 64 KB of LDS): three workgroups per CU instead of two, for a kernel whose
-// matrix-pipe occupancy (0.62-0.72) is bound by latency, not by issue slots.  Pipeline as in the bf16x6 variant above.
-template <int BNn = 128, int PRO = -1, bool P2 = false>
-__global__ __launch_bounds__(256, 3) void conv_wgrad_half_kernel(const WgradArgs a) {
-  constexpr int BNk = 128, BK = 32, HK = 16;
-  constexpr int TM = BNn / 64, TN = 2, AC = BNn / 4, BC = 32, APR = 256 / AC, BPR = 8, AJ = BK / APR, BJ = 4;
-  constexpr int AH = AJ / 2;      // dy pieces per 16-pixel half (2 for 128 columns, 1 for 64)
-  static_assert(BNn == 128 || BNn == 64, "dy tile of 128 or 64 columns");
-  __shared__ __attribute__((aligned(16))) float Ah[2][HK * BNn];      // 32 KB in all: three workgroups per CU
-  __shared__ __attribute__((aligned(16))) float Bh[2][HK * BNk];
-
-  const ConvGeom& g = a.g;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_k = (g.Kp + BNk - 1) / BNk;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = logical / a.tiles, tile = logical - split * a.tiles;
-  const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
-  const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
-  const int step0 = seg * a.seg_steps + sub * a.steps_per_split;
-  const int step1 = min(step0 + a.steps_per_split, (seg + 1) * a.seg_steps);
-
-  const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;
-  const int ac = tid % AC, ap = tid / AC;
-  const int an = n0 + ac * 4;
-  const unsigned a_kill = an < g.Co ? 0u : 0x80000000u;
-  const int bc = tid % BC, bp = tid / BC;
-  const int kf = k0 + bc * 4;
-  const int tap = kf / g.Ci, kc = kf - tap * g.Ci;
-  const int kr = tap / g.S, ks = tap - kr * g.S;
-  const bool b_ok = kf < g.K;
-  const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
-  const int upm = g.up - 1, ush = g.up >> 1;
-  const int pstep = (g.Ci * 4) >> ush;
-  const int img_bytes = g.Hi * g.Wi * g.Ci * 4;
-  const unsigned ylim = (unsigned)g.Hi << ush, xlim = (unsigned)g.Wi << ush;
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
-  const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
-  f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-  if (affine && b_ok) {
-    psc = *reinterpret_cast<const f32x4*>(a.pro_scale + kc);
-    psh = *reinterpret_cast<const f32x4*>(a.pro_shift + kc);
-  }
-  // every piece j advances on its own (pieces 0,1 and 2,3 of a K-step are loaded at different times)
-  int pb[BJ], py[BJ], px[BJ], mst[BJ];
-  unsigned xoff[BJ], aoff[AJ];
-#pragma unroll
-  for (int j = 0; j < BJ; ++j) {
-    const int m = step0 * BK + bp + BPR * j;
-    const unsigned t = fdiv((unsigned)m, a.dWo);
-    px[j] = m - (int)t * g.Wo;
-    const unsigned b = fdiv(t, a.dHo);
-    py[j] = (int)t - (int)b * g.Ho;
-    pb[j] = (int)b;
-    mst[j] = step0 * BK;
-    xoff[j] = (unsigned)((m + dyo * g.Wi + dxo) * g.Ci * 4 + kc * 4);
-  }
-  const unsigned xstep = (unsigned)BK * g.Ci * 4u, astep = (unsigned)BK * g.Co * 4u;
-#pragma unroll
-  for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
-  f32x4 ra[AJ], rb[BJ];
-  unsigned bmask = 0;
-  const bool bias_tile = a.bias_off >= 0 && k0 == 0;
-  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
-
-  auto load_a = [&](int j) {
-    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ysrc, aoff[j] | a_kill, 0, 0));
-    aoff[j] += astep;
-  };
-  auto load_b = [&](int j) {
-    unsigned okb;
-    if (P2 && a.same) {
-      const int m = mst[j] + bp + BPR * j;
-      const int yn = ((m >> a.lgW) & (g.Ho - 1)) + dyo, xn = (m & (g.Wo - 1)) + dxo;
-      okb = (b_ok && m < a.M && (unsigned)yn < (unsigned)g.Hi && (unsigned)xn < (unsigned)g.Wi) ? 1u : 0u;
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, xoff[j] | ((okb ^ 1u) << 31), 0, 0));
-      xoff[j] += xstep;
-    } else {
-      int pbj, pyj, pxj;
-      if (P2) {
-        const int m = mst[j] + bp + BPR * j;
-        pxj = m & (g.Wo - 1);
-        pyj = (m >> a.lgW) & (g.Ho - 1);
-        pbj = m >> a.lgHW;
-      } else {
-        pbj = pb[j]; pyj = py[j]; pxj = px[j];
-      }
-      const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
-      okb = (b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0) ? 1u : 0u;
-      const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
-      rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
-      if (!P2) {
-        int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
-        const int cx = x >= g.Wo ? 1 : 0;
-        x -= cx ? g.Wo : 0;
-        y += cx;
-        const int cy = y >= g.Ho ? 1 : 0;
-        y -= cy ? g.Ho : 0;
-        b += cy;
-        px[j] = x; py[j] = y; pb[j] = b;
-      }
-    }
-    bmask = (bmask & ~(1u << j)) | (okb << j);
-    mst[j] += BK;
-  };
-  // exact 3-way bf16 split of four values into the three planes of an LDS tile
-  auto store_a = [&](int buf, int j) {
-    *reinterpret_cast<f32x4*>(&Ah[buf][((ap + APR * j) & (HK - 1)) * BNn + ac * 4]) = ra[j];
-    if (bias_tile) bacc += ra[j];
-  };
-  auto store_b = [&](int buf, int j) {
-    f32x4 v = rb[j];
-    if (pro_mode != PRO_NONE) {
-      if (affine) v = v * psc + psh;
-      if (pro_mode == PRO_LRELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
-      } else if (pro_mode != PRO_AFFINE) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (affine) v *= (float)((bmask >> j) & 1u);
-    }
-    *reinterpret_cast<f32x4*>(&Bh[buf][((bp + BPR * j) & (HK - 1)) * BNk + bc * 4]) = v;
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int fi = lane & 31, fh = lane >> 5;
-  // one 16-pixel half-step: 8 s-steps of 2 pixels; fragments are read one s-step ahead (as in conv_wgrad_kernel)
-  auto mfma_half = [&](int buf, auto&& slot_work) {
-    const float* Ac = Ah[buf];
-    const float* Bc = Bh[buf];
-    float fa[2][TM], fb[2][TN];
-    auto read_frag = [&](int sstep, int set) {
-      const int p = 2 * sstep + fh;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[set][i] = Ac[p * BNn + wm * (TM * 32) + i * 32 + fi];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[set][j] = Bc[p * BNk + wn * (TN * 32) + j * 32 + fi];
-    };
-    read_frag(0, 0);
-#pragma unroll
-    for (int sidx = 0; sidx < 8; ++sidx) {
-      if (sidx + 1 < 8) read_frag(sidx + 1, (sidx + 1) & 1);
-      slot_work(sidx);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sidx & 1][i], fb[sidx & 1][j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // prologue: the whole first K-step is loaded; its first half goes to buffer 0, and the registers of that half are
-  // re-loaded for the next K-step right away
-  if (step0 < step1) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) load_a(j);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) load_b(j);
-#pragma unroll
-    for (int t = 0; t < AH; ++t) store_a(0, t);
-    store_b(0, 0); store_b(0, 1);
-    if (step0 + 1 < step1) {
-#pragma unroll
-      for (int t = 0; t < AH; ++t) load_a(t);
-      load_b(0); load_b(1);
-    }
-  }
-  __syncthreads();
-  // s-steps 0 .. AH+1 of a half-step carry the stores of the OTHER half's pieces (AH dy pieces, 2 gathered pieces),
-  // s-steps 6 and 7 the re-loads of the registers just freed
-  for (int step = step0; step < step1; ++step) {
-    const bool next1 = step + 1 < step1, next2 = step + 2 < step1;
-    mfma_half(0, [&](int sidx) {
-      if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
-      if (sidx < AH) store_a(1, AH + sidx);
-      if (sidx == AH) store_b(1, 2);
-      if (sidx == AH + 1) store_b(1, 3);
-      if (next1 && sidx == 6) {
-#pragma unroll
-        for (int t = 0; t < AH; ++t) load_a(AH + t);
-      }
-      if (next1 && sidx == 7) { load_b(2); load_b(3); }
-    });
-    __syncthreads();
-    mfma_half(1, [&](int sidx) {
-      if (next1) {
-        if (sidx < AH + 2) __builtin_amdgcn_sched_barrier(0);
-        if (sidx < AH) store_a(0, sidx);
-        if (sidx == AH) store_b(0, 0);
-        if (sidx == AH + 1) store_b(0, 1);
-      }
-      if (next2 && sidx == 6) {
-#pragma unroll
-        for (int t = 0; t < AH; ++t) load_a(t);
-      }
-      if (next2 && sidx == 7) { load_b(0); load_b(1); }
-    });
-    __syncthreads();
-  }
-
-  float* out = a.slab + (long)split * a.slab_stride;
-  if (bias_tile) {
-    float* red = &Ah[0][0];      // tiles are done with: [APR][BNn] partial rows
-    __syncthreads();
-    *reinterpret_cast<f32x4*>(red + ap * BNn + ac * 4) = bacc;
-    __syncthreads();
-    if (tid < BNn && n0 + tid < g.Co) {
-      float t = 0.f;
-#pragma unroll
-      for (int r = 0; r < APR; ++r) t += red[r * BNn + tid];
-      out[a.bias_off + n0 + tid] = t;
-    }
-  }
-  const __amdgpu_buffer_rsrc_t osrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((unsigned)g.Co * g.Kp * 4u), 0x00020000);
-  const unsigned rowbytes = (unsigned)g.Kp * 4u;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int k = k0 + wn * (TN * 32) + j * 32 + fi;
-      const int nrow = n0 + wm * (TM * 32) + i * 32 + 4 * fh;
-      const unsigned vbase = k < g.Kp ? ((unsigned)nrow * g.Kp + k) * 4u : 0x80000000u;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float av = acc[i][j][e];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), osrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0);
-      }
-    }
-}
 
 // out[i] (+)= sum_s slab[s][i]; optionally per-block partial of <G, W> for the SN backward
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits,
@@ -1038,50 +516,27 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
       case PRO_AFFINE_RELU: DG_WG(BN_, PRO_AFFINE_RELU); break; \
       case PRO_LRELU: DG_WG(BN_, PRO_LRELU); break; \
       default: DG_WG(BN_, PRO_AFFINE); break; }
-#define DG_WGX(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_x6_kernel<BN_, PRO_, true>), grid, dim3(256), 0, st, a); \
-                               else hipLaunchKernelGGL((conv_wgrad_x6_kernel<BN_, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
-#define DG_WGX_ALL(BN_) switch (pro_mode) { \
-      case PRO_NONE: DG_WGX(BN_, PRO_NONE); break; \
-      case PRO_RELU: DG_WGX(BN_, PRO_RELU); break; \
-      case PRO_AFFINE_RELU: DG_WGX(BN_, PRO_AFFINE_RELU); break; \
-      default: DG_WGX(BN_, -1); break; }
-  static const int half = getenv("DIAGAN_WGRAD_HALF") ? atoi(getenv("DIAGAN_WGRAD_HALF")) : 0;
-#define DG_WGH(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_half_kernel<BN_, PRO_, true>), grid, dim3(256), 0, st, a); \
-                               else hipLaunchKernelGGL((conv_wgrad_half_kernel<BN_, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
-  if (half && bk == 128 && bn == 128 && diagan_get_mfma_mode() == 0) {
-    switch (pro_mode) {
-      case PRO_NONE: DG_WGH(128, PRO_NONE); break;
-      case PRO_RELU: DG_WGH(128, PRO_RELU); break;
-      case PRO_AFFINE_RELU: DG_WGH(128, PRO_AFFINE_RELU); break;
-      default: DG_WGH(128, -1); break;
-    }
-  } else
-  if (bk == 128 && diagan_get_mfma_mode() == 1) {      // bf16x6 (opt-in): dy tiles of 128 or 64 columns x 128 packed k
-    if (bn == 128) { DG_WGX_ALL(128) } else { DG_WGX_ALL(64) }
-  } else if (bn == 64 && bk == 64) {
+  if (bn == 64 && bk == 64) {
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
   } else if (bn == 64) {
     DG_WG_ALL(64)
   } else {
     DG_WG_ALL(128)
   }
-#undef DG_WGH
-#undef DG_WGX_ALL
-#undef DG_WGX
 #undef DG_WG_ALL
 #undef DG_WG
   return check_launch("conv_wgrad");
 }
 
 // The Winograd F(3x3,2x2) weight gradient (conv_wgrad_wino.hip) takes the 3x3 / stride 1 / pad 1 layers unless
-// DIAGAN_WINO=0 / diagan_conv_gemm_set_wino(0) or the bf16x6 mode is on.
+// DIAGAN_WINO=0 / diagan_conv_gemm_set_wino(0) is set.
 DIAGAN_API int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                            int off, int up, int Kp) {
   static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
   static const int wg_env = getenv("DIAGAN_WINO_WGRAD") ? atoi(getenv("DIAGAN_WINO_WGRAD")) : 1;
   const int sw = diagan_conv_gemm_get_wino();
   const int on = sw >= 0 ? sw : wino_env;
-  return on && wg_env && diagan_get_mfma_mode() == 0 &&
+  return on && wg_env &&
          wgrad_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp);
 }
 
@@ -1111,8 +566,7 @@ DIAGAN_API int diagan_conv_wgrad_splits(int M, int Co, int Kp) {
   if (smax > 256) smax = 256;
   int splits = 1;
   double best = 1e30;
-  static const int half = getenv("DIAGAN_WGRAD_HALF") ? atoi(getenv("DIAGAN_WGRAD_HALF")) : 0;
-  const int slots = (half && bn == 128 && bk == 128 && diagan_get_mfma_mode() == 0) ? 768 : 512;   // 3 workgroups per CU
+  const int slots = 512;                            // two resident workgroups per CU
   for (int s = 1; s <= smax; ++s) {
     const double t = (double)cdiv(tiles * s, slots) * ((double)total_steps / s + fixed);
     if (t < best * 0.995) { best = t; splits = s; }   // ties (and near-ties) go to fewer splits: less slab traffic

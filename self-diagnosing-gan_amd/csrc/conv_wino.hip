@@ -28,11 +28,8 @@ namespace diagan {
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 4 i + j, written in the LDS image order (see above).  flip: the data-gradient of a
 // stride-1 convolution is the correlation with the taps reversed.
-// staged: the plane order of conv_wino_s.hip -- element (column, channel) of a (f, k-quad) plane sits at
-// (((channel >> 1) * 32 + (column & 31)) * 2 + (column >> 5)) * 2 + (channel & 1): an MFMA lane's two k values of both column
-// halves are 16 contiguous bytes.
 __global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                         int Kp, int flip, int staged) {
+                                                         int Kp, int flip) {
   const int c4 = blockIdx.x, co = blockIdx.y * 64 + threadIdx.x, c = c4 * 4;
   f32x4 g[3][3];
 #pragma unroll
@@ -66,15 +63,7 @@ __global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict
     for (int j = 0; j < 4; ++j) {
       float* plane = base + ((i * 4 + j) * 2 + kq) * 256;
       const f32x4 v = u[j] * sg;
-      if (!staged) {
-        *reinterpret_cast<f32x4*>(plane + threadIdx.x * 4) = v;
-      } else {
-        const int fi = threadIdx.x & 31, h = threadIdx.x >> 5;
-        plane[((0 * 32 + fi) * 2 + h) * 2 + 0] = v[0];
-        plane[((0 * 32 + fi) * 2 + h) * 2 + 1] = v[1];
-        plane[((1 * 32 + fi) * 2 + h) * 2 + 0] = v[2];
-        plane[((1 * 32 + fi) * 2 + h) * 2 + 1] = v[3];
-      }
+      *reinterpret_cast<f32x4*>(plane + threadIdx.x * 4) = v;
     }
   }
 }
@@ -512,8 +501,8 @@ static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t s
   return check_launch("conv_wino");
 }
 
-void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, int staged, hipStream_t st) {
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(Ci / 4, cdiv(Co, WN)), dim3(64), 0, st, w, ug, Co, Ci, Kp, flip, staged);
+void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, hipStream_t st) {
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(Ci / 4, cdiv(Co, WN)), dim3(64), 0, st, w, ug, Co, Ci, Kp, flip);
 }
 
 // floats of workspace the transformed weights need
@@ -542,7 +531,7 @@ int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
-  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, 0, st);
+  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino_pro<PRO_NONE>(a, ws, st);
     case PRO_RELU: return launch_wino_pro<PRO_RELU>(a, ws, st);

@@ -206,7 +206,7 @@ class ConvLayer(nn.Module):
         g = self.geom
         return (g.kind == 'conv' and g.R == 3 and g.S == 3 and g.stride == 1 and g.pad == 1 and x.shape[1] % 2 == 0
                 and x.shape[2] % 2 == 0 and x.numel() >= (1 << 20)
-                and (dy_pooled.numel() // dy_pooled.shape[-1]) % 64 == 0 and C.get_mfma_mode() == 0
+                and (dy_pooled.numel() // dy_pooled.shape[-1]) % 64 == 0
                 and os.environ.get("DIAGAN_WGRAD_POOLED", "1") != "0")
 
     def wgrad_pooled(self, ctx, dy_pooled, x, relu_in=False, slot=0):

@@ -20,7 +20,6 @@ nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_pick_cfg_grouped", [I] * 15 + [I64, I])
 nat.register("diagan_conv_gemm_tile_rows", [I])
-nat.register("diagan_conv_wino_staged_supported", [I] * 5)
 nat.register("diagan_conv_wino_pool_supported", [I] * 14 + [I64])
 nat.register("diagan_conv_wino_unpool_supported", [I] * 13 + [I64])
 nat.register("diagan_conv_gemm_tile_cols", [I])
@@ -40,12 +39,10 @@ nat.register("diagan_sn_power_iter", [P, P, P, P, P, P, P, I, I, F, I, P])
 nat.register("diagan_sn_prepare_batched", [P, I, I, I, I, I, F, I, I, P])
 nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
 nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
-nat.register("diagan_set_mfma_mode", [I])
-nat.register("diagan_get_mfma_mode", [])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
-# kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO, X6, STAMP, FP; PRO = -1: run-time mode)
+# kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO, STAMP, FP; PRO = -1: run-time mode)
 TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3: (64, 64, 2, 2, 32, False),
                4: (128, 64, 4, 1, 32, False), 5: (256, 64, 4, 1, 32, False), 6: (64, 64, 2, 2, 64, False),
                7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True)}
@@ -54,8 +51,6 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
 def gemm_kernel_name(cfg, mode, Co=128):
     if cfg == 9:
         return f"conv_wino_kernel<{mode}>"
-    if cfg == 10:
-        return f"conv_wino_s_kernel<{mode}>"
     if cfg == 13:
         return f"conv_wino4_kernel<{mode}>"
     if cfg == 11:
@@ -63,9 +58,7 @@ def gemm_kernel_name(cfg, mode, Co=128):
     if cfg == 12:
         return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
-    if get_mfma_mode() == 1 and cfg in (1, 3):     # bf16x6: 16-wide K-steps, prologue modes 0-2 specialised
-        return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},16,{mode if mode <= 2 else -1},true,false,false>"
-    return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,false,{'true' if fp else 'false'}>"
+    return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,{'true' if fp else 'false'}>"
 
 
 class KernelTimer:
@@ -117,12 +110,6 @@ TIMER = None      # set to a KernelTimer by bench.py
 _NAME_CACHE = {}
 
 
-def set_mfma_mode(mode):
-    """0: exact fp32 MFMA (default); 1 or 'bf16x6': experimental fp32-accurate mode on the bf16 matrix pipe (every
-    operand split exactly into three bf16 pieces, six piece products accumulated in fp32)"""
-    nat.call("diagan_set_mfma_mode", 1 if mode in (1, 'bf16x6') else 0)
-
-
 def set_winograd(mode):
     """True / False: allow / forbid the Winograd kernel for auto-selected tile configurations; None: the default
     (on, or what DIAGAN_WINO says)"""
@@ -133,10 +120,6 @@ def set_winograd4(mode):
     """True / False: allow / forbid the F(4x4,3x3) kernel (tile_cfg 13) for auto-selected launches; None: the default (on, or
     what DIAGAN_WINO4 says)"""
     nat.call("diagan_conv_gemm_set_wino4", -1 if mode is None else (1 if mode else 0))
-
-
-def get_mfma_mode():
-    return nat.fn("diagan_get_mfma_mode")()
 
 
 def round_up(x, m):
@@ -231,8 +214,6 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         M = B * Ho * Wo
         cfg = tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, 0,
                                                                        ws.numel(), group_imgs * Ho * Wo)
-        if cfg == 10 and not nat.fn("diagan_conv_wino_staged_supported")(B, Ho, Wo, Ci, group_imgs * Ho * Wo):
-            cfg = 9                       # prologue groups that the staged kernel's image blocks straddle
         bm = nat.fn("diagan_conv_gemm_tile_rows")(cfg)
         tiles = (M + bm - 1) // bm
         stats = (torch.empty((tiles, 2, Co), dtype=torch.float32, device=x.device), tiles)
@@ -242,10 +223,10 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         # (cached per call signature: on launch-bound workloads the name lookup itself was 6 ms of host time per step)
         key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats, group_imgs)
         kname = _NAME_CACHE.get(key)
-        if kname is None or _NAME_CACHE.get('modes') != (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")()):
-            if _NAME_CACHE.get('modes') != (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")()):
+        if kname is None or _NAME_CACHE.get('modes') != nat.fn("diagan_conv_gemm_get_wino")():
+            if _NAME_CACHE.get('modes') != nat.fn("diagan_conv_gemm_get_wino")():
                 _NAME_CACHE.clear()
-                _NAME_CACHE['modes'] = (get_mfma_mode(), nat.fn("diagan_conv_gemm_get_wino")())
+                _NAME_CACHE['modes'] = nat.fn("diagan_conv_gemm_get_wino")()
             allow = 0 if want_stats else 1
             kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(
                 B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co)
@@ -474,9 +455,6 @@ def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0, wino=False):
         bn = 64
     if bk != 128:
         return f"conv_wgrad_kernel<{bn},{bk},-1,false>"
-    if get_mfma_mode() == 1:
-        p2x = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
-        return f"conv_wgrad_x6_kernel<{bn},{mode if mode <= 2 else -1},{'true' if p2x else 'false'}>"
     p2 = Ho > 0 and Wo > 0 and (Ho & (Ho - 1)) == 0 and (Wo & (Wo - 1)) == 0
     return f"conv_wgrad_kernel<{bn},128,{mode},{'true' if p2 else 'false'}>"
 

@@ -379,26 +379,3 @@ for (B, H, Ci, Co, pro) in ((16, 32, 128, 128, 1), (8, 16, 256, 256, 2), (6, 12,
     out[(B, H, Ci, Co, pro)] = grad.cpu()
 torch.save(out, sys.argv[3])
 """
-
-
-def test_half_step_weight_gradient_kernel_in_a_child_process(tmp_path):
-    """conv_wgrad_half_kernel (DIAGAN_WGRAD_HALF=1, read once per process into a static) against the default fp32
-    implicit-GEMM weight gradient on the same inputs, both with the Winograd path off: equal to summation-order
-    rounding (the opt-in kernel had no test)."""
-    import os
-    import subprocess
-    import sys
-    from conftest import PKG, ROOT
-    script = tmp_path / "child.py"
-    script.write_text(_HALF_CHILD)
-    res = {}
-    for tag, extra in (("default", {}), ("half", {"DIAGAN_WGRAD_HALF": "1"})):
-        env = dict(os.environ, DIAGAN_WINO="0", **extra)
-        out = tmp_path / f"{tag}.pt"
-        r = subprocess.run([sys.executable, str(script), ROOT, PKG, str(out)], env=env, capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[tag] = torch.load(out)
-    for k, ref in res["default"].items():
-        got = res["half"][k]
-        assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item() + 1e-7, k

@@ -57,7 +57,6 @@ def test_launch_selection_queries_are_host_logic():
     pick = nat.fn("diagan_conv_gemm_pick_cfg_geom")
     pool, unpool = nat.fn("diagan_conv_wino_pool_supported"), nat.fn("diagan_conv_wino_unpool_supported")
     ws = 64 << 20
-    assert nat.fn("diagan_get_mfma_mode")() == 0
     assert pick(128, 32, 32, 128, 32, 32, 128, 3, 3, 1, 1, -1, 1, 1152, 1, ws) == 13     # D-32 block1.c2, pair pass: 512 workgroups of F(4x4,3x3)
     nat.call("diagan_conv_gemm_set_wino4", 0)
     try:

@@ -95,19 +95,16 @@ def test_forward_eval_and_train(dataset, res):
             relclose(sD[k], v, 1e-4, k)
 
 
-@pytest.mark.parametrize("mode", ["fp32", "fp32-implicit-gemm", "bf16x6"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32-implicit-gemm"])
 @pytest.mark.parametrize("dataset,res,loss", [("cifar10", 32, "ns"), ("cifar10", 32, "hinge"), ("celeba", 64, "ns")])
 def test_train_steps_match_oracle(dataset, res, loss, mode):
     """two D + G updates against the CPU oracle in every arithmetic mode of the GEMM kernels: the default (fp32 MFMA,
-    Winograd where it qualifies), fp32 MFMA on the implicit GEMM only, and the opt-in bf16x6 mode (DIAGAN_MFMA=bf16x6)"""
+    Winograd where it qualifies) and fp32 MFMA on the implicit GEMM only"""
     from diagan.ops import conv as C
-    start = C.get_mfma_mode()
-    C.set_mfma_mode(1 if mode == "bf16x6" else 0)
     C.set_winograd(False if mode == "fp32-implicit-gemm" else None)
     try:
         _train_steps_match_oracle(dataset, res, loss)
     finally:
-        C.set_mfma_mode(start)
         C.set_winograd(None)
 
 
@@ -168,7 +165,7 @@ def test_full_batch_updates_match_oracle_through_the_fused_kernels(dataset, res)
     B = 64
     c2 = netD.block1.c2
     relu = (C.PRO_RELU, None, None)
-    if C.get_mfma_mode() == 0:                                        # (DIAGAN_MFMA=bf16x6 for the whole suite: implicit GEMM only)
+    if True:
         assert C.pool_fused(c2.geom, 2 * B, res, res, relu) and C.unpool_fused(c2.geom, 2 * B, res, res)
         last = netG.block4 if res == 32 else netG.block5             # the generator's last up-sampling block, at full size
         assert C.res_up_fused(last.c2.geom, B, res, res, want_stats=True)

@@ -112,7 +112,4 @@ def test_bench_line_for_the_stylegan2_workload():
     assert "StyleGAN2" in line["config"]["workload"] and line["config"]["global_batch"] == 4
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
     assert "cpu_baseline" not in line
-    if os.environ.get("DIAGAN_MFMA") == "bf16x6":       # the whole run is in the experimental mode: labelled as such
-        assert "bf16" in line["dtype"] and "bf16x6_mode" not in line
-    else:
-        assert line["dtype"] == "f32" and line["bf16x6_mode"]["value"] > 0
+    assert line["dtype"] == "f32"

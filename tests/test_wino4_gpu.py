@@ -9,9 +9,9 @@ import torch
 import torch.nn.functional as F
 
 from test_conv_gpu import close, nchw, nhwc, ref_pro
-from test_wino_gpu import _fp32_mode, make
+from test_wino_gpu import make
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _fp32_mode(), reason="Winograd kernels belong to the fp32 MFMA mode")]
+pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 # B, H, W, Ci, Co: ragged tile counts (tiles % 32 != 0), non-square images, Co not a multiple of 64, SNGAN block shapes

@@ -8,16 +8,7 @@ import torch.nn.functional as F
 
 from test_conv_gpu import close, nchw, nhwc, ref_pro
 
-def _fp32_mode():
-    try:
-        from diagan.ops import conv as C
-        return C.get_mfma_mode() == 0
-    except Exception:            # no library here (CPU collection): the gpu mark deselects these anyway
-        return True
-
-
-# the Winograd kernels are fp32-MFMA kernels: with DIAGAN_MFMA=bf16x6 forced for the whole suite they are never selected
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _fp32_mode(), reason="Winograd kernels belong to the fp32 MFMA mode")]
+pytestmark = pytest.mark.gpu
 
 # B, H, W, Ci, Co: square / non-square images, ragged tile counts, Co not a multiple of 64, the SNGAN block shapes
 CASES = [(4, 8, 8, 64, 64), (3, 6, 10, 16, 24), (5, 16, 16, 128, 72), (2, 32, 32, 256, 256), (8, 64, 64, 64, 64),
@@ -65,63 +56,6 @@ def test_data_gradient_with_mask_and_residual(case):
     close(nchw(dx), (xr.grad + res.double()) * (msk > 0).double(), tol=2e-5)
     dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), mask_src=nhwc(msk).cuda(), mask_slope=0.2, tile_cfg=9)
     close(nchw(dx), torch.where(msk > 0, xr.grad, 0.2 * xr.grad), tol=2e-5)
-
-
-# the staged-input kernel (tile_cfg 10, csrc/conv_wino_s.hip; opt-in): block shapes 8x4x1, 4x4x2, 8x2x2 and 4x2x4, Co not a
-# multiple of 64, the data-gradient, split-K
-STAGED = [(2, 32, 32, 32, 64), (6, 8, 8, 64, 72), (4, 4, 16, 16, 8), (8, 4, 8, 48, 32), (64, 8, 8, 256, 128)]
-
-
-@pytest.mark.parametrize("case", STAGED)
-@pytest.mark.parametrize("pro", [0, 1, 2, 3, 4])
-def test_staged_kernel_forward_and_data_gradient(case, pro):
-    from diagan import _native as nat
-    from diagan.ops import conv as C
-    B, H, W, Ci, Co = case
-    assert nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, 0)
-    geom, x, w, wp = make(*case, seed=11)
-    g = torch.Generator().manual_seed(12)
-    bias, scale, shift = torch.randn(Co, generator=g), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
-    ref = F.conv2d(ref_pro(x.double(), pro, scale.double(), shift.double()), w.double(), bias.double(), padding=1)
-    res = torch.randn(ref.shape, generator=g)
-    y, st = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=10,
-                       want_stats=True)
-    close(nchw(y), ref, tol=2e-5)
-    close(st[0][:, 0].sum(0), ref.sum((0, 2, 3)), tol=2e-5)
-    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(), res_relu=True,
-                   pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=10)
-    close(nchw(y), ref + F.relu(res.double()), tol=2e-5)
-    if pro == 0 and Co % 16 == 0:
-        dy = torch.randn(B, Co, H, W, generator=g)
-        xr = x.double().requires_grad_(True)
-        F.conv2d(xr, w.double(), padding=1).backward(dy.double())
-        msk = torch.randn(B, Ci, H, W, generator=g)
-        wd = torch.zeros(Ci, geom.Kd, device="cuda")
-        C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
-        dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), mask_src=nhwc(msk).cuda(), mask_slope=0.2, tile_cfg=10)
-        close(nchw(dx), torch.where(msk > 0, xr.grad, 0.2 * xr.grad), tol=2e-5)
-
-
-def test_staged_kernel_split_k_and_refusals():
-    from diagan import _native as nat
-    from diagan.ops import conv as C
-    geom, x, w, wp = make(64, 8, 8, 256, 128, seed=13)
-    ref = F.conv2d(F.relu(x.double()), w.double(), padding=1)
-    try:
-        for ks in (2, 4):
-            nat.call("diagan_conv_gemm_tune", ks, -1, 0)
-            y = C.conv_fwd(geom, nhwc(x).cuda(), wp, pro=(C.PRO_RELU, None, None), tile_cfg=10)
-            close(nchw(y), ref, tol=2e-5)
-    finally:
-        nat.call("diagan_conv_gemm_tune", 0, -1, 0)
-    sup = nat.fn("diagan_conv_wino_staged_supported")
-    assert not sup(64, 32, 32, 24, 0)            # Ci % 16
-    assert not sup(3, 8, 8, 64, 0)               # 4x4 tiles of TWO images per block: odd batch
-    assert not sup(64, 4, 4, 64, 0)              # 2x2 tiles of 8 images: the input region does not fit
-    assert not sup(64, 8, 8, 64, 3 * 64)         # prologue groups of 3 images straddle the 2-image blocks
-    with pytest.raises(RuntimeError, match="staged"):
-        g2, x2, w2, wp2 = make(3, 8, 8, 64, 64)
-        C.conv_fwd(g2, nhwc(x2).cuda(), wp2, tile_cfg=10)
 
 
 def test_pair_scales_res_relu_statistics_and_groups():

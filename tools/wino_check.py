@@ -52,7 +52,7 @@ def main():
         s0, s1 = torch.tensor([0.7], device=dev), torch.tensor([1.3], device=dev)
         big = B * H * W >= 2048
         from diagan import _native as nat
-        staged = bool(nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, 0))
+        staged = False        # (the staged-input kernel, tile_cfg 10, was retired in round 3)
         variants = {
             "fwd plain": lambda cfg: C.conv_fwd(geom, x, wp, tile_cfg=cfg),
             "fwd relu+bias": lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, pro=(C.PRO_RELU, None, None), tile_cfg=cfg),
@@ -105,7 +105,7 @@ def main():
             gsc, gsh = torch.rand(4, Ci, device=dev) + 0.5, torch.randn(4, Ci, device=dev) * 0.3
             pro = (C.PRO_AFFINE_RELU, gsc, gsh, B // 4)
             e = relerr(C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=9), C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=7))
-            if staged and nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, (B // 4) * H * W):
+            if staged:
                 e = max(e, relerr(C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=10), C.conv_fwd(geom, x, wp, pro=pro, tile_cfg=7)))
             worst = max(worst, e)
             print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {'fwd grouped bn+relu':22s} err {e:.2e}", flush=True)
@@ -126,7 +126,7 @@ def main():
             worst = max(worst, e)
             t = timeit(lambda: f(9))
             line += f"  ks{ks} err {e:.1e} {t*1e6:7.1f} us"
-        if nat.fn("diagan_conv_wino_staged_supported")(B, H, W, Ci, 0):
+        if False:
             line += " | staged"
             for ks in (1, 2, 4):
                 nat.call("diagan_conv_gemm_tune", ks, -1, 0)
