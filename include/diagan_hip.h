@@ -219,6 +219,9 @@ typedef struct {
                             layer's first workgroup in the finish kernels' 1-D grid (prefix sum of ceil(n_elem/1024)) */
 } diagan_wgrad_layer;
 int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t total_blocks, int any_sn, void* stream);
+/* elements of a layer that one workgroup of the finish kernels handles, for a layer of `splits` splits per context: the host
+ * lays out diagan_wgrad_layer::first_block (and sizes the <G, W> partial arrays) in units of it */
+int diagan_wgrad_finish_block_elems(int splits);
 
 /* out (+)= sum_s slab[s]; if w: dot_partials[block] = partial <sum, w> (fp64, for the SN backward);
  * ceil(n_elem/1024) partials. */

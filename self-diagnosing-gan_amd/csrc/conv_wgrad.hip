@@ -321,7 +321,7 @@ struct WgFinish {          // mirrored by diagan_wgrad_layer in include/diagan_h
   int nctx, first_block; // first_block: index of the layer's first workgroup in the 1-D grid of the finish kernels
 };
 
-// The finish kernels run on a 1-D grid with exactly ceil(n_elem / 1024) workgroups per layer (a [blocks of the largest
+// The finish kernels run on a 1-D grid with exactly ceil(n_elem / (1024 fin_u(splits))) workgroups per layer (a [blocks of the largest
 // layer] x [layers] grid launched 69 000 mostly empty workgroups for SNGAN-64 and spent its time dispatching them).
 __device__ __forceinline__ int find_layer(const WgFinish* __restrict__ tab, int n_layers, int bid) {
   int l = 0;
@@ -329,46 +329,63 @@ __device__ __forceinline__ int find_layer(const WgFinish* __restrict__ tab, int 
   return l;
 }
 
-// phase A: G_c = sum over the splits of context c (fixed order).  plain layers: grad += sum_c G_c.
-// SN layers: G_c kept in slab[c][0..] and the block's partial of <G_c, W> is written.
-__global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab, int n_layers) {
-  const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
-  const int lb = blockIdx.x - L.first_block;          // workgroup index inside the layer
-  const long i = ((long)lb * 256 + threadIdx.x) * 4;
+// Elements of a layer handled by one workgroup of the finish kernels: 256 threads x U positions x 4 floats, U = 4 for layers of
+// at most 8 splits per context and 1 otherwise (fin_u).  With one position per thread a layer of few splits (the large
+// layers, which carry the bytes: every layer's slab is one round of workgroup tiles, ~34 MB) had only `splits` = 2..8 loads in
+// flight per thread (2 TB/s); four positions keep 8 in flight.  Layers of many splits (small weights, huge pixel counts)
+// keep the small blocks: their per-thread chain is splits / 8 rounds long and more, smaller workgroups shorten the tail.
+__host__ __device__ __forceinline__ int fin_u(int splits) { return splits <= 8 ? 4 : 1; }
+
+template <int U>
+__device__ __forceinline__ void fin_a(const WgFinish& L, int lb, double* red) {
+  constexpr int ELEMS = 1024 * U;
   const bool sn = L.W != nullptr;
-  if ((long)lb * 1024 >= L.n_elem) return;
-  __shared__ double red[4];
-  f32x4 total = {0.f, 0.f, 0.f, 0.f};
+  long pos[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) pos[u] = (long)lb * ELEMS + (u * 256 + threadIdx.x) * 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 total[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) total[u] = z4;
+  constexpr int R = 8 / U;                     // splits per round: R x U = 8 independent loads in flight
   for (int c = 0; c < L.nctx; ++c) {
     double dot = 0.0;
-    if (i < L.n_elem) {
-      float* sl = L.slab[c];
-      // eight independent partial sums: the split loads stay in flight together (fixed order: deterministic)
-      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 s = *reinterpret_cast<const f32x4*>(sl + i), s1 = z4, s2 = z4, s3 = z4, s4 = z4, s5 = z4, s6 = z4, s7 = z4;
-      int k = 1;
-      for (; k + 7 < L.splits; k += 8) {
-        const float* q = sl + (long)k * L.stride + i;
-        s += *reinterpret_cast<const f32x4*>(q);
-        s1 += *reinterpret_cast<const f32x4*>(q + L.stride);
-        s2 += *reinterpret_cast<const f32x4*>(q + 2 * L.stride);
-        s3 += *reinterpret_cast<const f32x4*>(q + 3 * L.stride);
-        s4 += *reinterpret_cast<const f32x4*>(q + 4 * L.stride);
-        s5 += *reinterpret_cast<const f32x4*>(q + 5 * L.stride);
-        s6 += *reinterpret_cast<const f32x4*>(q + 6 * L.stride);
-        s7 += *reinterpret_cast<const f32x4*>(q + 7 * L.stride);
-      }
-      for (; k < L.splits; ++k) s += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + i);
-      s2 += s6; s3 += s7; s += s4; s1 += s5;
-      s = (s + s1) + (s2 + s3);
-      if (sn) {
-        if (i < L.n_w) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + i);
-          dot = (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
+    float* sl = L.slab[c];
+    f32x4 acc[U][R];                           // fixed assignment of splits to partial sums: deterministic
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[u][r] = z4;
+    int k = 0;
+    for (; k + R <= L.splits; k += R) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (pos[u] < L.n_elem) {
+          const float* q = sl + (long)k * L.stride + pos[u];
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc[u][r] += *reinterpret_cast<const f32x4*>(q + r * L.stride);
         }
-        *reinterpret_cast<f32x4*>(sl + i) = s;
-      } else {
-        total += s;
+    }
+    for (; k < L.splits; ++k) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (pos[u] < L.n_elem) acc[u][0] += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + pos[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      f32x4 s = acc[u][0];
+      if (R == 2) s += acc[u][1];
+      if (R == 8) s = ((acc[u][0] + acc[u][4]) + (acc[u][1] + acc[u][5])) + ((acc[u][2] + acc[u][6]) + (acc[u][3] + acc[u][7]));
+      if (pos[u] < L.n_elem) {
+        if (sn) {
+          if (pos[u] < L.n_w) {
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + pos[u]);
+            dot += (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
+          }
+          *reinterpret_cast<f32x4*>(sl + pos[u]) = s;
+        } else {
+          total[u] += s;
+        }
       }
     }
     if (sn) {
@@ -379,7 +396,23 @@ __global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __r
       if (threadIdx.x == 0) L.partials[c][lb] = (red[0] + red[1]) + (red[2] + red[3]);
     }
   }
-  if (!sn && i < L.n_elem) *reinterpret_cast<f32x4*>(L.grad + i) += total;
+  if (!sn) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (pos[u] < L.n_elem) *reinterpret_cast<f32x4*>(L.grad + pos[u]) += total[u];
+  }
+}
+
+// phase A: G_c = sum over the splits of context c (fixed order).  plain layers: grad += sum_c G_c.
+// SN layers: G_c kept in slab[c][0..] and the block's partial of <G_c, W> is written.
+__global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab, int n_layers) {
+  const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
+  const int lb = blockIdx.x - L.first_block;          // workgroup index inside the layer
+  const int U = fin_u(L.splits);
+  if ((long)lb * 1024 * U >= L.n_elem) return;
+  __shared__ double red[4];
+  if (U == 4) fin_a<4>(L, lb, red);
+  else fin_a<1>(L, lb, red);
 }
 
 // between A and B: <G_c, W> of every SN layer = sum of its phase-A partials, ONCE per layer (one workgroup each,
@@ -388,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_dot_kernel(const WgFinish* _
   const WgFinish L = tab[blockIdx.x];
   if (L.W == nullptr) return;
   __shared__ double red[256];
-  const int nparts = (L.n_elem + 1023) / 1024;
+  const int fe = 1024 * fin_u(L.splits), nparts = (L.n_elem + fe - 1) / fe;
   for (int c = 0; c < L.nctx; ++c) {
     double d = 0.0;
     for (int k = threadIdx.x; k < nparts; k += 256) d += L.partials[c][k];
@@ -404,30 +437,59 @@ __global__ __launch_bounds__(256) void wgrad_finish_dot_kernel(const WgFinish* _
 }
 
 // phase B (SN layers): grad += sum_c (G_c - <G_c,W>/sigma_c * u_c^T v_c) / sigma_c ; bias part: += G_c
+template <int U>
+__device__ __forceinline__ void fin_b(const WgFinish& L, int lb) {
+  constexpr int ELEMS = 1024 * U;
+  const int nparts = (L.n_elem + ELEMS - 1) / ELEMS;
+  float inv[2], coef[2];
+  for (int c = 0; c < L.nctx; ++c) {
+    inv[c] = L.state[c][1];
+    coef[c] = (float)(L.partials[c][nparts] * (double)inv[c]);
+  }
+  // all loads of the U positions first (G_c of both contexts, v, u, the gradient itself), then the arithmetic
+  long pos[U];
+  f32x4 gq[U][2], vv[U][2], og[U];
+  float uu[U][2];
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    pos[u] = (long)lb * ELEMS + (u * 256 + threadIdx.x) * 4;
+    const bool ok = pos[u] < L.n_elem, okw = ok && pos[u] < L.n_w;
+    const int n = okw ? (int)((unsigned)pos[u] / (unsigned)L.Kp) : 0;      // (i < n_w < 2^31: no 64-bit division)
+    const int k = okw ? (int)pos[u] - n * L.Kp : 0;
+    og[u] = ok ? *reinterpret_cast<const f32x4*>(L.grad + pos[u]) : z4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const bool oc = ok && c < L.nctx;
+      gq[u][c] = oc ? *reinterpret_cast<const f32x4*>(L.slab[c] + pos[u]) : z4;
+      vv[u][c] = oc && okw ? *reinterpret_cast<const f32x4*>(L.v[c] + k) : z4;
+      uu[u][c] = oc && okw ? L.u[c][n] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (pos[u] >= L.n_elem) continue;
+    f32x4 o = z4;
+    for (int c = 0; c < L.nctx; ++c) {
+      if (pos[u] < L.n_w) o += (gq[u][c] - (uu[u][c] * coef[c]) * vv[u][c]) * inv[c];
+      else o += gq[u][c];
+    }
+    *reinterpret_cast<f32x4*>(L.grad + pos[u]) = og[u] + o;
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab, int n_layers) {
   const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
   const int lb = blockIdx.x - L.first_block;
-  if (L.W == nullptr || (long)lb * 1024 >= L.n_elem) return;
-  const int nparts = (L.n_elem + 1023) / 1024;
-  double sdot[2];
-  for (int c = 0; c < L.nctx; ++c) sdot[c] = L.partials[c][nparts];
-  const long i = ((long)lb * 256 + threadIdx.x) * 4;
-  if (i >= L.n_elem) return;
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < L.nctx; ++c) {
-    const f32x4 g = *reinterpret_cast<const f32x4*>(L.slab[c] + i);
-    if (i < L.n_w) {
-      const float inv = L.state[c][1];
-      const float coef = (float)(sdot[c] * (double)inv);
-      const int n = (int)((unsigned)i / (unsigned)L.Kp), k = (int)i - n * L.Kp;       // (i < n_w < 2^31: no 64-bit division)
-      const f32x4 vv = *reinterpret_cast<const f32x4*>(L.v[c] + k);
-      o += (g - (L.u[c][n] * coef) * vv) * inv;
-    } else {
-      o += g;
-    }
-  }
-  *reinterpret_cast<f32x4*>(L.grad + i) += o;
+  const int U = fin_u(L.splits);
+  if (L.W == nullptr || (long)lb * 1024 * U >= L.n_elem) return;
+  if (U == 4) fin_b<4>(L, lb);
+  else fin_b<1>(L, lb);
 }
+
+// elements of a layer per workgroup of the finish kernels for a layer of `splits` splits per context (the host sizes
+// first_block and the partial arrays with it)
+extern "C" __attribute__((visibility("default"))) int diagan_wgrad_finish_block_elems(int splits) { return 1024 * fin_u(splits); }
 
 }  // namespace diagan
 

@@ -569,7 +569,7 @@ class WgradBatch:
             e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, bias_off=n_w if has_bias else -1,
                      segments=segments,
                      slab=torch.empty(splits * stride, dtype=torch.float32, device=dev),
-                     partials=torch.empty((segments, (stride + 1023) // 1024 + 1), dtype=torch.float64, device=dev))
+                     partials=torch.empty((segments, (stride + 1023) // 1024 + 1), dtype=torch.float64, device=dev))   # (>= blocks of any size + 1)
             self.entries[(layer, slot)] = e
             self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
         return e
@@ -646,7 +646,8 @@ class WgradBatch:
                 pp[11] = layer.weight.data.data_ptr() if sn else 0
                 tab[li]['p'], tab[li]['stride'] = pp, e['stride']
                 tab[li]['i'] = [per, e['n_elem'], e['n_w'], layer.geom.Kp, nctx, total_blocks]
-                total_blocks += (e['n_elem'] + 1023) // 1024
+                be = nat.fn("diagan_wgrad_finish_block_elems")(per)          # elements per workgroup of the finish kernels
+                total_blocks += (e['n_elem'] + be - 1) // be
             t = (torch.from_numpy(tab.view(np.uint8).copy()).to(layers[0].weight.device), len(layers), total_blocks, any_sn)
             self.tables[key] = t
         nat.call("diagan_wgrad_finish_batched", t[0].data_ptr(), t[1], t[2], t[3], nat.current_stream())

@@ -33,6 +33,7 @@ nat.register("diagan_conv3x3_co4_wgrad", [P, P, P, I64, I64, P, P, I, I, I, I, I
 nat.register("diagan_conv_wgrad", [P, P, P, I, I, I64, I64, P, P, I] + [I] * 14 + [P])
 nat.register("diagan_pack_batched", [P, I, I, I, I, I, P])
 nat.register("diagan_wgrad_finish_batched", [P, I, I64, I, P])
+nat.register("diagan_wgrad_finish_block_elems", [I])
 nat.register("diagan_conv_wgrad_splits", [I, I, I])
 nat.register("diagan_wgrad_reduce", [P, I, I64, P, I, P, P, P])
 nat.register("diagan_sn_power_iter", [P, P, P, P, P, P, P, I, I, F, I, P])
