@@ -193,7 +193,7 @@ def phase2(argv=None):
             logits = pickle.load(f)
         # window [p1_step - 5000, p1_step) of the record (train_mimicry_phase2.py:90-92); scored on the device
         scores = calculate_scores(logits, start_epoch=args.p1_step - args.window, end_epoch=args.p1_step,
-                                  device=run.device)
+                                  device=run.device, keys=[args.resample_score])
         weights = scores[args.resample_score]
         print(f'sample_weights mean: {weights.mean()}, var: {weights.var()}, max: {weights.max()}, min: {weights.min()}')
 
@@ -319,7 +319,8 @@ def color_mnist_phase2(argv=None, dataset=None):
     print(f'Use logit from: {record}')
     with open(record, "rb") as f:
         logits = pickle.load(f)
-    scores = calculate_scores(logits, start_epoch=args.p1_step - 5000, end_epoch=args.p1_step, device=run.device)
+    scores = calculate_scores(logits, start_epoch=args.p1_step - 5000, end_epoch=args.p1_step, device=run.device,
+                              keys=None if args.resample_score is None else [args.resample_score])
     weights = scores[args.resample_score] if args.resample_score is not None else None
     if weights is not None:
         print(f'sample_weights mean: {weights.mean()}, var: {weights.var()}, max: {weights.max()}, min: {weights.min()}')

@@ -162,7 +162,8 @@ def main(phase, argv=None, dataset=None):
         with open(logit_path, "rb") as f:
             logits = pickle.load(f)
         window = 5000                                                               # train_ffhq_phase2.py:649-652
-        score_dict = calculate_scores(logits, start_epoch=args.p1_step - window, end_epoch=args.p1_step + 1)
+        score_dict = calculate_scores(logits, start_epoch=args.p1_step - window, end_epoch=args.p1_step + 1,
+                                      keys=[args.resample_score])
         weights = score_dict[args.resample_score]
         print(f'weight_list max: {weights.max()} min: {weights.min()} mean: {weights.mean()} var: {weights.var()}')
         extra['drs_loader'] = _loader(dataset, args)

@@ -127,22 +127,33 @@ def ldr_scores_device(rec_rows, t_values=None, want_stats=True, exact=True):
 
 
 def calculate_scores(logits, start_epoch=50, end_epoch=75, clip_val=1.5, conf=1, device='cuda',
-                     exact=True):
+                     exact=True, keys=None):
     """Drop-in for plot.py:220 -- same keys, float64 ndarray values, window [start, end).
 
-    `logits` is the reference's dict{step -> ndarray[N]} or a resident LogitRecord."""
+    `logits` is the reference's dict{step -> ndarray[N]} or a resident LogitRecord.
+    keys (not in the reference): the scores the caller will read -- the phase-2 command lines consume ONE of the 103
+    (train_mimicry_phase2.py:93 `scores[args.resample_score]`); then only the four statistics and the requested
+    `ldr_conf_<t>_ratio_50` rows are computed, copied to the host and returned (same values, bit for bit)."""
     rec = logits if isinstance(logits, LogitRecord) else LogitRecord.from_dict(logits, device=device)
     rows = rec.window(start_epoch, end_epoch)
     print(f'calculate_scores -- start_epoch: {start_epoch} end_epoch: {end_epoch} '
           f'logits_arr: {tuple(rows.shape)}')
-    stats, conf_dev, tv = ldr_scores_device(rows, exact=exact)
+    t_values = None
+    if keys is not None:
+        by_key = {conf_key(t): t for t in conf_t_values()}
+        unknown = [k for k in keys if k not in by_key and k not in ('ldr', 'ldrd', 'ldrv', 'ldrm')]
+        if unknown:
+            raise KeyError(f"calculate_scores: unknown score key(s) {unknown}")
+        t_values = [by_key[k] for k in keys if k in by_key]
+    stats, conf_dev, tv = ldr_scores_device(rows, t_values=t_values, exact=exact)
     score_dict = dict()
     host_stats = torch.stack([stats[k] for k in ('ldr', 'ldrd', 'ldrv', 'ldrm')]).double().cpu().numpy()
     for j, k in enumerate(('ldr', 'ldrd', 'ldrv', 'ldrm')):
         score_dict[k] = host_stats[j]
-    host_conf = conf_dev.double().cpu().numpy()
-    for j, t in enumerate(tv):
-        score_dict[conf_key(t)] = host_conf[j]
+    if conf_dev is not None:
+        host_conf = conf_dev.double().cpu().numpy()
+        for j, t in enumerate(tv):
+            score_dict[conf_key(t)] = host_conf[j]
     return score_dict
 
 

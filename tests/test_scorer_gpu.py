@@ -131,3 +131,22 @@ def test_logit_scatter_and_record_roundtrip():
     rec.scatter(0, torch.tensor([N]), torch.zeros(1).cuda())
     with pytest.raises(IndexError):
         rec.check_bounds()
+
+
+def test_requested_keys_only_bit_exact(golden_dir):
+    """calculate_scores(..., keys=[...]) -- what the phase-2 command lines ask for (train_mimicry_phase2.py:93 reads ONE of the
+    103 scores) -- returns the four statistics and exactly the requested confidence scores, bit-identical to the full call."""
+    from diagan.utils.plot import calculate_scores
+    g = np.load(os.path.join(golden_dir, "scorer_main.npz"))
+    logits = {int(s): g["rec32"][i].astype(np.float64) for i, s in enumerate(g["steps"])}
+    start, end = int(g["start"]), int(g["end"])
+    full = calculate_scores(logits, start, end)
+    want = ["ldr_conf_0.3_ratio_50", "ldr_conf_5.0_ratio_50", "ldrm"]
+    part = calculate_scores(logits, start, end, keys=want)
+    assert sorted(part) == sorted(["ldr", "ldrd", "ldrv", "ldrm", "ldr_conf_0.3_ratio_50", "ldr_conf_5.0_ratio_50"])
+    for k in part:
+        assert np.array_equal(part[k], full[k]), k
+    only_stats = calculate_scores(logits, start, end, keys=["ldr"])
+    assert sorted(only_stats) == ["ldr", "ldrd", "ldrm", "ldrv"] and np.array_equal(only_stats["ldr"], full["ldr"])
+    with pytest.raises(KeyError):
+        calculate_scores(logits, start, end, keys=["ldr_conf_0.35_ratio_50"])

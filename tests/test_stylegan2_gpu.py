@@ -374,3 +374,55 @@ def test_256_generator_discriminator_losses_and_regularisers_vs_reference():
     close(pl, g["path_loss"])
     (2.0 * 4 * pl + 0 * fake[0, 0, 0, 0]).backward()
     _check_norms256(g, "path_grad", G)
+
+
+# ---- BASELINE configs[4] as it is trained: 256 x 256, channel_multiplier 2, batch 32 (stylegan2/train_ffhq.py:393,442) --------
+@pytest.mark.timeout(1800)
+def test_real_configuration_256_cm2_batch32_vs_oracle():
+    """The configuration the reference trains: at batch 32 every convolution takes the launch sizes of the
+    real run (the large Winograd / F(4x4) launches, the parity-split transposed gathers at 128^2 and 256^2), which the
+    channel_multiplier-1 / batch-2 fixture never reaches.  The pinned oracle (oracle/stylegan2.py: float32 PyTorch on the host,
+    stated the reference's way with per-sample grouped convolutions) evaluates the SAME 32 latents and images: generator
+    images, discriminator logits (whose minibatch-stddev layer couples the samples in groups of 4, so the whole batch is
+    compared), both losses; then one full training iteration of the HIP engine at this configuration with R1 and
+    path-length regularisation must leave finite parameters that moved."""
+    from diagan.models import stylegan2 as M
+    from diagan.trainer import stylegan2 as TR
+    size, cm, batch = 256, 2, 32
+    sg = O.seeded_state(O.generator_shapes(size, mult=cm), 41)
+    sd_ = O.seeded_state(O.discriminator_shapes(size, mult=cm), 42)
+    G, D = M.StyleGANGenerator(size=size, channel_multiplier=cm), M.StyleGANDiscriminator(size=size, channel_multiplier=cm)
+    G.load_state_dict(sg, strict=False), D.load_state_dict(sd_, strict=False)
+    G.cuda(), D.cuda()
+    gen = torch.Generator().manual_seed(256)
+    z = torch.randn(batch, 512, generator=gen)
+    x = torch.randn(batch, 3, size, size, generator=gen).clamp_(-2, 2) * 0.5
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    with torch.no_grad():
+        img, _ = G([z.cuda()], randomize_noise=False)
+        ref, _ = O.generator(sg, size, [z])
+        assert img.shape == (batch, 3, size, size)
+        close(img, ref, what="generator images, 256^2 cm 2 batch 32")
+        fp, rp = D(img), D(x.cuda())
+        fp_ref, rp_ref = O.discriminator(sd_, size, ref), O.discriminator(sd_, size, x)
+        close(fp, fp_ref, what="fake logits")
+        close(rp, rp_ref, what="real logits")
+        close(TR.d_logistic_loss(rp, fp), O.d_logistic_loss(rp_ref, fp_ref))
+        close(TR.g_nonsaturating_loss(fp), O.g_nonsaturating_loss(fp_ref))
+    # one full iteration of the trainer at this configuration (D step + R1, G step + path length): finite, and the step was taken
+    import types
+    g_ema = M.StyleGANGenerator(size=size, channel_multiplier=cm).cuda().eval()
+    TR.accumulate(g_ema, G, 0)
+    g_optim, d_optim = TR.make_optimizers(G, D)
+    a = types.SimpleNamespace(iter=10 ** 9, start_iter=0, batch=batch, latent=512, mixing=0.9, r1=10.0, d_reg_every=1,
+                              g_reg_every=1, path_regularize=2.0, path_batch_shrink=2, logit_save_steps=10 ** 9,
+                              save_logit_after=10 ** 9, stop_save_logit_after=0, n_sample=16, augment=False)
+    ds = torch.utils.data.TensorDataset(x.cuda(), torch.arange(batch, device='cuda'))
+    loader = torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False, drop_last=True)
+    tr = TR.StyleGAN2Trainer(a, loader, G, D, g_optim, d_optim, g_ema, torch.device('cuda'), "/tmp/diagan_test_sg2_real")
+    w0, d0 = G.flat_params.clone(), D.flat_params.clone()
+    tr.train_step(0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(G.flat_params).all() and torch.isfinite(D.flat_params).all()
+    assert float((G.flat_params - w0).abs().max()) > 1e-4 and float((D.flat_params - d0).abs().max()) > 1e-4
+    assert all(torch.isfinite(v).all() for v in (tr.r1_loss, tr.path_loss, tr.path_lengths))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profiles on the GPU box (run through gpurun): rocprofv3 kernel-trace stats of the default bench.py run and of
 # the SNGAN-64 workload, then the PMC passes (separate runs, --kernel-trace only, as MI355X_MICROARCH.md prescribes):
-# FETCH_SIZE, WRITE_SIZE, and SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE.  Output: gpurun_out/prof_<tag>/...
+# FETCH_SIZE, WRITE_SIZE, and SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CU_CYCLES + GRBM_GUI_ACTIVE.  Output: gpurun_out/prof_<tag>/...
 # usage: tools/profile_round.sh <tag>
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
@@ -16,8 +16,8 @@ PM="--steps 3 --warmup 2 --no_cpu_baseline --no_x6_leg --no_sngan64_leg --no_ker
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc32_$C -- python3 $R/bench.py $PM > $OUT/pmc32_$C.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc32_mfma -- python3 $R/bench.py $PM > $OUT/pmc32_mfma.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc64_mfma -- python3 $R/bench.py --workload sngan64 $PM > $OUT/pmc64_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc32_mfma -- python3 $R/bench.py $PM > $OUT/pmc32_mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc64_mfma -- python3 $R/bench.py --workload sngan64 $PM > $OUT/pmc64_mfma.log 2>&1
 # keep the summaries, drop the per-dispatch traces of the stats runs (large)
 find $OUT/kt32 $OUT/kt64 -name "*kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
