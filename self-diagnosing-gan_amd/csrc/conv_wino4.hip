@@ -494,6 +494,21 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       y4[1] = qq + 2.f * tt;
       y4[2] = pp + 4.f * rr;
       y4[3] = qq + 8.f * tt + s6[5];
+      // half-resolution residual (GBlock shortcut): output row oy0 + ar blends half-resolution rows (jy - 1, jy) [ar = 0] or
+      // (jy, jy + 1) [ar = 1], jy = oy0 / 2, and its four pixels blend columns 2 tx - 1 .. 2 tx + 2, edges clamped: eight
+      // loads for the row instead of four per pixel
+      f32x4 rup[8];
+      if (hr && a.res_up && ok) {
+        const int Hh = g.Ho >> 1, Wh = g.Wo >> 1, jy = oy0 >> 1, jx = ox0 >> 1;
+        const int y0 = ar ? jy : max(jy - 1, 0), y1 = ar ? min(jy + 1, Hh - 1) : jy;
+        const int xx[4] = {max(jx - 1, 0), jx, jx + 1, min(jx + 2, Wh - 1)};
+        const float* rb = a.residual + ((long)eb * Hh * Wh) * g.Co + n;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rup[q] = *reinterpret_cast<const f32x4*>(rb + ((long)y0 * Wh + xx[q]) * g.Co);
+          rup[4 + q] = *reinterpret_cast<const f32x4*>(rb + ((long)y1 * Wh + xx[q]) * g.Co);
+        }
+      }
 #pragma unroll
       for (int bc = 0; bc < 4; ++bc) {
         const int soff = ar * rowb + bc * pixb;
@@ -501,7 +516,12 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         if (hr) {
           f32x4 r;
           if (a.res_up) {
-            r = ok ? residual_up2(a.residual, (int)eb, oy0 + ar, ox0 + bc, g.Ho >> 1, g.Wo >> 1, g.Co, n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // upsample2x_kernel's arithmetic: (w0 * a + w1 * b) along x inside the y blend
+            const int c0 = bc == 0 ? 0 : (bc == 3 ? 2 : 1);
+            const float wy0 = ar ? 0.75f : 0.25f, wx0 = (bc & 1) ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx1 = 1.f - wx0;
+            const f32x4 top = wx0 * rup[c0] + wx1 * rup[c0 + 1];
+            const f32x4 bot = wx0 * rup[4 + c0] + wx1 * rup[4 + c0 + 1];
+            r = wy0 * top + wy1 * bot;
           } else {
             r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 #pragma unroll

@@ -30,7 +30,9 @@ for B, H, W, Ci, Co in shapes:
     res = torch.randn(B, H, W, Co, device=dev)
     bias = torch.randn(Co, device=dev)
     flop = 2.0 * B * H * W * Co * 9 * Ci
+    resh = torch.randn(B, H // 2, W // 2, Co, device=dev)
     for name, f in (("plain", lambda cfg: C.conv_fwd(geom, x, wp, tile_cfg=cfg)),
+                    ("bn+relu+bias+res_up", lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, residual=resh, res_up=True, pro=(C.PRO_AFFINE_RELU, sc, sh), tile_cfg=cfg)),
                     ("bn+relu+bias+res", lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, residual=res, pro=(C.PRO_AFFINE_RELU, sc, sh), tile_cfg=cfg))):
         e = ((f(13) - f(9)).abs().max() / f(9).abs().max()).item()
         t9, t13 = timeit(lambda: f(9)), timeit(lambda: f(13))
