@@ -194,7 +194,7 @@ def executed_flop(name, flop):
     if name.startswith("conv_wino_pool_kernel"):
         return flop * WINO_POOL_MAC_RATIO
     if name.startswith("conv_wino4_kernel"):     # Winograd F(4x4,3x3): 36 products per 4x4 output tile instead of 144
-        return flop * 0.25
+        return flop * (25.0 / 144.0 if name.endswith((",1>", ",2>")) else 0.25)     # ... 25 with the 2x2 average pool folded in
     if name.endswith("[pooled gradient]"):     # weight gradient through the average pool as a strided convolution over box sums
         return flop * 0.25
     return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel")) else flop

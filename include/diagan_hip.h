@@ -161,6 +161,10 @@ int diagan_conv_gemm_get_wino(void);
  * error ~1e-5 of the output scale (cuDNN's non-fused Winograd for the reference's F.conv2d is the same F(4x4,3x3)).  The
  * automatic choice takes it for launches of >= 512 workgroups (32 tiles x 64 channels each).  0 = never, 1 / -1 = default. */
 int diagan_conv_gemm_set_wino4(int mode);
+/* tile_cfg 11 / 12 (convolution + 2x2 average pool, and its data gradient from the pooled gradient) run on the same F(4x4) kernel
+ * in 25 products per 4x4 tile (frequency row / column 2 never reaches a pooling-window sum) where the launch has >= 192 workgroups
+ * and H, W are multiples of 4; this query says whether a geometry does (kernel names, executed-FLOP accounting). */
+int diagan_conv_wino4_pool_used(int B, int Ho, int Wo, int Ci, int Co, int64_t ws_floats);
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* The same choice for a launch with a GROUPED prologue (pro_group_rows > 0: one affine row per group of that many GEMM

@@ -42,6 +42,9 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st);     // conv_wino4.h
 long wino4_ws_floats(int Co, int Ci);
 bool wino4_geom_ok(int Ho, int Wo, int Ci);
 int wino4_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats);
+bool wino4_pool_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force);
+int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st);
+int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs);
@@ -821,6 +824,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                    (pro_mode == PRO_NONE || pro_mode == PRO_RELU) && !mask_src && !stat_partials && !a.res_up && pro_group_rows == 0,
                "conv_gemm: tile_cfg 11 (Winograd + average pool) needs a forward 3x3 / stride 1 / pad 1 geometry with even H, W, "
                "Ci %% 8 == 0, Co %% 64 == 0, prologue none / ReLU, no mask, statistics or half-resolution residual");
+    if (g_wino4 != 0 && splitk_ws && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats, g_wino4 == 2)) {     // 25 products per 4x4 tile (conv_wino4.hip)
+      a.ksplit = 1;
+      return launch_wino4_pool(a, splitk_ws, st);
+    }
     const long wfl = wino_ws_floats(Co, Ci);
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 11 needs %ld floats of workspace for the transformed weights", wfl);
     int ks = wino_pool_ksplit(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats - wfl, 192);
@@ -846,6 +853,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                    pro_mode == PRO_NONE && !stat_partials && !a.res_up && pro_group_rows == 0,
                "conv_gemm: tile_cfg 12 (data-gradient through an average pool, Winograd) needs the data-gradient geometry of a "
                "3x3 / stride 1 / pad 1 layer with even H, W, Ci %% 8 == 0, Co %% 64 == 0, no prologue, statistics or half-resolution residual");
+    if (g_wino4 != 0 && splitk_ws && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats, g_wino4 == 2)) {     // the same on the pooled gradient
+      a.ksplit = 1;
+      return launch_wino4_unpool(a, splitk_ws, st);
+    }
     const long wfl = wino_ws_floats(Co, Ci);
     DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 12 needs %ld floats of workspace for the transformed weights", wfl);
     long slab_tiles = ((long)splitk_ws_floats - wfl) / 4;             // a split's partial is the FULL-resolution output: 4 pixels per tile
@@ -1028,10 +1039,16 @@ DIAGAN_API int diagan_conv_gemm_set_wino(int mode) {
   return DIAGAN_OK;
 }
 
+// Do the pooled launches of this geometry (tile_cfg 11 / 12) run on the F(4x4) kernel (25 products per 4x4 tile) rather than on
+// conv_wino_pool.hip's F(2x2) kernels (9 per 2x2 tile)?  Host-only; for kernel names / executed-FLOP accounting.
+DIAGAN_API int diagan_conv_wino4_pool_used(int B, int Ho, int Wo, int Ci, int Co, int64_t ws_floats) {
+  return g_wino4 != 0 && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, g_wino4 == 2) ? 1 : 0;
+}
+
 // Run-time form of DIAGAN_WINO4: 0 = the automatic choice never takes the F(4x4,3x3) kernel (tile_cfg 13), 1 / -1 = where it
 // qualifies (like-with-like tests, A/B runs)
 DIAGAN_API int diagan_conv_gemm_set_wino4(int mode) {
-  DG_REQUIRE(mode >= -1 && mode <= 1, "set_wino4: -1, 0 or 1");
+  DG_REQUIRE(mode >= -1 && mode <= 2, "set_wino4: -1, 0, 1 or 2 (2: also the pooled launches of any size -- tests)");
   g_wino4 = mode;
   return DIAGAN_OK;
 }

@@ -42,32 +42,38 @@ constexpr int W4_PS = 132;              // floats between consecutive V planes (
 constexpr int W4_VSTAGE = 84 * W4_PS;   // V planes of one stage: 2 channel quads x 42
 constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency, column half) of 64 lanes x 4 floats
 #ifndef W4_ROW_AT
-#define W4_ROW_AT 3
+#define W4_ROW_AT 3           // slot of a K-step after which the next step's row pass / column pass is placed
 #endif
 #ifndef W4_COL_AT
 #define W4_COL_AT 5
 #endif
-#ifndef W4_STAGGER            // the two waves of a SIMD (w, w + 4) transform at different slots of the step
-#define W4_STAGGER 0
-#endif
-#ifndef W4_ROW_LATE
-#define W4_ROW_LATE 5
-#endif
-#ifndef W4_COL_LATE
-#define W4_COL_LATE 7
-#endif
-#ifndef W4_NT_STORE           // non-temporal output stores
-#define W4_NT_STORE 0
-#endif
-#ifndef W4_PAIR               // MFMAs of two slots interleaved (no back-to-back dependent accumulators)
-#define W4_PAIR 0
-#endif
 constexpr int W4_LDS_FLOATS = 2 * W4_VSTAGE + W4_U;      // 162 432 bytes of the 163 840 (the epilogue's 36 x 32 x 32 floats fit inside)
+
+// MODE 0: the convolution.  MODE 1 ("pool"): the convolution FOLLOWED BY F.avg_pool2d(., 2) -- the end of mimicry's DBlock /
+// DBlockOptimized with downsample = True (predefined_models.py:38-40,76-78), y / residual are the POOLED tensors.  A 4x4 tile
+// holds four pooling windows; window sums are (P A^T) M (P A^T)^T with P A^T = [[1, 2, 0, 3, -1, 0], [0, 2, 0, 12, -4, 1]]:
+// frequency row / column 2 never contributes, 25 of the 36 products remain (6.25 per pooled pixel; the F(2x2) pooled kernel
+// needs 9, the direct convolution 36).  MODE 2 ("unpool"): the data gradient of such a layer from the POOLED gradient --
+// avg_pool2d_backward is constant over each window, the 6-pixel patch of a tile reads (a, b, b, c, c, d) along each axis and
+// B^T (a, b, b, c, c, d) = (4a - 5b + c, -8b + 2c, 0, 3c - 3b, b - c, 4b - 5c + d): the same 25 frequencies, and the loader
+// reads the 4x4 HALF-resolution neighbourhood (16 instead of 36 pixels per tile).
+// The 25 live frequencies l = 5 i' + j' (i', j' index {0, 1, 3, 4, 5}) are dealt to the four wave groups as 7 + 6 + 6 + 6;
+// every wave runs 7 slots (the seventh of groups 1-3 multiplies a dummy unit into an accumulator nobody reads).
+template <int MODE> struct W4M {
+  static constexpr bool pooled = MODE != 0;
+  static constexpr int NS = pooled ? 7 : 9;          // slots (frequency, column half) per wave
+  static constexpr int U_FLOATS = 8 * NS * 256;       // weight units of one K-step
+  static constexpr int NI = MODE == 2 ? 4 : 6;        // input loads per thread and K-step
+};
+__host__ __device__ __forceinline__ int w4p_start(int g) { return g == 0 ? 0 : 7 + 6 * (g - 1); }
+__host__ __device__ __forceinline__ int w4p_count(int g) { return g == 0 ? 7 : 6; }
+__host__ __device__ __forceinline__ int w4p_freq(int v) { return v < 2 ? v : v + 1; }        // {0, 1, 3, 4, 5}
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 6 i + j, in the order the main kernel's waves consume it:
 // [64-column block][K-step][unit = wave * 9 + slot][lane = k half * 32 + column][4 channels], wave = group * 2 + column half,
 // group = (i / 3) * 2 + j / 3 (a 3 x 3 block of the 6 x 6 frequencies), slot = 3 (i % 3) + j % 3.
 // flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
+template <int MODE>
 __global__ __launch_bounds__(64) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
                                                           int Kp, int flip) {
   const int c = blockIdx.x * 4, nb = blockIdx.y, col = threadIdx.x, co = nb * 64 + col;
@@ -92,16 +98,22 @@ __global__ __launch_bounds__(64) void wino4_weight_kernel(const float* __restric
 #pragma unroll
   for (int s = 0; s < 3; ++s) gt(g[0][s], g[1][s], g[2][s], t[s]);
   const int nk = Ci >> 3, ks = c >> 3, kh = (c >> 2) & 1, nh = col >> 5, n = col & 31;
-  float* base = ug + ((long)nb * nk + ks) * W4_U + (kh * 32 + n) * 4;
+  float* base = ug + ((long)nb * nk + ks) * W4M<MODE>::U_FLOATS + (kh * 32 + n) * 4;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     f32x4 u[6];
     gt(t[0][i], t[1][i], t[2][i], u);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      // wave group g owns the 3 x 3 block of frequencies i in 3 (g >> 1) .. + 2, j in 3 (g & 1) .. + 2; slot 3 (i % 3) + j % 3
-      const int unit = ((((i / 3) * 2 + j / 3) * 2 + nh) * 9) + (i % 3) * 3 + j % 3;
-      *reinterpret_cast<f32x4*>(base + unit * 256) = u[j];
+      if (MODE == 0) {
+        // wave group g owns the 3 x 3 block of frequencies i in 3 (g >> 1) .. + 2, j in 3 (g & 1) .. + 2; slot 3 (i % 3) + j % 3
+        const int unit = ((((i / 3) * 2 + j / 3) * 2 + nh) * 9) + (i % 3) * 3 + j % 3;
+        *reinterpret_cast<f32x4*>(base + unit * 256) = u[j];
+      } else if (i != 2 && j != 2) {
+        const int l = 5 * (i < 2 ? i : i - 1) + (j < 2 ? j : j - 1);          // live frequency index
+        const int gq = l < 7 ? 0 : 1 + (l - 7) / 6, sl = l - w4p_start(gq);
+        *reinterpret_cast<f32x4*>(base + ((gq * 2 + nh) * 7 + sl) * 256) = u[j];
+      }
     }
   }
 }
@@ -130,6 +142,18 @@ __device__ __forceinline__ void w4_bt(f32x4* d, const W4Consts& k) {
   d[5] = t5;
 }
 
+// B^T of the patch (a, b, b, c, c, d) of an up-sampled (2x2-replicated) tensor, from d[0..3] = (a, b, c, d):
+// (4a - 5b + c, -8b + 2c, 0, 3c - 3b, b - c, 4b - 5c + d)
+__device__ __forceinline__ void w4_bt_dup(const f32x4* d, f32x4* t, const W4Consts& k) {
+  const f32x4 e = d[1] * k.m1 + d[2], f = d[1] * k.m4 + d[2];
+  t[0] = d[0] * k.p4 + (d[1] * k.m5 + d[2]);
+  t[1] = f * k.p2;
+  t[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  t[3] = e * k.p2 + e;
+  t[4] = e * k.m1;
+  t[5] = d[1] * k.p4 + (d[2] * k.m5 + d[3]);
+}
+
 // Diagnostic build only (make EXTRA=-DDIAGAN_WINO_ABLATE; tools/wino4_ablate.py): ConvGemmArgs::tune bits switch parts of the K
 // loop off (16 row pass, 4096 column pass, 32 input loads, 64 weight DMA, 128 barrier, 256 MFMAs, 2048 fragment reads: the
 // results are then garbage) so that their cost can be read off the launch time.
@@ -139,9 +163,12 @@ __device__ __forceinline__ void w4_bt(f32x4* d, const W4Consts& k) {
 #define W4_ON(bit) true
 #endif
 
-template <int PRO>
+template <int PRO, int MODE = 0>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 V stages | U] = 146 KB
+  using MD = W4M<MODE>;
+  constexpr int NS = MD::NS, NI = MD::NI;
+  constexpr bool POOL = MODE == 1, UNPOOL = MODE == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 V stages | U] <= 159 KB
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (g.Co + W4N - 1) / W4N;
@@ -155,23 +182,26 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   constexpr bool affine = PRO == PRO_AFFINE_RELU || PRO == PRO_AFFINE;
 
   // ---- loader role: (tile lt, channel quad lq, patch row / column lr < 6); a 16-lane group holds one tile ----
+  // (unpool: the patch is the 4 x 4 HALF-resolution neighbourhood, rows / columns 2 t - 1 .. 2 t + 2 of the pooled gradient)
   const int lr = tid & 7, lq = (tid >> 3) & 1, lt = tid >> 4;
-  const bool lact = lr < 6;
-  unsigned off[6];                                       // byte offsets of this row's 6 patch pixels, bit 31 set if outside
-  int kbound[6];                                         // upper clamp of the activation: 0 on padding pixels
+  const bool ract = lr < (UNPOOL ? 4 : 6);                                  // row pass: this lane holds patch row lr
+  const bool cact = lr < 6 && !(MD::pooled && lr == 2);                     // column pass: this lane holds column j = lr
+  unsigned off[NI];                                      // byte offsets of this row's patch pixels, bit 31 set if outside
+  int kbound[NI];                                        // upper clamp of the activation: 0 on padding pixels
   {
     const int gt = t0 + lt;
-    const bool tv = gt < MT && lact;
+    const bool tv = gt < MT && ract;
     const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);          // dWo: divisor TW
     const int tx = (tv ? gt : 0) - (int)q1 * TW;
     const unsigned b = fdiv(q1, a.dHo);                                // dHo: divisor TH
     const int ty = (int)q1 - (int)b * TH;
-    const int iy = 4 * ty - 1 + lr, ix0 = 4 * tx - 1;
-    const bool rv = tv && iy >= 0 && iy < g.Hi;
-    const int rowbase = (((int)b * g.Hi + iy) * g.Wi + ix0) * g.Ci * 4 + lq * 16;
+    const int Hx = UNPOOL ? g.Hi >> 1 : g.Hi, Wx = UNPOOL ? g.Wi >> 1 : g.Wi;     // the gathered tensor's own size
+    const int iy = (UNPOOL ? 2 : 4) * ty - 1 + lr, ix0 = (UNPOOL ? 2 : 4) * tx - 1;
+    const bool rv = tv && iy >= 0 && iy < Hx;
+    const int rowbase = (((int)b * Hx + iy) * Wx + ix0) * g.Ci * 4 + lq * 16;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      const bool ok = rv && ix0 + c >= 0 && ix0 + c < g.Wi;
+    for (int c = 0; c < NI; ++c) {
+      const bool ok = rv && ix0 + c >= 0 && ix0 + c < Wx;
       off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0x80000000u;  // beyond num_records: the hardware returns zeros
       kbound[c] = ok ? 0x7fffffff : 0;
     }
@@ -186,7 +216,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     const unsigned long long xb = (unsigned long long)a.x;
     xsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
     xsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffffu));
-    xsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u));
+    xsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * (UNPOOL ? 1u : 4u)));
     xsrc[3] = 0x00020000;
   }
   const int pro_group_off = a.pro_group_rows > 0 ? ((t0 * 16) / a.pro_group_rows) * g.Ci : 0;
@@ -204,26 +234,28 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   // (the idle lanes lr = 6, 7 of a group point far outside the LDS allocation: the hardware drops such writes and returns
   //  zeros for such reads -- no branch around the passes, which keeps the K loop one basic block: behind a join the
   //  compiler's wait-count pass loses track of the in-flight LDS-DMA units and waits for ALL of them before any ds_read)
-  float* const vrow = smem + (lact ? (lq * 42 + lr) * W4_PS + lt * 4 : (1 << 22));          // + j * 7 * W4_PS
-  float* const vcol = smem + (lact ? (lq * 42 + 7 * lr) * W4_PS + lt * 4 : (1 << 22));      // + i * W4_PS
+  float* const vrow = smem + (ract ? (lq * 42 + lr) * W4_PS + lt * 4 : (1 << 22));          // + j * 7 * W4_PS
+  float* const vcol = smem + (cact ? (lq * 42 + 7 * lr) * W4_PS + lt * 4 : (1 << 22));      // + i * W4_PS
 
   float* const ulds = smem + 2 * W4_VSTAGE;
   // (weight units are stored [group][column half]: this wave's nine are unit block (wave & 3) * 2 + (wave >> 2))
-  const float* ublock = ug + (long)nb * nk * W4_U + ((wave & 3) * 2 + (wave >> 2)) * 9 * 256;
-  float* const uslot = ulds + wave * 9 * 256;                          // this wave's nine private units
+  const float* ublock = ug + (long)nb * nk * MD::U_FLOATS + ((wave & 3) * 2 + (wave >> 2)) * NS * 256;
+  float* const uslot = ulds + wave * NS * 256;                         // this wave's private units
 
   // wave-uniform unit address (kernel argument + block / wave / step indices: scalar registers) + the lane's 16 bytes
   auto issue_u = [&](int kk, int s) {
-    const float* up = ublock + (long)kk * W4_U + s * 256 + lane * 4;
+    const float* up = ublock + (long)kk * MD::U_FLOATS + s * 256 + lane * 4;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)up,
                                      (__attribute__((address_space(3))) void*)(uslot + s * 256), 16, 0, 0);
   };
   const W4Consts kc = w4_consts();
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = NI; c < 6; ++c) ra[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto issue_x = [&](int kk) {
     const int soff = __builtin_amdgcn_readfirstlane(kk * (W4K * 4));
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
+    for (int c = 0; c < NI; ++c)
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
     if (affine) {                     // BatchNorm scale / shift of this lane's channel quad, same mechanism
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(psc) : "v"(poff), "s"(scsrc), "s"(soff) : "memory");
@@ -247,7 +279,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   // prologue on the loaded pixels + row transform + park in the V planes of `stage`
   auto row_pass = [&](int stage) {
 #pragma unroll
-    for (int c = 0; c < 6; ++c) {
+    for (int c = 0; c < NI; ++c) {
       f32x4 v = ra[c];
       if (PRO != PRO_NONE) {
         if (affine) v = v * psc + psh;
@@ -270,36 +302,51 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       }
       ra[c] = v;
     }
-    w4_bt(ra, kc);
+    f32x4 t[6];
+    if (UNPOOL) w4_bt_dup(ra, t, kc);
+    else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) t[c] = ra[c];
+      w4_bt(t, kc);
+    }
     float* vs = vrow + stage * W4_VSTAGE;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(vs + j * 7 * W4_PS) = ra[j];
+    for (int j = 0; j < 6; ++j)
+      if (!(MD::pooled && j == 2)) *reinterpret_cast<f32x4*>(vs + j * 7 * W4_PS) = t[j];
   };
   // column transform of column lr, in place (reads what the row pass of this 16-lane group parked)
   auto col_pass = [&](int stage) {
     float* vs = vcol + stage * W4_VSTAGE;
     f32x4 d[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * W4_PS);
-    w4_bt(d, kc);
+    for (int i = 0; i < (UNPOOL ? 4 : 6); ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * W4_PS);
+    if (UNPOOL) {
+      f32x4 t[6];
+      w4_bt_dup(d, t, kc);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x4*>(vs + i * W4_PS) = d[i];
+      for (int i = 0; i < 6; ++i) d[i] = t[i];
+    } else {
+      w4_bt(d, kc);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (!(MD::pooled && i == 2)) *reinterpret_cast<f32x4*>(vs + i * W4_PS) = d[i];
   };
 
   // wave w owns the 3 x 3 frequency block of group w & 3 on column half w >> 2
   // (column half = wave >> 2: the two waves of a SIMD, w and w + 4, then sit in different halves, and each epilogue phase
   //  below keeps one wave per SIMD busy)
   const int grp = wave & 3, nh = wave >> 2;
-  f32x16 acc[9];
+  f32x16 acc[NS];
 #pragma unroll
-  for (int s = 0; s < 9; ++s)
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
   const int fi = lane & 31, kh = lane >> 5;
 
   if (k_begin < k_end) {
 #pragma unroll
-    for (int s = 0; s < 9; ++s) issue_u(k_begin, s);
+    for (int s = 0; s < NS; ++s) issue_u(k_begin, s);
     issue_x(k_begin);
     wait_inputs(0);
     row_pass(0);
@@ -308,13 +355,24 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int fi0 = 3 * (grp >> 1), fj0 = 3 * (grp & 1);      // this wave's block of frequencies
-  const float* const fa_base = smem + (kh * 42 + 7 * fj0 + fi0) * W4_PS + fi * 4;     // slot s = 3 di + dj: + (7 dj + di) planes
+  const int fi0 = 3 * (grp >> 1), fj0 = 3 * (grp & 1);      // (MODE 0) this wave's block of frequencies
+  // plane (7 j + i) of this wave's slot s, relative to plane 0 of its channel quad:
+  //   MODE 0: slot s = 3 di + dj of the block at (fi0, fj0): a compile-time distance from the block's first plane;
+  //   pooled : live frequency l = w4p_start(group) + s (the dummy seventh slot of groups 1-3 re-reads the group's first plane)
+  auto slot_plane = [&](int s) {                              // (MODE 0: relative to the block's first plane, a compile-time constant)
+    if (!MD::pooled) return 7 * (s % 3) + s / 3;
+    const int l = w4p_start(grp) + (s < w4p_count(grp) ? s : 0);
+    return 7 * w4p_freq(l % 5) + w4p_freq(l / 5);
+  };
+  const float* const fa_lane = smem + (kh * 42 + (MD::pooled ? 0 : 7 * fj0 + fi0)) * W4_PS + fi * 4;
+  int fa_off[NS];                                             // pooled modes: wave-uniform (scalar registers)
+#pragma unroll
+  for (int s = 0; s < NS; ++s) fa_off[s] = slot_plane(s) * W4_PS;
   const float* const fb_base = uslot + lane * 4;
   // vm-counter bookkeeping: a wave's DMA unit of slot s for step kk + 1 is issued right after slot s of step kk has been
   // consumed and gets a WHOLE step to land -- the wait sits in front of the fragment read of step kk + 1, not at the end
-  // of step kk.  Operations younger than D(kk, s + 1) when fragment s + 1 is about to be read: D(kk, s + 2 .. 8), the six
-  // input loads of step kk + 1 (eight with the BatchNorm rows) and D(kk + 1, 0 .. s - 1): 13 (15) in every slot.
+  // of step kk.  Operations younger than D(kk, s + 1) when fragment s + 1 is about to be read: D(kk, s + 2 .. NS - 1), the NI
+  // input loads of step kk + 1 (+ 2 with the BatchNorm rows) and D(kk + 1, 0 .. s - 1): NS - 2 + NI (+ 2) in every slot.
 #define W4_WAIT_VM(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
   auto wait_vm = [&](int n) {          // n is a compile-time constant after unrolling: the switch folds to one s_waitcnt
     switch (n) {
@@ -327,34 +385,21 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   auto kstep = [&](int kk, auto has_next) {
     constexpr bool HN = decltype(has_next)::value;
     const int cur = (kk - k_begin) & 1;
-    if (HN) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // D(kk, 0) has landed (D(kk, 1 .. 8) may still fly)
+    if (HN) wait_vm(NS - 1);                                  // D(kk, 0) has landed (D(kk, 1 .. NS - 1) may still fly)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool late = W4_STAGGER && (wave >> 2);
-    // s: slot (group in the W4_PAIR variant) whose MFMAs have just been issued; issued: DMA units of the next step issued so
-    // far in this step = operations younger than the input loads
-    auto transform_at = [&](int s, int issued) {
-      const bool row_now = W4_STAGGER ? ((s == W4_ROW_AT && !late) || (s == W4_ROW_LATE && late)) : s == W4_ROW_AT;
-      const bool col_now = W4_STAGGER ? ((s == W4_COL_AT && !late) || (s == W4_COL_LATE && late)) : s == W4_COL_AT;
-      if (row_now) {
-        wait_inputs(issued);                              // the input loads have landed (the younger DMAs may still fly)
-        if (W4_ON(16)) row_pass(cur ^ 1);
-      } else if (col_now) {
-        if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
-      }
-    };
-#if !W4_PAIR
+    const float* const fa_base = fa_lane + cur * W4_VSTAGE;
     f32x4 fa[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, fb[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
     if (W4_ON(2048)) {
-      fa[0] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE);
+      fa[0] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[0]);
       fb[0] = *reinterpret_cast<const f32x4*>(fb_base);
     }
     if (HN && W4_ON(32)) issue_x(kk + 1);
 #pragma unroll
-    for (int s = 0; s < 9; ++s) {
-      if (s + 1 < 9) {
-        if (HN) wait_vm(affine ? 15 : 13);
+    for (int s = 0; s < NS; ++s) {
+      if (s + 1 < NS) {
+        if (HN) wait_vm(NS - 2 + NI + (affine ? 2 : 0));
         if (W4_ON(2048)) {
-          fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (7 * ((s + 1) % 3) + (s + 1) / 3) * W4_PS);
+          fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[s + 1]);
           fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
         }
       }
@@ -366,50 +411,15 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         // slot s has been read into registers (the MFMAs above needed it): re-fill it for the next step
         __builtin_amdgcn_sched_barrier(0);
         if (W4_ON(64)) issue_u(kk + 1, s);
-        transform_at(s, s + 1);
+        if (s == (W4_ROW_AT < NS - 2 ? W4_ROW_AT : NS - 4)) {
+          wait_inputs(s + 1);                             // the input loads have landed (the s + 1 younger DMAs may still fly)
+          if (W4_ON(16)) row_pass(cur ^ 1);
+        } else if (s == (W4_COL_AT < NS - 1 ? W4_COL_AT : NS - 2)) {
+          if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#else
-    // slots in groups (0,1) (2,3) (4,5) (6,7) (8): the MFMAs of a pair alternate between its two accumulators; the
-    // fragments of the next group are read before the MFMAs of this one
-    f32x4 fa[2][2], fb[2][2];
-    fa[0][0] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE);
-    fb[0][0] = *reinterpret_cast<const f32x4*>(fb_base);
-    // (D(kk, 1): one more unit must have landed than the top-of-step wait guarantees)
-    if (HN) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    fa[0][1] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + 7 * W4_PS);
-    fb[0][1] = *reinterpret_cast<const f32x4*>(fb_base + 256);
-    if (HN && W4_ON(32)) issue_x(kk + 1);
-#pragma unroll
-    for (int gq = 0; gq < 5; ++gq) {
-      const int s0 = 2 * gq, ns = gq < 4 ? 2 : 1;
-      if (gq < 4) {
-        // next group: slots s0 + 2 (, s0 + 3).  Younger than D(kk, s0 + 3): D(kk, s0 + 4 .. 8) = 5 - s0, NI, D(kk + 1, 0 .. s0 - 1) = s0
-        if (HN) wait_vm(affine ? 13 : 11);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (s0 + 2 + u < 9) {
-            fa[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fa_base + cur * W4_VSTAGE + (7 * ((s0 + 2 + u) % 3) + (s0 + 2 + u) / 3) * W4_PS);
-            fb[(gq + 1) & 1][u] = *reinterpret_cast<const f32x4*>(fb_base + (s0 + 2 + u) * 256);
-          }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (u < ns)
-            acc[s0 + u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[gq & 1][u][e], fb[gq & 1][u][e], acc[s0 + u], 0, 0, 0);
-      if (HN) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (u < ns) issue_u(kk + 1, s0 + u);
-        transform_at(gq, gq < 4 ? 2 * (gq + 1) : 9);      // (group index: W4_ROW_AT / W4_COL_AT count groups in this variant)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#endif
     // V of the next step is complete (LDS writes: lgkmcnt; U is wave-private and waited for where it is read).  NOT
     // __syncthreads(): its fence would make the compiler wait for every DMA unit in flight
     if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -425,55 +435,101 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #endif
   // ---- epilogue ----
   const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
-  const int split = a.scale0 ? a.scale_split : 0x7fffffff;            // pixel-row index where the second sigma starts
+  // pixel-row index (of the tensor that is written: the pooled one in MODE 1) where the second sigma starts
+  const int split = a.scale0 ? (POOL ? a.scale_split >> 2 : a.scale_split) : 0x7fffffff;
   const bool raw = a.ksplit > 1;                                       // split-K: un-scaled partial sums to the slab
   const bool hr = !raw && a.residual != nullptr, hm = !raw && a.mask_src != nullptr, hs = !raw && a.stat_partials != nullptr;
-  float* ydst = raw ? a.slab + (long)blockIdx.y * a.M * g.Co : a.y;
+  const int Mout = POOL ? a.M >> 2 : a.M;                              // pixels of the written tensor
+  float* ydst = raw ? a.slab + (long)blockIdx.y * Mout * g.Co : a.y;
   const float rfloor = a.res_relu ? 0.f : -__builtin_huge_valf();
   const int et = tid >> 4, eq = (tid >> 1) & 7, eh = tid & 1;         // tile, channel quad (of a 32-column half), row pair
-  // this thread's tile and its 2 x 4 output pixels: ONE 32-bit byte offset per pass, the pixels' distances are wave-uniform
-  // (scalar offsets of raw buffer loads / stores)
+  // this thread's tile and its output pixels (2 x 4 of the tile's 4 x 4; pool: one row of the tile's 2 x 2 pooled pixels):
+  // ONE 32-bit byte offset per pass, the pixels' distances are wave-uniform (scalar offsets of raw buffer loads / stores)
   const int gt = t0 + et;
   const bool tv = gt < MT;
   const unsigned q1 = fdiv((unsigned)(tv ? gt : 0), a.dWo);
   const int tx = (tv ? gt : 0) - (int)q1 * TW;
   const unsigned eb = fdiv(q1, a.dHo);
   const int ty = (int)q1 - (int)eb * TH;
-  const int oy0 = 4 * ty + 2 * eh, ox0 = 4 * tx;
-  const int prow0 = ((int)eb * g.Ho + oy0) * g.Wo + ox0;              // pixel (GEMM row) index of the first of them
-  const float scv = prow0 < split ? sc0 : sc1;                        // (the halves of a paired pass are whole images)
-  const int ybytes = (int)((unsigned)a.M * (unsigned)g.Co * 4u);
+  const int Hy = POOL ? g.Ho >> 1 : g.Ho, Wy = POOL ? g.Wo >> 1 : g.Wo;        // the written tensor's size
+  const int oy0 = (POOL ? 2 * ty + eh : 4 * ty + 2 * eh), ox0 = (POOL ? 2 : 4) * tx;
+  const int prow0 = ((int)eb * Hy + oy0) * Wy + ox0;                   // pixel (GEMM row) index of the first of them
+  const float scv = (prow0 < split ? sc0 : sc1) * (MD::pooled ? 0.25f : 1.f);   // (the halves of a paired pass are whole images)
+  const int ybytes = (int)((unsigned)Mout * (unsigned)g.Co * 4u);
   const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(ydst, 0, ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0, hr && !a.res_up ? ybytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask_src), 0, hm ? ybytes : 0, 0x00020000);
-  const int pixb = g.Co * 4, rowb = g.Wo * pixb;                      // bytes to the next pixel / the next image row
+  const int pixb = g.Co * 4, rowb = Wy * pixb;                        // bytes to the next pixel / the next image row
   float* ss = smem;
   f32x4 cs1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, cs2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // index of frequency (i, j) in the exchange image [.][32 tiles][32 channels] (pooled modes: the 25 live ones)
+  auto xidx = [&](int i, int j) { return MD::pooled ? 5 * (i < 2 ? i : i - 1) + (j < 2 ? j : j - 1) : 6 * i + j; };
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     if (nh == p) {
 #pragma unroll
-      for (int s = 0; s < 9; ++s)
+      for (int s = 0; s < NS; ++s) {
+        const int fx = MD::pooled ? w4p_start(grp) + s : 6 * (fi0 + s / 3) + fj0 + s % 3;
+        if (!MD::pooled || s < w4p_count(grp)) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = 8 * (e >> 2) + 4 * kh + (e & 3);
-          ss[((6 * (fi0 + s / 3) + fj0 + s % 3) * 32 + m) * 32 + fi] = acc[s][e];
+          for (int e = 0; e < 16; ++e) {
+            const int m = 8 * (e >> 2) + 4 * kh + (e & 3);
+            ss[(fx * 32 + m) * 32 + fi] = acc[s][e];
+          }
         }
+      }
     }
     __syncthreads();
     const int n = n0 + p * 32 + eq * 4;
     const bool ok = tv && n < g.Co;
     const unsigned voff = ok ? (unsigned)(prow0 * g.Co + n) * 4u : 0x80000000u;   // (nothing to store: beyond the descriptor)
+    f32x4 bv = z4;
+    if (!raw && a.bias && ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    if (POOL) {
+      // pooled row eh of the tile: (P A^T) M (P A^T)^T with P A^T = [[1, 2, 0, 3, -1, 0], [0, 2, 0, 12, -4, 1]]
+      f32x4 sj[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j == 2) continue;
+        f32x4 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (i != 2) m[i] = *reinterpret_cast<const f32x4*>(ss + (xidx(i, j) * 32 + et) * 32 + eq * 4);
+        sj[j] = eh ? (2.f * m[1] + 12.f * m[3]) + (m[5] - 4.f * m[4]) : (m[0] + 2.f * m[1]) + (3.f * m[3] - m[4]);
+      }
+      f32x4 y2[2];
+      y2[0] = (sj[0] + 2.f * sj[1]) + (3.f * sj[3] - sj[4]);
+      y2[1] = (2.f * sj[1] + 12.f * sj[3]) + (sj[5] - 4.f * sj[4]);
+#pragma unroll
+      for (int bc = 0; bc < 2; ++bc) {
+        const int soff = bc * pixb;
+        f32x4 y = raw ? y2[bc] * 0.25f : y2[bc] * scv + bv;
+        if (hr) {
+          f32x4 r = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+          y += r;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), ysrc, voff, soff, 0);
+      }
+    } else {
     // s[a][j] = sum_i A^T[a][i] M[i][j] for this thread's two rows a = 2 eh, 2 eh + 1:
     //   a = 0: m0 + (m1 + m2) + (m3 + m4)        a = 1: (m1 - m2) + 2 (m3 - m4)
     //   a = 2: (m1 + m2) + 4 (m3 + m4)           a = 3: (m1 - m2) + 8 (m3 - m4) + m5
+    // (unpool: the products of frequency row / column 2 are zero and were neither computed nor exchanged)
     f32x4 sr[2][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
+      if (UNPOOL && j == 2) {
+        sr[0][j] = sr[1][j] = z4;
+        continue;
+      }
       f32x4 m[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(ss + ((i * 6 + j) * 32 + et) * 32 + eq * 4);
+      for (int i = 0; i < 6; ++i)
+        m[i] = (UNPOOL && i == 2) ? z4 : *reinterpret_cast<const f32x4*>(ss + (xidx(i, j) * 32 + et) * 32 + eq * 4);
       const f32x4 pp = m[1] + m[2], qq = m[1] - m[2], rr = m[3] + m[4], tt = m[3] - m[4];
       if (eh == 0) {
         sr[0][j] = m[0] + pp + rr;
@@ -483,8 +539,6 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         sr[1][j] = qq + 8.f * tt + m[5];
       }
     }
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (!raw && a.bias && ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
     for (int ar = 0; ar < 2; ++ar) {
       const f32x4* s6 = sr[ar];
@@ -512,7 +566,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
       for (int bc = 0; bc < 4; ++bc) {
         const int soff = ar * rowb + bc * pixb;
-        f32x4 y = raw ? y4[bc] : y4[bc] * scv + bv;
+        f32x4 y = raw ? (UNPOOL ? y4[bc] * 0.25f : y4[bc]) : y4[bc] * scv + bv;
         if (hr) {
           f32x4 r;
           if (a.res_up) {
@@ -545,6 +599,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
           cs2[p] += y * y;
         }
       }
+    }
     }
     __syncthreads();
   }
@@ -582,12 +637,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   }
 }
 
-template <int PRO>
+template <int PRO, int MODE = 0>
 static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
   const int MT = a.g.B * (a.g.Ho >> 2) * (a.g.Wo >> 2);
   const int wgs = cdiv(MT, W4T) * cdiv(a.g.Co, W4N);
-  const size_t lds = (size_t)W4_LDS_FLOATS * sizeof(float);
-  auto kern = conv_wino4_kernel<PRO>;
+  // [2 V stages | U]; the epilogue's exchange image (36 or 25 frequencies x 32 tiles x 32 channels) fits inside
+  const size_t lds = (size_t)(2 * W4_VSTAGE + W4M<MODE>::U_FLOATS) * sizeof(float);
+  auto kern = conv_wino4_kernel<PRO, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -623,7 +679,7 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
+  hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
                      g.dr < 0 ? 1 : 0);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ws, st);
@@ -632,6 +688,35 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
     case PRO_LRELU: return launch_wino4_pro<PRO_LRELU>(a, ws, st);
     default: return launch_wino4_pro<PRO_AFFINE>(a, ws, st);
   }
+}
+
+// tile_cfg 11 / 12 on the F(4x4) kernel (MODE 1 / 2): convolution + 2x2 average pool in 25 products per 4x4 tile, and its data
+// gradient from the pooled gradient.  Same arguments as launch_wino_pool / launch_wino_unpool (conv_wino_pool.hip).
+// Taken where the launch fills the chip (>= 192 workgroups of 32 tiles x 64 channels, no channel split) and H, W are
+// multiples of 4; DIAGAN_WINO4_POOL=0 keeps the F(2x2) pooled kernels; force: any launch size (diagan_conv_gemm_set_wino4(2), tests).
+bool wino4_pool_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force) {
+  static const int env = getenv("DIAGAN_WINO4_POOL") ? atoi(getenv("DIAGAN_WINO4_POOL")) : 1;
+  static const int w4 = getenv("DIAGAN_WINO4") ? atoi(getenv("DIAGAN_WINO4")) : 1;
+  static const int min_wgs = getenv("DIAGAN_WINO4_POOL_MIN_WGS") ? atoi(getenv("DIAGAN_WINO4_POOL_MIN_WGS")) : 192;
+  if (!env || !w4 || !wino4_geom_ok(Ho, Wo, Ci) || (Co & 3) || Ci < 32) return false;
+  const long wgs = (long)cdiv((long)B * (Ho >> 2) * (Wo >> 2), W4T) * cdiv(Co, W4N);
+  return (force || wgs >= min_wgs) && (long)cdiv(Co, W4N) * W4N * Ci * 28 <= ws_floats;      // 56 units x 256 floats per 8 channels and column block
+}
+
+int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
+  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0);
+  return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1>(a, ws, st) : launch_wino4_pro<PRO_NONE, 1>(a, ws, st);
+}
+
+int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
+  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 1);
+  return launch_wino4_pro<PRO_NONE, 2>(a, ws, st);
 }
 
 }  // namespace diagan

@@ -15,6 +15,7 @@ nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
+nat.register("diagan_conv_wino4_pool_used", [I] * 5 + [I64])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
@@ -49,11 +50,13 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
                7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True)}
 
 
-def gemm_kernel_name(cfg, mode, Co=128):
+def gemm_kernel_name(cfg, mode, Co=128, w4pool=False):
+    if cfg in (11, 12) and w4pool:            # the pooled launches on the F(4x4) kernel (MODE 1 / 2)
+        return f"conv_wino4_kernel<{mode if cfg == 11 else 0},{cfg - 10}>"
     if cfg == 9:
         return f"conv_wino_kernel<{mode}>"
     if cfg == 13:
-        return f"conv_wino4_kernel<{mode}>"
+        return f"conv_wino4_kernel<{mode},0>"
     if cfg == 11:
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
@@ -118,9 +121,9 @@ def set_winograd(mode):
 
 
 def set_winograd4(mode):
-    """True / False: allow / forbid the F(4x4,3x3) kernel (tile_cfg 13) for auto-selected launches; None: the default (on, or
-    what DIAGAN_WINO4 says)"""
-    nat.call("diagan_conv_gemm_set_wino4", -1 if mode is None else (1 if mode else 0))
+    """True / False: allow / forbid the F(4x4,3x3) kernel (tile_cfg 13, and the pooled launches 11 / 12 on it) for auto-selected
+    launches; None: the default (on, or what DIAGAN_WINO4 says); 'force-pool': the pooled launches take it at any size (tests)"""
+    nat.call("diagan_conv_gemm_set_wino4", -1 if mode is None else (2 if mode == 'force-pool' else (1 if mode else 0)))
 
 
 def round_up(x, m):
@@ -230,7 +233,8 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
                 _NAME_CACHE['modes'] = nat.fn("diagan_conv_gemm_get_wino")()
             allow = 0 if want_stats else 1
             kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(
-                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co)
+                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co,
+                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())))
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),

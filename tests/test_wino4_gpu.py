@@ -137,3 +137,70 @@ def test_auto_selection_split_k_and_refusals():
     g2, x2, w2, wp2 = make(2, 6, 10, 16, 24)                     # H, W not multiples of 4
     with pytest.raises(RuntimeError, match="tile_cfg 13"):
         C.conv_fwd(g2, nhwc(x2).cuda(), wp2, tile_cfg=13)
+
+
+# ---- the pooled launches on this kernel (MODE 1 / 2 of conv_wino4.hip): 25 of the 36 products per 4x4 tile -----------------------
+# B, H, W, Ci, Co with H, W multiples of 4 and Co a multiple of 64 (what pool_fused admits): ragged tile counts, 4x4 maps
+POOL_CASES = [(4, 32, 32, 128, 128), (6, 16, 16, 64, 256), (3, 4, 12, 32, 192), (16, 8, 8, 256, 128), (2, 4, 4, 256, 128),
+              (4, 32, 32, 64, 64), (5, 16, 16, 128, 64)]
+
+
+@pytest.fixture
+def force_pool():
+    from diagan.ops import conv as C
+    C.set_winograd4('force-pool')            # the pooled launches take the F(4x4) kernel at any launch size
+    yield
+    C.set_winograd4(None)
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+@pytest.mark.parametrize("pro", [0, 1])
+def test_convolution_plus_average_pool_in_25_products(case, pro, force_pool):
+    """F.avg_pool2d(conv3x3(pro(x)) + bias, 2) + residual -- the end of mimicry's DBlock / DBlockOptimized with downsample=True
+    (predefined_models.py:38-40,76-78) -- in one launch, against float64 PyTorch; with the pair pass's two 1/sigma scalars."""
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=21)
+    assert nat.fn("diagan_conv_wino4_pool_used")(B, H, W, Ci, Co, C._splitk_ws(torch.device('cuda', 0)).numel())
+    g = torch.Generator().manual_seed(22)
+    bias, res = torch.randn(Co, generator=g), torch.randn(B, Co, H // 2, W // 2, generator=g)
+    ref = F.avg_pool2d(F.conv2d(ref_pro(x.double(), pro, None, None), w.double(), bias.double(), padding=1), 2) + res.double()
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(), pro=(pro, None, None), pool=True)
+    assert tuple(y.shape) == (B, H // 2, W // 2, Co)
+    close(nchw(y), ref, tol=TOL)
+    if B % 2 == 0:
+        s0, s1 = torch.tensor([0.7]).cuda(), torch.tensor([1.9]).cuda()
+        y = C.conv_fwd(geom, nhwc(x).cuda(), wp, pro=(pro, None, None), row_scale=(s0, s1), pool=True)
+        ref = F.avg_pool2d(F.conv2d(ref_pro(x.double(), pro, None, None), w.double(), padding=1), 2)
+        ref[:B // 2] *= 0.7
+        ref[B // 2:] *= 1.9
+        close(nchw(y), ref, tol=TOL)
+
+
+@pytest.mark.parametrize("case", POOL_CASES)
+def test_data_gradient_through_the_average_pool_from_the_pooled_gradient(case, force_pool):
+    """dx = conv^T(avg_pool2d_backward(g)) * relu'(mask) (+ residual) from the POOLED gradient -- the backward of the
+    down-sampling DBlocks' c2 -- against float64 autograd of avg_pool2d(conv2d(x)); with the pair pass's two 1/sigma scalars."""
+    from diagan.ops import conv as C
+    B, H, W, Co, Ci = case                                  # (the data gradient's output channels are the layer's INPUT channels)
+    if Ci % 8:
+        pytest.skip("the data gradient gathers the layer's output channels: a multiple of 8")
+    geom, x, w, wp = make(B, H, W, Ci, Co, seed=31)
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    g = torch.Generator().manual_seed(32)
+    gp = torch.randn(B, Co, H // 2, W // 2, generator=g)
+    mask, res = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Ci, H, W, generator=g)
+    xx = x.double().requires_grad_(True)
+    F.avg_pool2d(F.conv2d(xx, w.double(), padding=1), 2).backward(gp.double())
+    ref = (xx.grad + res.double()) * (mask.double() > 0)
+    dx = C.conv_dgrad(geom, nhwc(gp).cuda(), wd, (H, W), residual=nhwc(res).cuda(), mask_src=nhwc(mask).cuda(), unpool=True)
+    close(nchw(dx), ref, tol=TOL)
+    if B % 2 == 0:
+        s0, s1 = torch.tensor([0.7]).cuda(), torch.tensor([1.9]).cuda()
+        dx = C.conv_dgrad(geom, nhwc(gp).cuda(), wd, (H, W), row_scale=(s0, s1), unpool=True)
+        ref = xx.grad.clone()
+        ref[:B // 2] *= 0.7
+        ref[B // 2:] *= 1.9
+        close(nchw(dx), ref, tol=TOL)

@@ -301,10 +301,21 @@ def test_pooled_launches_at_the_discriminators_full_sizes(case):
     gp = torch.randn(B, H // 2, W // 2, Co, device="cuda", generator=g)
     relu = (C.PRO_RELU, None, None)
     assert C.pool_fused(geom, B, H, W, relu) and C.unpool_fused(geom, B, H, W)
-    close(C.conv_fwd(geom, x, wp, bias=bias, pro=relu, residual=sc, pool=True),
-          E.avgpool2(C.conv_fwd(geom, x, wp, bias=bias, pro=relu, tile_cfg=9), residual=sc), tol=5e-6)
-    close(C.conv_dgrad(geom, gp, wd, (H, W), mask_src=x, unpool=True),
-          C.conv_dgrad(geom, E.avgpool2_bwd(gp), wd, (H, W), mask_src=x, tile_cfg=9), tol=5e-6)
+    from diagan import _native as nat
+    ws = C._splitk_ws(torch.device('cuda', 0)).numel()
+    # at these sizes the pooled launches run on the F(4x4) kernel (25 products per 4x4 tile, rounding ~1e-5 of scale); with that
+    # kernel set aside they run on conv_wino_pool.hip's F(2x2) kernels (9 products per 2x2 tile, ~1e-6): both against the
+    # two-launch path
+    for w4, tol in ((None, 1e-4), (False, 5e-6)):
+        C.set_winograd4(w4)
+        try:
+            assert bool(nat.fn("diagan_conv_wino4_pool_used")(B, H, W, Ci, Co, ws)) == (w4 is None)
+            close(C.conv_fwd(geom, x, wp, bias=bias, pro=relu, residual=sc, pool=True),
+                  E.avgpool2(C.conv_fwd(geom, x, wp, bias=bias, pro=relu, tile_cfg=9), residual=sc), tol=tol)
+            close(C.conv_dgrad(geom, gp, wd, (H, W), mask_src=x, unpool=True),
+                  C.conv_dgrad(geom, E.avgpool2_bwd(gp), wd, (H, W), mask_src=x, tile_cfg=9), tol=tol)
+        finally:
+            C.set_winograd4(None)
     ga, gb = torch.zeros(Co, geom.Kp, device="cuda"), torch.zeros(Co, geom.Kp, device="cuda")
     C.conv_wgrad(C.Geom("conv", Ci, Co, 3, 3, 2, 0), gp, E.boxsum2(x, relu_in=True), ga, accumulate=False)
     C.conv_wgrad(geom, E.avgpool2_bwd(gp), x, gb, accumulate=False, pro=relu)
