@@ -37,7 +37,7 @@ for cfg in (13, 9):
             rounds = (B * H * W // rows) * (Co // 64) / 256
             slope = (ts[512] - ts[128]) / (384 / 8) / rounds          # seconds per K-step of 8 channels per round
             icpt = ts[128] / rounds - slope * 16
-            mf = (36 if cfg == 13 else 16) * (32 if cfg == 13 else 64) * 64 * 8 * 2 / 4 / (64 * 4)   # MFMA cycles per SIMD per K-step
+            mf = 4608 if cfg == 13 else 4096   # MFMA issue cycles per SIMD and K-step: 2 waves x (36 | 32) instructions x 64 cycles
             print(f"cfg {cfg} B={B} {H}x{W} Co={Co} {name:28s} " + " ".join(f"Ci={c}: {t*1e6:7.1f} us" for c, t in ts.items()) +
                   f" | per K-step {slope*1e6:6.3f} us = {slope*2.2e9:6.0f} cyc (MFMA {mf:.0f}), fixed per workgroup round {icpt*1e6:6.2f} us", flush=True)
 if ablate:
