@@ -196,8 +196,9 @@ def test_full_batch_gradients_against_float64(dataset, res):
     """The same D and G updates at batch 64, measured against the TRUTH: oracle/nets.py evaluated in float64 from the same
     weights, images and noise.  Bounds are per-parameter relative L2 distances to the float64 gradient,
     set from what was measured on MI355X for BOTH fp32 implementations (tools/sngan_f64_parity.py,
-    profiles/r03_f64_parity.md): D-update gradients -- no ReLU mask flips at these sizes -- HIP <= 2.3e-5, CPU oracle in
-    fp32 <= 3.4e-4; G-update gradients (through D's and G's masks: a pre-activation within rounding of zero flips an O(1)
+    profiles/r03_f64_parity.md): D-update gradients HIP 2.3e-5 - 3.4e-4, CPU oracle in fp32 <= 3.4e-4 (the 3.4e-4 is ONE
+    parameter, block1.c_sc.weight, where a single ReLU mask element within rounding of zero flips against float64: the fp32
+    oracle flips it always, the HIP path with some kernel selections and not with others -- bound 1e-3 for both); G-update gradients (through D's and G's masks: a pre-activation within rounding of zero flips an O(1)
     mask element) HIP <= 2.2e-3, fp32 oracle <= 6.0e-3.  The fp32 oracle is run beside the HIP path and held to the same
     bounds, so the allowance is a statement about fp32, not about this engine; and over a whole network the HIP path may not
     be systematically further from float64 than plain PyTorch fp32 (rms over the parameters within 8x: measured 0.002x -
@@ -227,7 +228,8 @@ def test_full_batch_gradients_against_float64(dataset, res):
     for (k, p32), (_, p64) in zip(oD.named_parameters(), dD.named_parameters()):
         hip.append(rel(gr[k], p64.grad))
         o32.append(rel(p32.grad, p64.grad))
-        assert hip[-1] < 3e-4, f"D grad {k}: {hip[-1]:.2e} from float64 (fp32 oracle: {o32[-1]:.2e})"
+        assert hip[-1] < 1e-3, f"D grad {k}: {hip[-1]:.2e} from float64 (fp32 oracle: {o32[-1]:.2e})"
+        assert o32[-1] < 1e-3, f"(oracle fp32) D grad {k}: {o32[-1]:.2e} from float64"
     assert rms(hip) <= 8 * rms(o32) + 1e-6, (rms(hip), rms(o32))
     g32 = oG.train_step((x, None), oD, ooptG, noise=zg)
     g64 = dG.train_step((x.double(), None), dD, doptG, noise=zg.double())
