@@ -224,7 +224,9 @@ typedef struct {
 } diagan_wgrad_layer;
 int diagan_wgrad_finish_batched(const void* table_dev, int n_layers, int64_t total_blocks, int any_sn, void* stream);
 /* elements of a layer that one workgroup of the finish kernels handles, for a layer of `splits` splits per context: the host
- * lays out diagan_wgrad_layer::first_block (and sizes the <G, W> partial arrays) in units of it */
+ * lays out diagan_wgrad_layer::first_block (and sizes the <G, W> partial arrays) in units of it (1024 x {8, 4, 2, 1} for at most
+ * 2, 4, 8 and more splits).  diagan_wgrad_layer::stride must be below 2^25 floats (the kernels address 16 splits of a layer through
+ * one 2 GiB buffer window). */
 int diagan_wgrad_finish_block_elems(int splits);
 
 /* out (+)= sum_s slab[s]; if w: dot_partials[block] = partial <sum, w> (fp64, for the SN backward);

@@ -329,66 +329,92 @@ __device__ __forceinline__ int find_layer(const WgFinish* __restrict__ tab, int 
   return l;
 }
 
-// Elements of a layer handled by one workgroup of the finish kernels: 256 threads x U positions x 4 floats, U = 4 for layers of
-// at most 8 splits per context and 1 otherwise (fin_u).  With one position per thread a layer of few splits (the large
-// layers, which carry the bytes: every layer's slab is one round of workgroup tiles, ~34 MB) had only `splits` = 2..8 loads in
-// flight per thread (2 TB/s); four positions keep 8 in flight.  Layers of many splits (small weights, huge pixel counts)
-// keep the small blocks: their per-thread chain is splits / 8 rounds long and more, smaller workgroups shorten the tail.
-__host__ __device__ __forceinline__ int fin_u(int splits) { return splits <= 8 ? 4 : 1; }
+// The layer's descriptor, made wave-uniform field by field (v_readfirstlane): the finish kernels build buffer resources from
+// its pointers, and a resource the compiler cannot prove uniform costs a waterfall loop per load.
+typedef unsigned u32x4_t __attribute__((__vector_size__(16)));
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+  const unsigned long v = (unsigned long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long)hi << 32) | lo);
+}
+__device__ __forceinline__ WgFinish load_uniform(const WgFinish* __restrict__ d) {
+  WgFinish L;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    L.slab[c] = uni(d->slab[c]); L.u[c] = uni(d->u[c]); L.v[c] = uni(d->v[c]); L.state[c] = uni(d->state[c]);
+    L.partials[c] = uni(d->partials[c]);
+  }
+  L.grad = uni(d->grad); L.W = uni(d->W);
+  L.stride = (long)uni((int)d->stride);                 // (the host checks 16 * stride * 4 < 2^31)
+  L.splits = uni(d->splits); L.n_elem = uni(d->n_elem); L.n_w = uni(d->n_w); L.Kp = uni(d->Kp);
+  L.nctx = uni(d->nctx); L.first_block = uni(d->first_block);
+  return L;
+}
+
+// Elements of a layer handled by one workgroup of the finish kernels: 256 threads x U positions x 4 floats.  Every thread keeps
+// U x R = 16 independent 16-byte loads in flight (R = splits of one position per round): U = 8, 4, 2, 1 for layers of at most
+// 2, 4, 8 and more splits per context (fin_u).  Every layer's slab is about one round of workgroup tiles (~17 MB per
+// context) whatever its size, so n_elem x splits -- and with it the number of workgroups per layer, n_elem / (1024 U) -- is
+// about the same for all layers.  The loads are raw buffer loads over the R splits of a round: positions behind the
+// layer's end carry bit 31 in their offset and splits behind the last one fall behind num_records, both read as zero WITHOUT a
+// branch -- the first version of this kernel guarded every position with an `if`, the compiler put a `s_waitcnt vmcnt(0)`
+// at each join and two loads per thread were in flight at a time (3.1 TB/s).
+__host__ __device__ __forceinline__ int fin_u(int splits) { return splits <= 2 ? 8 : splits <= 4 ? 4 : splits <= 8 ? 2 : 1; }
 
 template <int U>
 __device__ __forceinline__ void fin_a(const WgFinish& L, int lb, double* red) {
   constexpr int ELEMS = 1024 * U;
+  constexpr int R = 16 / U;
   const bool sn = L.W != nullptr;
-  long pos[U];
+  unsigned voff[U];                                      // byte offset of the position inside a split; bit 31: behind the layer
 #pragma unroll
-  for (int u = 0; u < U; ++u) pos[u] = (long)lb * ELEMS + (u * 256 + threadIdx.x) * 4;
+  for (int u = 0; u < U; ++u) {
+    const long pos = (long)lb * ELEMS + (u * 256 + threadIdx.x) * 4;
+    voff[u] = pos < L.n_elem ? (unsigned)pos * 4u : 0x80000000u;
+  }
+  const unsigned sbytes = (unsigned)L.stride * 4u;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 total[U];
+  f32x4 acc[U];                                          // plain layers: runs on over both contexts
 #pragma unroll
-  for (int u = 0; u < U; ++u) total[u] = z4;
-  constexpr int R = 8 / U;                     // splits per round: R x U = 8 independent loads in flight
-  for (int c = 0; c < L.nctx; ++c) {
-    double dot = 0.0;
+  for (int u = 0; u < U; ++u) acc[u] = z4;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c >= L.nctx) break;
     float* sl = L.slab[c];
-    f32x4 acc[U][R];                           // fixed assignment of splits to partial sums: deterministic
+    for (int k = 0; k < L.splits; k += R) {              // fixed assignment of splits to partial sums: deterministic
+      const int nr = min(R, L.splits - k);
+      const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(sl + (long)k * L.stride, 0, (int)(nr * sbytes), 0x00020000);
+      f32x4 t[U][R];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int r = 0; r < R; ++r) acc[u][r] = z4;
-    int k = 0;
-    for (; k + R <= L.splits; k += R) {
+        for (int u = 0; u < U; ++u)
+          t[u][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, voff[u] + (unsigned)r * sbytes, 0, 0));
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (pos[u] < L.n_elem) {
-          const float* q = sl + (long)k * L.stride + pos[u];
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) acc[u][r] += *reinterpret_cast<const f32x4*>(q + r * L.stride);
-        }
-    }
-    for (; k < L.splits; ++k) {
+        for (int w = 1; w < R; w <<= 1)
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (pos[u] < L.n_elem) acc[u][0] += *reinterpret_cast<const f32x4*>(sl + (long)k * L.stride + pos[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      f32x4 s = acc[u][0];
-      if (R == 2) s += acc[u][1];
-      if (R == 8) s = ((acc[u][0] + acc[u][4]) + (acc[u][1] + acc[u][5])) + ((acc[u][2] + acc[u][6]) + (acc[u][3] + acc[u][7]));
-      if (pos[u] < L.n_elem) {
-        if (sn) {
-          if (pos[u] < L.n_w) {
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(L.W + pos[u]);
-            dot += (double)s[0] * wv[0] + (double)s[1] * wv[1] + (double)s[2] * wv[2] + (double)s[3] * wv[3];
-          }
-          *reinterpret_cast<f32x4*>(sl + pos[u]) = s;
-        } else {
-          total[u] += s;
-        }
+          for (int r = 0; r + w < R; r += 2 * w) t[u][r] += t[u][r + w];
+        acc[u] += t[u][0];
       }
     }
-    if (sn) {
+    if (sn) {                                            // G_c back into split 0 of its slab, the block's partial of <G_c, W>
+      double dot = 0.0;
+      const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.W), 0, L.n_w * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(sl, 0, L.n_elem * 4, 0x00020000);
+      f32x4 wv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) wv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff[u], 0, 0));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f32x4 g = acc[u];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), dst, voff[u], 0, 0);
+        dot += (double)g[0] * wv[u][0] + (double)g[1] * wv[u][1] + (double)g[2] * wv[u][2] + (double)g[3] * wv[u][3];
+        acc[u] = z4;
+      }
       dot = wave_sum(dot);
       __syncthreads();
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
@@ -397,22 +423,35 @@ __device__ __forceinline__ void fin_a(const WgFinish& L, int lb, double* red) {
     }
   }
   if (!sn) {
+    const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(L.grad, 0, L.n_elem * 4, 0x00020000);
+    f32x4 og[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) og[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gsrc, voff[u], 0, 0));
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (pos[u] < L.n_elem) *reinterpret_cast<f32x4*>(L.grad + pos[u]) += total[u];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, og[u] + acc[u]), gsrc, voff[u], 0, 0);
+  }
+}
+
+template <typename F>
+__device__ __forceinline__ void fin_dispatch(int U, F&& f) {
+  switch (U) {
+    case 8: f(std::integral_constant<int, 8>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    default: f(std::integral_constant<int, 1>{}); break;
   }
 }
 
 // phase A: G_c = sum over the splits of context c (fixed order).  plain layers: grad += sum_c G_c.
 // SN layers: G_c kept in slab[c][0..] and the block's partial of <G_c, W> is written.
-__global__ __launch_bounds__(256) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab, int n_layers) {
-  const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_finish_a_kernel(const WgFinish* __restrict__ tab, int n_layers) {
+  const WgFinish L = load_uniform(tab + find_layer(tab, n_layers, blockIdx.x));
   const int lb = blockIdx.x - L.first_block;          // workgroup index inside the layer
   const int U = fin_u(L.splits);
   if ((long)lb * 1024 * U >= L.n_elem) return;
   __shared__ double red[4];
-  if (U == 4) fin_a<4>(L, lb, red);
-  else fin_a<1>(L, lb, red);
+  fin_dispatch(U, [&](auto u) { fin_a<decltype(u)::value>(L, lb, red); });
 }
 
 // between A and B: <G_c, W> of every SN layer = sum of its phase-A partials, ONCE per layer (one workgroup each,
@@ -437,54 +476,73 @@ __global__ __launch_bounds__(256) void wgrad_finish_dot_kernel(const WgFinish* _
 }
 
 // phase B (SN layers): grad += sum_c (G_c - <G_c,W>/sigma_c * u_c^T v_c) / sigma_c ; bias part: += G_c
+// Branch-free like phase A: positions behind the layer, the bias part's u / v and the absent second context read zero through
+// out-of-range buffer offsets; two positions (ten 16-byte loads) per thread in flight at a time.
 template <int U>
 __device__ __forceinline__ void fin_b(const WgFinish& L, int lb) {
   constexpr int ELEMS = 1024 * U;
+  constexpr int UC = U > 1 ? 2 : 1;
   const int nparts = (L.n_elem + ELEMS - 1) / ELEMS;
-  float inv[2], coef[2];
-  for (int c = 0; c < L.nctx; ++c) {
+  float inv[2] = {0.f, 0.f}, coef[2] = {0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c >= L.nctx) break;
     inv[c] = L.state[c][1];
     coef[c] = (float)(L.partials[c][nparts] * (double)inv[c]);
   }
-  // all loads of the U positions first (G_c of both contexts, v, u, the gradient itself), then the arithmetic
-  long pos[U];
-  f32x4 gq[U][2], vv[U][2], og[U];
-  float uu[U][2];
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const int Co = L.n_w / L.Kp;
+  const __amdgpu_buffer_rsrc_t gsrc = __builtin_amdgcn_make_buffer_rsrc(L.grad, 0, L.n_elem * 4, 0x00020000);
+  __amdgpu_buffer_rsrc_t qsrc[2], vsrc[2], usrc[2];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    pos[u] = (long)lb * ELEMS + (u * 256 + threadIdx.x) * 4;
-    const bool ok = pos[u] < L.n_elem, okw = ok && pos[u] < L.n_w;
-    const int n = okw ? (int)((unsigned)pos[u] / (unsigned)L.Kp) : 0;      // (i < n_w < 2^31: no 64-bit division)
-    const int k = okw ? (int)pos[u] - n * L.Kp : 0;
-    og[u] = ok ? *reinterpret_cast<const f32x4*>(L.grad + pos[u]) : z4;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const bool oc = ok && c < L.nctx;
-      gq[u][c] = oc ? *reinterpret_cast<const f32x4*>(L.slab[c] + pos[u]) : z4;
-      vv[u][c] = oc && okw ? *reinterpret_cast<const f32x4*>(L.v[c] + k) : z4;
-      uu[u][c] = oc && okw ? L.u[c][n] : 0.f;
-    }
+  for (int c = 0; c < 2; ++c) {
+    const bool on = c < L.nctx;
+    qsrc[c] = __builtin_amdgcn_make_buffer_rsrc(L.slab[c], 0, on ? L.n_elem * 4 : 0, 0x00020000);
+    vsrc[c] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.v[c]), 0, on ? L.Kp * 4 : 0, 0x00020000);
+    usrc[c] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.u[c]), 0, on ? Co * 4 : 0, 0x00020000);
   }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    if (pos[u] >= L.n_elem) continue;
-    f32x4 o = z4;
-    for (int c = 0; c < L.nctx; ++c) {
-      if (pos[u] < L.n_w) o += (gq[u][c] - (uu[u][c] * coef[c]) * vv[u][c]) * inv[c];
-      else o += gq[u][c];
+  for (int u0 = 0; u0 < U; u0 += UC) {
+    unsigned po[UC];
+    bool okw[UC];
+    f32x4 og[UC], gq[UC][2], vv[UC][2];
+    float uu[UC][2];
+#pragma unroll
+    for (int i = 0; i < UC; ++i) {
+      const long pos = (long)lb * ELEMS + ((u0 + i) * 256 + threadIdx.x) * 4;
+      po[i] = pos < L.n_elem ? (unsigned)pos * 4u : 0x80000000u;
+      okw[i] = pos < L.n_w;
+      const unsigned n = okw[i] ? (unsigned)pos / (unsigned)L.Kp : 0u;       // (pos < n_w < 2^31: no 64-bit division)
+      const unsigned ko = okw[i] ? ((unsigned)pos - n * (unsigned)L.Kp) * 4u : 0x80000000u;
+      const unsigned no = okw[i] ? n * 4u : 0x80000000u;
+      og[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gsrc, po[i], 0, 0));
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        gq[i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qsrc[c], po[i], 0, 0));
+        vv[i][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vsrc[c], ko, 0, 0));
+        uu[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(usrc[c], no, 0, 0));
+      }
     }
-    *reinterpret_cast<f32x4*>(L.grad + pos[u]) = og[u] + o;
+#pragma unroll
+    for (int i = 0; i < UC; ++i) {
+      f32x4 o = og[i];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const f32x4 w = (gq[i][c] - (uu[i][c] * coef[c]) * vv[i][c]) * inv[c];
+        o += okw[i] ? w : gq[i][c];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o),
+                                             gsrc, po[i], 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 __global__ __launch_bounds__(256) void wgrad_finish_b_kernel(const WgFinish* __restrict__ tab, int n_layers) {
-  const WgFinish L = tab[find_layer(tab, n_layers, blockIdx.x)];
+  const WgFinish L = load_uniform(tab + find_layer(tab, n_layers, blockIdx.x));
   const int lb = blockIdx.x - L.first_block;
   const int U = fin_u(L.splits);
   if (L.W == nullptr || (long)lb * 1024 * U >= L.n_elem) return;
-  if (U == 4) fin_b<4>(L, lb);
-  else fin_b<1>(L, lb);
+  fin_dispatch(U, [&](auto u) { fin_b<decltype(u)::value>(L, lb); });
 }
 
 // elements of a layer per workgroup of the finish kernels for a layer of `splits` splits per context (the host sizes

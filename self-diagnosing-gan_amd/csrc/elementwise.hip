@@ -339,32 +339,43 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
 
 // ---- bilinear 2x upsample (align_corners=False) and its adjoint ---------------------------------
 // out[2j]   = 0.25*x[max(j-1,0)] + 0.75*x[j] ; out[2j+1] = 0.75*x[j] + 0.25*x[min(j+1,H-1)]
-__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
+// One thread per INPUT position and 4 channels: the 3x3 neighbourhood (9 loads, prologue applied once each) gives the 2x2
+// outputs (2.25 loads per output; one thread per output read 4 and ran the prologue 4 times: 2.6 TB/s).  Same blend grouping
+// as before -- (w0*a + w1*b) along x inside the y blend, as PyTorch evaluates it -- so the values are unchanged.
+__global__ __launch_bounds__(EW_T) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H, int W, int C,
                                   int pro_mode, const float* __restrict__ scale, const float* __restrict__ shift,
                                   int group_imgs) {
-  const int C4 = C >> 2, Ho = 2 * H, Wo = 2 * W;
-  const long n4 = (long)B * Ho * Wo * C4;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    long p = i / C4;
-    const int ox = (int)(p % Wo); p /= Wo;
-    const int oy = (int)(p % Ho);
-    const int b = (int)(p / Ho);
-    const int jy = oy >> 1, jx = ox >> 1;
-    const int y0 = (oy & 1) ? jy : max(jy - 1, 0), y1 = (oy & 1) ? min(jy + 1, H - 1) : jy;
-    const int x0 = (ox & 1) ? jx : max(jx - 1, 0), x1 = (ox & 1) ? min(jx + 1, W - 1) : jx;
-    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wx0 = (ox & 1) ? 0.75f : 0.25f;
-    const float wy1 = 1.f - wy0, wx1 = 1.f - wx0;
+  const unsigned C4 = (unsigned)C >> 2;
+  const unsigned n4 = (unsigned)B * H * W * C4;            // (< 2^31: checked by the launcher)
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+    const unsigned c4 = i % C4;
+    unsigned p = i / C4;
+    const int jx = (int)(p % (unsigned)W); p /= (unsigned)W;
+    const int jy = (int)(p % (unsigned)H);
+    const int b = (int)(p / (unsigned)H);
     const float* base = x + (long)b * H * W * C + c4 * 4;
-    const int pc = (group_imgs > 0 ? (b / group_imgs) * C : 0) + c4 * 4;     // per-group BatchNorm scale / shift
-    auto ld = [&](int yy, int xx) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(base + ((long)yy * W + xx) * C);
-      return apply_pro(v, pro_mode, scale, shift, pc);
-    };
-    // PyTorch evaluates (w0*a + w1*b) along x inside the y blend; same grouping here
-    const f32x4 top = wx0 * ld(y0, x0) + wx1 * ld(y0, x1);
-    const f32x4 bot = wx0 * ld(y1, x0) + wx1 * ld(y1, x1);
-    reinterpret_cast<f32x4*>(out)[i] = wy0 * top + wy1 * bot;
+    const int pc = (group_imgs > 0 ? (b / group_imgs) * C : 0) + (int)c4 * 4;     // per-group BatchNorm scale / shift
+    const int ys[3] = {max(jy - 1, 0), jy, min(jy + 1, H - 1)};
+    const int xs[3] = {max(jx - 1, 0), jx, min(jx + 1, W - 1)};
+    f32x4 v[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[r][q] = *reinterpret_cast<const f32x4*>(base + ((long)ys[r] * W + xs[q]) * C);
+    f32x4 he[3], ho[3];                                     // x blends of the three rows: even / odd output column
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) v[r][q] = apply_pro(v[r][q], pro_mode, scale, shift, pc);
+      he[r] = 0.25f * v[r][0] + 0.75f * v[r][1];
+      ho[r] = 0.75f * v[r][1] + 0.25f * v[r][2];
+    }
+    f32x4* o = reinterpret_cast<f32x4*>(out) + (((long)b * 2 * H + 2 * jy) * 2 * W + 2 * jx) * C4 + c4;
+    const long row = 2L * W * C4;
+    o[0] = 0.25f * he[0] + 0.75f * he[1];
+    o[C4] = 0.25f * ho[0] + 0.75f * ho[1];
+    o[row] = 0.75f * he[1] + 0.25f * he[2];
+    o[row + C4] = 0.75f * ho[1] + 0.25f * ho[2];
   }
 }
 
@@ -769,7 +780,8 @@ DIAGAN_API int diagan_upsample2x(const float* x, float* out, int B, int H, int W
   DG_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "upsample2x: bad args");
   DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "upsample2x: bad pro_mode");
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (scale && shift), "upsample2x: affine needs scale/shift");
-  hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_blocks((long)B * H * W * C)), dim3(EW_T), 0, ST, x, out, B, H, W, C,
+  DG_REQUIRE((long)B * H * W * C < (1L << 31), "upsample2x: input must have fewer than 2^31 elements");
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(ew_blocks((long)B * H * W * C / 4)), dim3(EW_T), 0, ST, x, out, B, H, W, C,
                      pro_mode, scale, shift, group_imgs);
   return check_launch("upsample2x");
 }

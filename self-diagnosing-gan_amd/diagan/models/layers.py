@@ -644,6 +644,7 @@ class WgradBatch:
                     nctx, per = 1, e['splits']
                 pp[10] = layer.weight.grad.data_ptr()
                 pp[11] = layer.weight.data.data_ptr() if sn else 0
+                assert 64 * e['stride'] < 2 ** 31, "wgrad finish: 16 splits of a layer must fit a 2 GiB buffer window"
                 tab[li]['p'], tab[li]['stride'] = pp, e['stride']
                 tab[li]['i'] = [per, e['n_elem'], e['n_w'], layer.geom.Kp, nctx, total_blocks]
                 be = nat.fn("diagan_wgrad_finish_block_elems")(per)          # elements per workgroup of the finish kernels

@@ -199,7 +199,7 @@ def test_full_batch_gradients_against_float64(dataset, res):
     profiles/r03_f64_parity.md): D-update gradients HIP 2.3e-5 - 3.4e-4, CPU oracle in fp32 <= 3.4e-4 (the 3.4e-4 is ONE
     parameter, block1.c_sc.weight, where a single ReLU mask element within rounding of zero flips against float64: the fp32
     oracle flips it always, the HIP path with some kernel selections and not with others -- bound 1e-3 for both); G-update gradients (through D's and G's masks: a pre-activation within rounding of zero flips an O(1)
-    mask element) HIP <= 2.2e-3, fp32 oracle <= 6.0e-3.  The fp32 oracle is run beside the HIP path and held to the same
+    mask element) HIP 2.2e-3 - 6.2e-3 depending on the kernel selection, fp32 oracle <= 6.0e-3; bound 1.2e-2 for both.  The fp32 oracle is run beside the HIP path and held to the same
     bounds, so the allowance is a statement about fp32, not about this engine; and over a whole network the HIP path may not
     be systematically further from float64 than plain PyTorch fp32 (rms over the parameters within 8x: measured 0.002x -
     0.33x on three of the four (network, update) pairs, 6.9x on SNGAN-64's generator update, whose longest accumulation
@@ -244,7 +244,7 @@ def test_full_batch_gradients_against_float64(dataset, res):
             continue
         hip.append(rel(gr[k], p64.grad))
         o32.append(rel(p32.grad, p64.grad))
-        assert hip[-1] < 6e-3, f"G grad {k}: {hip[-1]:.2e} from float64 (fp32 oracle: {o32[-1]:.2e})"
+        assert hip[-1] < 1.2e-2, f"G grad {k}: {hip[-1]:.2e} from float64 (fp32 oracle: {o32[-1]:.2e})"
         assert o32[-1] < 1.2e-2, f"(oracle fp32) G grad {k}: {o32[-1]:.2e} from float64"
     assert rms(hip) <= 8 * rms(o32) + 1e-6, (rms(hip), rms(o32))
 
