@@ -95,25 +95,47 @@ __global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
       mu = reinterpret_cast<const f32x4*>(a.mean)[c4];
       is = reinterpret_cast<const f32x4*>(a.invstd)[c4];
     }
-    for (long r = r0 + rl; r < r1; r += RL) {
-      const f32x4 xv = reinterpret_cast<const f32x4*>(a.x)[r * C4 + c4];
-      if (MODE == 0) {
+    // Four rows' loads in flight per thread (one row per iteration left a thread with two loads in flight: 1.5 TB/s); the rows
+    // are accumulated in the same order as before, so the sums are unchanged.  Rows behind the range re-read its last row
+    // (no branch around the loads) and are skipped by the accumulation.
+    constexpr int UR = 4;
+    for (long rb = r0 + rl; rb < r1; rb += (long)UR * RL) {
+      f32x4 xs[UR], gs[UR], ds[UR];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s1[e] += xv[e]; s2[e] += (double)xv[e] * xv[e]; }
-      } else if (MODE == 2) {
+      for (int k = 0; k < UR; ++k) {
+        const long r = rb + (long)k * RL < r1 ? rb + (long)k * RL : r1 - 1;
+        xs[k] = reinterpret_cast<const f32x4*>(a.x)[r * C4 + c4];
+        if (MODE == 1) gs[k] = reinterpret_cast<const f32x4*>(a.g)[r * C4 + c4];
+      }
+      if (MODE == 1 && a.drop) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s1[e] += xv[e];
-      } else {
-        f32x4 gv = reinterpret_cast<const f32x4*>(a.g)[r * C4 + c4];
-        const f32x4 xh = (xv - mu) * is;
-        if (a.drop) gv *= reinterpret_cast<const f32x4*>(a.drop)[r * C4 + c4];
-        if (a.relu) {
-          const f32x4 y = xv * sc + sh;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : gv[e] * a.slope;
+        for (int k = 0; k < UR; ++k) {
+          const long r = rb + (long)k * RL < r1 ? rb + (long)k * RL : r1 - 1;
+          ds[k] = reinterpret_cast<const f32x4*>(a.drop)[r * C4 + c4];
         }
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { s1[e] += gv[e]; s2[e] += (double)gv[e] * xh[e]; }
+      for (int k = 0; k < UR; ++k) {
+        if (rb + (long)k * RL >= r1) break;
+        const f32x4 xv = xs[k];
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += xv[e]; s2[e] += (double)xv[e] * xv[e]; }
+        } else if (MODE == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s1[e] += xv[e];
+        } else {
+          f32x4 gv = gs[k];
+          const f32x4 xh = (xv - mu) * is;
+          if (a.drop) gv *= ds[k];
+          if (a.relu) {
+            const f32x4 y = xv * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[e] = y[e] > 0.f ? gv[e] : gv[e] * a.slope;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { s1[e] += gv[e]; s2[e] += (double)gv[e] * xh[e]; }
+        }
       }
     }
   }
@@ -637,7 +659,7 @@ static int colred_geometry(long M, int C, int* splits, int* rows_per_split, dim3
   const int C4 = C / 4;
   const int CW = C4 < 64 ? C4 : 64;
   const int gx = cdiv(C4, CW);
-  int s = cdiv(512, gx);                        // ~2 blocks per CU in total
+  int s = cdiv(1024, gx);                       // ~4 blocks per CU in total
   const long max_s = (M + 255) / 256;           // at least 256 rows per split
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;

@@ -70,3 +70,31 @@ def test_avgpool2_and_adjoint(B, H, W, C):
     F.avg_pool2d(x2, 2).backward(gy)
     got = nchw(E.avgpool2_bwd(nhwc(gy).cuda()).cpu())
     assert (got - x2.grad).abs().max().item() <= 1e-6 * max(1.0, x2.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("M,C", [(7, 4), (300, 12), (4096, 64), (65536, 256), (1000, 260)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_batchnorm_backward_column_sums(M, C, relu):
+    """dgamma / dbeta / dx of BatchNorm (+ the ReLU behind it) against torch autograd in float64 -- the column reduction
+    `colred_kernel<1>` and `bn_bwd_apply_kernel` (mimicry GBlock: `self.activation(self.b1(h))`, resblocks.py:73-78)."""
+    from diagan.ops import eltwise as E
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g, dtype=torch.float64, requires_grad=True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_()
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_()
+    gy = torch.randn(M, C, generator=g, dtype=torch.float64)
+    y = F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5)
+    (F.relu(y) if relu else y).backward(gy)
+    xc = x.detach().float().cuda().reshape(1, M, 1, C)
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    ctx = E.bn_stats(xc, gamma.detach().float().cuda(), beta.detach().float().cuda(), rm, rv, True)
+    dgamma, dbeta = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    gx = E.bn_bwd(gy.float().cuda().reshape(1, M, 1, C), xc, ctx, relu, dgamma, dbeta, False)
+    tol = 3e-5 if M > 8 else 1e-3                 # (M = 7: variance of seven samples, conditioning of 1/std)
+    if relu:                                      # a pre-activation within fp32 rounding of zero may take the other branch
+        tol = max(tol, 2e-4)
+    for got, want in ((dgamma, gamma.grad), (dbeta, beta.grad)):
+        assert (got.cpu() - want.float()).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    far = (y.detach().abs() > 1e-4) if relu else torch.ones(M, C, dtype=torch.bool)
+    err = ((gx.reshape(M, C).cpu() - x.grad.float()).abs() * far).max().item()
+    assert err <= tol * max(1.0, x.grad.abs().max().item())
