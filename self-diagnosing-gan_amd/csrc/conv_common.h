@@ -145,6 +145,33 @@ struct WgradArgs {
   int same;                 // stride-1, un-dilated, same-size conv (Hi == Ho, Wi == Wo): linear gather offsets
 };
 
+// Loader of the Winograd weight-transform kernels (conv_wino.hip, conv_wino4.hip): the 3x3 taps of a block of 64 output x 32
+// input channels of the packed weights w[Co][Kp], for thread (column = tid & 63, channel quad = tid >> 6) of a 512-thread
+// workgroup.  Read with eight lanes along the input channels -- one whole 128-byte line per output channel and tap; with the
+// lanes along the output channels, as the transform and its stores want them, every lane touched a line of its own for 16
+// bytes -- and transposed through LDS ([tap][quad][64 + 1 columns]: the eight quads of a column fall on eight different bank
+// quads).  flip: taps reversed (data gradient).  Returns false for a thread whose channel quad lies behind Ci.
+constexpr int WT_LDS_F4 = 9 * 8 * 65;                  // f32x4 elements of the staging buffer (74 880 bytes)
+__device__ __forceinline__ bool wino_stage_taps(const float* __restrict__ w, int co0, int c0, int Co, int Ci, int Kp, int flip,
+                                                f32x4* __restrict__ sg, f32x4 (&g)[3][3]) {
+  const int tid = threadIdx.x;
+  {
+    const int col = tid >> 3, q = tid & 7;
+    const bool ok = co0 + col < Co && c0 + q * 4 < Ci;
+    const float* src = w + (long)(co0 + col) * Kp + c0 + q * 4;
+    f32x4 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = ok ? *reinterpret_cast<const f32x4*>(src + (flip ? 8 - t : t) * Ci) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sg[(t * 8 + q) * 65 + col] = v[t];
+  }
+  __syncthreads();
+  const int col = tid & 63, q = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = sg[(t * 8 + q) * 65 + col];
+  return c0 + q * 4 < Ci;
+}
+
 // Bijective XCD-aware remap of a linear workgroup id (cdna guide T1): consecutive logical tiles
 // land on the same XCD (= same L2), so neighbouring tiles share halo rows and weight panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -28,17 +28,12 @@ namespace diagan {
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 4 i + j, written in the LDS image order (see above).  flip: the data-gradient of a
 // stride-1 convolution is the correlation with the taps reversed.
-__global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                         int Kp, int flip) {
-  const int c4 = blockIdx.x, co = blockIdx.y * 64 + threadIdx.x, c = c4 * 4;
+__global__ __launch_bounds__(512) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                          int Kp, int flip) {
+  __shared__ f32x4 sg[WT_LDS_F4];
   f32x4 g[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
-      g[r][s] = co < Co ? *reinterpret_cast<const f32x4*>(w + (long)co * Kp + (rr * 3 + ss) * Ci + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  if (!wino_stage_taps(w, blockIdx.y * 64, blockIdx.x * 32, Co, Ci, Kp, flip, sg, g)) return;
+  const int col = threadIdx.x & 63, c = blockIdx.x * 32 + (threadIdx.x >> 6) * 4;
   f32x4 t[4][3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
@@ -63,7 +58,7 @@ __global__ __launch_bounds__(64) void wino_weight_kernel(const float* __restrict
     for (int j = 0; j < 4; ++j) {
       float* plane = base + ((i * 4 + j) * 2 + kq) * 256;
       const f32x4 v = u[j] * sg;
-      *reinterpret_cast<f32x4*>(plane + threadIdx.x * 4) = v;
+      *reinterpret_cast<f32x4*>(plane + col * 4) = v;
     }
   }
 }
@@ -502,7 +497,7 @@ static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t s
 }
 
 void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, hipStream_t st) {
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(Ci / 4, cdiv(Co, WN)), dim3(64), 0, st, w, ug, Co, Ci, Kp, flip);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(cdiv(Ci, 32), cdiv(Co, WN)), dim3(512), 0, st, w, ug, Co, Ci, Kp, flip);
 }
 
 // floats of workspace the transformed weights need

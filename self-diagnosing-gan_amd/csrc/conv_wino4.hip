@@ -74,17 +74,13 @@ __host__ __device__ __forceinline__ int w4p_freq(int v) { return v < 2 ? v : v +
 // group = (i / 3) * 2 + j / 3 (a 3 x 3 block of the 6 x 6 frequencies), slot = 3 (i % 3) + j % 3.
 // flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
 template <int MODE>
-__global__ __launch_bounds__(64) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                          int Kp, int flip) {
-  const int c = blockIdx.x * 4, nb = blockIdx.y, col = threadIdx.x, co = nb * 64 + col;
+__global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                           int Kp, int flip) {
+  __shared__ f32x4 sg[WT_LDS_F4];
   f32x4 g[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int rr = flip ? 2 - r : r, ss = flip ? 2 - s : s;
-      g[r][s] = co < Co ? *reinterpret_cast<const f32x4*>(w + (long)co * Kp + (rr * 3 + ss) * Ci + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  const int nb = blockIdx.y;
+  if (!wino_stage_taps(w, nb * 64, blockIdx.x * 32, Co, Ci, Kp, flip, sg, g)) return;
+  const int col = threadIdx.x & 63, c = blockIdx.x * 32 + (threadIdx.x >> 6) * 4;
   constexpr float k4 = 0.25f, k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
   auto gt = [&](const f32x4& g0, const f32x4& g1, const f32x4& g2, f32x4* o) {
     o[0] = k4 * g0;
@@ -679,7 +675,7 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
+  hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
                      g.dr < 0 ? 1 : 0);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ws, st);
@@ -707,7 +703,7 @@ int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0);
+  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0);
   return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1>(a, ws, st) : launch_wino4_pro<PRO_NONE, 1>(a, ws, st);
 }
 
@@ -715,7 +711,7 @@ int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(g.Ci / 4, cdiv(g.Co, W4N)), dim3(64), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 1);
+  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 1);
   return launch_wino4_pro<PRO_NONE, 2>(a, ws, st);
 }
 
