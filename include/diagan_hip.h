@@ -74,7 +74,9 @@ int diagan_logit_scatter(const float* logit, const int64_t* idx, int64_t n, void
  *        no ReLU on it.
  * Replaces F.conv2d / nn.ConvTranspose2d forward and their input gradient
  * (SNGAN blocks: SURVEY §8 a2-a7; DCGAN: diagan-pkg/diagan/models/mnist.py:55-71,163-190).
- * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto, 1 = 128x128, 3 = 64x64.
+ * x NHWC [B,Hi,Wi,Ci] (Ci % 4 == 0), w packed [Co][Kp], y NHWC [B,Ho,Wo,Co]. tile_cfg 0 = auto, 1 = 128x128, 3 / 7 = 64x64,
+ * 5 = 256x64, 8 = 128x64, 14 = 64x64 with the K loop shared by two four-wave groups of ONE workgroup (launches of at most one
+ * tile per CU; round 3), 9 / 11 / 12 / 13 = the Winograd kernels below.
  * scale0/scale1 (device scalars, optional): pixel rows m < scale_split are scaled by *scale0, the rest
  * by *scale1 instead of out_scale -- two forwards of one spectral-norm layer (different sigma) batched
  * into one GEMM on the un-normalised weight. */

@@ -50,8 +50,14 @@ int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs);
 
 
-template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool STAMP = false, bool FP = false>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
+// KG = 2 (tile_cfg 14): TWO K-groups of four waves in one workgroup.  Each group is the KG = 1 kernel on its own half of the
+// K-steps with its own LDS stages; the second group's accumulators join the first's through LDS before the epilogue.  For
+// launches with at most one 64x64 tile per CU (the 8x8 / 4x4 blocks): a lone four-wave workgroup leaves every SIMD with ONE
+// wave and runs at 0.58 of the MFMA rate; split-K LAUNCHES pay for a slab and a second kernel (31.6 us unsplit, 36 split at
+// M = 8192, N = 128, K = 1152).  Measured: 29-32 -> 26-29 us on that shape (HIP events around the launch); FOUR groups (nine K-steps
+// each) take the same 27 us -- what is left is the launch's fixed cost, not its K loop -- so KG = 2 is the only instantiation.
+template <int BM, int BN, int WM, int WN, int BK = 32, int PRO = -1, bool STAMP = false, bool FP = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int CH = BK / 4;                           // 16-byte chunks per tile row
   constexpr int RP = 256 / CH;                         // tile rows covered by one pass of the 256 loaders
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wave
@@ -62,7 +68,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     return BK == 64 ? (q ^ (row & 15)) : BK == 32 ? (q ^ ((row >> 1) & 7)) : (q ^ ((row >> 2) & 3));
   };
   static_assert(WM * WN == 4, "4 waves");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  constexpr int STAGE_FLOATS = 2 * (BM + BN) * BK;                       // both stages of A and B of one K-group
+  const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+  float* const smem = smem_all + kg * STAGE_FLOATS;
   float* As = smem;                  // [2][BM*32]
   float* Bs = smem + 2 * BM * BK;    // [2][BN*32]
 
@@ -82,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   stamp(0);
   const ConvGeom& g = a.g;
   const int pro_mode = PRO >= 0 ? PRO : a.pro_mode;   // compile-time in the specialised kernels: straight-line store phase
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = KG > 1 ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63, wave = tid >> 6;   // (roles inside the K-group)
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (g.Co + BN - 1) / BN;
   const int nwg = gridDim.x;
@@ -135,9 +144,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
     }
   }
   // K-step range of this workgroup (split-K over gridDim.y for problems with few output tiles)
+  // (K-group 0 gets the first and never the shorter range of its workgroup: it is the one that waits for the other)
   const int nk_all = g.Kp / BK;
-  const int k_per = (nk_all + a.ksplit - 1) / a.ksplit;
-  const int k_begin = blockIdx.y * k_per, k_end = min(k_begin + k_per, nk_all);
+  const int k_per = (nk_all + a.ksplit * KG - 1) / (a.ksplit * KG);
+  const int k_begin = min((int)(blockIdx.y * KG + kg) * k_per, nk_all), k_end = min(k_begin + k_per, nk_all);
   // (tap, c) of this thread's chunk, advanced incrementally by BK channels per K-step
   int kc, kr, ks;
   {
@@ -478,6 +488,31 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmArgs a) {
   }
   stamp(3);
   if (a.tune & 2) __builtin_amdgcn_s_setprio(3);
+  if constexpr (KG > 1) {
+    // join: K-groups 1 .. KG - 1 park their accumulators in THEIR OWN stage regions (their K loops are over; no other group
+    // touches those) and leave; group 0 adds them in group order.  The groups may run different numbers of K-step barriers:
+    // a barrier completes when every live wave has arrived at one, a later group's last arrival is the one below, and
+    // group 0 -- whose range is never the shorter -- reads after its own arrival here, which cannot precede theirs.
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) smem[((i * TN + j) * 16 + e) * 256 + tid] = acc[i][j][e];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 1; q < KG; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] += smem_all[q * STAGE_FLOATS + ((i * TN + j) * 16 + e) * 256 + tid];
+    static_assert(TM * TN * 16 * 256 <= STAGE_FLOATS, "the accumulators of a K-group fit its stage region");
+  }
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5) ----
   // Straight-line per variant (residual / mask / statistics / raw split-K partials are compile-time flags of the
@@ -641,19 +676,19 @@ static int g_wino = -1;                           // -1: DIAGAN_WINO / default (
 static int g_wino4 = -1;                          // -1: DIAGAN_WINO4 / default (on); 0 / 1: diagan_conv_gemm_set_wino4
 constexpr int kDefaultTune = 0;
 
-template <int BM, int BN, int WM, int WN, int BK, int PRO, bool STAMP = false, bool FP = false>
+template <int BM, int BN, int WM, int WN, int BK, int PRO, bool STAMP = false, bool FP = false, int KG = 1>
 static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
   // (g_lds_delta: occupancy probe of the tuning sweeps, timing only -- a negative value leaves part of the tile outside
   //  the allocation, where LDS accesses are dropped by the hardware's range check)
-  const size_t lds = (size_t)((long)((size_t)2 * (BM + BN) * BK * sizeof(float)) + g_lds_delta);
-  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, STAMP, FP>;
+  const size_t lds = (size_t)((long)((size_t)2 * KG * (BM + BN) * BK * sizeof(float)) + g_lds_delta);
+  auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, STAMP, FP, KG>;
   static size_t attr_set = 0;
   if (attr_set < lds) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit), dim3(256 * KG), lds, st, a);
   if (a.ksplit > 1) {
     long blocks = ((long)a.M * (a.g.Co / 4) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -663,8 +698,9 @@ static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
 }
 
 // SPEC: one kernel per prologue mode (the production tiles); otherwise the mode is a run-time argument.
-template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false, bool FP = false>
+template <int BM, int BN, int WM, int WN, int BK = 32, bool SPEC = false, bool FP = false, int KG = 1>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
+  if (a.stamps && KG > 1) return set_err(DIAGAN_EUNSUP, "conv_gemm: no stamped build of the two-group kernel");
   if (a.stamps) {                             // diagnostic build: the two most common prologue modes only
     if (a.pro_mode == PRO_NONE) return launch_one<BM, BN, WM, WN, BK, PRO_NONE, true, FP>(a, st);
     if (a.pro_mode == PRO_RELU) return launch_one<BM, BN, WM, WN, BK, PRO_RELU, true, FP>(a, st);
@@ -672,14 +708,14 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t st) {
   }
   if (SPEC) {
     switch (a.pro_mode) {
-      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1, false, FP>(a, st);
-      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1, false, FP>(a, st);
-      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1, false, FP>(a, st);
-      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1, false, FP>(a, st);
-      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1, false, FP>(a, st);
+      case PRO_NONE: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_NONE : -1, false, FP, KG>(a, st);
+      case PRO_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_RELU : -1, false, FP, KG>(a, st);
+      case PRO_AFFINE_RELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE_RELU : -1, false, FP, KG>(a, st);
+      case PRO_LRELU: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_LRELU : -1, false, FP, KG>(a, st);
+      default: return launch_one<BM, BN, WM, WN, BK, SPEC ? PRO_AFFINE : -1, false, FP, KG>(a, st);
     }
   }
-  return launch_one<BM, BN, WM, WN, BK, -1, false, FP>(a, st);
+  return launch_one<BM, BN, WM, WN, BK, -1, false, FP, KG>(a, st);
 }
 
 }  // namespace diagan
@@ -719,7 +755,12 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split)
   const double waste128 = (double)M * Co / ((double)t128 * 128 * 128);
   const double waste64 = (double)M * Co / ((double)t64 * 64 * 64);
   const double bias = 1.08;
-  return bias * q128 * waste128 > q64 * waste64 ? 1 : small;
+  if (bias * q128 * waste128 > q64 * waste64) return 1;
+  // at most one 64x64 tile per CU and a K loop that is worth halving but too short for split-K launches: two K-groups in
+  // one workgroup (tile_cfg 14) put two waves on every SIMD.  DIAGAN_KG2=0: off.
+  static const int kg2 = getenv("DIAGAN_KG2") ? atoi(getenv("DIAGAN_KG2")) : 1;
+  if (kg2 && t64 <= 256 && Kp >= 16 * 32 && diagan_conv_gemm_pick_ksplit(M, Co, Kp, small) == 1) return 14;
+  return small;
 }
 
 // Split-K factor for the 64x64 tile (1 = none), re-measured with the overlapped K-step schedule
@@ -931,16 +972,17 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     case 5: return launch_cfg<256, 64, 4, 1, 32, true>(a, st);
     case 7: return launch_cfg<64, 64, 2, 2, 32, true, true>(a, st);
     case 8: return launch_cfg<128, 64, 2, 2, 32, true, true>(a, st);
+    case 14: return launch_cfg<64, 64, 2, 2, 32, true, true, 2>(a, st);
     default: return set_err(DIAGAN_EINVAL, "conv_gemm: unknown tile_cfg %d", tile_cfg);
   }
 }
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: return 128; case 3: case 7: return 64; case 5: case 9: case 11: case 12: return 256; case 13: return 512; default: return 0; }
+  switch (cfg) { case 1: case 8: return 128; case 3: case 7: case 14: return 64; case 5: case 9: case 11: case 12: return 256; case 13: return 512; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of

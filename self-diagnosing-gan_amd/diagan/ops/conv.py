@@ -47,7 +47,7 @@ PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO, STAMP, FP; PRO = -1: run-time mode)
 TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3: (64, 64, 2, 2, 32, False),
                4: (128, 64, 4, 1, 32, False), 5: (256, 64, 4, 1, 32, False), 6: (64, 64, 2, 2, 64, False),
-               7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True)}
+               7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True), 14: (64, 64, 2, 2, 32, True)}
 
 
 def gemm_kernel_name(cfg, mode, Co=128, w4pool=False):
@@ -62,7 +62,8 @@ def gemm_kernel_name(cfg, mode, Co=128, w4pool=False):
     if cfg == 12:
         return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
-    return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,{'true' if fp else 'false'}>"
+    kg = ",2" if cfg == 14 else ""            # two K-groups per workgroup (rocprofv3 prints the defaulted KG = 1 too: ",1")
+    return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,{'true' if fp else 'false'}{kg}>"
 
 
 class KernelTimer:

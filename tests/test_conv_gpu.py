@@ -86,7 +86,50 @@ def test_fwd(case, pro):
     close(nchw(y), ref + res)
 
 
-@pytest.mark.parametrize("tile_cfg", [1, 3])
+@pytest.mark.parametrize("case", [
+    ("conv", 2, 8, 8, 128, 128, 3, 1, 1),        # 36 K-steps: 18 + 18 (the D-32 8x8 blocks' shape)
+    ("conv", 2, 8, 8, 40, 72, 3, 1, 1),          # 12 K-steps of the general loader path (Ci % 32 != 0), Co no tile multiple
+    ("conv", 3, 5, 7, 96, 64, 3, 1, 1),          # 27 K-steps: 14 + 13, ragged M
+    ("conv", 2, 4, 4, 32, 64, 1, 1, 0),          # ONE K-step: the second group has nothing to do
+    ("conv", 2, 8, 8, 64, 64, 1, 1, 0),          # two K-steps: one each
+    ("convT", 2, 8, 8, 96, 48, 4, 2, 1),         # transposed gather
+    ("conv", 2, 16, 16, 64, 32, 3, 2, 1),        # strided
+])
+@pytest.mark.parametrize("pro", [0, 2])
+@pytest.mark.parametrize("cfg", [14])
+def test_two_k_groups_per_workgroup(case, pro, cfg):
+    """tile_cfg 14: two K-groups of four waves per workgroup, joined through LDS -- every K-split (even, odd,
+    groups with nothing to do), both loader paths, prologue, bias + residual epilogue; and the same launch against tile_cfg 7 bit for bit where
+    the split leaves the summation order of a K-group's steps unchanged only up to the final add (so: tolerance, not equality)."""
+    from diagan.ops import conv as C
+    kind, B, H, W, Ci, Co, R, stride, pad = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(1)
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.1
+    bias = torch.randn(Co, generator=g)
+    ref = ref_fwd(kind, ref_pro(x, pro, scale, shift), w, bias, stride, pad)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(),
+                   pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=cfg)
+    close(nchw(y), ref + res)
+    y7 = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(),
+                    pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=7)
+    close(nchw(y), nchw(y7), tol=2e-6)
+
+
+def test_two_k_groups_chosen_for_lone_tiles():
+    """The automatic choice takes tile_cfg 14 for at most one 64x64 tile per CU with 16 <= K-steps < 64 (the 8x8 blocks of
+    SNGAN-32's discriminator at batch 128: M = 8192, N = 128, K = 1152), not for short or long K loops or larger launches."""
+    from diagan import _native as nat
+    from diagan.ops import conv as C  # noqa: F401
+    pick = nat.fn("diagan_conv_gemm_pick_cfg")
+    assert pick(8192, 128, 1152, 1) == 14
+    assert pick(8192, 128, 256, 1) == 7            # short K loop
+    assert pick(32768, 128, 1152, 1) != 14         # 1024 tiles
+    assert pick(2048, 512, 4608, 1) != 14 or nat.fn("diagan_conv_gemm_pick_ksplit")(2048, 512, 4608, 7) == 1
+
+
+@pytest.mark.parametrize("tile_cfg", [1, 3, 5, 7, 8, 14])
 def test_fwd_all_tile_configs(tile_cfg):
     from diagan.ops import conv as C
     case = ("conv", 3, 9, 11, 64, 96, 3, 1, 1)

@@ -432,13 +432,14 @@ def test_resume_from_torch_adam_state(tmp_path):
             assert (sG[k].cpu() - v).abs().max() < 2e-3, k
 
 
-@pytest.mark.parametrize("winograd,tol", [(False, 2e-6), (True, 1e-5)])
+@pytest.mark.parametrize("winograd,tol", [(False, 1e-5), (True, 1e-5)])
 @pytest.mark.parametrize("dataset", ["cifar10", "celeba"])
 def test_stacked_generator_forward_equals_successive_forwards(dataset, winograd, tol):
     """prefetch_fakes: the n_dis generator forwards of a global step as ONE stacked forward with per-batch BatchNorm
     statistics -- same images, same running statistics (momentum chain in order), same RNG state afterwards.
-    With the implicit GEMM on both sides the images agree to 2e-6; with Winograd allowed the stacked (3x larger) launches
-    and the single-batch ones do not all take the same kernel (launch-size policy), which moves them by rounding: 1e-5."""
+    The stacked (3x larger) launches and the single-batch ones do not all take the same kernel (launch-size policy: Winograd
+    or not, and since round 3 the 64x64 tile with one or two K-groups, which sums K in two halves), which moves the images
+    by rounding: 1e-5 (2e-6 while both sides took the same implicit-GEMM kernel)."""
     from diagan.models import base as MB
     from diagan.ops import conv as C
     C.set_winograd(winograd)
