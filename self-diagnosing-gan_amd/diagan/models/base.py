@@ -174,6 +174,8 @@ class BaseGenerator(BaseModel):
 
 
 class BaseDiscriminator(BaseModel):
+    supports_defer_step = True      # train_step(defer_step=True) leaves optD.step() to the caller (LogTrainer, DP phase 2)
+
     def __init__(self, ndf, loss_type, **kwargs):
         super().__init__()
         self.ndf, self.loss_type = ndf, loss_type

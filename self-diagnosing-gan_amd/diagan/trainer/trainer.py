@@ -238,7 +238,9 @@ class LogTrainer:
                      device=self.device, g_step=True)
         # data parallel phase 2: D and D_drs are independent (reference trainer.py:250-277), so D's gradient all-reduce
         # stays in flight under D_drs's forward / backward and D's Adam step follows it
-        overlap = self.train_drs and self.world > 1
+        # (only with a discriminator that declares the protocol: one that swallowed the extra keyword and stepped anyway
+        #  would get two Adam steps per update)
+        overlap = self.train_drs and self.world > 1 and getattr(self.netD, 'supports_defer_step', False)
         for i in range(self.n_dis):
             batch = batches[i]
             extra = dict(defer_step=True) if overlap else {}
