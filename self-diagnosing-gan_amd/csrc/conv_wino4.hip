@@ -665,7 +665,16 @@ int wino4_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws
   const long wgs4 = (long)cdiv((long)B * (Ho >> 2) * (Wo >> 2), W4T) * cdiv(Co, W4N);
   const long wgs2 = (long)cdiv((long)B * (Ho >> 1) * (Wo >> 1), 64) * cdiv(Co, 64);
   auto fill = [](long w) { return (double)w / (256.0 * ((w + 255) / 256)); };
-  if (wgs4 >= 192) return 1.27 * fill(wgs4) / (wgs2 >= 192 ? fill(wgs2) : 1.0) >= 1.05 ? 1 : 0;
+  if (wgs4 >= 192) {
+    // a launch of 1 - 2 rounds whose last round is badly filled, with a long K loop (>= 32 K-steps per half): split two ways
+    // when that fills the rounds better (0.93: the slab and the second-stage kernel).  SNGAN-64's stacked generator forward at
+    // 8x8 (384 workgroups = 1.5 rounds, Ci = 1024): 852 us on the F(2x2) kernel's exact 3 rounds.
+    const bool can2 = allow_split && wgs4 <= 512 && Ci >= 512 && wino4_ws_floats(Co, Ci) + 2L * B * Ho * Wo * Co <= ws_floats;
+    const double f1 = fill(wgs4), f2 = can2 ? 0.93 * fill(2 * wgs4) : 0.0;
+    const double f = f2 > f1 ? f2 : f1;
+    if (1.27 * f / (wgs2 >= 192 ? fill(wgs2) : 1.0) < 1.05) return 0;
+    return f2 > f1 ? 2 : 1;
+  }
   if (allow_split && wgs4 * 2 >= 192 && Ci >= 256 && wino4_ws_floats(Co, Ci) + 2L * B * Ho * Wo * Co <= ws_floats) return 2;
   return 0;
 }

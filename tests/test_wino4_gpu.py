@@ -134,6 +134,15 @@ def test_auto_selection_split_k_and_refusals():
     geom, x, w, wp = make(64, 16, 16, 256, 256, seed=8)
     auto = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'))
     close(auto, C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=torch.ones(256, device='cuda'), tile_cfg=13), tol=TOL / 2)
+    # 1.5 rounds of workgroups with a long K loop (SNGAN-64's stacked generator forward at 8x8: 384 workgroups, Ci = 1024):
+    # F(4x4) split two ways rather than the F(2x2) kernel; same values as the unsplit launch
+    assert pick(384, 8, 8, 1024, 8, 8, 512, 3, 3, 1, 1, -1, 1, 9216, 1, ws) == 13
+    assert pick(384, 8, 8, 1024, 8, 8, 512, 3, 3, 1, 1, -1, 1, 9216, 0, ws) == 9           # no workspace for a slab: F(2x2)
+    geom, x, w, wp = make(96, 8, 8, 512, 512, seed=9)            # 96 images x 4 tiles = 12 blocks x 8 column blocks... x 4
+    x4 = torch.cat([x, x, x, x])                                 # 384 images: 384 workgroups
+    auto = C.conv_fwd(geom, nhwc(x4).cuda(), wp)
+    close(auto, C.conv_fwd(geom, nhwc(x4).cuda(), wp, tile_cfg=13), tol=TOL / 2)
+    close(nchw(auto[:2]), F.conv2d(x[:2].double(), w.double(), padding=1), tol=TOL)
     g2, x2, w2, wp2 = make(2, 6, 10, 16, 24)                     # H, W not multiples of 4
     with pytest.raises(RuntimeError, match="tile_cfg 13"):
         C.conv_fwd(g2, nhwc(x2).cuda(), wp2, tile_cfg=13)
