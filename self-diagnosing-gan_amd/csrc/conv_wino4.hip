@@ -47,7 +47,8 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_COL_AT
 #define W4_COL_AT 5
 #endif
-constexpr int W4_LDS_FLOATS = 2 * W4_VSTAGE + W4_U;      // 162 432 bytes of the 163 840 (the epilogue's 36 x 32 x 32 floats fit inside)
+static_assert((2 * W4_VSTAGE + W4_U) * 4 <= 163840 && 36 * 32 * 32 <= 2 * W4_VSTAGE + W4_U,
+              "162 432 bytes of the CU's 163 840; the epilogue's 36 x 32 x 32 floats fit inside");
 
 // MODE 0: the convolution.  MODE 1 ("pool"): the convolution FOLLOWED BY F.avg_pool2d(., 2) -- the end of mimicry's DBlock /
 // DBlockOptimized with downsample = True (predefined_models.py:38-40,76-78), y / residual are the POOLED tensors.  A 4x4 tile
