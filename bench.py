@@ -307,6 +307,15 @@ def scorer_leg(device, N=50000, T=50):
     e.record()
     torch.cuda.synchronize()
     gpu_ms = s.elapsed_time(e) / 10
+    # what the phase-2 command line consumes: the four statistics + ONE ldr_conf row (calculate_scores(keys=[...]))
+    ldr_scores_device(rows, t_values=[0.3])
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(10):
+        ldr_scores_device(rows, t_values=[0.3])
+    e.record()
+    torch.cuda.synchronize()
+    gpu_ms_one = s.elapsed_time(e) / 10
     t0 = time.time()
     ref = osc.calculate_scores_c(logits, 0, 10 ** 9)
     cpu_ms = (time.time() - t0) * 1e3
@@ -318,6 +327,7 @@ def scorer_leg(device, N=50000, T=50):
             err = max(err, float(np.abs(conf[j].cpu().numpy() - ref[f"ldr_conf_{t:.1f}_ratio_50"]).max()))
     bytes_alg = 8.0 * T * N + 8.0 * N * (4 + len(tv))
     return {"record": f"T={T} x N={N} float64", "max_abs_err": err, "gpu_ms_all_103_scores": round(gpu_ms, 4),
+            "gpu_ms_requested_key_only": round(gpu_ms_one, 4),
             "cpu_oracle_ms_1_core": round(cpu_ms, 1), "algorithmic_GBps": round(bytes_alg / gpu_ms / 1e6, 1)}
 
 
