@@ -62,7 +62,7 @@ def gemm_kernel_name(cfg, mode, Co=128, w4pool=False):
     if cfg == 12:
         return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
-    kg = ",2" if cfg == 14 else ""            # two K-groups per workgroup (rocprofv3 prints the defaulted KG = 1 too: ",1")
+    kg = ",2" if cfg == 14 else ",1"          # K-groups per workgroup (rocprofv3 prints the defaulted template argument too)
     return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,{'true' if fp else 'false'}{kg}>"
 
 
