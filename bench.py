@@ -333,9 +333,14 @@ def scorer_leg(device, N=50000, T=50):
 
 def self_launch(args):
     """--gpus N > 1 without a torch.distributed.run environment: start the N ranks as a child process group and relay
-    its output.  Runs before anything touches the GPU (device_count() does not initialise it); never os.exec."""
+    its output.  The parent only counts devices and spawns: it never execs (torch.cuda.device_count() may bring the HIP
+    runtime up in this process on builds without amdsmi), and every rank is a fresh child of torch.distributed.run.
+    A rank whose native RCCL context does not come up in time leaves with a non-zero status and a flag file
+    (diagan/trainer/distributed.py::_StartupWatchdog); the job is then started ONCE more, as new processes, with the
+    exchange on torch.distributed's process group."""
     import socket
     import subprocess
+    import tempfile
     ndev = torch.cuda.device_count()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -348,12 +353,23 @@ def self_launch(args):
         print(f"WARNING: --gpus {args.gpus} on a node with {ndev} device(s): ranks share devices, exchange over gloo",
               file=sys.stderr)
         env["DIAGAN_DIST_BACKEND"] = "gloo"
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    flag = os.path.join(tempfile.mkdtemp(prefix="diagan_bench_"), "native_comm_timeout")
+    env["DIAGAN_COMM_TIMEOUT_FLAG"] = flag
+    rc = 1
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc == 0 or not os.path.exists(flag) or env.get("DIAGAN_COMM", "").lower() == "torch":
+            break
+        print("WARNING: the native RCCL context did not come up; starting the ranks again with DIAGAN_COMM=torch",
+              file=sys.stderr)
+        os.remove(flag)
+        env["DIAGAN_COMM"] = "torch"
+    return rc
 
 
 def main():
@@ -368,7 +384,6 @@ def main():
     ap.add_argument("--n_dis", type=int, default=5)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_kernel_timer", action="store_true")
-    ap.add_argument("--no_x6_leg", action="store_true", help="(no effect: the bf16x6 mode and its bench leg were retired in round 3)")
     ap.add_argument("--no_sngan64_leg", action="store_true",
                     help="skip the extra (un-scored) SNGAN-64 conv-block roofline leg of the default sngan32 run")
     ap.add_argument("--graph", action="store_true",

@@ -579,6 +579,12 @@ class WgradBatch:
         batched forward; the pixel range is cut accordingly and each part gets its own correction).
         geom: gather geometry of THIS launch when it differs from the layer's (ConvLayer.wgrad_pooled)."""
         M = dy.numel() // dy.shape[-1]
+        if self.hold and slot in self.pending:
+            # a second backward pass into a slot whose reduction is being held back (a network that runs real and fake
+            # through the same slot, e.g. MNIST_DCGAN_Discriminator): conv_wgrad_into WRITES the slab, so the first pass
+            # has to be reduced into the gradient before its partials are overwritten
+            self.pending.remove(slot)
+            self._finish_layers(slot, self.launched.pop(slot, []))
         e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape), geom)
         e['sn_ctx'] = sn_ctx
         C.conv_wgrad_into(geom if geom is not None else layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'],

@@ -54,12 +54,20 @@ def init_native_comm(rank, world, device_index):
     import ctypes
     nat = _register_native()
     ident = ctypes.create_string_buffer(128)
+    id_err = None
     if rank == 0:
-        nat.call("diagan_comm_unique_id", ctypes.cast(ident, ctypes.c_void_p))
+        try:
+            nat.call("diagan_comm_unique_id", ctypes.cast(ident, ctypes.c_void_p))
+        except Exception as e:      # noqa: BLE001 -- the other ranks sit in the broadcast below: tell them
+            id_err = repr(e)
     if world > 1:
-        box = [ident.raw]
+        box = [None if id_err else ident.raw]
         dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            raise RuntimeError("rank 0 could not draw the RCCL unique id" + (f": {id_err}" if id_err else ""))
         ident = ctypes.create_string_buffer(box[0], 128)
+    elif id_err:
+        raise RuntimeError(id_err)
     handle = ctypes.c_void_p()
     nat.call("diagan_ctx_create", ctypes.cast(ctypes.pointer(handle), ctypes.c_void_p), ctypes.cast(ident, ctypes.c_void_p),
              rank, world, device_index)
@@ -89,14 +97,27 @@ def _all_ranks_agree(ok):
 
 def _native_selftest(rank, world):
     """The native context against the process group on the same data: a 1 Mi-element SUM all-reduce (values that sum
-    exactly in any order) and a float64 all-gather.  Returns an error string or None."""
+    exactly in any order) on the current stream, the same all-reduce issued on the SIDE stream the way FlatNet.sync_grads
+    issues it under data parallelism (two slab halves in flight beside compute on the current stream), and a float64
+    all-gather.  Collectives of the two communicators are never in flight together: a device synchronisation separates
+    every native collective from the process group's (two RCCL communicators whose kernels the ranks may order
+    differently are the known deadlock).  Returns an error string or None."""
     try:
         from diagan import _native as nat
         n = 1 << 20
         a = (torch.arange(n, device='cuda', dtype=torch.float32) % 1024) + rank
-        b = a.clone()
-        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], a.data_ptr(), a.numel(), nat.current_stream())
+        b, c = a.clone(), a.clone()
+        torch.cuda.synchronize()
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        nat.call("diagan_allreduce_grads", _NATIVE['ctx'], a.data_ptr(), a.numel(), nat.current_stream())
+        # the overlapped form: late half, compute on the current stream, early half, then both waits
+        cut = n // 2
+        works = [_native_allreduce(c[cut:], True)]
+        busy = torch.ones(1 << 22, device='cuda').mul_(2.0).sum()
+        works.append(_native_allreduce(c[:cut], True))
+        for w in works:
+            w.wait()
         row = torch.full((4096,), float(rank), dtype=torch.float64, device='cuda')
         out = torch.empty(world * 4096, dtype=torch.float64, device='cuda')
         nat.call("diagan_allgather_logits", _NATIVE['ctx'], row.data_ptr(), out.data_ptr(), row.numel(), 8,
@@ -105,11 +126,51 @@ def _native_selftest(rank, world):
         want = torch.arange(world, device='cuda', dtype=torch.float64).repeat_interleave(4096)
         if not torch.equal(a, b):
             return "native all-reduce disagrees with the process group's"
+        if not torch.equal(c, b) or float(busy) != float(2 << 22):
+            return "native side-stream all-reduce (the overlapped gradient exchange) disagrees with the process group's"
         if not torch.equal(out, want):
             return "native all-gather returned the wrong rows"
         return None
     except Exception as e:      # noqa: BLE001 -- any failure here means: use the process group
         return repr(e)
+
+
+# exit status of a rank whose native-context start-up did not finish in time (bench.py's launcher starts the job again
+# on the process group when it sees it: a process that has touched the GPU is never re-exec'ed)
+NATIVE_INIT_TIMEOUT_EXIT = 75
+
+
+class _StartupWatchdog:
+    """ncclCommInitRank and the first collectives block inside native code until EVERY rank has arrived; a rank that died
+    before it got there leaves the others waiting for good.  While this is armed, a process that is still inside after
+    DIAGAN_COMM_INIT_TIMEOUT seconds (default 180) writes the reason to stderr and leaves with NATIVE_INIT_TIMEOUT_EXIT."""
+
+    def __init__(self, rank, what):
+        import threading
+        self.secs = float(os.environ.get("DIAGAN_COMM_INIT_TIMEOUT", "180"))
+        self.timer = threading.Timer(self.secs, self._expire, args=(rank, what))
+        self.timer.daemon = True
+
+    def _expire(self, rank, what):
+        import sys
+        try:
+            flag = os.environ.get("DIAGAN_COMM_TIMEOUT_FLAG")
+            if flag:
+                open(flag, "w").close()
+            print(f"FATAL: rank {rank}: {what} did not finish within {self.secs:.0f} s (another rank never arrived?); "
+                  f"exiting with status {NATIVE_INIT_TIMEOUT_EXIT}.  DIAGAN_COMM=torch keeps the exchange on "
+                  "torch.distributed's process group.", file=sys.stderr, flush=True)
+        finally:
+            os._exit(NATIVE_INIT_TIMEOUT_EXIT)
+
+    def __enter__(self):
+        if self.secs > 0:
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
 
 
 def _maybe_init_native(rank, world, local_rank, backend):
@@ -124,17 +185,29 @@ def _maybe_init_native(rank, world, local_rank, backend):
         _NATIVE['why'] = ("ranks share a device" if not own_device else f"backend {backend}")
         return
     err = None
-    try:
-        init_native_comm(rank, world, local_rank % max(torch.cuda.device_count(), 1))
-    except Exception as e:      # noqa: BLE001
-        err = repr(e)
+    with _StartupWatchdog(rank, "creating the native RCCL context and its self-test"):
+        try:
+            init_native_comm(rank, world, local_rank % max(torch.cuda.device_count(), 1))
+        except Exception as e:      # noqa: BLE001
+            err = repr(e)
+        # the self-test's first collective would wait for good on a communicator that not every rank joined
+        created = _all_ranks_agree(err is None)
+        if created:
+            err = _native_selftest(rank, world)
+            torch.cuda.synchronize()
+        elif err is None:
+            err = "context creation failed on another rank"
+        ok = _all_ranks_agree(err is None)
     if policy == "rccl":
-        if err:
-            raise RuntimeError(f"DIAGAN_COMM=rccl: {err}")
+        if not ok:
+            raise RuntimeError(f"DIAGAN_COMM=rccl: {err or 'failed on another rank'}")
+        if rank == 0:
+            print(f"native RCCL exchange: {world} ranks, self-test passed (DIAGAN_COMM=rccl)", file=sys.stderr)
         return
-    if err is None:
-        err = _native_selftest(rank, world)
-    if not _all_ranks_agree(err is None):
+    if ok and rank == 0:
+        print(f"native RCCL exchange: {world} ranks, self-test passed (all-reduce on the compute stream and on the side "
+              "stream, all-gather); DIAGAN_COMM=torch selects torch.distributed's process group instead", file=sys.stderr)
+    if not ok:
         if _NATIVE['ctx'] is not None:
             try:
                 destroy_native_comm()

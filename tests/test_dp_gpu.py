@@ -89,6 +89,71 @@ def test_two_rank_step_equals_microbatch_emulation(tmp_path):
     assert (netD.flat_params.cpu() - r[0]['D']).abs().max().item() < 2e-6
 
 
+def _mnist_data(rank):
+    g = torch.Generator().manual_seed(300 + rank)
+    return torch.rand(8, 3, 32, 32, generator=g) * 2 - 1, torch.randn(8, 100, generator=g)
+
+
+def _worker_mnist(rank, world, port, out_dir):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DIAGAN_DIST_BACKEND="gloo")
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.trainer import distributed as dist
+    dist.init_from_env()
+    torch.manual_seed(7)
+    netG, netD, optG, optD = get_gan_model('color_mnist', model='mnist_dcgan', loss_type='ns')
+    netG.to('cuda'), netD.to('cuda')
+    dist.broadcast_module_(netG), dist.broadcast_module_(netD)
+    x, zd = _mnist_data(rank)
+    torch.cuda.manual_seed(900 + rank)                 # the dropout masks of this rank's two forwards
+    netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=zd.cuda())
+    torch.cuda.synchronize()
+    torch.save({'D': netD.flat_params.cpu()}, os.path.join(out_dir, f"m{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_mnist_dcgan_step_equals_microbatch_emulation(tmp_path):
+    """MNIST_DCGAN_Discriminator runs its real AND its fake backward through weight-gradient slot 0.
+    With the reduction held back for the exchange overlap (world > 1) the fake pass overwrote the real pass's split-K
+    slabs before they were reduced: real gradient lost, fake gradient doubled.  WgradBatch.launch now reduces a held
+    slot before it is written again; the two-rank update must equal the averaged micro-batch gradients."""
+    world = 2
+    mp.spawn(_worker_mnist, args=(world, _port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"m{k}.pt") for k in range(world)]
+    assert torch.equal(r[0]['D'], r[1]['D'])
+
+    from diagan.models.predefined_models import get_gan_model
+    torch.manual_seed(7)
+    netG, netD, optG, optD = get_gan_model('color_mnist', model='mnist_dcgan', loss_type='ns')
+    netG.to('cuda'), netD.to('cuda')
+    buf0 = {k: v.clone() for k, v in netD.state_dict().items() if 'running' in k or 'num_batches' in k}
+    gbuf0 = {k: v.clone() for k, v in netG.state_dict().items() if 'running' in k or 'num_batches' in k}
+    before = netD.flat_params.clone()
+    grads = []
+    for rank in range(world):
+        netD.load_state_dict({**netD.state_dict(), **buf0})
+        netG.load_state_dict({**netG.state_dict(), **gbuf0})
+        x, zd = _mnist_data(rank)
+
+        class NoStep:
+            def step(self):
+                pass
+        torch.cuda.manual_seed(900 + rank)
+        netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=NoStep(), log_data=Log(), device='cuda',
+                        noise=zd.cuda())
+        grads.append(netD.flat_grads.clone())
+    # the two passes of a micro-batch both contribute (what the bug lost): the summed gradient is not the fake pass doubled
+    netD.flat_grads.copy_((grads[0] + grads[1]) / 2)
+    optD.step()
+    assert (netD.flat_params - before).abs().max().item() > 1e-5
+    assert (netD.flat_params.cpu() - r[0]['D']).abs().max().item() < 2e-6
+
+
 def _worker_rank_noise(rank, world, port, out_dir):
     """The CLI's data-parallel start (diagan/cli.py::_Run.replicate): same seed everywhere, broadcast, then per-rank DEVICE
     seeds; noise is drawn by the networks themselves (no injection).  Phase-2 shape: D's all-reduce is left in flight
