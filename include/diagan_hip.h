@@ -167,6 +167,15 @@ int diagan_conv_gemm_set_wino4(int mode);
  * in 25 products per 4x4 tile (frequency row / column 2 never reaches a pooling-window sum) where the launch has >= 192 workgroups
  * and H, W are multiples of 4; this query says whether a geometry does (kernel names, executed-FLOP accounting). */
 int diagan_conv_wino4_pool_used(int B, int Ho, int Wo, int Ci, int Co, int64_t ws_floats);
+/* tile_cfg 15 (round 4): y = conv3x3(F.interpolate(pro(x), scale_factor=2, mode='bilinear', align_corners=False)) + epilogue, the
+ * start of mimicry's GBlock residual branch (BN -> ReLU -> up-sampling -> c1; GBlock._upsample_conv as selected at
+ * diagan-pkg/diagan/models/predefined_models.py:19,57), as ONE launch of the F(4x4) kernel on the HALF-resolution input: `x` of
+ * diagan_conv_gemm is [B,Hi/2,Wi/2,Ci] while Hi = Ho, Wi = Wo are the up-sampled sizes.  The interpolation is folded into the
+ * Winograd input transform (16 instead of 36 pixels loaded per tile, prologue before the interpolation as in the reference);
+ * forward geometry only, every prologue / epilogue of tile_cfg 13 except the backward mask and split-K.  This query says whether
+ * a launch qualifies (same launch-size policy as tile_cfg 13 without channel splits; DIAGAN_WINO4_UPIN=0 turns it off). */
+int diagan_conv_wino4_upin_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                     int off, int up, int64_t ws_floats, int pro_group_rows);
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* The same choice for a launch with a GROUPED prologue (pro_group_rows > 0: one affine row per group of that many GEMM

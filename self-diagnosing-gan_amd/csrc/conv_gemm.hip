@@ -45,6 +45,8 @@ int wino4_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws
 bool wino4_pool_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force);
 int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
+bool wino4_upin_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force);
+int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs);
@@ -842,7 +844,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.pro_group_rows = pro_group_rows;
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 = 64x64 with fragment "
-             "prefetch, 8 = 128x64 with fragment prefetch, 9 = Winograd F(2x2,3x3), 11 / 12 = Winograd + average pool and its data-gradient, 13 = Winograd F(4x4,3x3); 2, 4, 6, 10 were retired)", tile_cfg);
+             "prefetch, 8 = 128x64 with fragment prefetch, 9 = Winograd F(2x2,3x3), 11 / 12 = Winograd + average pool and its data-gradient, 13 = Winograd F(4x4,3x3), 15 = the same on the bilinear x2 of a half-resolution input; 2, 4, 6, 10 were retired)", tile_cfg);
   DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % bm == 0 && a.M % pro_group_rows == 0)),
              "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, bm, a.M);
   a.slab = splitk_ws;
@@ -914,6 +916,17 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     }
     return rc;
   }
+  if (cfg == 15) {
+    // F(4x4,3x3) of the bilinear x2 up-sampling of a HALF-resolution input (conv_wino4.hip MODE 3): x is [B, Hi/2, Wi/2, Ci]
+    DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && dr == 1 && wino4_geom_ok(Ho, Wo, Ci) &&
+                   !mask_src && (pro_group_rows == 0 || pro_group_rows % 512 == 0),
+               "conv_gemm: tile_cfg 15 (Winograd F(4x4,3x3) on an up-sampled input) needs a forward 3x3 / stride 1 / pad 1 geometry, "
+               "H and W multiples of 4, Ci %% 8 == 0, no backward mask, prologue groups of whole 512-row tiles");
+    const long wfl = wino4_ws_floats(Co, Ci);
+    DG_REQUIRE(splitk_ws && splitk_ws_floats >= wfl, "conv_gemm: tile_cfg 15 needs %ld floats of workspace for the transformed weights", wfl);
+    a.ksplit = 1;
+    return launch_wino4_upin(a, splitk_ws, st);
+  }
   if (cfg == 13) {
     // Winograd F(4x4,3x3) (conv_wino4.hip): 32 tiles of 4x4 outputs x 64 channels per workgroup
     DG_REQUIRE(diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up) && wino4_geom_ok(Ho, Wo, Ci),
@@ -979,10 +992,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: return 128; case 3: case 7: case 14: return 64; case 5: case 9: case 11: case 12: return 256; case 13: return 512; default: return 0; }
+  switch (cfg) { case 1: case 8: return 128; case 3: case 7: case 14: return 64; case 5: case 9: case 11: case 12: return 256; case 13: case 15: return 512; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: case 15: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -1085,6 +1098,17 @@ DIAGAN_API int diagan_conv_gemm_set_wino(int mode) {
 // conv_wino_pool.hip's F(2x2) kernels (9 per 2x2 tile)?  Host-only; for kernel names / executed-FLOP accounting.
 DIAGAN_API int diagan_conv_wino4_pool_used(int B, int Ho, int Wo, int Ci, int Co, int64_t ws_floats) {
   return g_wino4 != 0 && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, g_wino4 == 2) ? 1 : 0;
+}
+
+// tile_cfg 15: does conv3x3(bilinear_x2(pro(x))) of this layer (Hi, Wi, Ho, Wo: the UP-SAMPLED size) run as one launch of the
+// F(4x4) kernel on the half-resolution input?  Host-only (GBlock asks before it decides whether to write the up-sampled tensor).
+DIAGAN_API int diagan_conv_wino4_upin_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                                int off, int up, int64_t ws_floats, int pro_group_rows) {
+  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  const int wino = g_wino >= 0 ? g_wino : wino_env;
+  if (!wino || g_wino4 == 0 || dr != 1 || !diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
+  if (pro_group_rows > 0 && pro_group_rows % 512 != 0) return 0;
+  return wino4_upin_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, g_wino4 == 2) ? 1 : 0;
 }
 
 // Run-time form of DIAGAN_WINO4: 0 = the automatic choice never takes the F(4x4,3x3) kernel (tile_cfg 13), 1 / -1 = where it

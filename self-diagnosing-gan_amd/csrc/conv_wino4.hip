@@ -31,6 +31,8 @@
 
 namespace diagan {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int W4T = 32;                 // 4x4-output tiles per workgroup
 constexpr int W4N = 64;                 // output channels per workgroup
 constexpr int W4K = 8;                  // input channels per K-step
@@ -60,11 +62,23 @@ static_assert((2 * W4_VSTAGE + W4_U) * 4 <= 163840 && 36 * 32 * 32 <= 2 * W4_VST
 // reads the 4x4 HALF-resolution neighbourhood (16 instead of 36 pixels per tile).
 // The 25 live frequencies l = 5 i' + j' (i', j' index {0, 1, 3, 4, 5}) are dealt to the four wave groups as 7 + 6 + 6 + 6;
 // every wave runs 7 slots (the seventh of groups 1-3 multiplies a dummy unit into an accumulator nobody reads).
+//
+// MODE 3 ("upin"): the convolution of the BILINEAR x2 UP-SAMPLING (align_corners = False) of a half-resolution input --
+// the start of mimicry's GBlock residual branch, BN -> ReLU -> F.interpolate(scale_factor = 2, bilinear) -> c1
+// (GBlock._upsample_conv, selected at predefined_models.py:19,57).  The six up-sampled pixels of a tile's patch along one
+// axis are a fixed linear map of the four half-resolution pixels (a, b, c, d) = rows / columns 2 t - 1 .. 2 t + 2:
+//   (3a + b, a + 3b, 3b + c, b + 3c, 3c + d, c + 3d) / 4,
+// so the transform passes interpolate first (w4_up below; the two factors 1/4 go into the transformed weights) and the loader
+// reads the 4 x 4 half-resolution neighbourhood -- 16 instead of 36 pixels per tile, the prologue (BatchNorm + ReLU acts
+// BEFORE the interpolation) on 16 instead of 36, and the up-sampled tensor is never written.  All 36 frequencies are live.
+// Borders: interpolation clamps its taps at the image edge (the loads clamp their coordinates), while the convolution's
+// zero padding lies at the HIGH resolution: patch position 0 of a first tile / 5 of a last tile is multiplied by zero.
 template <int MODE> struct W4M {
-  static constexpr bool pooled = MODE != 0;
+  static constexpr bool pooled = MODE == 1 || MODE == 2;
+  static constexpr bool upin = MODE == 3;
   static constexpr int NS = pooled ? 7 : 9;          // slots (frequency, column half) per wave
   static constexpr int U_FLOATS = 8 * NS * 256;       // weight units of one K-step
-  static constexpr int NI = MODE == 2 ? 4 : 6;        // input loads per thread and K-step
+  static constexpr int NI = (MODE == 2 || MODE == 3) ? 4 : 6;        // input loads per thread and K-step
 };
 __host__ __device__ __forceinline__ int w4p_start(int g) { return g == 0 ? 0 : 7 + 6 * (g - 1); }
 __host__ __device__ __forceinline__ int w4p_count(int g) { return g == 0 ? 7 : 6; }
@@ -76,11 +90,15 @@ __host__ __device__ __forceinline__ int w4p_freq(int v) { return v < 2 ? v : v +
 // flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
 template <int MODE>
 __global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                           int Kp, int flip) {
+                                                           int Kp, int flip, float wscale) {
   __shared__ f32x4 sg[WT_LDS_F4];
   f32x4 g[3][3];
   const int nb = blockIdx.y;
   if (!wino_stage_taps(w, nb * 64, blockIdx.x * 32, Co, Ci, Kp, flip, sg, g)) return;
+  if (wscale != 1.f) {                                  // (MODE 3: the 1/16 of the two interpolation passes, exact)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] *= wscale;
+  }
   const int col = threadIdx.x & 63, c = blockIdx.x * 32 + (threadIdx.x >> 6) * 4;
   constexpr float k4 = 0.25f, k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
   auto gt = [&](const f32x4& g0, const f32x4& g1, const f32x4& g2, f32x4* o) {
@@ -120,17 +138,18 @@ __global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restri
 // 12 per pair, 24 per call; written with literal constants the compiler turns the +-1 / +-2 products back into
 // subtractions and sign flips that it does not pack (24 v_sub_f32 + 20 v_xor_b32 per call on top of the packed ones).
 struct W4Consts {
-  float m1, p1, m2, p2, m4, p4, m5;
+  float m1, p1, m2, p2, m4, p4, m5, p3;
 };
 __device__ __forceinline__ W4Consts w4_consts() {
-  W4Consts k = {-1.f, 1.f, -2.f, 2.f, -4.f, 4.f, -5.f};
-  asm volatile("" : "+s"(k.m1), "+s"(k.p1), "+s"(k.m2), "+s"(k.p2), "+s"(k.m4), "+s"(k.p4), "+s"(k.m5));
+  W4Consts k = {-1.f, 1.f, -2.f, 2.f, -4.f, 4.f, -5.f, 3.f};
+  asm volatile("" : "+s"(k.m1), "+s"(k.p1), "+s"(k.m2), "+s"(k.p2), "+s"(k.m4), "+s"(k.p4), "+s"(k.m5), "+s"(k.p3));
   return k;
 }
-__device__ __forceinline__ void w4_bt(f32x4* d, const W4Consts& k) {
-  const f32x4 t0 = d[0] * k.p4 + (d[2] * k.m5 + d[4]);
-  const f32x4 t5 = d[1] * k.p4 + (d[3] * k.m5 + d[5]);
-  const f32x4 a = d[2] * k.m4 + d[4], b = d[1] * k.m4 + d[3], c = d[2] * k.m1 + d[4], e = d[1] * k.m1 + d[3];
+template <typename V>
+__device__ __forceinline__ void w4_bt(V* d, const W4Consts& k) {
+  const V t0 = d[0] * k.p4 + (d[2] * k.m5 + d[4]);
+  const V t5 = d[1] * k.p4 + (d[3] * k.m5 + d[5]);
+  const V a = d[2] * k.m4 + d[4], b = d[1] * k.m4 + d[3], c = d[2] * k.m1 + d[4], e = d[1] * k.m1 + d[3];
   d[0] = t0;
   d[1] = b * k.p1 + a;
   d[2] = b * k.m1 + a;
@@ -151,6 +170,21 @@ __device__ __forceinline__ void w4_bt_dup(const f32x4* d, f32x4* t, const W4Cons
   t[5] = d[1] * k.p4 + (d[2] * k.m5 + d[3]);
 }
 
+// MODE 3: the six up-sampled patch values (times 4) from the four half-resolution values d[0..3] = (a, b, c, d), then B^T:
+//   4 u = (3a + b, a + 3b, 3b + c, b + 3c, 3c + d, c + 3d)
+// (6 + 12 multiply-adds per channel, the constant 3 beside w4_bt's).  f0 / f5: per-lane 1, or 0 on a first / last tile, where
+// patch position 0 / 5 lies in the convolution's zero padding (with the loads' clamped coordinates it would read 4b / 4c).
+template <typename V>
+__device__ __forceinline__ void w4_up(const V* d, V* t, const W4Consts& k, float f0, float f5) {
+  t[0] = (d[0] * k.p3 + d[1]) * f0;
+  t[1] = d[1] * k.p3 + d[0];
+  t[2] = d[1] * k.p3 + d[2];
+  t[3] = d[2] * k.p3 + d[1];
+  t[4] = d[2] * k.p3 + d[3];
+  t[5] = (d[3] * k.p3 + d[2]) * f5;
+  w4_bt(t, k);
+}
+
 // Diagnostic build only (make EXTRA=-DDIAGAN_WINO_ABLATE; tools/wino4_ablate.py): ConvGemmArgs::tune bits switch parts of the K
 // loop off (16 row pass, 4096 column pass, 32 input loads, 64 weight DMA, 128 barrier, 256 MFMAs, 2048 fragment reads: the
 // results are then garbage) so that their cost can be read off the launch time.
@@ -164,7 +198,7 @@ template <int PRO, int MODE = 0>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
   using MD = W4M<MODE>;
   constexpr int NS = MD::NS, NI = MD::NI;
-  constexpr bool POOL = MODE == 1, UNPOOL = MODE == 2;
+  constexpr bool POOL = MODE == 1, UNPOOL = MODE == 2, UPIN = MODE == 3;
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 V stages | U] <= 159 KB
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,11 +214,15 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 
   // ---- loader role: (tile lt, channel quad lq, patch row / column lr < 6); a 16-lane group holds one tile ----
   // (unpool: the patch is the 4 x 4 HALF-resolution neighbourhood, rows / columns 2 t - 1 .. 2 t + 2 of the pooled gradient)
+  // (upin: the row pass splits a tile's 4 rows x 2 channel quads over ALL sixteen lanes -- lane = (row lr >> 1, channel PAIR
+  //  lr & 1) with 8-byte loads and LDS writes -- so no lane idles in it and its arithmetic is on two channels, not four)
   const int lr = tid & 7, lq = (tid >> 3) & 1, lt = tid >> 4;
-  const bool ract = lr < (UNPOOL ? 4 : 6);                                  // row pass: this lane holds patch row lr
+  const int ur = lr >> 1, uc = lr & 1;
+  const bool ract = UPIN || lr < (UNPOOL ? 4 : 6);                          // row pass: this lane holds patch row lr
   const bool cact = lr < 6 && !(MD::pooled && lr == 2);                     // column pass: this lane holds column j = lr
   unsigned off[NI];                                      // byte offsets of this row's patch pixels, bit 31 set if outside
   int kbound[NI];                                        // upper clamp of the activation: 0 on padding pixels
+  float ex0 = 1.f, ex5 = 1.f, ey0 = 1.f, ey5 = 1.f;      // upin: border factors of the row (x) / column (y) pass, see w4_up
   {
     const int gt = t0 + lt;
     const bool tv = gt < MT && ract;
@@ -192,7 +230,23 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     const int tx = (tv ? gt : 0) - (int)q1 * TW;
     const unsigned b = fdiv(q1, a.dHo);                                // dHo: divisor TH
     const int ty = (int)q1 - (int)b * TH;
-    const int Hx = UNPOOL ? g.Hi >> 1 : g.Hi, Wx = UNPOOL ? g.Wi >> 1 : g.Wi;     // the gathered tensor's own size
+    const bool half = UNPOOL || UPIN;
+    const int Hx = half ? g.Hi >> 1 : g.Hi, Wx = half ? g.Wi >> 1 : g.Wi;     // the gathered tensor's own size
+    if (UPIN) {
+      // interpolation taps clamp at the image edge: every load is a real pixel (no "padding is zero" in the prologue)
+      const int iy = min(max(2 * ty - 1 + ur, 0), Hx - 1);
+      const int rowbase = ((int)b * Hx + iy) * Wx;
+#pragma unroll
+      for (int c = 0; c < NI; ++c) {
+        const int ix = min(max(2 * tx - 1 + c, 0), Wx - 1);
+        off[c] = tv ? (unsigned)((rowbase + ix) * g.Ci * 4 + lq * 16 + uc * 8) : 0x80000000u;
+        kbound[c] = 0x7fffffff;
+      }
+      ex0 = tx == 0 ? 0.f : 1.f;
+      ex5 = tx == TW - 1 ? 0.f : 1.f;
+      ey0 = ty == 0 ? 0.f : 1.f;
+      ey5 = ty == TH - 1 ? 0.f : 1.f;
+    } else {
     const int iy = (UNPOOL ? 2 : 4) * ty - 1 + lr, ix0 = (UNPOOL ? 2 : 4) * tx - 1;
     const bool rv = tv && iy >= 0 && iy < Hx;
     const int rowbase = (((int)b * Hx + iy) * Wx + ix0) * g.Ci * 4 + lq * 16;
@@ -201,6 +255,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       const bool ok = rv && ix0 + c >= 0 && ix0 + c < Wx;
       off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0x80000000u;  // beyond num_records: the hardware returns zeros
       kbound[c] = ok ? 0x7fffffff : 0;
+    }
     }
   }
   // raw buffer descriptor {base, stride 0, num_records, flags}.  The six input loads of a step are issued through inline
@@ -213,12 +268,12 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     const unsigned long long xb = (unsigned long long)a.x;
     xsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
     xsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffffu));
-    xsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * (UNPOOL ? 1u : 4u)));
+    xsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * ((UNPOOL || UPIN) ? 1u : 4u)));
     xsrc[3] = 0x00020000;
   }
   const int pro_group_off = a.pro_group_rows > 0 ? ((t0 * 16) / a.pro_group_rows) * g.Ci : 0;
   i32x4 scsrc = xsrc, shsrc = xsrc;
-  const unsigned poff = (unsigned)(pro_group_off + lq * 4) * 4u;
+  const unsigned poff = (unsigned)(pro_group_off + lq * 4 + (UPIN ? uc * 2 : 0)) * 4u;
   if (affine) {
     const unsigned long long sb = (unsigned long long)a.pro_scale, hb = (unsigned long long)a.pro_shift;
     scsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)sb);
@@ -231,7 +286,8 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   // (the idle lanes lr = 6, 7 of a group point far outside the LDS allocation: the hardware drops such writes and returns
   //  zeros for such reads -- no branch around the passes, which keeps the K loop one basic block: behind a join the
   //  compiler's wait-count pass loses track of the in-flight LDS-DMA units and waits for ALL of them before any ds_read)
-  float* const vrow = smem + (ract ? (lq * 42 + lr) * W4_PS + lt * 4 : (1 << 22));          // + j * 7 * W4_PS
+  float* const vrow = smem + (UPIN ? (lq * 42 + ur) * W4_PS + lt * 4 + uc * 2
+                                   : (ract ? (lq * 42 + lr) * W4_PS + lt * 4 : (1 << 22)));          // + j * 7 * W4_PS
   float* const vcol = smem + (cact ? (lq * 42 + 7 * lr) * W4_PS + lt * 4 : (1 << 22));      // + i * W4_PS
 
   float* const ulds = smem + 2 * W4_VSTAGE;
@@ -247,10 +303,21 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   };
   const W4Consts kc = w4_consts();
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+  f32x2 rb[4], psc2 = {1.f, 1.f}, psh2 = {0.f, 0.f};    // upin: this lane's channel PAIR of the four pixels
 #pragma unroll
   for (int c = NI; c < 6; ++c) ra[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto issue_x = [&](int kk) {
     const int soff = __builtin_amdgcn_readfirstlane(kk * (W4K * 4));
+    if (UPIN) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
+      if (affine) {
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(psc2) : "v"(poff), "s"(scsrc), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(psh2) : "v"(poff), "s"(shsrc), "s"(soff) : "memory");
+      }
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < NI; ++c)
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
@@ -261,20 +328,50 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   };
 #define W4_WAIT_IN(n)                                                                                            \
   case n:                                                                                                        \
-    asm volatile("s_waitcnt vmcnt(" #n ")"                                                                       \
-                 : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)::"memory"); \
+    if (UPIN)                                                                                                    \
+      asm volatile("s_waitcnt vmcnt(" #n ")"                                                                     \
+                   : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(psc2), "+v"(psh2)::"memory");        \
+    else                                                                                                         \
+      asm volatile("s_waitcnt vmcnt(" #n ")"                                                                     \
+                   : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)::"memory"); \
     break;
   // the input loads have landed when at most n younger operations (weight units of the next step) are still in flight
   auto wait_inputs = [&](int n) {
     switch (n) {
       W4_WAIT_IN(0) W4_WAIT_IN(1) W4_WAIT_IN(2) W4_WAIT_IN(3) W4_WAIT_IN(4) W4_WAIT_IN(5) W4_WAIT_IN(6) W4_WAIT_IN(7) W4_WAIT_IN(8)
       W4_WAIT_IN(9)
-      default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)::"memory");
+      default:
+        if (UPIN) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(psc2), "+v"(psh2)::"memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)::"memory");
     }
   };
 #undef W4_WAIT_IN
   // prologue on the loaded pixels + row transform + park in the V planes of `stage`
   auto row_pass = [&](int stage) {
+    if (UPIN) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        f32x2 v = rb[c];
+        if (affine) v = v * psc2 + psh2;
+        if (PRO == PRO_RELU || PRO == PRO_AFFINE_RELU) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) v[e] = __int_as_float(max(__float_as_int(v[e]), 0));
+        } else if (PRO == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float q = v[e], q2 = 0.2f * q;
+            asm("v_max_f32 %0, %1, %2" : "=v"(v[e]) : "v"(q), "v"(q2));
+          }
+        }
+        rb[c] = v;
+      }
+      f32x2 t[6];
+      w4_up(rb, t, kc, ex0, ex5);
+      float* vs = vrow + stage * W4_VSTAGE;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vs + j * 7 * W4_PS) = t[j];
+      return;
+    }
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
       f32x4 v = ra[c];
@@ -316,8 +413,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     float* vs = vcol + stage * W4_VSTAGE;
     f32x4 d[6];
 #pragma unroll
-    for (int i = 0; i < (UNPOOL ? 4 : 6); ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * W4_PS);
-    if (UNPOOL) {
+    for (int i = 0; i < ((UNPOOL || UPIN) ? 4 : 6); ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * W4_PS);
+    if (UPIN) {
+      f32x4 t[6];
+      w4_up(d, t, kc, ey0, ey5);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i] = t[i];
+    } else if (UNPOOL) {
       f32x4 t[6];
       w4_bt_dup(d, t, kc);
 #pragma unroll
@@ -686,7 +788,7 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
   hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
-                     g.dr < 0 ? 1 : 0);
+                     g.dr < 0 ? 1 : 0, 1.f);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ws, st);
     case PRO_RELU: return launch_wino4_pro<PRO_RELU>(a, ws, st);
@@ -713,7 +815,7 @@ int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0);
+  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0, 1.f);
   return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1>(a, ws, st) : launch_wino4_pro<PRO_NONE, 1>(a, ws, st);
 }
 
@@ -721,8 +823,34 @@ int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 1);
+  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 1, 1.f);
   return launch_wino4_pro<PRO_NONE, 2>(a, ws, st);
+}
+
+// tile_cfg 15 on the F(4x4) kernel (MODE 3): conv3x3(bilinear x2 (pro(x))) from the HALF-resolution input -- GBlock's
+// BN -> ReLU -> up-sampling -> c1 in one launch.  a.g.Hi / Wi are the up-sampled sizes (= Ho / Wo), a.x is [B, Hi/2, Wi/2, Ci].
+// Taken where the plain F(4x4) launch of the same convolution would be (wino4_ksplit == 1: >= 192 workgroups that fill their
+// rounds at least as well as the F(2x2) kernel's); DIAGAN_WINO4_UPIN=0: off; force: any launch size (tests).
+bool wino4_upin_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force) {
+  static const int env = getenv("DIAGAN_WINO4_UPIN") ? atoi(getenv("DIAGAN_WINO4_UPIN")) : 1;
+  static const int w4 = getenv("DIAGAN_WINO4") ? atoi(getenv("DIAGAN_WINO4")) : 1;
+  if (!env || !w4 || !wino4_geom_ok(Ho, Wo, Ci) || (Co & 3) || wino4_ws_floats(Co, Ci) > ws_floats) return false;
+  return force || (Ci >= 64 && wino4_ksplit(B, Ho, Wo, Ci, Co, 0, ws_floats) == 1);
+}
+
+int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st) {
+  const ConvGeom& g = a.g;
+  a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
+  a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
+  hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0,
+                     0.0625f);
+  switch (a.pro_mode) {
+    case PRO_NONE: return launch_wino4_pro<PRO_NONE, 3>(a, ws, st);
+    case PRO_RELU: return launch_wino4_pro<PRO_RELU, 3>(a, ws, st);
+    case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU, 3>(a, ws, st);
+    case PRO_LRELU: return launch_wino4_pro<PRO_LRELU, 3>(a, ws, st);
+    default: return launch_wino4_pro<PRO_AFFINE, 3>(a, ws, st);
+  }
 }
 
 }  // namespace diagan

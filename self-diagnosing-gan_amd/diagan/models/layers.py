@@ -157,11 +157,18 @@ class ConvLayer(nn.Module):
                                                                   want_stats=want_stats, group_imgs=group_imgs))
         return (residual, True) if fused else (E.upsample2x(residual), False)
 
-    def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0, res_up=False):
+    def upin_fused(self, x, pro=None):
+        """Will fwd / fwd_bn(..., up_in=True) on the half-resolution `x` run as one launch (the bilinear x2 folded into the
+        F(4x4) kernel's input transform)?  Otherwise the caller up-samples first (E.upsample2x)."""
+        group_imgs = pro[3] if (pro is not None and len(pro) > 3) else 0
+        return (self.geom.kind == 'conv' and os.environ.get("DIAGAN_UPIN", "1") != "0"
+                and C.upin_fused(self.geom, x.shape[0], x.shape[1], x.shape[2], group_imgs=group_imgs))
+
+    def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0, res_up=False, up_in=False):
         residual, res_up = self._res_up(x, residual, res_up, False, tile_cfg, pro)
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale,
-                          res_up=res_up)
+                          res_up=res_up, up_in=up_in)
 
     def fwd_pool(self, ctx, x, pro=None, residual=None):
         """avg_pool2d(conv(pro(x)) + bias, 2) + residual (the end of a down-sampling DBlock): ONE launch on 9/16 of the
@@ -171,16 +178,16 @@ class ConvLayer(nn.Module):
                               pro=pro, row_scale=ctx.row_scale, pool=True)
         return E.avgpool2(self.fwd(ctx, x, pro=pro), residual=residual)
 
-    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1, res_up=False):
+    def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1, res_up=False, up_in=False):
         """Forward + the BatchNorm statistics of the layer that consumes the output, taken from the GEMM
         epilogue's per-tile sums (no second pass over the activation).  Returns (y, bn context).
         groups > 1: the batch is `groups` stacked batches with separate statistics (tiles never straddle groups)."""
         if not training:
-            y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up)
+            y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up, up_in=up_in)
             return y, bn.stats(y, False)
         residual, res_up = self._res_up(x, residual, res_up, True, pro=pro)
         y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
-                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up)
+                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up, up_in=up_in)
         M = y.numel() // y.shape[-1]
         if stats is None or stats[1] % groups or (M // groups) % (M // stats[1]):
             return y, bn.stats(y, True, groups=groups)

@@ -53,12 +53,19 @@ class GBlock(nn.Module):
             raise RuntimeError("GBlock: a stacked forward keeps the context of one group only (save_group)")
         if bn1 is None:
             bn1 = self.b1.stats(x, training, groups=groups)
-        if self.upsample:
-            c1_in, c1_pro = E.upsample2x(x, pro=_bn_pro(bn1)), None
-        else:
-            c1_in, c1_pro = x, _bn_pro(bn1)
         k1 = self.c1.prepare(training, need_dgrad)
-        h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro, groups=groups)
+        if self.upsample and self.c1.upin_fused(x, _bn_pro(bn1)):
+            # BN -> ReLU -> bilinear x2 -> c1 as ONE launch on the low-resolution input: the interpolation is part of the
+            # Winograd input transform and the up-sampled tensor is never written (the backward pass of the ONE batch that has
+            # one makes its own copy for c1's weight gradient)
+            c1_in, c1_pro = None, None
+            h1, bn2 = self.c1.fwd_bn(k1, x, self.b2, training, pro=_bn_pro(bn1), groups=groups, up_in=True)
+        else:
+            if self.upsample:
+                c1_in, c1_pro = E.upsample2x(x, pro=_bn_pro(bn1)), None
+            else:
+                c1_in, c1_pro = x, _bn_pro(bn1)
+            h1, bn2 = self.c1.fwd_bn(k1, c1_in, self.b2, training, pro=c1_pro, groups=groups)
         # shortcut: a 1x1 conv commutes with the (linear) bilinear upsampling, so c_sc runs on the LOW
         # resolution input (4x fewer FLOP): c_sc(up(x)) == up(c_sc(x)); the up-sampling itself is blended into c2's
         # epilogue from the low-resolution tensor (res_up), which is never written out at full resolution
@@ -79,7 +86,8 @@ class GBlock(nn.Module):
             b = x.shape[0] // groups
             sl = slice(save_group * b, (save_group + 1) * b)
             g1 = E.bn_ctx_group(bn1, save_group)
-            ctx = dict(x=x[sl], bn1=g1, c1_in=c1_in[sl], c1_pro=None if c1_pro is None else _bn_pro(g1), k1=k1, h1=h1[sl],
+            ctx = dict(x=x[sl], bn1=g1, c1_in=None if c1_in is None else c1_in[sl],
+                       c1_pro=None if c1_pro is None else _bn_pro(g1), k1=k1, h1=h1[sl],
                        bn2=E.bn_ctx_group(bn2, save_group), ksc=ksc, k2=k2)
         elif save:
             ctx = dict(x=x, bn1=bn1, c1_in=c1_in, c1_pro=c1_pro, k1=k1, h1=h1, bn2=bn2, ksc=ksc, k2=k2)
@@ -91,8 +99,11 @@ class GBlock(nn.Module):
         self.c2.wgrad(ctx['k2'], gout, h1, pro=_bn_pro(ctx['bn2']))
         g_a2 = self.c2.dgrad(ctx['k2'], gout, hw1)
         g_h1 = self.b2.bwd(g_a2, h1, ctx['bn2'], relu=True)
-        self.c1.wgrad(ctx['k1'], g_h1, ctx['c1_in'], pro=ctx['c1_pro'])
-        g_c1in = self.c1.dgrad(ctx['k1'], g_h1, ctx['c1_in'].shape[1:3])
+        c1_in = ctx['c1_in']
+        if c1_in is None:                    # the forward ran on the low-resolution input (up_in): c1's weight gradient wants
+            c1_in = E.upsample2x(x, pro=_bn_pro(ctx['bn1']))       # the up-sampled activation of THIS batch
+        self.c1.wgrad(ctx['k1'], g_h1, c1_in, pro=ctx['c1_pro'])
+        g_c1in = self.c1.dgrad(ctx['k1'], g_h1, c1_in.shape[1:3])
         if self.learnable_sc:
             # gradient of the low-resolution shortcut: adjoint of the upsampling applied to gout
             g_sc = E.upsample2x_bwd(gout) if self.upsample else gout

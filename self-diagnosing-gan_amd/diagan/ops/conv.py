@@ -16,6 +16,7 @@ nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_wino4_pool_used", [I] * 5 + [I64])
+nat.register("diagan_conv_wino4_upin_supported", [I] * 13 + [I64, I])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
@@ -57,6 +58,8 @@ def gemm_kernel_name(cfg, mode, Co=128, w4pool=False):
         return f"conv_wino_kernel<{mode}>"
     if cfg == 13:
         return f"conv_wino4_kernel<{mode},0>"
+    if cfg == 15:
+        return f"conv_wino4_kernel<{mode},3>"
     if cfg == 11:
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
@@ -175,11 +178,15 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False):
+          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False, up_in=False):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
+    if up_in:                             # `x` is the half-resolution input whose bilinear x2 is convolved: tile_cfg 15
+        Hi, Wi, tile_cfg = 2 * Hi, 2 * Wi, 15
+        if pool or unpool or mask_src is not None:
+            raise RuntimeError("conv_gemm: the up-sampled-input launch takes no pooling and no backward mask")
     if unpool:                            # `x` is the half-resolution (pooled) gradient: tile_cfg 12
         Hi, Wi, tile_cfg = 2 * Hi, 2 * Wi, 12
     if pool:                              # `out` (and `residual`) are the 2x2-average-pooled tensors: tile_cfg 11
@@ -280,6 +287,18 @@ def res_up_fused(geom, B, Hi, Wi, want_stats=False, group_imgs=0):
                                                        group_imgs * Ho * Wo) in (9, 13)
 
 
+def upin_fused(geom, B, Hl, Wl, group_imgs=0):
+    """Will conv_fwd(geom, x[B,Hl,Wl,Ci], ..., up_in=True) run?  True iff conv3x3(bilinear_x2(pro(x))) of this layer qualifies
+    for the one-launch F(4x4) kernel on the half-resolution input (tile_cfg 15); otherwise the caller up-samples first
+    (diagan_upsample2x).  group_imgs: images per prologue group (stacked generator forward), 0: ungrouped."""
+    Hi, Wi = 2 * Hl, 2 * Wl
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    sy, dr, off, up = geom.fwd_params()
+    ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
+    return bool(nat.fn("diagan_conv_wino4_upin_supported")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up,
+                                                           ws.numel(), group_imgs * Ho * Wo))
+
+
 def pool_fused(geom, B, Hi, Wi, pro=None):
     """Will conv_fwd(geom, x[B,Hi,Wi,Ci], ..., pool=True) run?  True iff avg_pool2d(conv(pro(x)), 2) of this layer qualifies
     for the one-launch Winograd + pooling kernel (tile_cfg 11: 9 of the 16 transform-domain products) and the launch is
@@ -293,20 +312,22 @@ def pool_fused(geom, B, Hi, Wi, pro=None):
 
 
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False):
+             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False, up_in=False):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co].
     res_up: `residual` is [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling is added (see res_up_fused).
-    pool: y = avg_pool2d(conv(pro(x)) + bias, 2) + residual, y and residual [B,Ho/2,Wo/2,Co] (see pool_fused)."""
+    pool: y = avg_pool2d(conv(pro(x)) + bias, 2) + residual, y and residual [B,Ho/2,Wo/2,Co] (see pool_fused).
+    up_in: y = conv(bilinear_x2(pro(x))) + ..., x [B,Hi,Wi,Ci] -> y [B,2Hi,2Wi,Co] (see upin_fused)."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
         raise RuntimeError(f"conv_fwd: input has {Ci} channels, layer expects {geom.Ci}")
-    Ho, Wo = geom.out_hw(Hi, Wi)
+    Ho, Wo = geom.out_hw(2 * Hi, 2 * Wi) if up_in else geom.out_hw(Hi, Wi)
     if pool:
         Ho, Wo = Ho // 2, Wo // 2
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
-                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up, pool=pool)
+                 tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up, pool=pool,
+                 up_in=up_in)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,

@@ -213,3 +213,91 @@ def test_data_gradient_through_the_average_pool_from_the_pooled_gradient(case, f
         ref[:B // 2] *= 0.7
         ref[B // 2:] *= 1.9
         close(nchw(dx), ref, tol=TOL)
+
+
+# ---- the convolution of an up-sampled input on this kernel (MODE 3 of conv_wino4.hip, tile_cfg 15) -----------------------------------
+# B, Hl, Wl, Ci, Co: HALF-resolution input sizes; one tile per axis (first AND last tile: 2x2 -> 4x4), ragged tile counts,
+# non-square maps, Co not a multiple of 64, the SNGAN generator's block shapes
+UPIN_CASES = [(3, 2, 2, 16, 24), (2, 2, 6, 8, 4), (4, 4, 4, 64, 64), (5, 8, 8, 128, 72), (2, 16, 16, 256, 256),
+              (2, 32, 32, 128, 64), (16, 4, 4, 512, 256)]
+
+
+@pytest.fixture
+def force_w4():
+    from diagan.ops import conv as C
+    C.set_winograd4('force-pool')            # the F(4x4) variants with a shape of their own take any launch size
+    yield
+    C.set_winograd4(None)
+
+
+@pytest.mark.parametrize("case", UPIN_CASES)
+@pytest.mark.parametrize("pro", [0, 1, 2, 3, 4])
+def test_convolution_of_the_bilinear_upsampling_from_the_half_resolution_input(case, pro, force_w4):
+    """conv3x3(F.interpolate(pro(x), scale_factor=2, mode='bilinear', align_corners=False)) + bias + residual -- the start of
+    mimicry's GBlock residual branch, BN -> ReLU -> up-sampling -> c1 (GBlock._upsample_conv, predefined_models.py:19,57) -- as
+    one launch on the low-resolution input, against float64 PyTorch: interior and border tiles (the interpolation clamps at the
+    image edge, the convolution pads with zeros at the HIGH resolution), every prologue (applied BEFORE the interpolation)."""
+    from diagan.ops import conv as C
+    B, Hl, Wl, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=41)
+    assert C.upin_fused(geom, B, Hl, Wl)
+    g = torch.Generator().manual_seed(42)
+    bias, scale, shift = torch.randn(Co, generator=g), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    up = F.interpolate(ref_pro(x.double(), pro, scale.double(), shift.double()), scale_factor=2, mode='bilinear',
+                       align_corners=False)
+    ref = F.conv2d(up, w.double(), bias.double(), padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, bias=bias.cuda(), residual=nhwc(res).cuda(),
+                   pro=(pro, scale.cuda(), shift.cuda()), up_in=True)
+    assert tuple(y.shape) == (B, 2 * Hl, 2 * Wl, Co)
+    close(nchw(y), ref + res.double(), tol=TOL)
+
+
+def test_upsampled_input_statistics_groups_and_the_two_launch_form(force_w4):
+    """what GBlock.c1 uses in the stacked generator forward: BatchNorm statistics of the output from the epilogue and one
+    BatchNorm row per stacked batch in the prologue; and the result against the two-launch form it replaces
+    (diagan_upsample2x with the same prologue, then the F(4x4) kernel)"""
+    from diagan.ops import conv as C
+    from diagan.ops import eltwise as E
+    B, Hl, Wl, Ci, Co = 8, 8, 8, 64, 128
+    geom, x, w, wp = make(B, Hl, Wl, Ci, Co, seed=43)
+    g = torch.Generator().manual_seed(44)
+    xg = nhwc(x).cuda()
+    groups = 4                                   # 2 images x 16 x 16 = 512 output rows per group: one workgroup tile
+    sc, sh = torch.rand(groups, Ci, generator=g) + 0.5, torch.randn(groups, Ci, generator=g) * 0.3
+    bias = torch.randn(Co, generator=g)
+    pro = (C.PRO_AFFINE_RELU, sc.cuda(), sh.cuda(), B // groups)
+    assert C.upin_fused(geom, B, Hl, Wl, group_imgs=B // groups)
+    y, st = C.conv_fwd(geom, xg, wp, bias=bias.cuda(), pro=pro, up_in=True, want_stats=True)
+    parts = [F.conv2d(F.interpolate(ref_pro(x[i * 2: i * 2 + 2].double(), 2, sc[i].double(), sh[i].double()), scale_factor=2,
+                                    mode='bilinear', align_corners=False), w.double(), bias.double(), padding=1)
+             for i in range(groups)]
+    full = torch.cat(parts)
+    close(nchw(y), full, tol=TOL)
+    assert st[1] == B * 4 * Hl * Wl // 512 and st[0].shape == (st[1], 2, Co)
+    close(st[0][:, 0].sum(0), full.sum((0, 2, 3)), tol=TOL)
+    close(st[0][:, 1].sum(0), (full * full).sum((0, 2, 3)), tol=TOL)
+    close(st[0][:, 0].sum(0), y.double().sum((0, 1, 2)), tol=1e-5)       # the sums are of the kernel's own outputs
+    two = C.conv_fwd(geom, E.upsample2x(xg, pro=pro), wp, bias=bias.cuda(), tile_cfg=13)
+    close(y, two, tol=TOL / 2)
+    assert not C.upin_fused(geom, B, Hl, Wl, group_imgs=1)              # 256-row groups: a 512-row tile would straddle two
+
+
+def test_upsampled_input_selection_and_refusals():
+    """the automatic policy (no force): the stacked SNGAN generator launches qualify, small launches and the data-gradient
+    geometry do not; DIAGAN_WINO4 off keeps it out; a backward mask is refused with the reason"""
+    from diagan.ops import conv as C
+    g256 = C.Geom("conv", 256, 256, 3, 3, 1, 1)
+    assert C.upin_fused(g256, 384, 16, 16, group_imgs=64) and C.upin_fused(g256, 384, 4, 4, group_imgs=64)
+    assert C.upin_fused(C.Geom("conv", 128, 64, 3, 3, 1, 1), 384, 32, 32, group_imgs=64)       # SNGAN-64 block5
+    assert not C.upin_fused(g256, 64, 4, 4)                                                    # 32 workgroups
+    assert not C.upin_fused(C.Geom("conv", 12, 64, 3, 3, 1, 1), 384, 16, 16)                   # Ci % 8
+    C.set_winograd4(False)
+    try:
+        assert not C.upin_fused(g256, 384, 16, 16)
+    finally:
+        C.set_winograd4(None)
+    geom, x, w, wp = make(2, 4, 4, 16, 16)
+    with pytest.raises(RuntimeError, match="backward mask"):
+        C._gemm(nhwc(x).cuda(), wp, torch.empty(2, 8, 8, 16, device='cuda'), geom.fwd_params(), 3, 3, geom.Kp, None, None,
+                torch.zeros(2, 8, 8, 16, device='cuda'), 0.0, None, 1.0, 0, up_in=True)
