@@ -467,17 +467,20 @@ def main():
     dist.synchronize()
     torch.cuda.synchronize()
     C.TIMER = timer
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.thread_time()
     for _ in range(args.steps):
         step()
+    issue_s, issue_cpu_s = time.perf_counter() - t0, time.thread_time() - c0      # the host's launch loop alone
     torch.cuda.synchronize()
     dist.synchronize()
     elapsed = time.perf_counter() - t0
     C.TIMER = None
+    host_rows = [(issue_s, issue_cpu_s, len(os.sched_getaffinity(0)))]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
+        host_rows = dist.all_gather(host_rows[0])
     # two more UN-timed steps on EVERY rank (each step contains the gradient all-reduces): every GEMM launch is
     # bracketed for the per-kernel table rank 0 prints
     summ_all = None
@@ -532,6 +535,12 @@ def main():
                    "steps_per_s": round(args.steps / elapsed, 3),
                    "D_updates_per_s": round(args.steps * args.n_dis / elapsed, 3)},
     }
+    # the host side of the timed region, rank by rank: wall time of the launch loop before the final synchronisation (the
+    # loop is throttled by the HIP queue once that is ~80 ms deep: profiles/r03_host_time.md) and the CPU time the launching
+    # thread itself consumed -- with N ranks sharing the box's hardware threads the second is the host margin per step
+    line["host"] = {"launch_loop_ms_per_step": [round(r[0] / args.steps * 1e3, 3) for r in host_rows],
+                    "launch_thread_cpu_ms_per_step": [round(r[1] / args.steps * 1e3, 3) for r in host_rows],
+                    "hardware_threads_available": host_rows[0][2], "cpu_count": os.cpu_count()}
     if timer is not None:
         summ = timer.summary()
         dom = max(summ.items(), key=lambda kv: kv[1]['seconds'])
@@ -545,11 +554,26 @@ def main():
                 traffic = json.load(open(tpath)).get(args.workload, {}).get(name)
             except Exception:
                 traffic = None
+        # algorithmic bytes of the dominant kernel's launches (3x3 Winograd kernels: input + output + weights, fp32; the
+        # pooled / up-sampled-input forms read or write a quarter of the pixels): what `traffic` is to be compared with
+        alg_bytes = None
+        if name.startswith("conv_wino"):
+            tot = 0.0
+            for key, v in timer.by_shape().items():
+                if key[0] != name or len(key) < 4:
+                    continue
+                M, Co, K = key[1], key[2], key[3]
+                m_in = M / 4 if name.endswith((",2>", ",3>")) else M
+                m_out = M / 4 if name.endswith(",1>") else M
+                tot += v['launches'] * 4.0 * (m_in * K / 9 + m_out * Co + Co * K)
+            alg_bytes = tot / d['launches'] if tot else None
         peak = MFMA_F32_PEAK
         line["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak / 1e12, 1),
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4), "frac_executed": round(achieved * 1e12 / peak, 4),
             "frac_algorithmic": round(algorithmic * 1e12 / peak, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": round(alg_bytes) if alg_bytes else None,
+            "traffic_ratio": round(traffic / alg_bytes, 3) if (traffic and alg_bytes) else None,
             "traffic_source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, "
                               "2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this run)" if traffic else None,
             "launches": d['launches'], "avg_launch_us": round(d['seconds'] / d['launches'] * 1e6, 2),

@@ -406,6 +406,35 @@ def reduce_loss_dict(loss_dict):
         return {k: v for k, v in zip(keys, stacked)}
 
 
+def reconcile_running_stats_(module):
+    """Make the BatchNorm running statistics of `module` the mean over the ranks, in place, on every rank (collective).
+
+    Under data parallelism every rank normalises with the statistics of its OWN micro-batch and folds those into its own
+    running_mean / running_var -- buffers are deliberately not synchronised per step, like DistributedDataParallel with
+    `broadcast_buffers=False` in stylegan2/train_ffhq.py:577.  Parameters stay in lock-step, the running statistics drift
+    apart by sampling noise, and a checkpoint written by rank 0 alone would carry the evaluation-mode statistics of an
+    arbitrary eighth of the data.  LogTrainer calls this right before it saves (all ranks take part, rank 0 writes): the
+    checkpoint then holds the average over all ranks' batches, and the ranks continue from identical buffers.
+    Spectral-norm buffers (sn_u, sn_sigma) need nothing: same weights and same start give the same power iterations.
+    Returns the number of buffers reconciled."""
+    world = get_world_size()
+    if world == 1:
+        return 0
+    bufs = [b for n, b in module.named_buffers()
+            if b.is_floating_point() and (n.endswith('running_mean') or n.endswith('running_var'))]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).to(torch.float32) for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.mul_(1.0 / world)
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off: off + n].view(b.shape))
+        off += n
+    return len(bufs)
+
+
 def broadcast_module_(module, src=0):
     """Make parameters and buffers identical on every rank (done once at start; afterwards the
     replicas stay in lock-step because they apply identical averaged gradients)."""

@@ -187,6 +187,11 @@ class LogTrainer:
         return global_step_G
 
     def _save_model_checkpoints(self, global_step):
+        # data parallel: every rank's BatchNorm running statistics come from its own batches -- average them over the
+        # ranks (collective: before the rank-0 gate) so the file does not carry one arbitrary rank's evaluation statistics
+        for net in (self.netG, self.netD, self.netD_drs if self.train_drs else None):
+            if net is not None:
+                dist.reconcile_running_stats_(net)
         if self.rank != 0:
             return
         self.netG.save_checkpoint(directory=self.netG_ckpt_dir, global_step=global_step, optimizer=self.optG)

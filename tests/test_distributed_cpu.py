@@ -78,6 +78,18 @@ def _worker(rank, world, port, out_dir):
     dist.gather_grad(lin2.parameters())                 # bias has no gradient: skipped
     res['gather_grad'] = lin2.weight.grad.clone()
     res['objects'] = dist.all_gather({'rank': rank, 'payload': 'x' * (rank + 1)})
+    # 9. BatchNorm running statistics reconciled at checkpoint time (mean over ranks; other buffers untouched)
+    from diagan.models.layers import BatchNorm
+    holder = torch.nn.Module()
+    holder.b1, holder.b2 = BatchNorm(4), BatchNorm(2)
+    holder.register_buffer('sn_u', torch.full((1, 3), float(rank)))
+    with torch.no_grad():
+        holder.b1.running_mean.fill_(float(rank)), holder.b1.running_var.fill_(1.0 + 2 * rank)
+        holder.b2.running_mean.copy_(torch.tensor([1.0, -1.0]) * (rank + 1))
+    holder.b1._pending_batches = 3
+    res['reconciled'] = dist.reconcile_running_stats_(holder)
+    res['bn'] = (holder.b1.running_mean.clone(), holder.b1.running_var.clone(), holder.b2.running_mean.clone(),
+                 holder.sn_u.clone(), holder.state_dict()['b1.num_batches_tracked'].item())
     dist.synchronize()
     torch.save(res, os.path.join(out_dir, f"r{rank}.pt"))
     torch.distributed.destroy_process_group()
@@ -99,6 +111,10 @@ def test_world_size_2_gloo(tmp_path):
         assert torch.equal(r[k]['bcast'], torch.ones(2, 3))
         assert torch.equal(r[k]['gather_grad'], torch.full((1, 2), 1.5))
         assert r[k]['objects'] == [{'rank': 0, 'payload': 'x'}, {'rank': 1, 'payload': 'xx'}]
+        assert r[k]['reconciled'] == 4
+        m1, v1, m2, u, nb = r[k]['bn']
+        assert torch.equal(m1, torch.full((4,), 0.5)) and torch.equal(v1, torch.full((4,), 2.0))
+        assert torch.equal(m2, torch.tensor([1.5, -1.5])) and torch.equal(u, torch.full((1, 3), float(k))) and nb == 3
     assert r[0]['range'] == (0, 6, 6) and r[1]['range'] == (6, 11, 6)
     assert r[0]['loss']['d'].item() == 0.5 and r[0]['loss']['g'].item() == 1.0
     # strided shards of the same multinomial draw

@@ -272,3 +272,45 @@ def test_bare_bench_gpus_2_starts_two_ranks_itself():
     assert len(rec["config"]["devices"]) == 2
     if torch.cuda.device_count() < 2:
         assert "gloo" in rec["config"]["comm"] and "share" in rec["config"]["comm"]
+
+
+@pytest.mark.timeout(1800)
+def test_bare_bench_gpus_8_rehearsal_on_one_device():
+    """the command the driver's scaling run uses at its largest size -- `python bench.py --gpus 8` --
+    rehearsed functionally on whatever this box has (one GPU: eight ranks share device 0 over gloo, and config says so):
+    one JSON line with n_gpus 8 and global_batch 512, a host-loop row per rank, exit status 0 inside the timeout, and no
+    process of the job left behind (the launcher's process group is empty afterwards)."""
+    import json
+    import signal
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "DIAGAN_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--no_cpu_baseline"]
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=1500)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        raise
+    assert proc.returncode == 0, err[-3000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["ranks"] == 8 and rec["config"]["global_batch"] == 512
+    assert rec["config"]["parallelism"] == "dp8" and rec["scaling"] == "weak" and rec["value"] > 0
+    assert len(rec["config"]["devices"]) == 8 and len(rec["host"]["launch_loop_ms_per_step"]) == 8
+    if torch.cuda.device_count() < 8:
+        assert "gloo" in rec["config"]["comm"] and "share" in rec["config"]["comm"]
+    # no leaked children: the session started for the launcher has no live process left
+    deadline = time.time() + 20
+    while True:
+        try:
+            os.killpg(proc.pid, 0)
+        except ProcessLookupError:
+            break
+        assert time.time() < deadline, "processes of the bench job are still alive 20 s after it returned"
+        time.sleep(0.5)
