@@ -49,6 +49,17 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_COL_AT
 #define W4_COL_AT 5
 #endif
+// The same for waves 4-7 (the SIMD partners of waves 0-3: a workgroup's waves w and w + 4 share a SIMD).  With equal placements
+// the two waves of a SIMD run their transform passes -- ~70 + ~45 vector / LDS instructions in a row -- at the same time and
+// the matrix pipe has only the eight MFMAs already in flight to chew on; with different placements one wave's pass sits beside
+// its partner's MFMA slots.  The two groups run two COPIES of the K loop, chosen once by a wave-uniform branch outside it (a
+// branch inside would put a control-flow join into the loop, behind which the compiler waits for every DMA in flight).
+#ifndef W4_ROW_AT2
+#define W4_ROW_AT2 W4_ROW_AT
+#endif
+#ifndef W4_COL_AT2
+#define W4_COL_AT2 W4_COL_AT
+#endif
 static_assert((2 * W4_VSTAGE + W4_U) * 4 <= 163840 && 36 * 32 * 32 <= 2 * W4_VSTAGE + W4_U,
               "162 432 bytes of the CU's 163 840; the epilogue's 36 x 32 x 32 floats fit inside");
 
@@ -481,8 +492,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     }
   };
 #undef W4_WAIT_VM
-  auto kstep = [&](int kk, auto has_next) {
+  auto kstep = [&](int kk, auto has_next, auto row_at, auto col_at) {
     constexpr bool HN = decltype(has_next)::value;
+    constexpr int ROW_AT = decltype(row_at)::value, COL_AT = decltype(col_at)::value;
     const int cur = (kk - k_begin) & 1;
     if (HN) wait_vm(NS - 1);                                  // D(kk, 0) has landed (D(kk, 1 .. NS - 1) may still fly)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -510,10 +522,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         // slot s has been read into registers (the MFMAs above needed it): re-fill it for the next step
         __builtin_amdgcn_sched_barrier(0);
         if (W4_ON(64)) issue_u(kk + 1, s);
-        if (s == (W4_ROW_AT < NS - 2 ? W4_ROW_AT : NS - 4)) {
+        if (s == (ROW_AT < NS - 2 ? ROW_AT : NS - 4)) {
           wait_inputs(s + 1);                             // the input loads have landed (the s + 1 younger DMAs may still fly)
           if (W4_ON(16)) row_pass(cur ^ 1);
-        } else if (s == (W4_COL_AT < NS - 1 ? W4_COL_AT : NS - 2)) {
+        } else if (s == (COL_AT < NS - 1 ? COL_AT : NS - 2)) {
           if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -523,8 +535,16 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     // __syncthreads(): its fence would make the compiler wait for every DMA unit in flight
     if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
-  for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{});
-  if (k_begin < k_end) kstep(k_end - 1, std::false_type{});
+  using RowA = std::integral_constant<int, W4_ROW_AT>;
+  using ColA = std::integral_constant<int, W4_COL_AT>;
+  using RowB = std::integral_constant<int, W4_ROW_AT2>;
+  using ColB = std::integral_constant<int, W4_COL_AT2>;
+  if ((W4_ROW_AT2 == W4_ROW_AT && W4_COL_AT2 == W4_COL_AT) || wave < 4) {
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{}, RowA{}, ColA{});
+  } else {
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{}, RowB{}, ColB{});
+  }
+  if (k_begin < k_end) kstep(k_end - 1, std::false_type{}, RowA{}, ColA{});
 
 #ifdef DIAGAN_WINO_ABLATE
   if (a.tune & 512) {

@@ -185,6 +185,9 @@ class ConvLayer(nn.Module):
         if not training:
             y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up, up_in=up_in)
             return y, bn.stats(y, False)
+        if os.environ.get("DIAGAN_FUSED_BN_STATS", "1") == "0":      # diagnostic: statistics by a separate pass over y
+            y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up, up_in=up_in)
+            return y, bn.stats(y, True, groups=groups)
         residual, res_up = self._res_up(x, residual, res_up, True, pro=pro)
         y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                               residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up, up_in=up_in)

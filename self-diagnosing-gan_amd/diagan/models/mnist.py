@@ -28,6 +28,8 @@ def _bn_pro(bn):
 
 
 class MNIST_DCGAN_Generator(BaseGenerator, TopKGenerator):
+    launch_bound = True      # ~1000 launches of ~10 us per global step: LogTrainer replays the step as one hipGraph
+
     def __init__(self, nz=100, nc=3, loss_type='hinge', topk=1, **kwargs):
         BaseGenerator.__init__(self, nz=100, ngf=128, bottom_width=4, loss_type=loss_type)
         TopKGenerator.__init__(self, use_topk=topk, decay_steps=10)
@@ -109,6 +111,8 @@ class OutLinear(nn.Module):
 
 
 class MNIST_DCGAN_Discriminator(BaseDiscriminator):
+    launch_bound = True      # ~1000 launches of ~10 us per global step: LogTrainer replays the step as one hipGraph
+
     CFG = ((None, 16, 2, False), (16, 32, 1, True), (32, 64, 2, True), (64, 128, 1, True), (128, 256, 2, True),
            (256, 512, 1, True))      # (in, out, stride, batch-norm)
 

@@ -224,6 +224,58 @@ class LogTrainer:
     # the G update on the LAST D batch, step += 1, LR schedule, then the periodic duties in the order
     # summaries, console line, sample grid, logit snapshot, checkpoint (+ pickle of the record).
     def _updates(self, step, streams, log):
+        batches, batches_drs = self._fetch_step(streams)
+        full = all(b[0].shape[0] == self.dataloader.batch_size for b in batches + batches_drs)
+        if full and self._graph_wanted():
+            return self._graphed_updates(step, batches, batches_drs)
+        return self._device_updates(step, batches, batches_drs, log, full)
+
+    # ---- launch-bound networks: the device work of a global step replayed as ONE hipGraph ------------------------------
+    # MNIST-DCGAN's step is ~1000 launches of ~10 us: bound by the per-launch floor, not by the GPU's arithmetic
+    # (bench.py --workload dcgan: 10.2 -> 9.2 ms per step with --graph).  Networks that declare `launch_bound = True` get the
+    # step captured once (diagan/utils/graph.py) after a few ordinary steps and replayed from then on: same kernels, same
+    # order, bit-identical parameters (tests/test_graph_gpu.py).  Not under data parallelism (collectives), top-k or GOLD
+    # (host values that change from step to step are baked into the captured launches); a step with a ragged last batch
+    # runs eagerly.  DIAGAN_GRAPH=0 / 1 forces it off / on.
+    _GRAPH_EAGER_STEPS = 3
+
+    def _graph_wanted(self):
+        env = os.environ.get("DIAGAN_GRAPH")
+        if env == "0" or self.world > 1 or self.topk or self.gold or self.device.type != 'cuda':
+            return False
+        nets = [n for n in (self.netG, self.netD, self.netD_drs) if n is not None]
+        return env == "1" or all(getattr(n, 'launch_bound', False) for n in nets)
+
+    def _graphed_updates(self, step, batches, batches_drs):
+        from diagan.utils.graph import GraphedStep
+        g = getattr(self, '_graph', None)
+        if g is None:
+            self._graph_seen = getattr(self, '_graph_seen', 0) + 1
+            if self._graph_seen <= self._GRAPH_EAGER_STEPS:      # ordinary steps first: every lazily built table exists
+                return self._device_updates(step, batches, batches_drs, MetricLog(), True)
+            # static input tensors the captured launches read; the capture itself runs the host code of ONE step without
+            # device work, the replay right below is this step's device work
+            self._graph_static = [tuple(t.clone() for t in b) for b in batches]
+            self._graph_static_drs = [tuple(t.clone() for t in b) for b in batches_drs]
+            cap_log, n0 = MetricLog(), len(self.events)
+            nets = (self.netG, self.netD, self.netD_drs)
+            g = GraphedStep(lambda: self._device_updates(step, self._graph_static, self._graph_static_drs, cap_log, True),
+                            nets, (self.optG, self.optD, self.optD_drs), warmup=0).capture()
+            self._graph_kinds = [k for _, k in self.events[n0:]]
+            del self.events[n0:]
+            self._graph_metrics = [(name, m._value, m.group, m.precision) for name, m in cap_log.items()]
+            self._graph = g
+        for dst, src in zip(self._graph_static + self._graph_static_drs, batches + batches_drs):
+            for d, t in zip(dst, src):
+                d.copy_(t, non_blocking=True)
+        g()
+        self.events.extend((step, k) for k in self._graph_kinds)
+        log = MetricLog()
+        for name, value, group, precision in self._graph_metrics:       # device scalars the replay has just rewritten
+            log.add_metric(name, value, group=group, precision=precision)
+        return log
+
+    def _fetch_step(self, streams):
         # The real batches of the step are fetched first, in the order the updates consume them (main, drs, main, ...: the
         # iterators advance -- and restart at an epoch's end -- in the reference's order).  Knowing their sizes keeps the
         # stacked generator forward honest: it draws the noise of all the D (and D_drs) updates up front, which equals the
@@ -236,9 +288,11 @@ class LogTrainer:
             if self.train_drs:
                 streams['drs'], b = self._fetch_data(iter_dataloader=streams['drs'], dataloader=self.dataloader_drs)
                 batches_drs.append(b)
+        return batches, batches_drs
+
+    def _device_updates(self, step, batches, batches_drs, log, full):
         prefetch = getattr(self.netG, 'prefetch_fakes', None)       # optional part of the generator protocol
         if prefetch is not None:
-            full = all(b[0].shape[0] == self.dataloader.batch_size for b in batches + batches_drs)
             prefetch(self.n_dis * (2 if self.train_drs else 1) if full else 0, self.dataloader.batch_size,
                      device=self.device, g_step=True)
         # data parallel phase 2: D and D_drs are independent (reference trainer.py:250-277), so D's gradient all-reduce

@@ -54,3 +54,43 @@ def test_graph_refuses_event_timing_and_multi_rank():
             GraphedStep(lambda: None, (), ()).capture()
     finally:
         C.TIMER = None
+
+
+def _train_color_mnist(tmp_path, graph, monkeypatch, steps=10, n_dis=2):
+    import os
+    from diagan.datasets.predefined import get_predefined_dataset
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.trainer.trainer import LogTrainer
+    from diagan.utils.settings import set_seed
+    monkeypatch.setenv("DIAGAN_QUIET", "1")
+    monkeypatch.setenv("DIAGAN_GRAPH", "1" if graph else "0")
+    set_seed(3)
+    netG, netD, optG, optD = get_gan_model('color_mnist', model='mnist_dcgan', loss_type='ns')
+    ds = get_predefined_dataset('color_mnist', num_data=32 * 7 + 8)          # a ragged last batch every 8th fetch
+    dl = torch.utils.data.DataLoader(ds, batch_size=32, shuffle=True)
+    out = os.path.join(str(tmp_path), "g" if graph else "e")
+    t = LogTrainer(output_path=out, netD=netD, netG=netG, optD=optD, optG=optG, dataloader=dl, num_steps=steps,
+                   log_dir=out, n_dis=n_dis, lr_decay='linear', device='cuda', print_steps=2, save_steps=100,
+                   logit_save_steps=100, save_logits=False)
+    t.train()
+    torch.cuda.synchronize()
+    return t
+
+
+def test_log_trainer_replays_launch_bound_steps_as_a_graph(tmp_path, monkeypatch):
+    """LogTrainer replays the device work of a launch-bound network's global step (MNIST-DCGAN declares
+    `launch_bound`) as one hipGraph after three ordinary steps -- same parameters bit for bit as the eager loop after ten
+    steps, including a step with a ragged last batch (which runs eagerly between replays), same event trace, metrics readable."""
+    e = _train_color_mnist(tmp_path, False, monkeypatch)
+    g = _train_color_mnist(tmp_path, True, monkeypatch)
+    assert getattr(e, '_graph', None) is None and g._graph is not None
+    assert torch.equal(e.netG.flat_params, g.netG.flat_params) and torch.equal(e.netD.flat_params, g.netD.flat_params)
+    assert e.events == g.events
+    assert e.optD._step == g.optD._step == 20 and e.optG._step == g.optG._step == 10
+    sd_e, sd_g = e.netD.state_dict(), g.netD.state_dict()
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_g[k]), k
+    monkeypatch.delenv("DIAGAN_GRAPH")
+    assert g._graph_wanted()                       # the default for this family; SNGAN stays eager (GPU-bound)
+    from diagan.models.predefined_models import get_gan_model
+    assert not getattr(get_gan_model('cifar10', model='sngan', loss_type='ns')[0], 'launch_bound', False)

@@ -191,8 +191,20 @@ def test_full_batch_updates_match_oracle_through_the_fused_kernels(dataset, res)
             l2close(gr[k], p.grad, 5e-2, f"G grad {k}")
 
 
-@pytest.mark.parametrize("dataset,res", [("cifar10", 32), ("celeba", 64)])
-def test_full_batch_gradients_against_float64(dataset, res):
+@pytest.fixture
+def wino4_mode(request):
+    """'off': the F(4x4,3x3) kernels (tile_cfg 13 / 15 and the pooled launches on them) are not selected -- the arithmetic the
+    rounds before 3 made their parity claims with (F(2x2) + implicit GEMM); restored afterwards"""
+    from diagan.ops import conv as C
+    if request.param == "off":
+        C.set_winograd4(False)
+    yield request.param
+    C.set_winograd4(None)
+
+
+@pytest.mark.parametrize("dataset,res,wino4_mode", [("cifar10", 32, "default"), ("celeba", 64, "default"), ("cifar10", 32, "off")],
+                         indirect=["wino4_mode"])
+def test_full_batch_gradients_against_float64(dataset, res, wino4_mode):
     """The same D and G updates at batch 64, measured against the TRUTH: oracle/nets.py evaluated in float64 from the same
     weights, images and noise.  Bounds are per-parameter relative L2 distances to the float64 gradient,
     set from what was measured on MI355X for BOTH fp32 implementations (tools/sngan_f64_parity.py,
