@@ -228,6 +228,10 @@ class LogTrainer:
         full = all(b[0].shape[0] == self.dataloader.batch_size for b in batches + batches_drs)
         if full and self._graph_wanted():
             return self._graphed_updates(step, batches, batches_drs)
+        if getattr(self, '_graph', None) is not None or getattr(self, '_graph_seen', 0):
+            # an ordinary step with another batch size re-allocates the per-layer weight-gradient slabs and descriptor
+            # tables the captured launches point to: drop the graph; one ordinary full step rebuilds them, then capture again
+            self._graph, self._graph_seen = None, self._GRAPH_EAGER_STEPS - 1
         return self._device_updates(step, batches, batches_drs, log, full)
 
     # ---- launch-bound networks: the device work of a global step replayed as ONE hipGraph ------------------------------
