@@ -360,12 +360,15 @@ def unpool_fused(geom, B, Hi, Wi):
 
 
 _slabs = {}
+_slabs_retired = []   # outgrown scratch stays allocated: a captured hipGraph may still point at it
 
 
 def _slab(dev, nfloat):
     key = (dev.index, )
     s = _slabs.get(key)
     if s is None or s.numel() < nfloat:
+        if s is not None:
+            _slabs_retired.append(s)
         s = torch.empty(max(nfloat, 1 << 22), dtype=torch.float32, device=dev)
         _slabs[key] = s
     return s

@@ -43,11 +43,14 @@ def _f32(shape, dev):
 
 
 _ws = {}
+_ws_retired = []      # outgrown scratch buffers stay allocated: a captured hipGraph (utils/graph.py) may still point at them
 
 
 def _workspace(dev, nbytes):
     w = _ws.get(dev.index)
     if w is None or w.numel() < nbytes:
+        if w is not None:
+            _ws_retired.append(w)
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
         _ws[dev.index] = w
     return w
