@@ -601,14 +601,16 @@ def test_stacked_forward_folds_the_upsampling_into_c1(dataset, nup, monkeypatch)
     # weight gradient.  Two-launch form: one stacked up-sampling per block in the forward.
     assert all(s[0] == B for s in calls_f) and len(calls_f) == nup, calls_f
     assert sum(1 for s in calls_t if s[0] == (n + 1) * B) == nup, calls_t
+    # (both forms run the F(4x4) transforms in fp32 -- ~1e-5 of the output scale per layer, tests/test_wino4_gpu.py -- but round
+    #  differently: the interpolation before or inside the input transform)
     for a, b in zip(fakes_f, fakes_t):
-        relclose(a, b, 2e-5, "fake batch")
+        relclose(a, b, 1e-4, "fake batch")
     for k in sd_f:
         if 'running' in k:
-            relclose(sd_f[k], sd_t[k], 2e-5, k)
+            relclose(sd_f[k], sd_t[k], 1e-4, k)
     wscale = max(v.norm().item() for v in g_t.values())
     for k in g_t:
         if is_dead_bias(k):
             assert g_f[k].abs().max().item() < 1e-4 * wscale, k
         else:
-            l2close(g_f[k], g_t[k], 1e-2, f"G grad {k}")
+            l2close(g_f[k], g_t[k], 2e-2, f"G grad {k}")
