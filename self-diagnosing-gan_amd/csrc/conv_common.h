@@ -172,6 +172,23 @@ __device__ __forceinline__ bool wino_stage_taps(const float* __restrict__ w, int
   return c0 + q * 4 < Ci;
 }
 
+// Transformed Winograd weights made AHEAD of the launches that use them (round 4): `diagan_wino_weights_batched` transforms the
+// weights of many layers in one launch; a launch whose transformed weights already sit in a caller-owned buffer is told so
+// through diagan_conv_gemm_weights_hint and skips its own per-launch transform kernel.  A format is (kind, flip, scale):
+// kind 2 = F(2x2,3x3) image of wino_weight_kernel, 40 = F(4x4,3x3) MODE 0 / 3 unit order, 41 = the pooled modes' 25-frequency order;
+// flip: taps reversed (data gradient); scale: 1, or 1/16 for the up-sampled-input mode.
+enum WinoKind : int { WK_F2 = 2, WK_F4 = 40, WK_F4_POOL = 41 };
+struct WinoJob {               // one layer of a batched transform (device table)
+  const float* w;              // packed weights [Co][Kp]
+  float* u;                    // transformed weights (format's own size: wino_ws_floats / wino4_ws_floats)
+  int Co, Ci, Kp, kind, flip, blk0;   // blk0: first workgroup of this job in the batched grid
+  float scale;
+  int pad_;
+};
+// (conv_gemm.hip) the transformed weights this launch may use instead of transforming into `ws`: returns the hinted buffer if
+// the caller's hint matches the format, else nullptr; either way notes the format for diagan_conv_gemm_last_weight_format
+const float* wino_weights_ready(int kind, int flip, float scale, long floats);
+
 // Bijective XCD-aware remap of a linear workgroup id (cdna guide T1): consecutive logical tiles
 // land on the same XCD (= same L2), so neighbouring tiles share halo rows and weight panels.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

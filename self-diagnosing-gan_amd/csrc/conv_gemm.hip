@@ -46,6 +46,8 @@ bool wino4_pool_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool f
 int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 bool wino4_upin_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force);
+int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st);     // conv_wino.hip
+int launch_wino4_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st);    // conv_wino4.hip
 int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
@@ -676,6 +678,11 @@ static int g_tune_flags = -1;                     // -1: production default (see
 static long g_lds_delta = 0;
 static int g_wino = -1;                           // -1: DIAGAN_WINO / default (on); 0 / 1: diagan_conv_gemm_set_wino
 static int g_wino4 = -1;                          // -1: DIAGAN_WINO4 / default (on); 0 / 1: diagan_conv_gemm_set_wino4
+// transformed-weights hand-over (conv_common.h): the hint set for the NEXT diagan_conv_gemm call of this thread, the one in
+// force during the current call, and the format the last call needed
+struct WinoFormat { const float* u; int kind, flip; float scale; long floats; };
+static thread_local WinoFormat g_hint_next = {nullptr, 0, 0, 0.f, 0}, g_hint_now = {nullptr, 0, 0, 0.f, 0}, g_fmt_last = {nullptr, 0, 0, 0.f, 0};
+static thread_local long g_weight_launches = 0;   // per-launch weight-transform kernels issued by this thread (tests)
 constexpr int kDefaultTune = 0;
 
 template <int BM, int BN, int WM, int WN, int BK, int PRO, bool STAMP = false, bool FP = false, int KG = 1>
@@ -801,6 +808,37 @@ DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   return sp < 2 ? 1 : (int)sp;
 }
 
+const float* diagan::wino_weights_ready(int kind, int flip, float scale, long floats) {
+  g_fmt_last = WinoFormat{nullptr, kind, flip, scale, floats};
+  if (g_hint_now.u && g_hint_now.kind == kind && g_hint_now.flip == flip && g_hint_now.scale == scale) return g_hint_now.u;
+  ++g_weight_launches;
+  return nullptr;
+}
+
+// see include/diagan_hip.h
+DIAGAN_API int diagan_conv_gemm_weights_hint(const float* u, int kind, int flip, float scale) {
+  g_hint_next = WinoFormat{u, kind, flip, scale, 0};
+  return DIAGAN_OK;
+}
+DIAGAN_API int diagan_conv_gemm_last_weight_format(int* kind, int* flip, float* scale, int64_t* floats, int64_t* launches) {
+  if (kind) *kind = g_fmt_last.kind;
+  if (flip) *flip = g_fmt_last.flip;
+  if (scale) *scale = g_fmt_last.scale;
+  if (floats) *floats = g_fmt_last.floats;
+  if (launches) *launches = g_weight_launches;
+  return DIAGAN_OK;
+}
+DIAGAN_API int64_t diagan_wino_weight_blocks(int Co, int Ci) { return (int64_t)cdiv(Ci, 32) * cdiv(Co, 64); }
+DIAGAN_API int diagan_wino_weights_batched(const void* jobs_f2, int n_f2, int blocks_f2, const void* jobs_f4, int n_f4, int blocks_f4,
+                                           void* stream) {
+  DG_REQUIRE((n_f2 == 0 || (jobs_f2 && blocks_f2 > 0)) && (n_f4 == 0 || (jobs_f4 && blocks_f4 > 0)) && n_f2 >= 0 && n_f4 >= 0,
+             "wino_weights_batched: bad job tables");
+  int rc = DIAGAN_OK;
+  if (n_f2 > 0) rc = launch_wino_weights_batched((const WinoJob*)jobs_f2, n_f2, blocks_f2, (hipStream_t)stream);
+  if (rc == DIAGAN_OK && n_f4 > 0) rc = launch_wino4_weights_batched((const WinoJob*)jobs_f4, n_f4, blocks_f4, (hipStream_t)stream);
+  return rc;
+}
+
 // see include/diagan_hip.h
 DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const float* bias,
                                 const float* residual, int res_relu, const float* mask_src, float mask_slope,
@@ -810,6 +848,9 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                                 int R, int S, int sy, int dr, int off, int up, int Kp, int tile_cfg,
                                 float* splitk_ws, int64_t splitk_ws_floats, float* stat_partials, int pro_group_rows,
                                 void* stream) {
+  g_hint_now = g_hint_next;                 // a hint holds for exactly one call, whatever path that call takes
+  g_hint_next = WinoFormat{nullptr, 0, 0, 0.f, 0};
+  g_fmt_last = WinoFormat{nullptr, 0, 0, 0.f, 0};
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);

@@ -28,12 +28,11 @@ namespace diagan {
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 4 i + j, written in the LDS image order (see above).  flip: the data-gradient of a
 // stride-1 convolution is the correlation with the taps reversed.
-__global__ __launch_bounds__(512) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                          int Kp, int flip) {
-  __shared__ f32x4 sg[WT_LDS_F4];
+__device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci, int Kp, int flip,
+                                                 int bx, int by, f32x4* __restrict__ sg) {
   f32x4 g[3][3];
-  if (!wino_stage_taps(w, blockIdx.y * 64, blockIdx.x * 32, Co, Ci, Kp, flip, sg, g)) return;
-  const int col = threadIdx.x & 63, c = blockIdx.x * 32 + (threadIdx.x >> 6) * 4;
+  if (!wino_stage_taps(w, by * 64, bx * 32, Co, Ci, Kp, flip, sg, g)) return;
+  const int col = threadIdx.x & 63, c = bx * 32 + (threadIdx.x >> 6) * 4;
   f32x4 t[4][3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
@@ -43,7 +42,7 @@ __global__ __launch_bounds__(512) void wino_weight_kernel(const float* __restric
     t[3][s] = g[2][s];
   }
   const int ks = c >> 3, kq = (c >> 2) & 1;
-  float* base = ug + ((long)blockIdx.y * (Ci >> 3) + ks) * (16 * 2 * 64 * 4);
+  float* base = ug + ((long)by * (Ci >> 3) + ks) * (16 * 2 * 64 * 4);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x4 u[4];
@@ -61,6 +60,23 @@ __global__ __launch_bounds__(512) void wino_weight_kernel(const float* __restric
       *reinterpret_cast<f32x4*>(plane + col * 4) = v;
     }
   }
+}
+
+__global__ __launch_bounds__(512) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                          int Kp, int flip) {
+  __shared__ f32x4 sg[WT_LDS_F4];
+  wino_weight_body(w, ug, Co, Ci, Kp, flip, blockIdx.x, blockIdx.y, sg);
+}
+
+// the same transform for MANY layers in one launch (diagan_wino_weights_batched): workgroup -> job through the jobs' first-block
+// prefix (a handful of jobs: linear scan), then the job's own (channel block, column block)
+__global__ __launch_bounds__(512) void wino_weight_batched_kernel(const WinoJob* __restrict__ jobs, int n) {
+  __shared__ f32x4 sg[WT_LDS_F4];
+  int j = 0;
+  while (j + 1 < n && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const WinoJob job = jobs[j];
+  const int lb = blockIdx.x - job.blk0, nbx = (job.Ci + 31) >> 5;
+  wino_weight_body(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, lb % nbx, lb / nbx, sg);
 }
 
 constexpr int WT = 64;                 // tiles per workgroup
@@ -496,8 +512,17 @@ static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t s
   return check_launch("conv_wino");
 }
 
-void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, hipStream_t st) {
+long wino_ws_floats(int Co, int Ci);
+// transformed weights of this launch: the caller's ready-made buffer if it hinted the right format, else `ug` after a transform
+const float* launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, hipStream_t st) {
+  if (const float* ready = wino_weights_ready(WK_F2, flip, 1.f, wino_ws_floats(Co, Ci))) return ready;
   hipLaunchKernelGGL(wino_weight_kernel, dim3(cdiv(Ci, 32), cdiv(Co, WN)), dim3(512), 0, st, w, ug, Co, Ci, Kp, flip);
+  return ug;
+}
+
+int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3(blocks), dim3(512), 0, st, jobs, n);
+  return check_launch("wino_weights_batched (F(2x2))");
 }
 
 // floats of workspace the transformed weights need
@@ -526,13 +551,13 @@ int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
-  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
+  const float* ug = launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
   switch (a.pro_mode) {
-    case PRO_NONE: return launch_wino_pro<PRO_NONE>(a, ws, st);
-    case PRO_RELU: return launch_wino_pro<PRO_RELU>(a, ws, st);
-    case PRO_AFFINE_RELU: return launch_wino_pro<PRO_AFFINE_RELU>(a, ws, st);
-    case PRO_LRELU: return launch_wino_pro<PRO_LRELU>(a, ws, st);
-    default: return launch_wino_pro<PRO_AFFINE>(a, ws, st);
+    case PRO_NONE: return launch_wino_pro<PRO_NONE>(a, ug, st);
+    case PRO_RELU: return launch_wino_pro<PRO_RELU>(a, ug, st);
+    case PRO_AFFINE_RELU: return launch_wino_pro<PRO_AFFINE_RELU>(a, ug, st);
+    case PRO_LRELU: return launch_wino_pro<PRO_LRELU>(a, ug, st);
+    default: return launch_wino_pro<PRO_AFFINE>(a, ug, st);
   }
 }
 

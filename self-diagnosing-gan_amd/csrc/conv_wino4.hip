@@ -100,17 +100,16 @@ __host__ __device__ __forceinline__ int w4p_freq(int v) { return v < 2 ? v : v +
 // group = (i / 3) * 2 + j / 3 (a 3 x 3 block of the 6 x 6 frequencies), slot = 3 (i % 3) + j % 3.
 // flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
 template <int MODE>
-__global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
-                                                           int Kp, int flip, float wscale) {
-  __shared__ f32x4 sg[WT_LDS_F4];
+__device__ __forceinline__ void wino4_weight_body(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci, int Kp, int flip,
+                                                  float wscale, int bx, int by, f32x4* __restrict__ sg) {
   f32x4 g[3][3];
-  const int nb = blockIdx.y;
-  if (!wino_stage_taps(w, nb * 64, blockIdx.x * 32, Co, Ci, Kp, flip, sg, g)) return;
+  const int nb = by;
+  if (!wino_stage_taps(w, nb * 64, bx * 32, Co, Ci, Kp, flip, sg, g)) return;
   if (wscale != 1.f) {                                  // (MODE 3: the 1/16 of the two interpolation passes, exact)
 #pragma unroll
     for (int t = 0; t < 9; ++t) g[t / 3][t % 3] *= wscale;
   }
-  const int col = threadIdx.x & 63, c = blockIdx.x * 32 + (threadIdx.x >> 6) * 4;
+  const int col = threadIdx.x & 63, c = bx * 32 + (threadIdx.x >> 6) * 4;
   constexpr float k4 = 0.25f, k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
   auto gt = [&](const f32x4& g0, const f32x4& g1, const f32x4& g2, f32x4* o) {
     o[0] = k4 * g0;
@@ -142,6 +141,24 @@ __global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restri
       }
     }
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                           int Kp, int flip, float wscale) {
+  __shared__ f32x4 sg[WT_LDS_F4];
+  wino4_weight_body<MODE>(w, ug, Co, Ci, Kp, flip, wscale, blockIdx.x, blockIdx.y, sg);
+}
+
+// the same transforms for MANY layers in one launch (diagan_wino_weights_batched; see conv_wino.hip's counterpart)
+__global__ __launch_bounds__(512) void wino4_weight_batched_kernel(const WinoJob* __restrict__ jobs, int n) {
+  __shared__ f32x4 sg[WT_LDS_F4];
+  int j = 0;
+  while (j + 1 < n && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
+  const WinoJob job = jobs[j];
+  const int lb = blockIdx.x - job.blk0, nbx = (job.Ci + 31) >> 5;
+  if (job.kind == WK_F4) wino4_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  else wino4_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
 }
 
 // 1-D input transform B^T (6 -> 6), in place.  Every line is a * K + b with a SCALAR K the compiler cannot see through
@@ -775,6 +792,22 @@ static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t 
 // floats of workspace the transformed weights need
 long wino4_ws_floats(int Co, int Ci) { return (long)cdiv(Co, W4N) * W4N * Ci * 36; }
 
+// transformed weights of this launch (weight-kernel mode WM: 0 = all 36 frequencies, 1 = the pooled modes' 25): the caller's
+// ready-made buffer if it hinted this format (diagan_conv_gemm_weights_hint), else `ws` after the per-launch transform
+template <int WM>
+static const float* wino4_weights(const ConvGemmArgs& a, float* ws, int flip, float scale, long floats, hipStream_t st) {
+  if (const float* ready = wino_weights_ready(WM ? WK_F4_POOL : WK_F4, flip, scale, floats)) return ready;
+  const ConvGeom& g = a.g;
+  hipLaunchKernelGGL(wino4_weight_kernel<WM>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, flip,
+                     scale);
+  return ws;
+}
+
+int launch_wino4_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(wino4_weight_batched_kernel, dim3(blocks), dim3(512), 0, st, jobs, n);
+  return check_launch("wino_weights_batched (F(4x4))");
+}
+
 // geometry the F(4x4,3x3) kernel takes on top of diagan_conv_wino_supported: H and W multiples of 4
 bool wino4_geom_ok(int Ho, int Wo, int Ci) { return !(Ho & 3) && !(Wo & 3) && (Ci & 7) == 0; }
 
@@ -812,14 +845,13 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp,
-                     g.dr < 0 ? 1 : 0, 1.f);
+  const float* ug = wino4_weights<0>(a, ws, g.dr < 0 ? 1 : 0, 1.f, wino4_ws_floats(g.Co, g.Ci), st);
   switch (a.pro_mode) {
-    case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ws, st);
-    case PRO_RELU: return launch_wino4_pro<PRO_RELU>(a, ws, st);
-    case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU>(a, ws, st);
-    case PRO_LRELU: return launch_wino4_pro<PRO_LRELU>(a, ws, st);
-    default: return launch_wino4_pro<PRO_AFFINE>(a, ws, st);
+    case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ug, st);
+    case PRO_RELU: return launch_wino4_pro<PRO_RELU>(a, ug, st);
+    case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU>(a, ug, st);
+    case PRO_LRELU: return launch_wino4_pro<PRO_LRELU>(a, ug, st);
+    default: return launch_wino4_pro<PRO_AFFINE>(a, ug, st);
   }
 }
 
@@ -840,16 +872,16 @@ int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0, 1.f);
-  return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1>(a, ws, st) : launch_wino4_pro<PRO_NONE, 1>(a, ws, st);
+  const float* ug = wino4_weights<1>(a, ws, 0, 1.f, (long)cdiv(g.Co, W4N) * W4N * g.Ci * 28, st);
+  return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1>(a, ug, st) : launch_wino4_pro<PRO_NONE, 1>(a, ug, st);
 }
 
 int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<1>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 1, 1.f);
-  return launch_wino4_pro<PRO_NONE, 2>(a, ws, st);
+  const float* ug = wino4_weights<1>(a, ws, 1, 1.f, (long)cdiv(g.Co, W4N) * W4N * g.Ci * 28, st);
+  return launch_wino4_pro<PRO_NONE, 2>(a, ug, st);
 }
 
 // tile_cfg 15 on the F(4x4) kernel (MODE 3): conv3x3(bilinear x2 (pro(x))) from the HALF-resolution input -- GBlock's
@@ -870,14 +902,13 @@ int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  hipLaunchKernelGGL(wino4_weight_kernel<0>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, 0,
-                     0.0625f);
+  const float* ug = wino4_weights<0>(a, ws, 0, 0.0625f, wino4_ws_floats(g.Co, g.Ci), st);
   switch (a.pro_mode) {
-    case PRO_NONE: return launch_wino4_pro<PRO_NONE, 3>(a, ws, st);
-    case PRO_RELU: return launch_wino4_pro<PRO_RELU, 3>(a, ws, st);
-    case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU, 3>(a, ws, st);
-    case PRO_LRELU: return launch_wino4_pro<PRO_LRELU, 3>(a, ws, st);
-    default: return launch_wino4_pro<PRO_AFFINE, 3>(a, ws, st);
+    case PRO_NONE: return launch_wino4_pro<PRO_NONE, 3>(a, ug, st);
+    case PRO_RELU: return launch_wino4_pro<PRO_RELU, 3>(a, ug, st);
+    case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU, 3>(a, ug, st);
+    case PRO_LRELU: return launch_wino4_pro<PRO_LRELU, 3>(a, ug, st);
+    default: return launch_wino4_pro<PRO_AFFINE, 3>(a, ug, st);
   }
 }
 

@@ -348,7 +348,7 @@ static int launch_wino_pool_pro(const ConvGemmArgs& a, const float* ug, hipStrea
   return check_launch("conv_wino_pool");
 }
 
-void launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, hipStream_t st);   // conv_wino.hip
+const float* launch_wino_weights(const float* w, float* ug, int Co, int Ci, int Kp, int flip, hipStream_t st);   // conv_wino.hip
 
 // Split-K factor of the pooled kernels: 1 when the launch has >= min_wgs workgroups, else the smallest split that reaches
 // 256 workgroups with at least 8 K-steps each; 0 = neither (the caller keeps the separate convolution + pooling).
@@ -367,10 +367,10 @@ int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
-  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
+  const float* ug = launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
   if (g.Co % 128 == 0)
-    return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU, false, 2>(a, ws, st) : launch_wino_pool_pro<PRO_NONE, false, 2>(a, ws, st);
-  return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU, false, 1>(a, ws, st) : launch_wino_pool_pro<PRO_NONE, false, 1>(a, ws, st);
+    return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU, false, 2>(a, ug, st) : launch_wino_pool_pro<PRO_NONE, false, 2>(a, ug, st);
+  return a.pro_mode == PRO_RELU ? launch_wino_pool_pro<PRO_RELU, false, 1>(a, ug, st) : launch_wino_pool_pro<PRO_NONE, false, 1>(a, ug, st);
 }
 
 // tile_cfg 12: a.x is the HALF-resolution gradient [B][Ho/2][Wo/2][Ci]; y / mask_src / residual are full resolution
@@ -378,8 +378,8 @@ int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
-  launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
-  return g.Co % 128 == 0 ? launch_wino_pool_pro<PRO_NONE, true, 2>(a, ws, st) : launch_wino_pool_pro<PRO_NONE, true, 1>(a, ws, st);
+  const float* ug = launch_wino_weights(a.w, ws, g.Co, g.Ci, g.Kp, g.dr < 0 ? 1 : 0, st);
+  return g.Co % 128 == 0 ? launch_wino_pool_pro<PRO_NONE, true, 2>(a, ug, st) : launch_wino_pool_pro<PRO_NONE, true, 1>(a, ug, st);
 }
 
 }  // namespace diagan

@@ -100,11 +100,35 @@ class ConvLayer(nn.Module):
 
     # ---- compute ----
     class Ctx:
-        __slots__ = ("wf", "wd", "u", "v", "state", "_keep", "row_scale", "pair")
+        __slots__ = ("wf", "wd", "u", "v", "state", "_keep", "row_scale", "pair", "wkey", "wver")
 
         def __init__(self):
             self.row_scale = None      # (inv_sigma0, inv_sigma1): two forwards batched into one GEMM
             self.pair = None           # their two per-forward SN contexts
+            self.wkey = None           # which of the layer's operand sets this is: None (plain layer), slot number, 'pair'
+            self.wver = None           # version of the operands wf / wd (what the batched Winograd transforms were made from)
+
+    # ---- Winograd weights transformed ahead, many layers per launch (ops/conv.py: WinoWeightBatch) ----
+    def _wsite(self, ctx, role):
+        """(site, version) of this layer's forward ('f') / data-gradient ('d') launches with the operand set `ctx`, or
+        (None, None) where no Winograd kernel can run (only 3x3 / stride 1 / pad 1 convolutions with Ci % 8 == 0 have one)"""
+        net = getattr(self, '_net', None)
+        g = self.geom
+        if (net is None or not C.WINO_BATCH or ctx.wver is None or g.kind != 'conv' or g.R != 3 or g.S != 3 or g.stride != 1
+                or g.pad != 1 or (g.Ci if role == 'f' else g.Co) % 8):
+            return None, None
+        sites = self.__dict__.setdefault('_wsites', {})
+        key = (role, ctx.wkey, id(ctx) if self.sn else 0)
+        site = sites.get(key)
+        if site is None:
+            batch = net.wino_batch((role, ctx.wkey))
+            if self.sn:
+                w_of = (lambda c=ctx: c.wf) if role == 'f' else (lambda c=ctx: c.wd)
+            else:
+                w_of = (lambda m=self: m.weight.data) if role == 'f' else (lambda m=self: m._wd)
+            dims = (g.Co, g.Ci, g.Kp) if role == 'f' else (g.Ci, g.Co, g.Kd)
+            site = sites[key] = batch.site(w_of, *dims)
+        return site, ctx.wver
 
     def prepare(self, training, need_dgrad=True, slot=None):
         """Per-forward operand preparation.  SN layers: one power iteration + scaled packing (done for
@@ -133,6 +157,7 @@ class ConvLayer(nn.Module):
             ctx.u = ctx.v = ctx.state = None
             ctx.wf = self.weight.data
             ctx.wd = None
+            ctx.wver = self._net.param_version if getattr(self, '_net', None) is not None else None
             if need_dgrad:
                 ver = self._net.param_version if getattr(self, '_net', None) is not None else -2
                 if self._wd is None or self._wd_version != ver or ver == -2:
@@ -166,16 +191,18 @@ class ConvLayer(nn.Module):
 
     def fwd(self, ctx, x, pro=None, residual=None, res_relu=False, tile_cfg=0, res_up=False, up_in=False):
         residual, res_up = self._res_up(x, residual, res_up, False, tile_cfg, pro)
+        ws, wv = self._wsite(ctx, 'f')
         return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
                           residual=residual, pro=pro, tile_cfg=tile_cfg, res_relu=res_relu, row_scale=ctx.row_scale,
-                          res_up=res_up, up_in=up_in)
+                          res_up=res_up, up_in=up_in, wsite=ws, wversion=wv)
 
     def fwd_pool(self, ctx, x, pro=None, residual=None):
         """avg_pool2d(conv(pro(x)) + bias, 2) + residual (the end of a down-sampling DBlock): ONE launch on 9/16 of the
         Winograd products where the layer qualifies (C.pool_fused), else the convolution followed by diagan_avgpool2."""
         if C.pool_fused(self.geom, x.shape[0], x.shape[1], x.shape[2], pro):
+            ws, wv = self._wsite(ctx, 'f')
             return C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data, residual=residual,
-                              pro=pro, row_scale=ctx.row_scale, pool=True)
+                              pro=pro, row_scale=ctx.row_scale, pool=True, wsite=ws, wversion=wv)
         return E.avgpool2(self.fwd(ctx, x, pro=pro), residual=residual)
 
     def fwd_bn(self, ctx, x, bn, training, pro=None, residual=None, groups=1, res_up=False, up_in=False):
@@ -189,8 +216,10 @@ class ConvLayer(nn.Module):
             y = self.fwd(ctx, x, pro=pro, residual=residual, res_up=res_up, up_in=up_in)
             return y, bn.stats(y, True, groups=groups)
         residual, res_up = self._res_up(x, residual, res_up, True, pro=pro)
+        ws, wv = self._wsite(ctx, 'f')
         y, stats = C.conv_fwd(self.geom, x, ctx.wf, bias=None if self.bias is None else self.bias.data,
-                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up, up_in=up_in)
+                              residual=residual, pro=pro, row_scale=ctx.row_scale, want_stats=True, res_up=res_up, up_in=up_in,
+                              wsite=ws, wversion=wv)
         M = y.numel() // y.shape[-1]
         if stats is None or stats[1] % groups or (M // groups) % (M // stats[1]):
             return y, bn.stats(y, True, groups=groups)
@@ -202,12 +231,14 @@ class ConvLayer(nn.Module):
     def dgrad_unpool(self, ctx, dy_pooled, in_hw, residual=None, mask_src=None, mask_slope=0.0):
         """conv^T(avg_pool2d_backward(dy_pooled)): the data-gradient of a layer whose output was average-pooled, from the
         pooled gradient in one launch (callers check dgrad_unpool_fused first)"""
+        ws, wv = self._wsite(ctx, 'd')
         return C.conv_dgrad(self.geom, dy_pooled, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
-                            mask_slope=mask_slope, row_scale=ctx.row_scale, unpool=True)
+                            mask_slope=mask_slope, row_scale=ctx.row_scale, unpool=True, wsite=ws, wversion=wv)
 
     def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
+        ws, wv = self._wsite(ctx, 'd')
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
-                            mask_slope=mask_slope, row_scale=ctx.row_scale)
+                            mask_slope=mask_slope, row_scale=ctx.row_scale, wsite=ws, wversion=wv)
 
     def wgrad_pooled_ok(self, dy_pooled, x):
         """The weight gradient of avg_pool2d(conv3x3(act(x)), 2) from the POOLED gradient: a 3x3 / stride 2 / pad 0 weight
@@ -475,7 +506,7 @@ class SNBatch:
                     ctx = HeadLinear.Ctx()
                 ctx.u, ctx.v, ctx.state = torch.zeros(Co, **f32), torch.zeros(Kp, **f32), torch.ones(2, **f32)
                 if isinstance(m, ConvLayer):
-                    ctx.wf, ctx.wd = wf, wd
+                    ctx.wf, ctx.wd, ctx.wkey = wf, wd, slot
                 work = torch.zeros(8 * Kp + Co, **f32)
                 ctx._keep = (work,)
                 if not hasattr(m, '_slot_ctx') or m._slot_ctx is None or len(m._slot_ctx) != n_slots:
@@ -503,12 +534,16 @@ class SNBatch:
             pc.u = pc.v = pc.state = None
             pc.row_scale = (m._slot_ctx[0].state[1:], m._slot_ctx[1].state[1:])
             pc.pair = (m._slot_ctx[0], m._slot_ctx[1])
+            pc.wkey = 'pair'
             m._pair_ctx = pc
             ptab[li]['p'] = [m.weight.data.data_ptr(), 0, 0, 0, 0, self.unit.data_ptr(), 0, 0, wd_raw.data_ptr()]
             ptab[li]['i'] = [g.Co, g.Ci, g.R * g.S, g.Kp, g.Kd, 0]
         self.pair_table = torch.from_numpy(ptab.view(np.uint8).copy()).to(dev)
         self.n_convs = len(convs)
         self.pair_version = None
+        self.convs = convs
+        self.runs = 0                 # operand-set versions: every run() that re-packs W / sigma of its slot makes a new one
+        self.slot_ver = {}
 
     def stale(self):
         self.net.flat_params                      # (builds the slabs if they do not exist yet)
@@ -524,6 +559,8 @@ class SNBatch:
             nat.call("diagan_pack_batched", self.pair_table.data_ptr(), self.n_convs, self.max[0], self.max[1],
                      self.max[2], 1, nat.current_stream())
             self.pair_version = self.net.param_version
+        for m in self.convs:          # pair mode runs on the un-normalised master weight: its operands change with the parameters
+            m._pair_ctx.wver = ('p', self.net.param_version)
 
     def run(self, slot, training, write_wd):
         nat = self.nat
@@ -531,6 +568,11 @@ class SNBatch:
                  self.max[1], self.max[2], self.max[3], 1e-12, 1 if training else 0,
                  write_wd if isinstance(write_wd, int) and not isinstance(write_wd, bool) else (1 if write_wd else 0),
                  nat.current_stream())
+        if write_wd != -1:            # (-1: power iteration only, pair mode) W / sigma of this slot was re-packed
+            self.runs += 1
+            self.slot_ver[slot] = ('s', self.runs)
+            for m in self.convs:
+                m._slot_ctx[slot].wver = self.slot_ver[slot]
 
 
 class WgradBatch:
@@ -682,6 +724,14 @@ class FlatNet(nn.Module):
         self._flat = None
         self._flat_grad = None
         object.__setattr__(self, 'wgrad_batch', WgradBatch(self))
+        object.__setattr__(self, '_wino_batches', {})
+
+    def wino_batch(self, key):
+        """the WinoWeightBatch of one part of a pass: key = ('f' | 'd', None | slot | 'pair')"""
+        b = self._wino_batches.get(key)
+        if b is None:
+            b = self._wino_batches[key] = C.WinoWeightBatch()
+        return b
 
     def _link_layers(self):
         for m in self.modules():
@@ -712,9 +762,11 @@ class FlatNet(nn.Module):
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn)
         self._build_flat()
+        self._wino_batches.clear()
         for m in self.modules():
             if isinstance(m, ConvLayer):
                 m._wd = None
+                m.__dict__.pop('_wsites', None)
         return out
 
     def zero_grad(self, set_to_none=False):

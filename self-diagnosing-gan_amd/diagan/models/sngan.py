@@ -253,6 +253,7 @@ class SNGANBaseGenerator(BaseGenerator):
         statistics and running-statistics updates per batch, in order) at the GEMM efficiency of the large batch.
         Forward only (save=False), or with the backward context of ONE batch (save=True, save_group)."""
         z = z.to(dtype=self.l1.weight.dtype)
+        self.wino_batch(('f', None)).prepare(self.param_version)       # Winograd weights of all blocks in one launch
         x0, h = self.l1.fwd(z)
         bctx = []
         blocks = self._blocks()
@@ -275,6 +276,7 @@ class SNGANBaseGenerator(BaseGenerator):
 
     def backward_nhwc(self, ctx, g_img):
         g_pre = E.tanh_bwd(ctx['y'], g_img)
+        self.wino_batch(('d', None)).prepare(self.param_version)
         h = ctx['h']
         self._last_conv.wgrad(ctx['k'], g_pre, h, pro=_bn_pro(ctx['bn']))
         g_a = self._last_conv.dgrad(ctx['k'], g_pre, h.shape[1:3])
@@ -361,6 +363,7 @@ class SNGANBaseDiscriminator(BaseDiscriminator):
 
     def forward_nhwc(self, x, training, save=True, need_dgrad=True, need_in_dgrad=True, slot=0):
         self._sn_prepare(slot, training, need_dgrad)
+        self.wino_batch(('f', slot)).prepare(self._wino_version(slot))
         blocks = self._blocks()
         h, c0 = blocks[0].forward(x, training, save=save, need_dgrad=need_dgrad, need_in_dgrad=need_in_dgrad,
                                   slot=slot)
@@ -371,7 +374,12 @@ class SNGANBaseDiscriminator(BaseDiscriminator):
         hctx, logit = self._head.fwd(h, training, slot=slot)
         return logit, (dict(bctx=bctx, hctx=hctx, slot=slot) if save else None)
 
+    def _wino_version(self, slot):
+        sb = self._sn_batch
+        return ('p', self.param_version) if slot == 'pair' else sb.slot_ver.get(slot)
+
     def backward_nhwc(self, ctx, dlogit, need_wgrad=True, need_gx=False):
+        self.wino_batch(('d', ctx['slot'])).prepare(self._wino_version(ctx['slot']))
         g = self._head.bwd(ctx['hctx'], dlogit, need_wgrad=need_wgrad)
         blocks = self._blocks()
         for i in range(len(blocks) - 1, -1, -1):

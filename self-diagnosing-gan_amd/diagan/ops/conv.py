@@ -17,6 +17,10 @@ nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_wino4_pool_used", [I] * 5 + [I64])
 nat.register("diagan_conv_wino4_upin_supported", [I] * 13 + [I64, I])
+nat.register("diagan_conv_gemm_weights_hint", [P, I, I, F])
+nat.register("diagan_conv_gemm_last_weight_format", [P, P, P, P, P])
+nat.register("diagan_wino_weight_blocks", [I, I])
+nat.register("diagan_wino_weights_batched", [P, I, I, P, I, I, P])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
@@ -118,6 +122,93 @@ TIMER = None      # set to a KernelTimer by bench.py
 _NAME_CACHE = {}
 
 
+# ---- Winograd weights transformed ahead of their launches, many layers per launch (include/diagan_hip.h, round 4) -------------
+# Every Winograd launch otherwise starts with a 5-7 us weight-transform kernel of its own (48 / 124 per SNGAN-32 / -64 step).
+# A `WinoWeights` object stands for ONE call site of one layer (its forward, its data gradient, ...): the first pass through
+# the site runs as before and notes which format the launch needed; from then on the network's `WinoWeightBatch` transforms
+# all its sites' weights in one launch per pass (F(2x2) and F(4x4) formats apart) and the launches take the ready buffer.
+# A launch that turns out to need another format than last time (another batch size -> another kernel) ignores the hint
+# and transforms its own weights, and the site re-learns.  DIAGAN_WINO_BATCH=0: every launch transforms its own, as before.
+import ctypes as _ct
+import os as _os
+
+WINO_BATCH = _os.environ.get("DIAGAN_WINO_BATCH", "1") != "0"
+
+
+class WinoWeights:
+    __slots__ = ("w_of", "Co", "Ci", "Kp", "fmt", "u", "ready", "used")
+
+    def __init__(self, w_of, Co, Ci, Kp):
+        self.w_of, self.Co, self.Ci, self.Kp = w_of, Co, Ci, Kp       # w_of(): the packed operand this site's launches read
+        self.fmt, self.u, self.ready, self.used = None, None, None, False
+
+
+def last_weight_format():
+    k, f, sc, n, cnt = _ct.c_int(), _ct.c_int(), _ct.c_float(), _ct.c_int64(), _ct.c_int64()
+    nat.call("diagan_conv_gemm_last_weight_format", _ct.byref(k), _ct.byref(f), _ct.byref(sc), _ct.byref(n), _ct.byref(cnt))
+    return (k.value, f.value, sc.value, n.value), cnt.value
+
+
+class WinoWeightBatch:
+    """The call sites of one network pass (e.g. "D forward, pair mode") whose transformed weights are made together."""
+
+    def __init__(self):
+        self.sites = []
+        self._table_key, self._tables = None, None
+
+    def site(self, w_of, Co, Ci, Kp):
+        s = WinoWeights(w_of, Co, Ci, Kp)
+        self.sites.append(s)
+        return s
+
+    def prepare(self, version):
+        """Transform the weights of every site with a known format whose buffer is not at `version` yet (one launch per
+        format family).  Called at the start of the pass, after the operands the sites read have been written."""
+        if not WINO_BATCH:
+            return
+        import numpy as np
+        todo = [s for s in self.sites if s.fmt is not None and s.fmt[0] and s.used and s.ready != version]
+        if not todo:
+            return
+        key = tuple((id(s), s.fmt, s.w_of().data_ptr()) for s in todo)
+        if key != self._table_key:
+            desc = np.dtype([('w', np.uint64), ('u', np.uint64), ('i', np.int32, 6), ('scale', np.float32), ('pad', np.int32)])
+            tabs = []
+            for fam in ((2,), (40, 41)):
+                jobs = [s for s in todo if s.fmt[0] in fam]
+                tab, blk = np.zeros(max(len(jobs), 1), dtype=desc), 0
+                for j, s in enumerate(jobs):
+                    w = s.w_of()
+                    if s.u is None or s.u.numel() != s.fmt[3] or s.u.device != w.device:
+                        s.u = torch.empty(s.fmt[3], dtype=torch.float32, device=w.device)
+                    tab[j]['w'], tab[j]['u'] = w.data_ptr(), s.u.data_ptr()
+                    tab[j]['i'] = [s.Co, s.Ci, s.Kp, s.fmt[0], s.fmt[1], blk]
+                    tab[j]['scale'] = s.fmt[2]
+                    blk += nat.fn("diagan_wino_weight_blocks")(s.Co, s.Ci)
+                dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(todo[0].w_of().device) if jobs else None
+                tabs.append((dev_tab, len(jobs), blk))
+            self._table_key, self._tables = key, tabs
+        (t2, n2, b2), (t4, n4, b4) = self._tables
+        nat.call("diagan_wino_weights_batched", nat.ptr(t2), n2, b2, nat.ptr(t4), n4, b4, nat.current_stream())
+        for s in todo:
+            s.ready = version
+
+
+def _hint(wsite, version):
+    """before a diagan_conv_gemm call of this site: hand over the ready buffer, if there is one for this version"""
+    if wsite is not None and WINO_BATCH and wsite.u is not None and wsite.ready == version and wsite.fmt is not None:
+        nat.call("diagan_conv_gemm_weights_hint", wsite.u.data_ptr(), wsite.fmt[0], wsite.fmt[1], wsite.fmt[2])
+
+
+def _learn(wsite):
+    """after the call: the format it needed (kind 0: no Winograd kernel ran)"""
+    if wsite is not None and WINO_BATCH:
+        fmt, _ = last_weight_format()
+        wsite.used = True
+        if fmt != wsite.fmt:
+            wsite.fmt, wsite.ready = fmt, None
+
+
 def set_winograd(mode):
     """True / False: allow / forbid the Winograd kernel for auto-selected tile configurations; None: the default
     (on, or what DIAGAN_WINO says)"""
@@ -178,7 +269,8 @@ def _chk(t, name):
 
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
-          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False, up_in=False):
+          res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False, up_in=False,
+          wsite=None, wversion=None):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
@@ -245,12 +337,14 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
                 w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())))
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
+    _hint(wsite, wversion)
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              (1 if res_relu else 0) | (2 if res_up else 0), nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
              (B // 2) * Ho * Wo if row_scale else 0,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
              nat.ptr(stats[0]) if stats else None, group_imgs * Ho * Wo, nat.current_stream())
+    _learn(wsite)
     if t0 is not None:
         TIMER.end(kname, 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                   (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}{'+res' if residual is not None else ''}"
@@ -312,7 +406,7 @@ def pool_fused(geom, B, Hi, Wi, pro=None):
 
 
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False, up_in=False):
+             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False, up_in=False, wsite=None, wversion=None):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co].
     res_up: `residual` is [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling is added (see res_up_fused).
     pool: y = avg_pool2d(conv(pro(x)) + bias, 2) + residual, y and residual [B,Ho/2,Wo/2,Co] (see pool_fused).
@@ -327,11 +421,11 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
                  tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up, pool=pool,
-                 up_in=up_in)
+                 up_in=up_in, wsite=wsite, wversion=wversion)
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,
-               row_scale=None, wino=True, unpool=False):
+               row_scale=None, wino=True, unpool=False, wsite=None, wversion=None):
     """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci].
     unpool: dy is the gradient of the 2x2-average-POOLED output, [B,Ho/2,Wo/2,Co]: dx = conv^T(avg_pool2d_backward(dy))
     in one launch (see unpool_fused)."""
@@ -344,7 +438,7 @@ def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0
     if out is None:
         out = torch.empty((B, Hi, Wi, geom.Ci), dtype=torch.float32, device=dy.device)
     return _gemm(dy, wd, out, geom.dgrad_params(), geom.R, geom.S, geom.Kd, None, residual, mask_src, mask_slope,
-                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino, unpool=unpool)
+                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino, unpool=unpool, wsite=wsite, wversion=wversion)
 
 
 def unpool_fused(geom, B, Hi, Wi):
