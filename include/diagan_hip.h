@@ -179,11 +179,11 @@ int diagan_conv_wino4_upin_supported(int B, int Hi, int Wi, int Ci, int Ho, int 
 /* Winograd weight transforms made ahead of the launches that use them (round 4).  Every Winograd launch of diagan_conv_gemm
  * (tile_cfg 9, 11, 12, 13, 15) first transforms its weights into `splitk_ws` with a small kernel of its own: 48 (SNGAN-32) to
  * 124 (SNGAN-64) launches of 5-7 us per training step.  A caller that knows which layers it is about to run can instead
- *   1. transform the weights of MANY layers in one launch into buffers it owns: diagan_wino_weights_batched takes two device
- *      tables of { const float* w; float* u; int Co, Ci, Kp, kind, flip, blk0; float scale; int pad; } records (kind 2:
+ *   1. transform the weights of MANY layers in one launch into buffers it owns: diagan_wino_weights_batched takes a device
+ *      table of n { const float* w; float* u; int Co, Ci, Kp, kind, flip, blk0; float scale; int pad; } records (kind 2:
  *      F(2x2,3x3) format, used by tile_cfg 9 and the F(2x2) pooled launches; 40: F(4x4,3x3), tile_cfg 13 and -- with scale
  *      1/16 -- 15; 41: the 25-frequency format of tile_cfg 11 / 12 on the F(4x4) kernel; flip = 1 for a data gradient;
- *      blk0 = prefix sum of diagan_wino_weight_blocks(Co, Ci) over the table), F(2x2) jobs and F(4x4) jobs apart;
+ *      blk0 = prefix sum of diagan_wino_weight_blocks(Co, Ci) over the table, `blocks` its total);
  *   2. tell the next diagan_conv_gemm call of this thread that its transformed weights are at `u` in that format
  *      (diagan_conv_gemm_weights_hint); the call uses them and skips its own transform if -- and only if -- the format is the
  *      one it needs, so a wrong guess costs nothing but the unused hint.
@@ -193,8 +193,7 @@ int diagan_conv_wino4_upin_supported(int B, int Hi, int Wi, int Ci, int Ho, int 
 int diagan_conv_gemm_weights_hint(const float* u, int kind, int flip, float scale);
 int diagan_conv_gemm_last_weight_format(int* kind, int* flip, float* scale, int64_t* floats, int64_t* launches);
 int64_t diagan_wino_weight_blocks(int Co, int Ci);
-int diagan_wino_weights_batched(const void* jobs_f2, int n_f2, int blocks_f2, const void* jobs_f4, int n_f4, int blocks_f4,
-                                void* stream);
+int diagan_wino_weights_batched(const void* jobs, int n, int blocks, void* stream);
 int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                    int off, int up, int Kp, int allow_split, int64_t ws_floats);
 /* The same choice for a launch with a GROUPED prologue (pro_group_rows > 0: one affine row per group of that many GEMM

@@ -46,8 +46,7 @@ bool wino4_pool_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool f
 int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 bool wino4_upin_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force);
-int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st);     // conv_wino.hip
-int launch_wino4_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st);    // conv_wino4.hip
+int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st);     // conv_wino4.hip (all formats)
 int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st);
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
@@ -829,14 +828,9 @@ DIAGAN_API int diagan_conv_gemm_last_weight_format(int* kind, int* flip, float* 
   return DIAGAN_OK;
 }
 DIAGAN_API int64_t diagan_wino_weight_blocks(int Co, int Ci) { return (int64_t)cdiv(Ci, 32) * cdiv(Co, 64); }
-DIAGAN_API int diagan_wino_weights_batched(const void* jobs_f2, int n_f2, int blocks_f2, const void* jobs_f4, int n_f4, int blocks_f4,
-                                           void* stream) {
-  DG_REQUIRE((n_f2 == 0 || (jobs_f2 && blocks_f2 > 0)) && (n_f4 == 0 || (jobs_f4 && blocks_f4 > 0)) && n_f2 >= 0 && n_f4 >= 0,
-             "wino_weights_batched: bad job tables");
-  int rc = DIAGAN_OK;
-  if (n_f2 > 0) rc = launch_wino_weights_batched((const WinoJob*)jobs_f2, n_f2, blocks_f2, (hipStream_t)stream);
-  if (rc == DIAGAN_OK && n_f4 > 0) rc = launch_wino4_weights_batched((const WinoJob*)jobs_f4, n_f4, blocks_f4, (hipStream_t)stream);
-  return rc;
+DIAGAN_API int diagan_wino_weights_batched(const void* jobs, int n, int blocks, void* stream) {
+  DG_REQUIRE(jobs && n > 0 && blocks > 0, "wino_weights_batched: bad job table");
+  return launch_wino_weights_batched((const WinoJob*)jobs, n, blocks, (hipStream_t)stream);
 }
 
 // see include/diagan_hip.h

@@ -23,60 +23,16 @@
 // Roofline: MFMA fp32; the kernel executes 16/36 of the direct convolution's multiply-accumulates.
 #include "conv_common.h"
 #include <type_traits>
+#include "wino_weights.h"
 
 namespace diagan {
 
 // U[f][co][ci] = (G g G^T)[i][j], f = 4 i + j, written in the LDS image order (see above).  flip: the data-gradient of a
 // stride-1 convolution is the correlation with the taps reversed.
-__device__ __forceinline__ void wino_weight_body(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci, int Kp, int flip,
-                                                 int bx, int by, f32x4* __restrict__ sg) {
-  f32x4 g[3][3];
-  if (!wino_stage_taps(w, by * 64, bx * 32, Co, Ci, Kp, flip, sg, g)) return;
-  const int col = threadIdx.x & 63, c = bx * 32 + (threadIdx.x >> 6) * 4;
-  f32x4 t[4][3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    t[0][s] = g[0][s];
-    t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-    t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-    t[3][s] = g[2][s];
-  }
-  const int ks = c >> 3, kq = (c >> 2) & 1;
-  float* base = ug + ((long)by * (Ci >> 3) + ks) * (16 * 2 * 64 * 4);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f32x4 u[4];
-    u[0] = t[i][0];
-    u[1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-    u[2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-    u[3] = t[i][2];
-    // row i = 3 of V is staged NEGATED (t3 - t1: every lane's column transform is then own + sc * partner); the sign
-    // moves into U so that the products are unchanged
-    const float sg = i == 3 ? -1.f : 1.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float* plane = base + ((i * 4 + j) * 2 + kq) * 256;
-      const f32x4 v = u[j] * sg;
-      *reinterpret_cast<f32x4*>(plane + col * 4) = v;
-    }
-  }
-}
-
 __global__ __launch_bounds__(512) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
                                                           int Kp, int flip) {
   __shared__ f32x4 sg[WT_LDS_F4];
   wino_weight_body(w, ug, Co, Ci, Kp, flip, blockIdx.x, blockIdx.y, sg);
-}
-
-// the same transform for MANY layers in one launch (diagan_wino_weights_batched): workgroup -> job through the jobs' first-block
-// prefix (a handful of jobs: linear scan), then the job's own (channel block, column block)
-__global__ __launch_bounds__(512) void wino_weight_batched_kernel(const WinoJob* __restrict__ jobs, int n) {
-  __shared__ f32x4 sg[WT_LDS_F4];
-  int j = 0;
-  while (j + 1 < n && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
-  const WinoJob job = jobs[j];
-  const int lb = blockIdx.x - job.blk0, nbx = (job.Ci + 31) >> 5;
-  wino_weight_body(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, lb % nbx, lb / nbx, sg);
 }
 
 constexpr int WT = 64;                 // tiles per workgroup
@@ -520,10 +476,6 @@ const float* launch_wino_weights(const float* w, float* ug, int Co, int Ci, int 
   return ug;
 }
 
-int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3(blocks), dim3(512), 0, st, jobs, n);
-  return check_launch("wino_weights_batched (F(2x2))");
-}
 
 // floats of workspace the transformed weights need
 long wino_ws_floats(int Co, int Ci) { return (long)cdiv(Co, WN) * WN * Ci * 16; }

@@ -28,6 +28,7 @@
 // Roofline: MFMA fp32; the kernel executes 36/144 of the direct convolution's multiply-accumulates.
 #include "conv_common.h"
 #include <type_traits>
+#include "wino_weights.h"
 
 namespace diagan {
 
@@ -84,65 +85,10 @@ static_assert((2 * W4_VSTAGE + W4_U) * 4 <= 163840 && 36 * 32 * 32 <= 2 * W4_VST
 // BEFORE the interpolation) on 16 instead of 36, and the up-sampled tensor is never written.  All 36 frequencies are live.
 // Borders: interpolation clamps its taps at the image edge (the loads clamp their coordinates), while the convolution's
 // zero padding lies at the HIGH resolution: patch position 0 of a first tile / 5 of a last tile is multiplied by zero.
-template <int MODE> struct W4M {
-  static constexpr bool pooled = MODE == 1 || MODE == 2;
-  static constexpr bool upin = MODE == 3;
-  static constexpr int NS = pooled ? 7 : 9;          // slots (frequency, column half) per wave
-  static constexpr int U_FLOATS = 8 * NS * 256;       // weight units of one K-step
-  static constexpr int NI = (MODE == 2 || MODE == 3) ? 4 : 6;        // input loads per thread and K-step
-};
-__host__ __device__ __forceinline__ int w4p_start(int g) { return g == 0 ? 0 : 7 + 6 * (g - 1); }
-__host__ __device__ __forceinline__ int w4p_count(int g) { return g == 0 ? 7 : 6; }
-__host__ __device__ __forceinline__ int w4p_freq(int v) { return v < 2 ? v : v + 1; }        // {0, 1, 3, 4, 5}
-
 // U[f][co][ci] = (G g G^T)[i][j], f = 6 i + j, in the order the main kernel's waves consume it:
 // [64-column block][K-step][unit = wave * 9 + slot][lane = k half * 32 + column][4 channels], wave = group * 2 + column half,
 // group = (i / 3) * 2 + j / 3 (a 3 x 3 block of the 6 x 6 frequencies), slot = 3 (i % 3) + j % 3.
 // flip: the data-gradient of a stride-1 convolution is the correlation with the taps reversed.
-template <int MODE>
-__device__ __forceinline__ void wino4_weight_body(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci, int Kp, int flip,
-                                                  float wscale, int bx, int by, f32x4* __restrict__ sg) {
-  f32x4 g[3][3];
-  const int nb = by;
-  if (!wino_stage_taps(w, nb * 64, bx * 32, Co, Ci, Kp, flip, sg, g)) return;
-  if (wscale != 1.f) {                                  // (MODE 3: the 1/16 of the two interpolation passes, exact)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] *= wscale;
-  }
-  const int col = threadIdx.x & 63, c = bx * 32 + (threadIdx.x >> 6) * 4;
-  constexpr float k4 = 0.25f, k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
-  auto gt = [&](const f32x4& g0, const f32x4& g1, const f32x4& g2, f32x4* o) {
-    o[0] = k4 * g0;
-    o[1] = -k6 * (g0 + g1 + g2);
-    o[2] = -k6 * (g0 - g1 + g2);
-    o[3] = k24 * g0 + k12 * g1 + k6 * g2;
-    o[4] = k24 * g0 - k12 * g1 + k6 * g2;
-    o[5] = g2;
-  };
-  f32x4 t[3][6];                                        // t[s][i] = (G g)[i][s]
-#pragma unroll
-  for (int s = 0; s < 3; ++s) gt(g[0][s], g[1][s], g[2][s], t[s]);
-  const int nk = Ci >> 3, ks = c >> 3, kh = (c >> 2) & 1, nh = col >> 5, n = col & 31;
-  float* base = ug + ((long)nb * nk + ks) * W4M<MODE>::U_FLOATS + (kh * 32 + n) * 4;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    f32x4 u[6];
-    gt(t[0][i], t[1][i], t[2][i], u);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (MODE == 0) {
-        // wave group g owns the 3 x 3 block of frequencies i in 3 (g >> 1) .. + 2, j in 3 (g & 1) .. + 2; slot 3 (i % 3) + j % 3
-        const int unit = ((((i / 3) * 2 + j / 3) * 2 + nh) * 9) + (i % 3) * 3 + j % 3;
-        *reinterpret_cast<f32x4*>(base + unit * 256) = u[j];
-      } else if (i != 2 && j != 2) {
-        const int l = 5 * (i < 2 ? i : i - 1) + (j < 2 ? j : j - 1);          // live frequency index
-        const int gq = l < 7 ? 0 : 1 + (l - 7) / 6, sl = l - w4p_start(gq);
-        *reinterpret_cast<f32x4*>(base + ((gq * 2 + nh) * 7 + sl) * 256) = u[j];
-      }
-    }
-  }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
                                                            int Kp, int flip, float wscale) {
@@ -150,15 +96,17 @@ __global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restri
   wino4_weight_body<MODE>(w, ug, Co, Ci, Kp, flip, wscale, blockIdx.x, blockIdx.y, sg);
 }
 
-// the same transforms for MANY layers in one launch (diagan_wino_weights_batched; see conv_wino.hip's counterpart)
-__global__ __launch_bounds__(512) void wino4_weight_batched_kernel(const WinoJob* __restrict__ jobs, int n) {
+// the transforms of MANY layers in one launch (diagan_wino_weights_batched): workgroup -> job through the jobs' first-block
+// prefix (a handful of jobs: linear scan), then the job's own (channel block, column block) in the job's format
+__global__ __launch_bounds__(512) void wino_weights_batched_kernel(const WinoJob* __restrict__ jobs, int n) {
   __shared__ f32x4 sg[WT_LDS_F4];
   int j = 0;
   while (j + 1 < n && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
   const WinoJob job = jobs[j];
   const int lb = blockIdx.x - job.blk0, nbx = (job.Ci + 31) >> 5;
   if (job.kind == WK_F4) wino4_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
-  else wino4_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  else if (job.kind == WK_F4_POOL) wino4_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  else wino_weight_body(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, lb % nbx, lb / nbx, sg);
 }
 
 // 1-D input transform B^T (6 -> 6), in place.  Every line is a * K + b with a SCALAR K the compiler cannot see through
@@ -803,9 +751,9 @@ static const float* wino4_weights(const ConvGemmArgs& a, float* ws, int flip, fl
   return ws;
 }
 
-int launch_wino4_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL(wino4_weight_batched_kernel, dim3(blocks), dim3(512), 0, st, jobs, n);
-  return check_launch("wino_weights_batched (F(4x4))");
+int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(wino_weights_batched_kernel, dim3(blocks), dim3(512), 0, st, jobs, n);
+  return check_launch("wino_weights_batched");
 }
 
 // geometry the F(4x4,3x3) kernel takes on top of diagan_conv_wino_supported: H and W multiples of 4

@@ -746,7 +746,9 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
 
 // split count of the two-stage path (1 = single stage); the workspace must hold groups * splits * 2 * C doubles
 DIAGAN_API int diagan_bn_stats_fused_splits(int tiles, int C, int groups) {
-  if (tiles < 256) return 1;
+  // (a stacked forward's groups are finalised IN ORDER by one workgroup per 16 channels: with six groups of 128 tiles that
+  //  serial walk took 21 us; summed first by splits x groups workgroups it is a handful of partials per group)
+  if ((long)tiles * groups < 256) return 1;
   long s = 1024 / ((long)cdiv(C, 16) * groups);
   const long smax = tiles / 32;          // at least two tiles per lane of a block
   if (s > smax) s = smax;

@@ -20,7 +20,7 @@ nat.register("diagan_conv_wino4_upin_supported", [I] * 13 + [I64, I])
 nat.register("diagan_conv_gemm_weights_hint", [P, I, I, F])
 nat.register("diagan_conv_gemm_last_weight_format", [P, P, P, P, P])
 nat.register("diagan_wino_weight_blocks", [I, I])
-nat.register("diagan_wino_weights_batched", [P, I, I, P, I, I, P])
+nat.register("diagan_wino_weights_batched", [P, I, I, P])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
@@ -126,7 +126,7 @@ _NAME_CACHE = {}
 # Every Winograd launch otherwise starts with a 5-7 us weight-transform kernel of its own (48 / 124 per SNGAN-32 / -64 step).
 # A `WinoWeights` object stands for ONE call site of one layer (its forward, its data gradient, ...): the first pass through
 # the site runs as before and notes which format the launch needed; from then on the network's `WinoWeightBatch` transforms
-# all its sites' weights in one launch per pass (F(2x2) and F(4x4) formats apart) and the launches take the ready buffer.
+# all its sites' weights in ONE launch per pass and the launches take the ready buffer.
 # A launch that turns out to need another format than last time (another batch size -> another kernel) ignores the hint
 # and transforms its own weights, and the site re-learns.  DIAGAN_WINO_BATCH=0: every launch transforms its own, as before.
 import ctypes as _ct
@@ -162,8 +162,8 @@ class WinoWeightBatch:
         return s
 
     def prepare(self, version):
-        """Transform the weights of every site with a known format whose buffer is not at `version` yet (one launch per
-        format family).  Called at the start of the pass, after the operands the sites read have been written."""
+        """Transform the weights of every site with a known format whose buffer is not at `version` yet, in one launch.
+        Called at the start of the pass, after the operands the sites read have been written."""
         if not WINO_BATCH:
             return
         import numpy as np
@@ -173,23 +173,19 @@ class WinoWeightBatch:
         key = tuple((id(s), s.fmt, s.w_of().data_ptr()) for s in todo)
         if key != self._table_key:
             desc = np.dtype([('w', np.uint64), ('u', np.uint64), ('i', np.int32, 6), ('scale', np.float32), ('pad', np.int32)])
-            tabs = []
-            for fam in ((2,), (40, 41)):
-                jobs = [s for s in todo if s.fmt[0] in fam]
-                tab, blk = np.zeros(max(len(jobs), 1), dtype=desc), 0
-                for j, s in enumerate(jobs):
-                    w = s.w_of()
-                    if s.u is None or s.u.numel() != s.fmt[3] or s.u.device != w.device:
-                        s.u = torch.empty(s.fmt[3], dtype=torch.float32, device=w.device)
-                    tab[j]['w'], tab[j]['u'] = w.data_ptr(), s.u.data_ptr()
-                    tab[j]['i'] = [s.Co, s.Ci, s.Kp, s.fmt[0], s.fmt[1], blk]
-                    tab[j]['scale'] = s.fmt[2]
-                    blk += nat.fn("diagan_wino_weight_blocks")(s.Co, s.Ci)
-                dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(todo[0].w_of().device) if jobs else None
-                tabs.append((dev_tab, len(jobs), blk))
-            self._table_key, self._tables = key, tabs
-        (t2, n2, b2), (t4, n4, b4) = self._tables
-        nat.call("diagan_wino_weights_batched", nat.ptr(t2), n2, b2, nat.ptr(t4), n4, b4, nat.current_stream())
+            tab, blk = np.zeros(len(todo), dtype=desc), 0
+            for j, s in enumerate(todo):
+                w = s.w_of()
+                if s.u is None or s.u.numel() != s.fmt[3] or s.u.device != w.device:
+                    s.u = torch.empty(s.fmt[3], dtype=torch.float32, device=w.device)
+                tab[j]['w'], tab[j]['u'] = w.data_ptr(), s.u.data_ptr()
+                tab[j]['i'] = [s.Co, s.Ci, s.Kp, s.fmt[0], s.fmt[1], blk]
+                tab[j]['scale'] = s.fmt[2]
+                blk += nat.fn("diagan_wino_weight_blocks")(s.Co, s.Ci)
+            dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(todo[0].w_of().device)
+            self._table_key, self._tables = key, (dev_tab, len(todo), blk)
+        tab, n, blocks = self._tables
+        nat.call("diagan_wino_weights_batched", nat.ptr(tab), n, blocks, nat.current_stream())
         for s in todo:
             s.ready = version
 
