@@ -457,6 +457,18 @@ int diagan_styled_bias_act(const float* x, const float* demod, const float* nois
  * * C floats.  Deterministic (fixed-order partial sums, combined in double). */
 int diagan_rowdot_chunks(int B, int P);
 int diagan_rowdot(const float* a, const float* b, float* out, float* workspace, int B, int P, int C, void* stream);
+/* First-order backward of diagan_styled_bias_act -- and of bias + leaky ReLU (diagan_fused_bias_act act 3) when x, demod and
+ * noise are NULL -- in ONE pass over the incoming gradient gy[B][P][C] (round 4; the reference's FusedLeakyReLU backward,
+ * op/fused_act.py:21-60, plus the NoiseInjection / demodulation gradients of stylegan2.py:268-329):
+ *   gpre = gy * scale * (y > 0 ? 1 : alpha);  gx = gpre * demod[b][c] (or gpre);
+ *   work_d[blk][c] = sum_p gpre * x, work_b[blk][c] = sum_p gpre, work_s[blk] = sum_p noise[p] * sum_c gpre
+ * for the B * diagan_rowdot_chunks(B, P) blocks of pixels (rows blk = b * chunks + k): the caller adds the blocks' rows -- d(demod)[b][c]
+ * over a sample's chunks, d(bias)[c] over all blocks, d(strength) over all blocks.  gx may be NULL; x / work_d and noise / work_s are
+ * given together or not at all.  C a power of two in [4, 1024].  Deterministic (fixed-order sums).  The higher-order
+ * backward (R1, path-length penalty) keeps the differentiable composition of diagan_fused_bias_act / diagan_rowdot. */
+int diagan_styled_bias_act_bwd(const float* gy, const float* y, const float* x, const float* demod, const float* noise,
+                               float* gx, float* work_d, float* work_b, float* work_s, int B, int P, int C,
+                               int noise_per_image, float alpha, float scale, void* stream);
 
 /* upfirdn2d.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up, down, pads), upfirdn2d.cpp:4-22.
  * out == NULL: size query only (writes *out_h, *out_w). */

@@ -102,6 +102,61 @@ __global__ __launch_bounds__(256) void rowdot_partial_kernel(const f32x4* __rest
   }
 }
 
+// First-order backward of the StyledConv tail / of bias + leaky ReLU in ONE pass over the incoming gradient (round 4):
+//   gpre = gy * scale * (y > 0 ? 1 : alpha)                      (the activation's gate: sign(y) = sign(pre-activation))
+//   gx[b,p,c]   = gpre * demod[b,c]          (or gpre)            -> gradient of the convolution output
+//   wd[blk][c]  = sum_p gpre * x             (x given)            -> d(demod):  summed over a block's pixels
+//   wb[blk][c]  = sum_p gpre                                      -> d(bias) after the sum over blocks
+//   ws[blk]     = sum_p noise[p] * sum_c gpre (noise given)       -> d(noise strength)
+// instead of the gate kernel + a broadcast multiply + rowdot + (multiply, sum) + sum: five to eight passes over activation-sized
+// tensors.  Block / thread layout and partial sums as rowdot_partial_kernel; the caller adds the blocks' rows (tiny).
+__global__ __launch_bounds__(256) void styled_act_bwd_kernel(const f32x4* __restrict__ gy, const f32x4* __restrict__ y,
+                                                             const f32x4* __restrict__ x, const float* __restrict__ demod,
+                                                             const float* __restrict__ noise, f32x4* __restrict__ gx,
+                                                             float* __restrict__ wd, float* __restrict__ wb, float* __restrict__ ws,
+                                                             int P, int C, int chunks, int noise_per_image, float alpha, float scale) {
+  __shared__ f32x4 red_d[256];
+  __shared__ f32x4 red_b[256];
+  __shared__ float red_s[256];
+  const int q = C >> 2, lanes = 256 / q;
+  const int cq = threadIdx.x % q, pl = threadIdx.x / q;
+  const int img = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int per = (P + chunks - 1) / chunks;
+  const int p0 = ch * per, p1 = min(p0 + per, P);
+  const long base = (long)img * P * q + cq;
+  f32x4 dm = {1.f, 1.f, 1.f, 1.f};
+  if (demod) dm = *reinterpret_cast<const f32x4*>(demod + (long)img * C + cq * 4);
+  f32x4 accd = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+  float accs = 0.f;
+  for (int p = p0 + pl; p < p1; p += lanes) {
+    const long i = base + (long)p * q;
+    f32x4 g = gy[i];
+    const f32x4 r = y[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = g[e] * (r[e] > 0.f ? scale : scale * alpha);
+    if (gx) gx[i] = demod ? g * dm : g;
+    if (x) accd += g * x[i];
+    accb += g;
+    if (noise) accs += noise[noise_per_image ? (long)img * P + p : p] * ((g[0] + g[1]) + (g[2] + g[3]));
+  }
+  red_d[threadIdx.x] = accd;
+  red_b[threadIdx.x] = accb;
+  red_s[threadIdx.x] = accs;
+  __syncthreads();
+  if (pl == 0) {
+    f32x4 sd = red_d[cq], sb = red_b[cq];
+    for (int l = 1; l < lanes; ++l) { sd += red_d[l * q + cq]; sb += red_b[l * q + cq]; }
+    if (wd) *reinterpret_cast<f32x4*>(wd + ((long)blockIdx.x * C) + cq * 4) = sd;
+    *reinterpret_cast<f32x4*>(wb + ((long)blockIdx.x * C) + cq * 4) = sb;
+  }
+  if (ws && threadIdx.x < 64) {                    // fixed-order sum of the 256 per-thread scalars
+    float t = (red_s[threadIdx.x] + red_s[threadIdx.x + 64]) + (red_s[threadIdx.x + 128] + red_s[threadIdx.x + 192]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (threadIdx.x == 0) ws[blockIdx.x] = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void rowdot_finish_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                             int BC, int C, int chunks) {
   const int i = blockIdx.x * 256 + threadIdx.x;       // b * C + c
@@ -280,6 +335,21 @@ DIAGAN_API int diagan_rowdot(const float* a, const float* b, float* out, float* 
   hipLaunchKernelGGL(rowdot_finish_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, (hipStream_t)stream, workspace, out,
                      B * C, C, chunks);
   return check_launch("rowdot");
+}
+
+// see include/diagan_hip.h: first-order backward of diagan_styled_bias_act / of bias + leaky ReLU in one pass
+DIAGAN_API int diagan_styled_bias_act_bwd(const float* gy, const float* y, const float* x, const float* demod, const float* noise,
+                                          float* gx, float* work_d, float* work_b, float* work_s, int B, int P, int C,
+                                          int noise_per_image, float alpha, float scale, void* stream) {
+  DG_REQUIRE(gy && y && work_b && B > 0 && P > 0, "styled_bias_act_bwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "styled_bias_act_bwd: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE(!x == !work_d && !noise == !work_s, "styled_bias_act_bwd: x / work_d and noise / work_s come in pairs");
+  DG_REQUIRE((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)demod | (uintptr_t)work_d | (uintptr_t)work_b) & 15) == 0,
+             "styled_bias_act_bwd: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)y,
+                     (const f32x4*)x, demod, noise, (f32x4*)gx, work_d, work_b, work_s, P, C, chunks, noise_per_image, alpha, scale);
+  return check_launch("styled_bias_act_bwd");
 }
 
 // out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL

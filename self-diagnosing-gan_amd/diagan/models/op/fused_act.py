@@ -15,6 +15,41 @@ nat.register("diagan_fused_bias_act", [P, P, P, P, I64, I64, I, I, I, F32, F32, 
 nat.register("diagan_rowdot_chunks", [I, I])
 nat.register("diagan_rowdot", [P, P, P, P, I, I, I, P])
 nat.register("diagan_styled_bias_act", [P, P, P, P, P, P, I, I, I, I, F32, F32, P])
+nat.register("diagan_styled_bias_act_bwd", [P, P, P, P, P, P, P, P, P, I, I, I, I, F32, F32, P])
+
+import os as _os
+FUSED_BWD = _os.environ.get("DIAGAN_SG2_FUSED_BWD", "1") != "0"
+
+
+def _fused_bwd_ok(gy):
+    """the one-pass first-order backward applies: no graph is being recorded for this backward (R1 / path-length penalties
+    differentiate THROUGH the backward and take the differentiable composition), channels-last 4-D gradient, C a power of
+    two in [4, 1024]"""
+    c = gy.shape[-1]
+    return (FUSED_BWD and not torch.is_grad_enabled() and gy.dim() == 4 and gy.is_cuda and gy.dtype == torch.float32
+            and 4 <= c <= 1024 and not (c & (c - 1)))
+
+
+def _fused_bwd(gy, y, x, demod, noise, slope, scale, need_gx=True):
+    """(gx, d(demod) [B,C] or None, d(bias) [C], d(strength) [1] or None) from one pass over gy (diagan_styled_bias_act_bwd)"""
+    b, h, w, c = gy.shape
+    gy, y = gy.contiguous(), y.contiguous()
+    chunks = nat.fn("diagan_rowdot_chunks")(b, h * w)
+    f32 = dict(dtype=torch.float32, device=gy.device)
+    gx = torch.empty_like(gy) if need_gx else None
+    wd = torch.empty((b, chunks, c), **f32) if x is not None else None
+    wb = torch.empty((b * chunks, c), **f32)
+    per_image = noise is not None and noise.shape[0] == b and b > 1
+    ws = torch.empty(b * chunks, **f32) if noise is not None else None
+    nat.call("diagan_styled_bias_act_bwd", nat.ptr(gy), nat.ptr(y), nat.ptr(x.contiguous()) if x is not None else None,
+             nat.ptr(demod.contiguous()) if demod is not None else None,
+             nat.ptr(noise.contiguous()) if noise is not None else None, nat.ptr(gx), nat.ptr(wd), nat.ptr(wb), nat.ptr(ws),
+             b, h * w, c, 1 if per_image else 0, float(slope), float(scale), nat.current_stream())
+    gd = wd.double().sum(1).float() if wd is not None else None           # (rows of a few dozen blocks: summed in double)
+    gb = wb.double().sum(0).float()
+    gs = ws.double().sum().float().reshape(1) if ws is not None else None
+    return gx, gd, gb, gs
+
 
 
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale, bias_dim=1):
@@ -69,6 +104,9 @@ class _BiasLeakyReLU(Function):
     @staticmethod
     def backward(ctx, gy):
         y, = ctx.saved_tensors
+        if ctx.has_bias and ctx.bias_dim == gy.dim() - 1 and _fused_bwd_ok(gy):
+            gx, _, gb, _ = _fused_bwd(gy, y, None, None, None, *ctx.hyper)      # gate + bias gradient in one pass
+            return gx, gb, None, None, None
         gx = _LeakyGate.apply(gy, y, *ctx.hyper)
         gb = gx.sum([d for d in range(gx.dim()) if d != ctx.bias_dim]) if ctx.has_bias else None
         return gx, gb, None, None, None
@@ -143,6 +181,11 @@ class _StyledAct(Function):
     def backward(ctx, gy):
         x, demod, noise, y = ctx.saved_tensors
         need = ctx.needs_input_grad
+        if _fused_bwd_ok(gy):
+            # first-order backward: gate, demodulated gradient, d(demod), d(bias), d(noise strength) from ONE pass over gy
+            gx, gd, gb, gs = _fused_bwd(gy, y, x if (demod is not None and need[1]) else None, demod,
+                                        noise if need[3] else None, *ctx.hyper, need_gx=need[0])
+            return gx, gd, None, gs, (gb if need[4] else None), None, None
         gpre = _LeakyGate.apply(gy, y, *ctx.hyper)
         gx = (scale_rows(gpre, demod) if demod is not None else gpre) if need[0] else None
         gd = rowdot(gpre, x) if demod is not None and need[1] else None

@@ -189,3 +189,49 @@ def test_rowdot_and_scale_rows_closed_pair(shape):
     ours, ref = run(True, "cuda", torch.float32), run(False, "cpu", torch.float64)
     for i, (p, q) in enumerate(zip(ours, ref)):
         np.testing.assert_allclose(p.numpy(), q.numpy(), rtol=1e-3, atol=1e-3 * float(q.abs().max()), err_msg=f"output {i}")
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 33, 31, 128), (4, 16, 16, 512), (2, 7, 9, 4)])
+@pytest.mark.parametrize("noise_kind", ["per_image", "shared", "none"])
+def test_styled_bias_act_one_pass_first_order_backward(shape, noise_kind):
+    """round 4: a plain backward (no graph recorded) of the StyledConv tail / of bias + leaky ReLU takes ONE pass over the
+    incoming gradient (diagan_styled_bias_act_bwd: gate, demodulated gradient, d(demod), d(bias), d(noise strength)); it must
+    equal the float64 composition, and the differentiable path that R1 / path-length penalties use (create_graph=True)."""
+    from diagan.models.op import fused_act as FA
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    vals = dict(x=torch.randn(B, H, W, C, generator=g), d=torch.rand(B, C, generator=g) + 0.5, s=torch.randn(1, generator=g),
+                b=torch.randn(C, generator=g))
+    noise = {"per_image": torch.randn(B, H, W, 1, generator=g), "shared": torch.randn(1, H, W, 1, generator=g),
+             "none": None}[noise_kind]
+    cot = torch.sin(torch.arange(B * H * W * C, dtype=torch.float64).view(B, H, W, C))
+
+    def ref():
+        t = {k: v.double().requires_grad_(True) for k, v in vals.items()}
+        pre = t['x'] * t['d'][:, None, None, :] + t['b']
+        if noise is not None:
+            pre = pre + t['s'] * noise.double()
+        y = torch.nn.functional.leaky_relu(pre, 0.2) * 2 ** 0.5
+        (y * cot).sum().backward()
+        return [t[k].grad for k in ('x', 'd', 'b')] + ([t['s'].grad] if noise is not None else [])
+
+    def ours(create_graph):
+        t = {k: v.cuda().requires_grad_(True) for k, v in vals.items()}
+        y = FA.styled_bias_act(t['x'], t['d'], noise.cuda() if noise is not None else None,
+                               t['s'] if noise is not None else None, t['b'])
+        keys = ['x', 'd', 'b'] + (['s'] if noise is not None else [])
+        gr = torch.autograd.grad((y * cot.cuda().float()).sum(), [t[k] for k in keys], create_graph=create_graph)
+        return [v.detach().double().cpu() for v in gr]
+
+    want, fast, slow = ref(), ours(False), ours(True)
+    for i, (a, b, c) in enumerate(zip(fast, want, slow)):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, f"one-pass backward, gradient {i}"
+        assert float((c - b).abs().max()) <= 2e-5 * scale + 1e-6, f"differentiable backward, gradient {i}"
+    # bias + leaky ReLU alone (FusedLeakyReLU of the discriminator's convolutions), channels-last
+    x, b = vals['x'].cuda().requires_grad_(True), vals['b'].cuda().requires_grad_(True)
+    (FA.fused_leaky_relu(x, b, bias_dim=-1) * cot.cuda().float()).sum().backward()
+    xr, br = vals['x'].double().requires_grad_(True), vals['b'].double().requires_grad_(True)
+    (torch.nn.functional.leaky_relu(xr + br, 0.2) * 2 ** 0.5 * cot).sum().backward()
+    assert float((x.grad.double().cpu() - xr.grad).abs().max()) <= 1e-6
+    assert float((b.grad.double().cpu() - br.grad).abs().max()) <= 2e-5 * float(br.grad.abs().max()) + 1e-6
