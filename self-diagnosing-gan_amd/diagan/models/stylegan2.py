@@ -125,10 +125,11 @@ class EqualConv2d(nn.Module):
         self.stride, self.padding = stride, padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, x):
-        y = dc.conv2d(x, self.weight * self.scale, self.stride, self.padding)
+    def forward(self, x, out_mul=1.0):
+        """out_mul: an extra factor on the OUTPUT, folded into the weight scale (ResBlock's 1 / sqrt 2 on its skip branch)"""
+        y = dc.conv2d(x, self.weight * (self.scale * out_mul), self.stride, self.padding)
         if self.bias is not None:
-            y = y + F.pad(self.bias, (0, y.shape[3] - self.bias.shape[0]))
+            y = y + F.pad(self.bias, (0, y.shape[3] - self.bias.shape[0])) * out_mul
         return y
 
     def __repr__(self):
@@ -374,7 +375,13 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
     def forward(self, input):
-        return (self.conv2(self.conv1(input)) + self.skip(input)) / SQRT2
+        """(conv2(conv1(x)) + skip(x)) / sqrt 2 (reference :597-614) without the pass over the sum that the division costs
+        (and its mirror image in the backward): the factor goes into what produces the two branches -- conv2's activation
+        leaky_relu(.) * sqrt 2 runs with scale 1, the skip convolution with its weight scale divided by sqrt 2."""
+        blur2, conv2, act2 = self.conv2
+        y = fused_leaky_relu(conv2(blur2(self.conv1(input))), act2.bias, act2.negative_slope, act2.scale / SQRT2, bias_dim=-1)
+        blur_s, conv_s = self.skip
+        return y + conv_s(blur_s(input), out_mul=1.0 / SQRT2)
 
 
 class StyleGANDiscriminator(FlatNet):

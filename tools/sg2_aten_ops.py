@@ -28,5 +28,11 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f"device time of all operators: {tot:.1f} ms per iteration")
-for ms, cnt, key, shp in rows[:60]:
-    print(f"{ms:8.3f} ms  {cnt:7.1f} calls  {key:45s} {shp}")
+aten = [r for r in rows if r[2].startswith("aten::")]
+print(f"aten:: operators (self device time): {sum(r[0] for r in aten):.1f} ms per iteration")
+for ms, cnt, key, shp in aten[:45]:
+    print(f"{ms:8.3f} ms  {cnt:7.1f} calls  {key:28s} {shp}")
+own = [r for r in rows if not r[2].startswith("aten::") and not r[2].startswith("void ") and "diagan::" not in r[2]]
+print("autograd Functions of this engine (self device time):")
+for ms, cnt, key, shp in own[:12]:
+    print(f"{ms:8.3f} ms  {cnt:7.1f} calls  {key:28s} {shp}")
