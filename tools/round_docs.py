@@ -39,7 +39,7 @@ Command (GPU box, `tools/profile_round.sh`): `rocprofv3 --kernel-trace --stats -
 {b32['value']} images/s under the profiler).
 
 Un-profiled default run of the same build (`python bench.py`): **{d['value']} images/s, {d['ms_per_step']} ms/step**
-(round 2: 4049 / 15.8; round 1: 2421 / 26.4).  Roofline kernel `{r['kernel']}` (Winograd F(4x4,3x3) forward / data-gradient,
+(round 3: 4636 / 13.8; round 2: 4049 / 15.8; round 1: 2421 / 26.4).  Roofline kernel `{r['kernel']}` (Winograd F(4x4,3x3) forward / data-gradient,
 `csrc/conv_wino4.hip`): HIP-event average {r['avg_launch_us']} us/launch over the {r['launches']} launches of the timed region
 (the rocprof average of the same template below also covers the table steps), {r['algorithmic_gflop_per_launch']} algorithmic
 GFLOP/launch (direct convolution, 2 M Co 9 Ci) = {r['algorithmic_tflops']} TFLOP/s = {r['frac_algorithmic']} of the 157.3 TFLOP/s
@@ -47,7 +47,7 @@ fp32 MFMA peak; the kernel EXECUTES 9/36 of those products = {r['executed_gflop_
 **{r['achieved']} TFLOP/s = {r['frac']} of the peak** (`frac` = `frac_executed`, the one convention of every table of this round;
 PMC cross-check: `{tag[:3]}_mfma_util.md`).
 Whole-step algorithmic rate: 2.871 TFLOP / {d['ms_per_step']} ms = {2871 / d['ms_per_step']:.0f} TFLOP/s
-({2871 / d['ms_per_step'] / 157.3:.2f} of the fp32 MFMA peak in direct-convolution FLOP; round 2: 182, round 1: 107).
+({2871 / d['ms_per_step'] / 157.3:.2f} of the fp32 MFMA peak in direct-convolution FLOP; round 3: 208, round 2: 182, round 1: 107).
 
 SNGAN-64 leg of the same default run (`sngan64_conv_blocks`): {s['images_per_s']} images/s, {s['ms_per_step']} ms/step;
 residual-block convolutions {s['executed_tflops']} TFLOP/s executed = **{s['frac']} of peak** (north_star's 0.60 bar is NOT met on
@@ -58,7 +58,7 @@ open(os.path.join(ROOT, f"profiles/{tag}_sngan64_summary.md"), 'w').write(f"""# 
 
 Command (GPU box, `tools/profile_round.sh`): `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload
 sngan64 --steps 5 --warmup 2 --no_cpu_baseline` ({STEPS} global steps profiled; {b64['value']} images/s under the profiler,
-{s['images_per_s']} in the un-profiled default run; round 2: 2326, round 1: 1319).
+{s['images_per_s']} in the un-profiled default run; round 3: 2702, round 2: 2326, round 1: 1319).
 
 north_star's kernel target -- >= 60 % of the MFMA roofline on the SNGAN 64x64 conv blocks at bs = 64 -- is emitted by the
 DEFAULT `python bench.py` run as `sngan64_conv_blocks` (definition in the JSON line and DESIGN 6):
