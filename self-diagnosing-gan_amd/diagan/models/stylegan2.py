@@ -197,11 +197,6 @@ class ModulatedConv2d(nn.Module):
         w = self.weight[0] * self.scale
         if self.downsample:
             x = self.blur(x)
-        if not (self.upsample or self.downsample) and dc.modulated_prologue_ok(x, 1):
-            # no gradient wanted (the fake batch of a D step): the style scale rides in the convolution's loader
-            y = dc.conv2d_modulated_nograd(x, w, s, padding=self.padding)
-            d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3))) + self.eps) if self.demodulate else None
-            return y, d
         x = scale_rows(x, s)
         if self.upsample:
             y = self.blur(dc.conv_transpose2d(x, w, stride=2, padding=0))

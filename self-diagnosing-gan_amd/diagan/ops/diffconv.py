@@ -173,25 +173,6 @@ def conv2d(x, w_oihw, stride=1, padding=0):
     return _Conv.apply(x, pack(w_oihw, geom), geom)
 
 
-MOD_PROLOGUE = os.environ.get("DIAGAN_SG2_MOD_PROLOGUE", "1") == "1"
-
-
-def modulated_prologue_ok(x, stride):
-    """conv2d(x * s[b, ci], w) can take the per-sample scale in the convolution's LOADER (the kernels' grouped affine
-    prologue with one group per image) instead of a pass over x: only where no gradient is wanted -- torch.no_grad(), e.g.
-    the fake batch of a D step (stylegan2/train_ffhq.py:237-238) -- because the any-order autograd of this module is
-    written for the plain convolution; stride 1; an image's H * W output rows must be whole 64-row tiles."""
-    return (MOD_PROLOGUE and not torch.is_grad_enabled() and stride == 1 and x.is_cuda and x.dim() == 4
-            and (x.shape[1] * x.shape[2]) % 64 == 0)
-
-
-def conv2d_modulated_nograd(x, w_oihw, s, padding=0):
-    """conv2d(x * s[:, None, None, :], w) on NHWC activations, forward only (see modulated_prologue_ok)"""
-    geom = K.Geom('conv', x.shape[3], K.round_up(w_oihw.shape[0], 4), w_oihw.shape[2], w_oihw.shape[3], 1, padding)
-    s = _c(s.to(torch.float32))
-    return K.conv_fwd(geom, _c(x), _c(pack(w_oihw, geom)), pro=(K.PRO_AFFINE, s, torch.zeros_like(s), 1), wino=SG2_WINO)
-
-
 def conv_transpose2d(x, w_oihw, stride=2, padding=0):
     """F.conv_transpose2d(x, w.transpose(0, 1)) on NHWC activations: w is given output-channel-major like conv2d's
     (the modulated convolution of the reference transposes it itself, stylegan2.py:243-248)."""

@@ -427,25 +427,3 @@ def test_real_configuration_256_cm2_batch32_vs_oracle():
     assert float((G.flat_params - w0).abs().max()) > 1e-4 and float((D.flat_params - d0).abs().max()) > 1e-4
     assert all(torch.isfinite(v).all() for v in (tr.r1_loss, tr.path_loss, tr.path_lengths))
 
-
-def test_modulated_convolution_with_the_style_scale_in_the_loader():
-    """round 4: under torch.no_grad() (the fake batch of a D step, stylegan2/train_ffhq.py:237-238) the stride-1 modulated
-    convolutions take the per-sample style scale in the convolution's loader (grouped affine prologue, one group per image)
-    instead of a pass over the activation: same values as the composed form; 4x4 maps and gradient-carrying calls keep it"""
-    from diagan.models.stylegan2 import ModulatedConv2d
-    from diagan.ops import diffconv as dc
-    torch.manual_seed(3)
-    for cin, cout, k, hw in ((64, 128, 3, 32), (128, 64, 3, 16), (64, 3, 1, 16), (32, 32, 3, 8), (32, 32, 3, 4)):
-        m = ModulatedConv2d(cin, cout, k, 64, demodulate=k == 3).cuda()
-        x, style = torch.randn(4, hw, hw, cin, device='cuda'), torch.randn(4, 64, device='cuda')
-        with torch.no_grad():
-            assert dc.modulated_prologue_ok(x, 1) == (hw >= 8)
-            fast = m(x, style)
-            dc.MOD_PROLOGUE = False
-            try:
-                slow = m(x, style)
-            finally:
-                dc.MOD_PROLOGUE = True
-        assert not dc.modulated_prologue_ok(x, 1)            # gradients enabled here: the differentiable composition
-        scale = slow.abs().max().item()
-        assert (fast - slow).abs().max().item() <= 2e-5 * scale, (cin, cout, k, hw)
