@@ -28,7 +28,11 @@ def table(csv, steps):
 
 d = line(bench_json)
 b32, b64 = line(f"{prof}/kt32.log"), line(f"{prof}/kt64.log")
-c32, c64 = glob.glob(f"{prof}/kt32/*/*kernel_stats.csv")[0], glob.glob(f"{prof}/kt64/*/*kernel_stats.csv")[0]
+def newest(pattern):                          # gpurun MERGES runs into gpurun_out/: take the latest one, never glob()[0]
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+c32, c64 = newest(f"{prof}/kt32/*/*kernel_stats.csv"), newest(f"{prof}/kt64/*/*kernel_stats.csv")
 shutil.copy(c32, os.path.join(ROOT, f"profiles/{tag}_sngan32_kernel_stats.csv"))
 shutil.copy(c64, os.path.join(ROOT, f"profiles/{tag}_sngan64_kernel_stats.csv"))
 r, s = d['roofline'], d['sngan64_conv_blocks']
