@@ -50,6 +50,9 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_COL_AT
 #define W4_COL_AT 5
 #endif
+#ifndef W4_DMA_IMM
+#define W4_DMA_IMM 1
+#endif
 // The same for waves 4-7 (the SIMD partners of waves 0-3: a workgroup's waves w and w + 4 share a SIMD).  With equal placements
 // the two waves of a SIMD run their transform passes -- ~70 + ~45 vector / LDS instructions in a row -- at the same time and
 // the matrix pipe has only the eight MFMAs already in flight to chew on; with different placements one wave's pass sits beside
@@ -174,6 +177,9 @@ template <int PRO, int MODE = 0>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
   using MD = W4M<MODE>;
   constexpr int NS = MD::NS, NI = MD::NI;
+#ifdef DIAGAN_W4_STAMP
+  const unsigned long long t_kernel = __builtin_amdgcn_s_memtime();
+#endif
   constexpr bool POOL = MODE == 1, UNPOOL = MODE == 2, UPIN = MODE == 3;
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 V stages | U] <= 159 KB
   const ConvGeom& g = a.g;
@@ -272,11 +278,32 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   float* const uslot = ulds + wave * NS * 256;                         // this wave's private units
 
   // wave-uniform unit address (kernel argument + block / wave / step indices: scalar registers) + the lane's 16 bytes
+#if W4_DMA_IMM
+  // ONE global base and ONE LDS base (M0) for units 0 .. 7 of a step: the unit's distance sits in the instruction's immediate
+  // offset, which the hardware adds to BOTH addresses (13 bits, signed: -4096 .. 3072 around unit 4; unit 8 has its own base) --
+  // instead of a 64-bit vector add, an M0 write and its wait state per unit
+#define W4_DMA_CASE(u)                                                                                                   \
+  case u:                                                                                                                \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(up + 4 * 256),                     \
+                                     (__attribute__((address_space(3))) void*)(uslot + 4 * 256), 16, ((u) - 4) * 1024, 0); \
+    break;
+  auto issue_u = [&](int kk, int s) {
+    const float* up = ublock + (long)kk * MD::U_FLOATS + lane * 4;
+    switch (s) {
+      W4_DMA_CASE(0) W4_DMA_CASE(1) W4_DMA_CASE(2) W4_DMA_CASE(3) W4_DMA_CASE(4) W4_DMA_CASE(5) W4_DMA_CASE(6) W4_DMA_CASE(7)
+      default:
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(up + s * 256),
+                                         (__attribute__((address_space(3))) void*)(uslot + s * 256), 16, 0, 0);
+    }
+  };
+#undef W4_DMA_CASE
+#else
   auto issue_u = [&](int kk, int s) {
     const float* up = ublock + (long)kk * MD::U_FLOATS + s * 256 + lane * 4;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)up,
                                      (__attribute__((address_space(3))) void*)(uslot + s * 256), 16, 0, 0);
   };
+#endif
   const W4Consts kc = w4_consts();
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   f32x2 rb[4], psc2 = {1.f, 1.f}, psh2 = {0.f, 0.f};    // upin: this lane's channel PAIR of the four pixels
@@ -457,12 +484,32 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     }
   };
 #undef W4_WAIT_VM
+#ifdef DIAGAN_W4_STAMP
+  // Diagnostic build only (tools/build_variant.sh stamp conv_wino4.hip "-DDIAGAN_W4_STAMP", tools/wino4_stamps.py): per-wave
+  // s_memtime deltas of the phases of a K-step, summed over the K loop, written to
+  // ConvGemmArgs::stamps[(workgroup * 8 + wave) * 16 + phase]; [12] the K loop, [13] its steps, [14] set-up, [15] epilogue.  No
+  // branch on a run-time flag (the K loop must stay one basic block); every stamp drains the wave's LDS queue (s_memtime
+  // returns through lgkmcnt), so a stamped step is a few hundred cycles longer than a production one.
+  unsigned tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_entry = tlast;
+  auto tick = [&](int i) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    tacc[i] += (unsigned)(now - tlast);
+    tlast = now;
+  };
+#define W4_TICK(i) tick(i)
+#else
+#define W4_TICK(i)
+#endif
   auto kstep = [&](int kk, auto has_next, auto row_at, auto col_at) {
     constexpr bool HN = decltype(has_next)::value;
     constexpr int ROW_AT = decltype(row_at)::value, COL_AT = decltype(col_at)::value;
     const int cur = (kk - k_begin) & 1;
+    W4_TICK(9);                                               // (behind the barrier of the previous step)
     if (HN) wait_vm(NS - 1);                                  // D(kk, 0) has landed (D(kk, 1 .. NS - 1) may still fly)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4_TICK(0);                                               // wait for the first weight unit
     const float* const fa_base = fa_lane + cur * W4_VSTAGE;
     f32x4 fa[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, fb[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
     if (W4_ON(2048)) {
@@ -488,17 +535,28 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         __builtin_amdgcn_sched_barrier(0);
         if (W4_ON(64)) issue_u(kk + 1, s);
         if (s == (ROW_AT < NS - 2 ? ROW_AT : NS - 4)) {
+          W4_TICK(1);                                     // slots 0 .. ROW_AT: fragment reads, input-load issue, MFMA issue
           wait_inputs(s + 1);                             // the input loads have landed (the s + 1 younger DMAs may still fly)
+          W4_TICK(2);                                     // wait for the input loads
           if (W4_ON(16)) row_pass(cur ^ 1);
+          W4_TICK(3);                                     // row pass (issue; the stamp also drains its LDS writes)
         } else if (s == (COL_AT < NS - 1 ? COL_AT : NS - 2)) {
+          W4_TICK(4);                                     // slots ROW_AT + 1 .. COL_AT
           if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
+          W4_TICK(5);                                     // column pass (LDS reads, arithmetic, LDS writes drained)
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     // V of the next step is complete (LDS writes: lgkmcnt; U is wave-private and waited for where it is read).  NOT
     // __syncthreads(): its fence would make the compiler wait for every DMA unit in flight
+    W4_TICK(6);                                               // slots COL_AT + 1 .. NS - 1
+#ifdef DIAGAN_W4_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_TICK(7);                                               // LDS queue drained
+#endif
     if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    W4_TICK(8);                                               // barrier
   };
   using RowA = std::integral_constant<int, W4_ROW_AT>;
   using ColA = std::integral_constant<int, W4_COL_AT>;
@@ -511,6 +569,16 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   }
   if (k_begin < k_end) kstep(k_end - 1, std::false_type{}, RowA{}, ColA{});
 
+#ifdef DIAGAN_W4_STAMP
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16;
+    for (int i = 0; i < 12; ++i) o[i] = tacc[i];
+    o[12] = __builtin_amdgcn_s_memtime() - t_entry;      // the K loop
+    o[13] = k_end - k_begin;
+    o[14] = t_entry - t_kernel;                          // set-up + first stage
+  }
+  const unsigned long long t_epi = __builtin_amdgcn_s_memtime();
+#endif
 #ifdef DIAGAN_WINO_ABLATE
   if (a.tune & 512) {
     if (acc[0][0] == 123.456f) a.y[0] = acc[1][3] + acc[5][5] + acc[8][7];
@@ -719,6 +787,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       if (n0 + col < g.Co) a.stat_partials[(long)(tile / tiles_n) * 2 * g.Co + which * g.Co + n0 + col] = t;
     }
   }
+#ifdef DIAGAN_W4_STAMP
+  if (a.stamps && lane == 0)      // the epilogue up to the issue of its last store
+    a.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_memtime() - t_epi;
+#endif
 }
 
 template <int PRO, int MODE = 0>

@@ -34,7 +34,16 @@ for B, H, W, Ci, Co in shapes:
     for name, f in (("plain", lambda cfg: C.conv_fwd(geom, x, wp, tile_cfg=cfg)),
                     ("bn+relu+bias+res_up", lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, residual=resh, res_up=True, pro=(C.PRO_AFFINE_RELU, sc, sh), tile_cfg=cfg)),
                     ("bn+relu+bias+res", lambda cfg: C.conv_fwd(geom, x, wp, bias=bias, residual=res, pro=(C.PRO_AFFINE_RELU, sc, sh), tile_cfg=cfg))):
-        e = ((f(13) - f(9)).abs().max() / f(9).abs().max()).item()
+        y13, y9 = f(13), f(9)
+        e = ((y13 - y9).abs().max() / y9.abs().max()).item()
+        if not e < 1e-3:       # seen twice on one (11 % slower) box and never again: say WHICH result is off, and where
+            ref = f(1)
+            for tag, y in (("first F(4x4)", y13), ("first F(2x2)", y9), ("second F(4x4)", f(13)), ("second F(2x2)", f(9))):
+                d = (y - ref).abs() > 1e-3 * ref.abs().max()
+                if d.any():
+                    w = d.nonzero()
+                    print(f"   MISMATCH {tag} vs implicit GEMM: {w.shape[0]} values, images {w[:, 0].unique().tolist()[:16]}, "
+                          f"rows {w[:, 1].unique().tolist()[:16]}, channels {w[:, 3].min().item()}..{w[:, 3].max().item()}", flush=True)
         t9, t13 = timeit(lambda: f(9)), timeit(lambda: f(13))
         print(f"B={B:3d} {H:2d}x{W:2d} Ci={Ci:4d} Co={Co:4d} {name:18s} err {e:.1e} | F(2x2) {t9*1e6:8.1f} us (MFMA {flop/2.25/t9/PEAK:5.1%}) | "
               f"F(4x4) {t13*1e6:8.1f} us {flop/t13/1e12:6.1f} TF-eq (MFMA {flop/4/t13/PEAK:5.1%})  {t9/t13:4.2f}x", flush=True)
