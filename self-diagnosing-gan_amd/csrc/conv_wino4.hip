@@ -53,6 +53,15 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_DMA_IMM
 #define W4_DMA_IMM 1
 #endif
+// Experiments on the arbitration between the two waves of a SIMD (profiles/r04_w4_kstep_stamps.md: waves 4-7 run ~1400 cycles per
+// step behind waves 0-3, which then wait at the barrier): W4_PRIO_B = n > 0 runs waves 4-7 at priority n for the whole kernel;
+// W4_PRIO_ALT = n > 0 alternates priority n / 0 slot by slot, in opposite phase for the two wave groups.
+#ifndef W4_PRIO_B
+#define W4_PRIO_B 0
+#endif
+#ifndef W4_PRIO_ALT
+#define W4_PRIO_ALT 0
+#endif
 // The same for waves 4-7 (the SIMD partners of waves 0-3: a workgroup's waves w and w + 4 share a SIMD).  With equal placements
 // the two waves of a SIMD run their transform passes -- ~70 + ~45 vector / LDS instructions in a row -- at the same time and
 // the matrix pipe has only the eight MFMAs already in flight to chew on; with different placements one wave's pass sits beside
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 V stages | U] <= 159 KB
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (W4_PRIO_B > 0 && wave >= 4) __builtin_amdgcn_s_setprio(W4_PRIO_B);
   const int tiles_n = (g.Co + W4N - 1) / W4N;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int t0 = (tile / tiles_n) * W4T, nb = tile % tiles_n, n0 = nb * W4N;
@@ -502,8 +512,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #else
 #define W4_TICK(i)
 #endif
-  auto kstep = [&](int kk, auto has_next, auto row_at, auto col_at) {
+  auto kstep = [&](int kk, auto has_next, auto row_at, auto col_at, auto prio_phase) {
     constexpr bool HN = decltype(has_next)::value;
+    constexpr int PPH = decltype(prio_phase)::value;          // experiment W4_PRIO_ALT: -1 none; 0 / 1: high priority in even / odd slots
     constexpr int ROW_AT = decltype(row_at)::value, COL_AT = decltype(col_at)::value;
     const int cur = (kk - k_begin) & 1;
     W4_TICK(9);                                               // (behind the barrier of the previous step)
@@ -525,6 +536,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
           fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[s + 1]);
           fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
         }
+      }
+      if (PPH >= 0) {
+        if ((s + PPH) & 1) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(W4_PRIO_ALT);
       }
       if (W4_ON(256))
 #pragma unroll
@@ -562,12 +577,16 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   using ColA = std::integral_constant<int, W4_COL_AT>;
   using RowB = std::integral_constant<int, W4_ROW_AT2>;
   using ColB = std::integral_constant<int, W4_COL_AT2>;
-  if ((W4_ROW_AT2 == W4_ROW_AT && W4_COL_AT2 == W4_COL_AT) || wave < 4) {
-    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{}, RowA{}, ColA{});
+  using PN = std::integral_constant<int, -1>;
+  using PA = std::integral_constant<int, (W4_PRIO_ALT > 0) ? 0 : -1>;
+  using PB = std::integral_constant<int, (W4_PRIO_ALT > 0) ? 1 : -1>;
+  if ((W4_ROW_AT2 == W4_ROW_AT && W4_COL_AT2 == W4_COL_AT && W4_PRIO_ALT == 0) || wave < 4) {
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{}, RowA{}, ColA{}, PA{});
   } else {
-    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{}, RowB{}, ColB{});
+    for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep(kk, std::true_type{}, RowB{}, ColB{}, PB{});
   }
-  if (k_begin < k_end) kstep(k_end - 1, std::false_type{}, RowA{}, ColA{});
+  if (W4_PRIO_ALT > 0) __builtin_amdgcn_s_setprio(0);
+  if (k_begin < k_end) kstep(k_end - 1, std::false_type{}, RowA{}, ColA{}, PN{});
 
 #ifdef DIAGAN_W4_STAMP
   if (a.stamps && lane == 0) {
