@@ -49,6 +49,11 @@ def lib():
                 f"libdiagan_hip.so not found at {LIB_PATH}: build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the device path.")
+        # torch FIRST: its wheel ships its own libamdhip64.so.7 / libhsa-runtime64 and dlopens them by path.  Loaded after this
+        # library (whose RUNPATH finds /opt/rocm's copy of the same SONAME) the process ends up with TWO HIP runtimes, and the
+        # one this library is bound to then reports "no ROCm-capable device" (seen with build() followed by smoke() in one
+        # process).  With torch's runtime already mapped, the DT_NEEDED entry resolves to it and there is exactly one.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, rt in _RESTYPE.items():
             getattr(L, name).restype = rt

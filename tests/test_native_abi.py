@@ -106,3 +106,21 @@ def test_grouped_prologue_never_gets_a_tile_that_straddles_two_groups():
     # a group that the F(4x4) kernel's 512-row tile does not divide but the F(2x2) kernel's 256 does: batch 12 at 8x8 = 768 rows
     geo = (24 * 12, 8, 8, 256, 8, 8, 256, 3, 3, 1, 1, -1, 1, 2304)
     assert pick(*geo, 1, ws) == 13 and grouped(*geo, 1, ws, 768) == 9
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """build() (which loads the library) followed by torch's device initialisation in ONE process used to map two HIP runtimes --
+    /opt/rocm's through the library's RUNPATH and the torch wheel's own copy -- and the library's then saw no device on a GPU
+    box.  The loader imports torch first: exactly one libamdhip64 may be mapped, torch's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {os.path.join(root, 'self-diagnosing-gan_amd')!r})\n"
+            "from diagan import _native as nat\n"
+            "assert 'torch' not in sys.modules\n"
+            "nat.lib()\n"
+            "import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "assert len(libs) == 1 and '/torch/lib/' in libs[0], libs\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
