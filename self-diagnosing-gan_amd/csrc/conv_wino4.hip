@@ -632,6 +632,18 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0, hr && !a.res_up ? ybytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t msrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mask_src), 0, hm ? ybytes : 0, 0x00020000);
   const int pixb = g.Co * 4, rowb = Wy * pixb;                        // bytes to the next pixel / the next image row
+#ifdef DIAGAN_W4_STAMP
+  unsigned eacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long elast = t_epi;
+  auto etick = [&](int i) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    eacc[i] += (unsigned)(now - elast);
+    elast = now;
+  };
+#define W4_ETICK(i) etick(i)
+#else
+#define W4_ETICK(i)
+#endif
   float* ss = smem;
   f32x4 cs1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, cs2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -639,6 +651,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   auto xidx = [&](int i, int j) { return MD::pooled ? 5 * (i < 2 ? i : i - 1) + (j < 2 ? j : j - 1) : 6 * i + j; };
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
+    W4_ETICK(p == 0 ? 0 : 9);                                  // (p = 0: the scalar set-up of the epilogue)
     if (nh == p) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -652,7 +665,12 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         }
       }
     }
+#ifdef DIAGAN_W4_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    W4_ETICK(1 + 4 * p);                                       // products parked (the four owner waves; drained)
     __syncthreads();
+    W4_ETICK(2 + 4 * p);                                       // barrier
     const int n = n0 + p * 32 + eq * 4;
     const bool ok = tv && n < g.Co;
     const unsigned voff = ok ? (unsigned)(prow0 * g.Co + n) * 4u : 0x80000000u;   // (nothing to store: beyond the descriptor)
@@ -772,7 +790,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       }
     }
     }
+    W4_ETICK(3 + 4 * p);                                       // LDS reads, output transform, residual / mask loads, store issue
     __syncthreads();
+    W4_ETICK(4 + 4 * p);                                       // barrier
   }
   if (hs) {
     // column sums over the workgroup's 512 pixels: lanes that differ in bit 0 (row pair) and bits 4, 5 (tile) hold the
@@ -807,8 +827,12 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     }
   }
 #ifdef DIAGAN_W4_STAMP
-  if (a.stamps && lane == 0)      // the epilogue up to the issue of its last store
-    a.stamps[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16 + 15] = __builtin_amdgcn_s_memtime() - t_epi;
+  if (a.stamps && lane == 0) {    // the epilogue up to the issue of its last store; its phases behind the K-loop stamps
+    unsigned long long* o = a.stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16;
+    o[15] = __builtin_amdgcn_s_memtime() - t_epi;
+    unsigned long long* o2 = a.stamps + ((size_t)gridDim.y * gridDim.x * 8 + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 16;
+    for (int i = 0; i < 10; ++i) o2[i] = eacc[i];
+  }
 #endif
 }
 

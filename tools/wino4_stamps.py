@@ -20,7 +20,7 @@ PHASES = ["wait: first weight unit", "slots 0..ROW_AT (frag reads, load issue, M
 
 def main():
     dev = "cuda"
-    slots = 1 << 18
+    slots = 1 << 19
     buf = torch.zeros(slots * 8, dtype=torch.int64, device=dev)
     cases = [("plain", 13, dict()), ("bn+relu", 13, dict(pro=True)), ("upin bn+relu", 15, dict(pro=True, up=True))]
     for B, H, W, Ci, Co in ((64, 32, 32, 256, 256), (384, 32, 32, 256, 256)):
@@ -54,6 +54,13 @@ def main():
             print(f"   {'sum of medians / K loop per step (median)':50s} {tot:8.0f} / {np.median(loop):8.0f}")
             print(f"   set-up + first stage {np.median(t[:, :, 14]):8.0f} cycles, K loop {np.median(t[:, :, 12]):8.0f}, "
                   f"epilogue {np.median(t[:, :, 15]):8.0f}  (per workgroup; medians over waves)")
+            te = buf[nwg * 128: 2 * nwg * 128].cpu().numpy().reshape(nwg, 8, 16).astype(np.float64)
+            names = ["scalar set-up", "p0: products parked", "p0: barrier", "p0: reads, transform, stores issued", "p0: barrier",
+                     "p1: products parked", "p1: barrier", "p1: reads, transform, stores issued", "p1: barrier", "(p1 loop overhead)"]
+            order = [0, 1, 2, 3, 4, 9, 5, 6, 7, 8]
+            print("   epilogue phases (cycles; waves 0-3 own column half 0 = phase p0, waves 4-7 phase p1):")
+            for i in order:
+                print(f"      {names[i]:40s} waves 0-3 {np.median(te[:, :4, i]):8.0f}   waves 4-7 {np.median(te[:, 4:, i]):8.0f}")
             # waves 0-3 against their SIMD partners 4-7
             for i in range(len(PHASES)):
                 a, b = t[:, :4, i].reshape(-1) / nk, t[:, 4:, i].reshape(-1) / nk
