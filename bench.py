@@ -27,6 +27,7 @@ import argparse
 import contextlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -563,8 +564,14 @@ def main():
                 if key[0] != name or len(key) < 4:
                     continue
                 M, Co, K = key[1], key[2], key[3]
-                m_in = M / 4 if name.endswith((",2>", ",3>")) else M
-                m_out = M / 4 if name.endswith(",1>") else M
+                # parsed family and template arguments, not name suffixes (conv_wino_pool_kernel's LAST template
+                # argument is its column-block count, its second one says whether it is the un-pooling data gradient)
+                m4 = re.match(r"conv_wino4\w*_kernel<\s*\d+\s*,\s*(\d+)", name)
+                mp = re.match(r"conv_wino_pool_kernel<\s*\d+\s*,\s*(true|false|[01])", name)
+                mode = int(m4.group(1)) if m4 else None
+                unpool = mp is not None and mp.group(1) in ("true", "1")
+                m_in = M / 4 if (mode in (2, 3) or unpool) else M
+                m_out = M / 4 if (mode == 1 or (mp is not None and not unpool)) else M
                 tot += v['launches'] * 4.0 * (m_in * K / 9 + m_out * Co + Co * K)
             alg_bytes = tot / d['launches'] if tot else None
         peak = MFMA_F32_PEAK

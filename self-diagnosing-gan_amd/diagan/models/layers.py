@@ -738,6 +738,23 @@ class FlatNet(nn.Module):
             if m is not self:
                 object.__setattr__(m, '_net', self)
 
+    def __deepcopy__(self, memo):
+        """A copy must not inherit what was learned about the ORIGINAL's launches: the Winograd call sites close over the
+        original's layers / contexts (their w_of would hand the copy the original's weights -- ADVICE r4) and the descriptor
+        tables bake raw pointers into the original's slabs.  Sites and batches are dropped (re-learned on the copy's first
+        pass, as after _apply) and the copy's slab generation moves on so that every baked table is rebuilt."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == '_wino_batches' else copy.deepcopy(v, memo)
+        for m in new.modules():
+            if isinstance(m, ConvLayer):
+                m.__dict__.pop('_wsites', None)
+                m._wd = None
+        new.slab_generation += 1
+        return new
+
     def _build_flat(self):
         """(Re)allocate one contiguous fp32 slab for all parameters and one for all gradients and
         re-point every nn.Parameter (and its .grad) at 16-byte aligned views of them."""

@@ -361,6 +361,10 @@ def all_gather_cat(tensor):
         send = tensor.contiguous()
         n = torch.tensor([send.numel(), -send.numel()], dtype=torch.int64, device=send.device)
         dist.all_reduce(n, op=dist.ReduceOp.MAX)
+        # two communicators (the process group's and the native context's) must never have collectives in flight at the
+        # same time: the process-group all-reduce above has to be COMPLETE on the device before the native all-gather below
+        # is enqueued.  Reading n on the host would do it implicitly; keep the dependence explicit.
+        torch.cuda.synchronize(send.device)
         if int(n[0]) != -int(n[1]):
             raise RuntimeError(f"all_gather_cat: per-rank element counts differ ({-int(n[1])} .. {int(n[0])})")
         recv = torch.empty((world * send.shape[0],) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)

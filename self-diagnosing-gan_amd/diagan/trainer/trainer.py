@@ -186,12 +186,16 @@ class LogTrainer:
             print(f'WARN: global_step_D {global_step_D} != global_step_G {global_step_G}, use global_step_G')
         return global_step_G
 
-    def _save_model_checkpoints(self, global_step):
+    def _save_model_checkpoints(self, global_step, collective=True):
         # data parallel: every rank's BatchNorm running statistics come from its own batches -- average them over the
-        # ranks (collective: before the rank-0 gate) so the file does not carry one arbitrary rank's evaluation statistics
-        for net in (self.netG, self.netD, self.netD_drs if self.train_drs else None):
-            if net is not None:
-                dist.reconcile_running_stats_(net)
+        # ranks (collective: before the rank-0 gate) so the file does not carry one arbitrary rank's evaluation statistics.
+        # collective=True is a promise that EVERY rank makes this call at the same step (the periodic and the final save);
+        # a rank-asymmetric caller (the KeyboardInterrupt handler: the ranks are interrupted at different points, one may
+        # already sit in a gradient all-reduce the others never enter) passes False and rank 0 writes its own statistics.
+        if collective:
+            for net in (self.netG, self.netD, self.netD_drs if self.train_drs else None):
+                if net is not None:
+                    dist.reconcile_running_stats_(net)
         if self.rank != 0:
             return
         self.netG.save_checkpoint(directory=self.netG_ckpt_dir, global_step=global_step, optimizer=self.optG)
@@ -236,7 +240,7 @@ class LogTrainer:
 
     # ---- launch-bound networks: the device work of a global step replayed as ONE hipGraph ------------------------------
     # MNIST-DCGAN's step is ~1000 launches of ~10 us: bound by the per-launch floor, not by the GPU's arithmetic
-    # (bench.py --workload dcgan: 10.2 -> 9.2 ms per step with --graph).  Networks that declare `launch_bound = True` get the
+    # (bench.py --workload dcgan: 8.75 -> 8.47 ms per step with --graph, profiles/r04_raw/bench_dcgan{,_graph}.json).  Networks that declare `launch_bound = True` get the
     # step captured once (diagan/utils/graph.py) after a few ordinary steps and replayed from then on: same kernels, same
     # order, bit-identical parameters (tests/test_graph_gpu.py).  Not under data parallelism (collectives), top-k or GOLD
     # (host values that change from step to step are baked into the captured launches); a step with a ragged last batch
@@ -347,9 +351,9 @@ class LogTrainer:
         self._get_logit(netD=net, eval_mode=(mode == 'eval'), record=self.logit_records[key], step=step)
         self.events.append((step, 'logit'))
 
-    def _persist(self, step, banner):
+    def _persist(self, step, banner, collective=True):
         print(banner)
-        self._save_model_checkpoints(step)
+        self._save_model_checkpoints(step, collective=collective)
         if self.save_logits and step >= self.save_logit_after:
             self._save_logit()
 
@@ -379,7 +383,7 @@ class LogTrainer:
                     self.events.append((step, 'ckpt'))
             self._persist(step, "INFO: Saving final checkpoints...")
         except KeyboardInterrupt:
-            self._persist(step, "INFO: Saving checkpoints from keyboard interrupt...")
+            self._persist(step, "INFO: Saving checkpoints from keyboard interrupt...", collective=False)
         finally:
             self.logger.close_writers()
         print("INFO: Training Ended.")

@@ -250,6 +250,29 @@ def test_batchnorm_counter_is_folded_into_state_dict():
     assert int(bn.state_dict()['num_batches_tracked']) == 3
 
 
+def test_deepcopy_of_a_flat_net_drops_learned_launch_state():
+    """the Winograd call sites of a FlatNet close over the ORIGINAL's layers; a deep copy must start without them,
+    with parameters that are views of its OWN slab and a new slab generation (baked descriptor tables are rebuilt)."""
+    import copy
+    from diagan.models.predefined_models import get_gan_model
+    netG, _ = get_gan_model(dataset_name='cifar10', gan_type='sngan', loss_type='ns')[:2]
+    conv = next(m for m in netG.modules() if m.__class__.__name__ == 'ConvLayer')
+    netG._wino_batches[('f', None)] = object()           # what a first pass leaves behind
+    conv.__dict__['_wsites'] = {('f', None, 0): object()}
+    gen = netG.slab_generation
+    twin = copy.deepcopy(netG)
+    assert twin._wino_batches == {} and netG._wino_batches != {}
+    tconv = next(m for m in twin.modules() if m.__class__.__name__ == 'ConvLayer')
+    assert '_wsites' not in tconv.__dict__ and '_wsites' in conv.__dict__
+    assert tconv._net is twin and twin.slab_generation == gen + 1
+    flat = twin.flat_params
+    for p in twin.parameters():
+        assert p.data.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+    assert flat.untyped_storage().data_ptr() != netG.flat_params.untyped_storage().data_ptr()
+    twin.flat_params.add_(1.0)                           # the copy diverges; the original does not move
+    assert not torch.equal(next(twin.parameters()), next(netG.parameters()))
+
+
 def test_color_mnist_front_ends_keep_the_reference_flags():
     """train_mimicry_color_mnist_phase{1,2}.py: flag names and defaults (reference :48-67 / :41-61)"""
     from diagan import cli

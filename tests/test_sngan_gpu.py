@@ -614,3 +614,30 @@ def test_stacked_forward_folds_the_upsampling_into_c1(dataset, nup, monkeypatch)
             assert g_f[k].abs().max().item() < 1e-4 * wscale, k
         else:
             l2close(g_f[k], g_t[k], 2e-2, f"G grad {k}")
+
+
+def test_deep_copy_after_forwards_uses_its_own_weights():
+    """a FlatNet deep-copied AFTER its Winograd call sites were learned kept sites whose weight getters returned
+    the ORIGINAL's weights; once the two diverge the copy convolved with the wrong ones.  The copy is perturbed, run, and
+    compared with a freshly built network that loaded the copy's state dict (never shared anything with the original)."""
+    from diagan.models.predefined_models import get_gan_model
+    (_, _, _, _), (netG, _, _, _) = build('cifar10', 'ns')
+    torch.manual_seed(3)
+    for _ in range(3):                                   # sites are learned on the first pass, batches used from the second
+        netG.generate_images_nhwc(8)
+    twin = copy.deepcopy(netG)
+    with torch.no_grad():
+        twin.flat_params.mul_(1.25)
+        twin.param_version += 1
+    fresh = get_gan_model('cifar10', model='sngan', loss_type='ns')[0]
+    fresh.load_state_dict(twin.state_dict())
+    fresh.to('cuda')
+    outs = []
+    for net in (twin, fresh, netG):
+        net.eval()
+        torch.manual_seed(4)
+        for _ in range(2):
+            y = net.generate_images_nhwc(8)[0]
+        outs.append(y)
+    relclose(outs[0], outs[1], 1e-5, "copy vs freshly loaded")
+    assert (outs[0] - outs[2]).abs().max().item() > 1e-3          # and it really differs from the original's images
