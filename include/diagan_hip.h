@@ -163,6 +163,12 @@ int diagan_conv_gemm_get_wino(void);
  * error ~1e-5 of the output scale (cuDNN's non-fused Winograd for the reference's F.conv2d is the same F(4x4,3x3)).  The
  * automatic choice takes it for launches of >= 512 workgroups (32 tiles x 64 channels each).  0 = never, 1 / -1 = default. */
 int diagan_conv_gemm_set_wino4(int mode);
+/* Round 5 ("X3"): the F(4x4,3x3) launches (tile_cfg 13 / 15) whose K loop is a multiple of four 8-channel steps (Ci % 32 == 0)
+ * run their 36 frequency GEMMs as v_mfma_f32_32x32x16_bf16 with every fp32 operand split EXACTLY into three bf16 pieces (six
+ * piece products, fp32 accumulation: ~2^-23 relative per product, i.e. fp32-level; no scaling, fp32's exponent range): the same
+ * reference ops, arguments and results to the tolerance of tile_cfg 13.  1 on, 0 off, -1 the environment's DIAGAN_WINO4_X3. */
+int diagan_conv_gemm_set_wino4x(int mode);
+int diagan_conv_gemm_get_wino4x(void);
 /* tile_cfg 11 / 12 (convolution + 2x2 average pool, and its data gradient from the pooled gradient) run on the same F(4x4) kernel
  * in 25 products per 4x4 tile (frequency row / column 2 never reaches a pooling-window sum) where the launch has >= 192 workgroups
  * and H, W are multiples of 4; this query says whether a geometry does (kernel names, executed-FLOP accounting). */

@@ -48,6 +48,8 @@ int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 bool wino4_upin_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool force);
 int launch_wino_weights_batched(const WinoJob* jobs, int n, int blocks, hipStream_t st);     // conv_wino4.hip (all formats)
 int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st);
+void wino4_set_x3(int mode);
+int wino4_get_x3();
 int launch_wino_pool(ConvGemmArgs a, float* ws, hipStream_t st); // conv_wino_pool.hip
 int launch_wino_unpool(ConvGemmArgs a, float* ws, hipStream_t st);
 int wino_pool_ksplit(int B, int Ho, int Wo, int Ci, int Co, long slab_floats, int min_wgs);
@@ -1153,6 +1155,16 @@ DIAGAN_API int diagan_conv_gemm_set_wino4(int mode) {
   g_wino4 = mode;
   return DIAGAN_OK;
 }
+
+// Run-time form of DIAGAN_WINO4_X3 (round 5): 1 = the F(4x4,3x3) launches whose K loop is a multiple of four steps run their 36
+// frequency GEMMs on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 pieces (conv_wino4.hip, X3);
+// 0 = fp32 MFMA; -1 = the environment's choice.  Returns the mode in force through diagan_conv_gemm_get_wino4x.
+DIAGAN_API int diagan_conv_gemm_set_wino4x(int mode) {
+  DG_REQUIRE(mode >= -1 && mode <= 1, "set_wino4x: -1, 0 or 1");
+  wino4_set_x3(mode);
+  return DIAGAN_OK;
+}
+DIAGAN_API int diagan_conv_gemm_get_wino4x(void) { return wino4_get_x3(); }
 
 // Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.
 //  * stamp buffer: while set, diagan_conv_gemm launches the STAMP build of the kernel, which records per workgroup

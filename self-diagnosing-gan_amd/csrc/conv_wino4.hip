@@ -76,6 +76,83 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 static_assert((2 * W4_VSTAGE + W4_U) * 4 <= 163840 && 36 * 32 * 32 <= 2 * W4_VSTAGE + W4_U,
               "162 432 bytes of the CU's 163 840; the epilogue's 36 x 32 x 32 floats fit inside");
 
+// ---- X3 (round 5): the 36 frequency GEMMs on the bf16 matrix pipe by exact operand splitting ----
+// Why: the fp32 MFMA issues at the vector rate on the datapath the transform passes need (profiles/r04_w4_kstep_stamps.md: a
+// SIMD's time is the SUM of its MFMAs and its vector instructions, K loop at 0.60 of the pipe at best); v_mfma_f32_32x32x16_bf16
+// has 16x the rate and holds the vector issue for 8 of its 32 cycles, so the transforms run UNDER the matrix work.  Every fp32
+// operand is split exactly into three bf16 pieces (wino_weights.h: x3_split) and the six piece products of order <= 2^-16
+// are accumulated in fp32: per slot and K-step (8 channels) three MFMAs whose k = 16 holds TWO pieces x 8 channels,
+//     acc += (a0 | a1) . (b0 | b0)  +  (a0 | a1) . (b1 | b1)  +  (a0 | a2) . (b2 | b0)
+// (lanes 0-31 | lanes 32-63) = 27 MFMAs of 32 cycles per wave and step instead of 36 of 64.
+// LDS (161 088 bytes): V as piece planes [stage][j][i][piece][32 tiles][8 channels bf16] -- 512 bytes per piece, 16 bytes of
+// padding per row i and per column j so that the row pass (lanes differ in i) and the column pass (lanes differ in j) write
+// conflict-free 8-byte chunks; the row pass parks its fp32 intermediate in the chunks of pieces 0 / 1 of the plane the column
+// pass then overwrites with the pieces (same thread, in-order LDS).  U: every wave streams its own units through a FOUR-unit
+// ring (6 KB) in 1 KB LDS-DMA granules: stream byte b lives at ring byte b mod 6144, a granule is issued as soon as the units
+// it overwrites have been read, ~3 slots before its own unit is.  The ring's phase repeats every four K-steps: the K loop is
+// unrolled four-fold (the launch takes this kernel only for K loops of a multiple of four steps).
+// Diagnostic builds only (tools/build_variant.sh <name> conv_wino4.hip "-DX3_ABL=<bits>"; results are then garbage): parts of the
+// X3 K loop removed at COMPILE time (the loop stays one basic block) so that their cost can be read off the launch time --
+// 1 MFMAs, 2 fragment reads, 4 weight granules, 8 the operand split's arithmetic, 16 row + column pass, 32 input loads, 64 barrier,
+// 128 (both builds, MODE 0 / 1): input loads at the addresses of a channel-blocked layout
+#ifndef X3_ABL
+#define X3_ABL 0
+#endif
+constexpr int X3_SP = 512;                       // bytes between the pieces of a frequency
+constexpr int X3_SI = 3 * X3_SP + 16;            // ... between rows i      (388 dwords = 4 mod 32)
+constexpr int X3_SJ = 6 * X3_SI + 16;            // ... between columns j   (2332 dwords = 28 mod 32)
+constexpr int X3_VSTAGE = 6 * X3_SJ;             // 55 968 bytes per stage
+constexpr int X3_RING = 4 * X3_UNIT;             // 6 144 bytes per wave
+constexpr int X3_LDS = 2 * X3_VSTAGE + 8 * X3_RING;
+static_assert(X3_LDS <= 163840 && 36 * 32 * 32 * 4 <= X3_LDS, "161 088 bytes of the CU's 163 840; the epilogue's exchange image fits inside");
+// granules (1 KB) of a wave's stream: the last one that may be in flight once unit u has been read, the last one unit v needs
+constexpr int x3_gmax(int u) { return (3 * (u + 1)) / 2 + 5; }
+constexpr int x3_gneed(int v) { return (3 * (v + 1) + 1) / 2 - 1; }
+// vmcnt bookkeeping, evaluated at compile time: the number of vector-memory operations (granules, input loads) a wave has issued
+// AFTER the operation it is about to wait for, in the steady state of the four-step schedule of kstep3 (ph: step mod 4; hn: a next
+// step exists; NX: input loads per step).  kind 0: the last granule of the unit read at the top of the step (s = -1) or inside
+// slot s (the unit of slot s + 1); kind 1: the input loads (issued at the top of slot load_at), waited for behind slot row_at's granules.
+constexpr int x3_vm_younger(int NS, int ph, bool hn, int NX, int load_at, int row_at, int kind, int s) {
+  int seq[256] = {};
+  for (int i = 0; i < 256; ++i) seq[i] = -1000;
+  int n = 0, seqx = -1000;
+  const int t = 4 + ph;
+  for (int tt = t - 2; tt <= t; ++tt) {
+    const bool h = tt < t ? true : hn;
+    const int last = x3_gneed(NS * tt + NS - 1);
+    if (tt == t && kind == 0 && s == -1) return n - seq[x3_gneed(NS * tt) - x3_gmax(NS * (t - 2) - 1)] - 1;
+    for (int ss = 0; ss < NS; ++ss) {
+      const int u = NS * tt + ss;
+      if (h && ss == load_at) {              // the input loads of the next step: at the top of slot load_at
+        n += NX;
+        seqx = n - 1;
+      }
+      if (ss + 1 < NS && tt == t && kind == 0 && s == ss) return n - seq[x3_gneed(u + 1) - x3_gmax(NS * (t - 2) - 1)] - 1;
+      for (int g = x3_gmax(u - 1) + 1; g <= x3_gmax(u); ++g)
+        if (h || g <= last) seq[g - x3_gmax(NS * (t - 2) - 1)] = n++;
+      if (ss == row_at && h && tt == t && kind == 1) return n - seqx - 1;
+    }
+  }
+  return -1;
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int... V>
+constexpr int x3_seq_at(std::integer_sequence<int, V...>, int i) {
+  const int v[] = {V...};
+  return v[i];
+}
+template <int N>
+__device__ __forceinline__ void x3_wait_vm() {
+  static_assert(N >= 0 && N < 48, "vmcnt bookkeeping of the X3 schedule");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 // MODE 0: the convolution.  MODE 1 ("pool"): the convolution FOLLOWED BY F.avg_pool2d(., 2) -- the end of mimicry's DBlock /
 // DBlockOptimized with downsample = True (predefined_models.py:38-40,76-78), y / residual are the POOLED tensors.  A 4x4 tile
 // holds four pooling windows; window sums are (P A^T) M (P A^T)^T with P A^T = [[1, 2, 0, 3, -1, 0], [0, 2, 0, 12, -4, 1]]:
@@ -107,6 +184,12 @@ __global__ __launch_bounds__(512) void wino4_weight_kernel(const float* __restri
   __shared__ f32x4 sg[WT_LDS_F4];
   wino4_weight_body<MODE>(w, ug, Co, Ci, Kp, flip, wscale, blockIdx.x, blockIdx.y, sg);
 }
+template <int MODE>
+__global__ __launch_bounds__(512) void wino4x_weight_kernel(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci,
+                                                            int Kp, int flip, float wscale) {
+  __shared__ f32x4 sg[WT_LDS_F4];
+  wino4x_weight_body<MODE>(w, ug, Co, Ci, Kp, flip, wscale, blockIdx.x, blockIdx.y, sg);
+}
 
 // the transforms of MANY layers in one launch (diagan_wino_weights_batched): workgroup -> job through the jobs' first-block
 // prefix (a handful of jobs: linear scan), then the job's own (channel block, column block) in the job's format
@@ -116,7 +199,9 @@ __global__ __launch_bounds__(512) void wino_weights_batched_kernel(const WinoJob
   while (j + 1 < n && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
   const WinoJob job = jobs[j];
   const int lb = blockIdx.x - job.blk0, nbx = (job.Ci + 31) >> 5;
-  if (job.kind == WK_F4) wino4_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  if (job.kind == WK_F4X) wino4x_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  else if (job.kind == WK_F4X_POOL) wino4x_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  else if (job.kind == WK_F4) wino4_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
   else if (job.kind == WK_F4_POOL) wino4_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
   else wino_weight_body(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, lb % nbx, lb / nbx, sg);
 }
@@ -182,7 +267,7 @@ __device__ __forceinline__ void w4_up(const V* d, V* t, const W4Consts& k, float
 #define W4_ON(bit) true
 #endif
 
-template <int PRO, int MODE = 0>
+template <int PRO, int MODE = 0, bool X3 = false>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
   using MD = W4M<MODE>;
   constexpr int NS = MD::NS, NI = MD::NI;
@@ -245,7 +330,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
     for (int c = 0; c < NI; ++c) {
       const bool ok = rv && ix0 + c >= 0 && ix0 + c < Wx;
-      off[c] = ok ? (unsigned)(rowbase + c * g.Ci * 4) : 0x80000000u;  // beyond num_records: the hardware returns zeros
+      off[c] = ok ? (unsigned)(rowbase + c * ((X3_ABL & 128) ? 32 : g.Ci * 4)) : 0x80000000u;  // beyond num_records: the hardware returns zeros
+      // (X3_ABL & 128, timing probe: the six pixels of a patch row as six consecutive 32-byte chunks -- the cache lines a
+      //  channel-blocked activation layout would touch, a third of NHWC's)
       kbound[c] = ok ? 0x7fffffff : 0;
     }
     }
@@ -281,6 +368,14 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   float* const vrow = smem + (UPIN ? (lq * 42 + ur) * W4_PS + lt * 4 + uc * 2
                                    : (ract ? (lq * 42 + lr) * W4_PS + lt * 4 : (1 << 22)));          // + j * 7 * W4_PS
   float* const vcol = smem + (cact ? (lq * 42 + 7 * lr) * W4_PS + lt * 4 : (1 << 22));      // + i * W4_PS
+  // X3: 8-byte chunks (4 channels bf16, or half of an fp32 quad) of plane (i, j, piece) at i * X3_SI + j * X3_SJ + piece * X3_SP
+  // (kept as 32-bit LDS offsets: the passes step ONE running offset from plane to plane behind an empty asm -- the padded strides
+  //  fit neither the 8-bit offsets of ds_write2_b64 nor each other's, and twelve ready-made addresses per stage cost registers
+  //  the loop does not have: the first X3 build spilled them to scratch inside the K loop)
+  char* const sm8 = reinterpret_cast<char*>(smem);
+  const unsigned vrow3 = UPIN ? ur * X3_SI + lt * 16 + lq * 8 + uc * X3_SP
+                              : (ract ? lr * X3_SI + lt * 16 + lq * 8 : (1u << 24));               // + j * X3_SJ
+  const unsigned vcol3 = cact ? lr * X3_SJ + lt * 16 + lq * 8 : (1u << 24);                       // + i * X3_SI
 
   float* const ulds = smem + 2 * W4_VSTAGE;
   // (weight units are stored [group][column half]: this wave's nine are unit block (wave & 3) * 2 + (wave >> 2))
@@ -319,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   f32x2 rb[4], psc2 = {1.f, 1.f}, psh2 = {0.f, 0.f};    // upin: this lane's channel PAIR of the four pixels
 #pragma unroll
   for (int c = NI; c < 6; ++c) ra[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto issue_x = [&](int kk) {
+  auto issue_x = [&](int kk) __attribute__((always_inline)) {
     const int soff = __builtin_amdgcn_readfirstlane(kk * (W4K * 4));
     if (UPIN) {
 #pragma unroll
@@ -360,7 +455,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   };
 #undef W4_WAIT_IN
   // prologue on the loaded pixels + row transform + park in the V planes of `stage`
-  auto row_pass = [&](int stage) {
+  auto row_pass = [&](int stage) __attribute__((always_inline)) {
     if (UPIN) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -380,6 +475,16 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       }
       f32x2 t[6];
       w4_up(rb, t, kc, ex0, ex5);
+      if (X3) {            // this lane's channel pair is half uc of the quad: chunk `piece uc` of the intermediate
+        unsigned o = vrow3 + stage * X3_VSTAGE;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          *reinterpret_cast<f32x2*>(sm8 + o) = t[j];
+          o += X3_SJ;
+          asm volatile("" : "+v"(o));
+        }
+        return;
+      }
       float* vs = vrow + stage * W4_VSTAGE;
 #pragma unroll
       for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x2*>(vs + j * 7 * W4_PS) = t[j];
@@ -416,17 +521,41 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       for (int c = 0; c < 6; ++c) t[c] = ra[c];
       w4_bt(t, kc);
     }
+    if (X3) {              // the fp32 intermediate of (row lr, column j) as two 8-byte halves in the chunks of pieces 0 / 1
+      unsigned o = vrow3 + stage * X3_VSTAGE;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (!(MD::pooled && j == 2)) {
+          *reinterpret_cast<f32x2*>(sm8 + o) = f32x2{t[j][0], t[j][1]};
+          *reinterpret_cast<f32x2*>(sm8 + o + X3_SP) = f32x2{t[j][2], t[j][3]};
+        }
+        o += X3_SJ;
+        asm volatile("" : "+v"(o));
+      }
+      return;
+    }
     float* vs = vrow + stage * W4_VSTAGE;
 #pragma unroll
     for (int j = 0; j < 6; ++j)
       if (!(MD::pooled && j == 2)) *reinterpret_cast<f32x4*>(vs + j * 7 * W4_PS) = t[j];
   };
   // column transform of column lr, in place (reads what the row pass of this 16-lane group parked)
-  auto col_pass = [&](int stage) {
+  auto col_pass = [&](int stage) __attribute__((always_inline)) {
     float* vs = vcol + stage * W4_VSTAGE;
     f32x4 d[6];
+    if (X3) {
+      unsigned o = vcol3 + stage * X3_VSTAGE;
+#pragma unroll
+      for (int i = 0; i < ((UNPOOL || UPIN) ? 4 : 6); ++i) {
+        const f32x2 lo = *reinterpret_cast<const f32x2*>(sm8 + o), hi = *reinterpret_cast<const f32x2*>(sm8 + o + X3_SP);
+        d[i] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+        o += X3_SI;
+        asm volatile("" : "+v"(o));
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < ((UNPOOL || UPIN) ? 4 : 6); ++i) d[i] = *reinterpret_cast<const f32x4*>(vs + i * W4_PS);
+    }
     if (UPIN) {
       f32x4 t[6];
       w4_up(d, t, kc, ey0, ey5);
@@ -439,6 +568,27 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       for (int i = 0; i < 6; ++i) d[i] = t[i];
     } else {
       w4_bt(d, kc);
+    }
+    if (X3) {              // split, and write the three pieces over the intermediate this thread has just read
+      unsigned o = vcol3 + stage * X3_VSTAGE;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (!(MD::pooled && i == 2)) {
+          u32x2 p0, p1, p2;
+          if (X3_ABL & 8) {
+            p0 = u32x2{__float_as_uint(d[i][0]), __float_as_uint(d[i][1])};
+            p1 = u32x2{__float_as_uint(d[i][2]), __float_as_uint(d[i][3])};
+            p2 = p0;
+          } else
+          x3_split(d[i], p0, p1, p2);
+          *reinterpret_cast<u32x2*>(sm8 + o) = p0;
+          *reinterpret_cast<u32x2*>(sm8 + o + X3_SP) = p1;
+          *reinterpret_cast<u32x2*>(sm8 + o + 2 * X3_SP) = p2;
+        }
+        o += X3_SI;
+        asm volatile("" : "+v"(o));
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -456,9 +606,29 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     for (int e = 0; e < 16; ++e) acc[s][e] = 0.f;
   const int fi = lane & 31, kh = lane >> 5;
 
+  // ---- X3: this wave's weight stream (bytes; + 3072: the six granules of a ring pass are addressed around its middle, the
+  // distance -3072 .. 2048 in the DMA instruction's immediate offset, which the hardware adds to the global AND the LDS address)
+  char* const uring = sm8 + 2 * X3_VSTAGE + wave * X3_RING;
+  const char* ugrp = reinterpret_cast<const char*>(ug) + ((long)(nb * 8 + wave) * nk + k_begin) * (NS * X3_UNIT) + lane * 16 + 3072;
+#define X3_DMA_CASE(r)                                                                                                  \
+  case r:                                                                                                                \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,                                  \
+                                     (__attribute__((address_space(3))) void*)(uring + 3072), 16, ((r) - 3) * 1024, 0);  \
+    break;
+  auto x3_issue_g = [&](const char* grp_base, int g) __attribute__((always_inline)) {        // g: granule of the four-step group (compile-time after unrolling)
+    const int r = g % 6;
+    const char* gp = grp_base + (g - r) * 1024;
+    switch (r) { X3_DMA_CASE(0) X3_DMA_CASE(1) X3_DMA_CASE(2) X3_DMA_CASE(3) X3_DMA_CASE(4) X3_DMA_CASE(5) }
+  };
+#undef X3_DMA_CASE
   if (k_begin < k_end) {
+    if (X3) {
+#pragma unroll
+      for (int g = 0; g <= x3_gmax(-1); ++g) x3_issue_g(ugrp, g);
+    } else {
 #pragma unroll
     for (int s = 0; s < NS; ++s) issue_u(k_begin, s);
+    }
     issue_x(k_begin);
     wait_inputs(0);
     row_pass(0);
@@ -525,39 +695,39 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     f32x4 fa[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, fb[2] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
     if (W4_ON(2048)) {
       fa[0] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[0]);
-      fb[0] = *reinterpret_cast<const f32x4*>(fb_base);
+      if (!(X3_ABL & 256)) fb[0] = *reinterpret_cast<const f32x4*>(fb_base);
     }
-    if (HN && W4_ON(32)) issue_x(kk + 1);
+    if (HN && W4_ON(32) && !(X3_ABL & 32)) issue_x(kk + 1);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       if (s + 1 < NS) {
         if (HN) wait_vm(NS - 2 + NI + (affine ? 2 : 0));
         if (W4_ON(2048)) {
           fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[s + 1]);
-          fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
+          if (!(X3_ABL & 256)) fb[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fb_base + (s + 1) * 256);
         }
       }
       if (PPH >= 0) {
         if ((s + PPH) & 1) __builtin_amdgcn_s_setprio(0);
         else __builtin_amdgcn_s_setprio(W4_PRIO_ALT);
       }
-      if (W4_ON(256))
+      if (W4_ON(256) && !(X3_ABL & 1))
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][e], fb[s & 1][e], acc[s], 0, 0, 0);
       if (HN) {
         // slot s has been read into registers (the MFMAs above needed it): re-fill it for the next step
         __builtin_amdgcn_sched_barrier(0);
-        if (W4_ON(64)) issue_u(kk + 1, s);
+        if (W4_ON(64) && !(X3_ABL & 4)) issue_u(kk + 1, s);
         if (s == (ROW_AT < NS - 2 ? ROW_AT : NS - 4)) {
           W4_TICK(1);                                     // slots 0 .. ROW_AT: fragment reads, input-load issue, MFMA issue
           wait_inputs(s + 1);                             // the input loads have landed (the s + 1 younger DMAs may still fly)
           W4_TICK(2);                                     // wait for the input loads
-          if (W4_ON(16)) row_pass(cur ^ 1);
+          if (W4_ON(16) && !(X3_ABL & 16)) row_pass(cur ^ 1);
           W4_TICK(3);                                     // row pass (issue; the stamp also drains its LDS writes)
         } else if (s == (COL_AT < NS - 1 ? COL_AT : NS - 2)) {
           W4_TICK(4);                                     // slots ROW_AT + 1 .. COL_AT
-          if (W4_ON(16) && W4_ON(4096)) col_pass(cur ^ 1);
+          if (W4_ON(16) && W4_ON(4096) && !(X3_ABL & 16)) col_pass(cur ^ 1);
           W4_TICK(5);                                     // column pass (LDS reads, arithmetic, LDS writes drained)
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -570,9 +740,155 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_TICK(7);                                               // LDS queue drained
 #endif
-    if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (X3_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     W4_TICK(8);                                               // barrier
   };
+  // ---- X3 K-step (see the notes at X3_SP above) ----
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int NX = NI + (affine ? 2 : 0);
+  // placement of the next step's input loads / row pass / column pass (the slot they follow): waves 0-3 early, their SIMD partners
+  // 4-7 late -- while one wave of a SIMD runs its transform passes (vector / LDS work) the other is in MFMA slots, and the two
+  // groups' load bursts and LDS write bursts do not coincide (two copies of the loop, chosen by a wave-uniform branch outside it)
+#ifndef X3_PLACE_A
+#define X3_PLACE_A 0, 3, 5
+#endif
+#ifndef X3_PLACE_B
+#define X3_PLACE_B 3, 6, 8
+#endif
+  constexpr int x3_pa[3] = {X3_PLACE_A}, x3_pb[3] = {X3_PLACE_B};
+  constexpr int sh3 = 9 - NS;                      // (pooled modes: seven slots)
+  using PlA = std::integer_sequence<int, x3_pa[0], x3_pa[1] - (x3_pa[1] > 2 ? sh3 : 0), x3_pa[2] - sh3>;
+  using PlB = std::integer_sequence<int, x3_pb[0] - (x3_pb[0] > 1 ? sh3 : 0), x3_pb[1] - sh3, x3_pb[2] - sh3>;
+  // fragment addresses: A = V pieces of (tile fi): (a0 | a1) and (a0 | a2) for lanes (0-31 | 32-63); B = this wave's ring:
+  // (b0 | b0) and (b1 | b1) through one address, (b2 | b0) through the other
+  const char* const aP = sm8 + (MD::pooled ? 0 : fi0 * X3_SI + fj0 * X3_SJ) + kh * X3_SP + fi * 16;
+  const char* const aQ = aP + kh * X3_SP;
+  const char* const b0 = uring + fi * 16;
+  const char* const b3 = uring + (kh ? 0 : 2 * X3_SP) + fi * 16;
+  int so3[NS];                                                 // slot s: byte offset of its frequency's piece-0 plane
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (!MD::pooled) so3[s] = (s / 3) * X3_SI + (s % 3) * X3_SJ;
+    else {
+      const int l = w4p_start(grp) + (s < w4p_count(grp) ? s : 0);
+      so3[s] = w4p_freq(l / 5) * X3_SI + w4p_freq(l % 5) * X3_SJ;
+    }
+  }
+  auto kstep3 = [&](int kk, auto phase, auto has_next, const char* grp_base, auto place) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phase)::value;
+    constexpr bool HN = decltype(has_next)::value;
+    constexpr int cur = PH & 1;
+    constexpr int X3_LOAD_AT = x3_seq_at(place, 0), X3_ROW_AT = x3_seq_at(place, 1), X3_COL_AT = x3_seq_at(place, 2);
+    static_assert(X3_LOAD_AT >= 0 && X3_LOAD_AT < X3_ROW_AT && X3_ROW_AT < X3_COL_AT && X3_COL_AT < NS, "placement of the passes");
+    W4_TICK(9);
+    x3_wait_vm<x3_vm_younger(NS, PH, HN, NX, X3_LOAD_AT, X3_ROW_AT, 0, -1)>();
+    W4_TICK(0);
+    const char* const fap = aP + cur * X3_VSTAGE;
+    const char* const faq = aQ + cur * X3_VSTAGE;
+    // ONE set of fragment registers, refilled on the fly: each read of the NEXT slot's fragments is issued right behind the last MFMA
+    // that uses its destination (fb[0] after the first, fa[0] / fb[1] after the second, fa[1] / fb[2] after the third) -- the
+    // partner wave's MFMAs and this wave's next two cover the LDS latency; a second set would cost 20 registers the loop lacks
+    u32x4 fa[2] = {{1, 1, 1, 1}, {1, 1, 1, 1}}, fb[3] = {{1, 1, 1, 1}, {1, 1, 1, 1}, {1, 1, 1, 1}};
+    if (!(X3_ABL & 2)) {
+      constexpr int ro = ((NS * PH) & 3) * X3_UNIT;
+      fa[0] = *reinterpret_cast<const u32x4*>(fap + so3[0]);
+      fa[1] = *reinterpret_cast<const u32x4*>(faq + so3[0]);
+      fb[0] = *reinterpret_cast<const u32x4*>(b0 + ro);
+      fb[1] = *reinterpret_cast<const u32x4*>(b0 + ro + X3_SP);
+      fb[2] = *reinterpret_cast<const u32x4*>(b3 + ro);
+    }
+    static_for<0, NS>([&](auto slot) __attribute__((always_inline)) {
+      constexpr int s = decltype(slot)::value, u = NS * PH + s;
+      if (HN && s == X3_LOAD_AT && !(X3_ABL & 32)) {
+        issue_x(kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      constexpr int sn = s + 1 < NS ? s + 1 : 0, ro = ((u + 1) & 3) * X3_UNIT;          // the next slot's planes and ring position
+      constexpr bool rd = s + 1 < NS && !(X3_ABL & 2), mm = !(X3_ABL & 1);
+      if (mm) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0]), __builtin_bit_cast(bf16x8, fb[0]), acc[s], 0, 0, 0);
+      if (s + 1 < NS) {
+        __builtin_amdgcn_sched_barrier(0);
+        x3_wait_vm<x3_vm_younger(NS, PH, HN, NX, X3_LOAD_AT, X3_ROW_AT, 0, s + 1 < NS ? s : 0)>();       // the next unit's granules have landed
+        if (rd) fb[0] = *reinterpret_cast<const u32x4*>(b0 + ro);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (mm) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[0]), __builtin_bit_cast(bf16x8, fb[1]), acc[s], 0, 0, 0);
+      if (rd) {
+        __builtin_amdgcn_sched_barrier(0);
+        fa[0] = *reinterpret_cast<const u32x4*>(fap + so3[sn]);
+        fb[1] = *reinterpret_cast<const u32x4*>(b0 + ro + X3_SP);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (mm) acc[s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[1]), __builtin_bit_cast(bf16x8, fb[2]), acc[s], 0, 0, 0);
+      if (rd) {
+        __builtin_amdgcn_sched_barrier(0);
+        fa[1] = *reinterpret_cast<const u32x4*>(faq + so3[sn]);
+        fb[2] = *reinterpret_cast<const u32x4*>(b3 + ro);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // unit u has been read into registers: the granules that overwrite nothing younger may fly
+#pragma unroll
+      for (int g = x3_gmax(u - 1) + 1; g <= x3_gmax(u); ++g)
+        if ((HN || g <= x3_gneed(NS * PH + NS - 1)) && !(X3_ABL & 4)) x3_issue_g(grp_base, g);
+      if (HN && !(X3_ABL & 16)) {
+        if (s == X3_ROW_AT) {
+          W4_TICK(1);
+          constexpr int NW = x3_vm_younger(NS, PH, true, NX, X3_LOAD_AT, X3_ROW_AT, 1, 0);
+          static_assert(NW >= 0 && NW < 48, "input-load wait of the X3 schedule");
+          if (UPIN)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(psc2), "+v"(psh2) : "n"(NW) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)
+                         : "n"(NW)
+                         : "memory");
+          W4_TICK(2);
+          row_pass(cur ^ 1);
+          W4_TICK(3);
+        } else if (s == X3_COL_AT) {
+          W4_TICK(4);
+          col_pass(cur ^ 1);
+          W4_TICK(5);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    W4_TICK(6);
+#ifdef DIAGAN_W4_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_TICK(7);
+#endif
+    if (X3_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    W4_TICK(8);
+  };
+  if constexpr (X3) {
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto kloop3 = [&](auto place) __attribute__((always_inline)) {
+      int kk = k_begin;
+      for (; kk + 4 < k_end; kk += 4) {                            // (k_end - k_begin is a multiple of four: launch condition)
+        kstep3(kk, I0{}, std::true_type{}, ugrp, place);
+        kstep3(kk + 1, I1{}, std::true_type{}, ugrp, place);
+        kstep3(kk + 2, I2{}, std::true_type{}, ugrp, place);
+        kstep3(kk + 3, I3{}, std::true_type{}, ugrp, place);
+        ugrp += 4 * NS * X3_UNIT;
+      }
+      if (k_begin < k_end) {
+        kstep3(kk, I0{}, std::true_type{}, ugrp, place);
+        kstep3(kk + 1, I1{}, std::true_type{}, ugrp, place);
+        kstep3(kk + 2, I2{}, std::true_type{}, ugrp, place);
+        kstep3(kk + 3, I3{}, std::false_type{}, ugrp, place);
+      }
+    };
+    if (std::is_same<PlA, PlB>::value || wave < 4) kloop3(PlA{});
+    else kloop3(PlB{});
+  } else {
   using RowA = std::integral_constant<int, W4_ROW_AT>;
   using ColA = std::integral_constant<int, W4_COL_AT>;
   using RowB = std::integral_constant<int, W4_ROW_AT2>;
@@ -587,6 +903,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   }
   if (W4_PRIO_ALT > 0) __builtin_amdgcn_s_setprio(0);
   if (k_begin < k_end) kstep(k_end - 1, std::false_type{}, RowA{}, ColA{}, PN{});
+  }
 
 #ifdef DIAGAN_W4_STAMP
   if (a.stamps && lane == 0) {
@@ -836,13 +1153,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #endif
 }
 
-template <int PRO, int MODE = 0>
+template <int PRO, int MODE = 0, bool X3 = false>
 static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
   const int MT = a.g.B * (a.g.Ho >> 2) * (a.g.Wo >> 2);
   const int wgs = cdiv(MT, W4T) * cdiv(a.g.Co, W4N);
   // [2 V stages | U]; the epilogue's exchange image (36 or 25 frequencies x 32 tiles x 32 channels) fits inside
-  const size_t lds = (size_t)(2 * W4_VSTAGE + W4M<MODE>::U_FLOATS) * sizeof(float);
-  auto kern = conv_wino4_kernel<PRO, MODE>;
+  const size_t lds = X3 ? (size_t)X3_LDS : (size_t)(2 * W4_VSTAGE + W4M<MODE>::U_FLOATS) * sizeof(float);
+  auto kern = conv_wino4_kernel<PRO, MODE, X3>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -852,15 +1169,33 @@ static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t 
   return check_launch("conv_wino4");
 }
 
-// floats of workspace the transformed weights need
-long wino4_ws_floats(int Co, int Ci) { return (long)cdiv(Co, W4N) * W4N * Ci * 36; }
+// X3 (bf16 x 3 operands, see X3_SP): -1 = DIAGAN_WINO4_X3 / default, 0 / 1 = diagan_conv_gemm_set_wino4x
+static int g_wino4x = -1;
+void wino4_set_x3(int mode) { g_wino4x = mode; }
+int wino4_get_x3() {
+  static const int env = getenv("DIAGAN_WINO4_X3") ? atoi(getenv("DIAGAN_WINO4_X3")) : 0;
+  return g_wino4x >= 0 ? g_wino4x : env;
+}
+// floats of workspace the transformed weights need (with X3 enabled: room for the split format, 6 instead of 4 bytes per element)
+static long x3_floats(long fp32_floats) { return wino4_get_x3() > 0 ? fp32_floats + fp32_floats / 2 : fp32_floats; }
+long wino4_ws_floats(int Co, int Ci) { return x3_floats((long)cdiv(Co, W4N) * W4N * Ci * 36); }
+// the X3 kernel takes a launch whose K loop is a multiple of four steps per channel split (Ci % 32 == 0)
+static bool wino4_x3_ok(const ConvGemmArgs& a) {
+  const int nk = a.g.Ci / W4K, ks = a.ksplit > 0 ? a.ksplit : 1;
+  return wino4_get_x3() > 0 && (a.g.Ci % 32) == 0 && nk % ks == 0 && (nk / ks) % 4 == 0;
+}
 
 // transformed weights of this launch (weight-kernel mode WM: 0 = all 36 frequencies, 1 = the pooled modes' 25): the caller's
 // ready-made buffer if it hinted this format (diagan_conv_gemm_weights_hint), else `ws` after the per-launch transform
 template <int WM>
-static const float* wino4_weights(const ConvGemmArgs& a, float* ws, int flip, float scale, long floats, hipStream_t st) {
-  if (const float* ready = wino_weights_ready(WM ? WK_F4_POOL : WK_F4, flip, scale, floats)) return ready;
+static const float* wino4_weights(const ConvGemmArgs& a, float* ws, int flip, float scale, long floats, hipStream_t st, bool x3 = false) {
+  const int kind = x3 ? (WM ? WK_F4X_POOL : WK_F4X) : (WM ? WK_F4_POOL : WK_F4);
+  if (const float* ready = wino_weights_ready(kind, flip, scale, floats)) return ready;
   const ConvGeom& g = a.g;
+  if (x3)
+    hipLaunchKernelGGL(wino4x_weight_kernel<WM>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, flip,
+                       scale);
+  else
   hipLaunchKernelGGL(wino4_weight_kernel<WM>, dim3(cdiv(g.Ci, 32), cdiv(g.Co, W4N)), dim3(512), 0, st, a.w, ws, g.Co, g.Ci, g.Kp, flip,
                      scale);
   return ws;
@@ -908,7 +1243,18 @@ int launch_wino4(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  const float* ug = wino4_weights<0>(a, ws, g.dr < 0 ? 1 : 0, 1.f, wino4_ws_floats(g.Co, g.Ci), st);
+  const long f32 = (long)cdiv(g.Co, W4N) * W4N * g.Ci * 36;
+  if (wino4_x3_ok(a)) {
+    const float* ug = wino4_weights<0>(a, ws, g.dr < 0 ? 1 : 0, 1.f, f32 + f32 / 2, st, true);
+    switch (a.pro_mode) {
+      case PRO_NONE: return launch_wino4_pro<PRO_NONE, 0, true>(a, ug, st);
+      case PRO_RELU: return launch_wino4_pro<PRO_RELU, 0, true>(a, ug, st);
+      case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU, 0, true>(a, ug, st);
+      case PRO_LRELU: return launch_wino4_pro<PRO_LRELU, 0, true>(a, ug, st);
+      default: return launch_wino4_pro<PRO_AFFINE, 0, true>(a, ug, st);
+    }
+  }
+  const float* ug = wino4_weights<0>(a, ws, g.dr < 0 ? 1 : 0, 1.f, f32, st);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino4_pro<PRO_NONE>(a, ug, st);
     case PRO_RELU: return launch_wino4_pro<PRO_RELU>(a, ug, st);
@@ -928,7 +1274,7 @@ bool wino4_pool_ok(int B, int Ho, int Wo, int Ci, int Co, long ws_floats, bool f
   static const int min_wgs = getenv("DIAGAN_WINO4_POOL_MIN_WGS") ? atoi(getenv("DIAGAN_WINO4_POOL_MIN_WGS")) : 192;
   if (!env || !w4 || !wino4_geom_ok(Ho, Wo, Ci) || (Co & 3) || Ci < 32) return false;
   const long wgs = (long)cdiv((long)B * (Ho >> 2) * (Wo >> 2), W4T) * cdiv(Co, W4N);
-  return (force || wgs >= min_wgs) && (long)cdiv(Co, W4N) * W4N * Ci * 28 <= ws_floats;      // 56 units x 256 floats per 8 channels and column block
+  return (force || wgs >= min_wgs) && x3_floats((long)cdiv(Co, W4N) * W4N * Ci * 28) <= ws_floats;      // 56 units x 256 floats per 8 channels and column block
 }
 
 int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
@@ -965,7 +1311,18 @@ int launch_wino4_upin(ConvGemmArgs a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
-  const float* ug = wino4_weights<0>(a, ws, 0, 0.0625f, wino4_ws_floats(g.Co, g.Ci), st);
+  const long f32 = (long)cdiv(g.Co, W4N) * W4N * g.Ci * 36;
+  if (wino4_x3_ok(a)) {
+    const float* ug = wino4_weights<0>(a, ws, 0, 0.0625f, f32 + f32 / 2, st, true);
+    switch (a.pro_mode) {
+      case PRO_NONE: return launch_wino4_pro<PRO_NONE, 3, true>(a, ug, st);
+      case PRO_RELU: return launch_wino4_pro<PRO_RELU, 3, true>(a, ug, st);
+      case PRO_AFFINE_RELU: return launch_wino4_pro<PRO_AFFINE_RELU, 3, true>(a, ug, st);
+      case PRO_LRELU: return launch_wino4_pro<PRO_LRELU, 3, true>(a, ug, st);
+      default: return launch_wino4_pro<PRO_AFFINE, 3, true>(a, ug, st);
+    }
+  }
+  const float* ug = wino4_weights<0>(a, ws, 0, 0.0625f, f32, st);
   switch (a.pro_mode) {
     case PRO_NONE: return launch_wino4_pro<PRO_NONE, 3>(a, ug, st);
     case PRO_RELU: return launch_wino4_pro<PRO_RELU, 3>(a, ug, st);

@@ -54,6 +54,84 @@ __host__ __device__ __forceinline__ int w4p_start(int g) { return g == 0 ? 0 : 7
 __host__ __device__ __forceinline__ int w4p_count(int g) { return g == 0 ? 7 : 6; }
 __host__ __device__ __forceinline__ int w4p_freq(int v) { return v < 2 ? v : v + 1; }        // {0, 1, 3, 4, 5}
 
+// ---- X3 (round 5): the frequency-domain operands as THREE bf16 pieces per fp32 value ----
+// v = p0 + p1 + p2 EXACTLY: each piece is the truncation of what is left to the top 16 bits of its fp32 pattern (a bf16 number:
+// 8 significant bits, fp32's exponent range -- no scaling, no overflow / underflow cases), so the three pieces carry all 24
+// significant bits.  The six piece products of order <= 2^-16 (p0 q0, p0 q1, p1 q0, p0 q2, p1 q1, p2 q0; each one exact in the
+// fp32 accumulator of v_mfma_f32_32x32x16_bf16) reproduce the fp32 product to ~2^-23 relative.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int X3_UNIT = 1536;          // bytes of one weight unit: 3 pieces x 32 columns x 8 channels bf16
+__device__ __forceinline__ void x3_split(const f32x4& v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  unsigned x[4], r[4], q[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] = __float_as_uint(v[e]);
+  p0[0] = __builtin_amdgcn_perm(x[1], x[0], 0x07060302u);        // (hi16 of x1) << 16 | hi16 of x0
+  p0[1] = __builtin_amdgcn_perm(x[3], x[2], 0x07060302u);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = __float_as_uint(v[e] - __uint_as_float(x[e] & 0xffff0000u));      // exact
+  p1[0] = __builtin_amdgcn_perm(r[1], r[0], 0x07060302u);
+  p1[1] = __builtin_amdgcn_perm(r[3], r[2], 0x07060302u);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) q[e] = __float_as_uint(__uint_as_float(r[e]) - __uint_as_float(r[e] & 0xffff0000u));
+  p2[0] = __builtin_amdgcn_perm(q[1], q[0], 0x07060302u);
+  p2[1] = __builtin_amdgcn_perm(q[3], q[2], 0x07060302u);
+}
+
+// U for the X3 kernels: the same (G g G^T) as wino4_weight_body, split, in the order ONE WAVE streams it:
+// [64-column block][wave = group + 4 * column half][K-step][slot][piece][column (32)][8 channels bf16] -- a contiguous stream
+// of NS x 1536 bytes per wave and K-step, fetched by that wave in 1 KB LDS-DMA granules through a 4-unit ring.
+template <int MODE>
+__device__ __forceinline__ void wino4x_weight_body(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci, int Kp, int flip,
+                                                   float wscale, int bx, int by, f32x4* __restrict__ sg) {
+  f32x4 g[3][3];
+  const int nb = by;
+  if (!wino_stage_taps(w, nb * 64, bx * 32, Co, Ci, Kp, flip, sg, g)) return;
+  if (wscale != 1.f) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] *= wscale;
+  }
+  const int col = threadIdx.x & 63, c = bx * 32 + (threadIdx.x >> 6) * 4;
+  constexpr float k4 = 0.25f, k6 = 1.f / 6.f, k12 = 1.f / 12.f, k24 = 1.f / 24.f;
+  auto gt = [&](const f32x4& g0, const f32x4& g1, const f32x4& g2, f32x4* o) {
+    o[0] = k4 * g0;
+    o[1] = -k6 * (g0 + g1 + g2);
+    o[2] = -k6 * (g0 - g1 + g2);
+    o[3] = k24 * g0 + k12 * g1 + k6 * g2;
+    o[4] = k24 * g0 - k12 * g1 + k6 * g2;
+    o[5] = g2;
+  };
+  f32x4 t[3][6];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) gt(g[0][s], g[1][s], g[2][s], t[s]);
+  constexpr int NS = W4M<MODE>::NS;
+  const int nk = Ci >> 3, ks = c >> 3, kh = (c >> 2) & 1, nh = col >> 5, n = col & 31;
+  char* base = reinterpret_cast<char*>(ug) + (long)nb * 8 * nk * NS * X3_UNIT + n * 16 + kh * 8;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    f32x4 u[6];
+    gt(t[0][i], t[1][i], t[2][i], u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      int grp, slot;
+      if (MODE == 0) {
+        grp = (i / 3) * 2 + j / 3;
+        slot = (i % 3) * 3 + j % 3;
+      } else {
+        if (i == 2 || j == 2) continue;
+        const int l = 5 * (i < 2 ? i : i - 1) + (j < 2 ? j : j - 1);
+        grp = l < 7 ? 0 : 1 + (l - 7) / 6;
+        slot = l - w4p_start(grp);
+      }
+      u32x2 p0, p1, p2;
+      x3_split(u[j], p0, p1, p2);
+      char* d = base + ((long)((grp + 4 * nh) * nk + ks) * NS + slot) * X3_UNIT;
+      *reinterpret_cast<u32x2*>(d) = p0;
+      *reinterpret_cast<u32x2*>(d + 512) = p1;
+      *reinterpret_cast<u32x2*>(d + 1024) = p2;
+    }
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ void wino4_weight_body(const float* __restrict__ w, float* __restrict__ ug, int Co, int Ci, int Kp, int flip,
                                                   float wscale, int bx, int by, f32x4* __restrict__ sg) {

@@ -15,6 +15,8 @@ nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
+nat.register("diagan_conv_gemm_set_wino4x", [I])
+nat.register("diagan_conv_gemm_get_wino4x", [])
 nat.register("diagan_conv_wino4_pool_used", [I] * 5 + [I64])
 nat.register("diagan_conv_wino4_upin_supported", [I] * 13 + [I64, I])
 nat.register("diagan_conv_gemm_weights_hint", [P, I, I, F])
@@ -209,6 +211,12 @@ def set_winograd(mode):
     """True / False: allow / forbid the Winograd kernel for auto-selected tile configurations; None: the default
     (on, or what DIAGAN_WINO says)"""
     nat.call("diagan_conv_gemm_set_wino", -1 if mode is None else (1 if mode else 0))
+
+
+def set_winograd4x(mode):
+    """True / False: the F(4x4,3x3) launches with K loops of a multiple of four steps run on the bf16 matrix pipe with exactly
+    split operands (conv_wino4.hip, X3) / on the fp32 one; None: what DIAGAN_WINO4_X3 says"""
+    nat.call("diagan_conv_gemm_set_wino4x", -1 if mode is None else (1 if mode else 0))
 
 
 def set_winograd4(mode):

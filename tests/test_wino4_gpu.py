@@ -301,3 +301,55 @@ def test_upsampled_input_selection_and_refusals():
     with pytest.raises(RuntimeError, match="backward mask"):
         C._gemm(nhwc(x).cuda(), wp, torch.empty(2, 8, 8, 16, device='cuda'), geom.fwd_params(), 3, 3, geom.Kp, None, None,
                 torch.zeros(2, 8, 8, 16, device='cuda'), 0.0, None, 1.0, 0, up_in=True)
+
+
+# ---- X3 (round 5): the same kernel with its frequency GEMMs on the bf16 matrix pipe, operands split exactly in three ----------
+# Off by default (profiles/r05_bf16x6_wino.md: correct, not faster); kept behind diagan_conv_gemm_set_wino4x / DIAGAN_WINO4_X3
+# and held to float64 here so that the switch stays usable.  Only launches with Ci % 32 == 0 take it.
+@pytest.fixture
+def x3():
+    from diagan.ops import conv as C
+    C.set_winograd4x(True)
+    yield
+    C.set_winograd4x(None)
+
+
+@pytest.mark.parametrize("case", [(4, 8, 8, 64, 64), (5, 16, 16, 128, 72), (2, 32, 32, 256, 256), (16, 4, 4, 512, 256)])
+@pytest.mark.parametrize("pro", [0, 2, 3])
+def test_x3_forward_and_data_gradient_against_float64(case, pro, x3):
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case)
+    g = torch.Generator().manual_seed(1)
+    bias, scale, shift = torch.randn(Co, generator=g), torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    ref = F.conv2d(ref_pro(x.double(), pro, scale.double(), shift.double()), w.double(), bias.double(), padding=1)
+    res = torch.randn(ref.shape, generator=g)
+    args = dict(bias=bias.cuda(), residual=nhwc(res).cuda(), pro=(pro, scale.cuda(), shift.cuda()), tile_cfg=13)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, **args)
+    close(nchw(y), ref + res.double(), tol=TOL)
+    C.set_winograd4x(False)
+    y32 = C.conv_fwd(geom, nhwc(x).cuda(), wp, **args)
+    C.set_winograd4x(True)
+    assert not torch.equal(y, y32), "the X3 switch changed nothing: the bf16 kernel did not run"
+    if pro == 0 and Co % 32 == 0:            # the data gradient's K loop runs over Co
+        dy = torch.randn(B, Co, H, W, generator=g)
+        xr = x.double().requires_grad_(True)
+        F.conv2d(xr, w.double(), padding=1).backward(dy.double())
+        msk = torch.randn(B, Ci, H, W, generator=g)
+        wd = torch.zeros(Ci, geom.Kd, device="cuda")
+        C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+        dx = C.conv_dgrad(geom, nhwc(dy).cuda(), wd, (H, W), mask_src=nhwc(msk).cuda(), tile_cfg=13)
+        close(nchw(dx), xr.grad * (msk > 0).double(), tol=TOL)
+
+
+@pytest.mark.parametrize("case", [(4, 4, 4, 64, 64), (5, 8, 8, 128, 72), (2, 16, 16, 256, 256)])
+def test_x3_upsampled_input_against_float64(case, x3, force_w4):
+    from diagan.ops import conv as C
+    B, Hl, Wl, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=41)
+    g = torch.Generator().manual_seed(42)
+    scale, shift = torch.rand(Ci, generator=g) + 0.5, torch.randn(Ci, generator=g) * 0.3
+    up = F.interpolate(ref_pro(x.double(), 2, scale.double(), shift.double()), scale_factor=2, mode='bilinear', align_corners=False)
+    ref = F.conv2d(up, w.double(), padding=1)
+    y = C.conv_fwd(geom, nhwc(x).cuda(), wp, pro=(2, scale.cuda(), shift.cuda()), up_in=True)
+    close(nchw(y), ref, tol=TOL)
