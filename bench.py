@@ -278,6 +278,58 @@ def sngan64_leg(args, device, steps=10, warmup=3):
                         for k, v in sorted(per_kernel.items())}}
 
 
+def phase2_leg(args, device, steps=10, warmup=3):
+    """BASELINE.json configs[2] on the driver's own line: the SNGAN-32 global step of phase 2 -- n_dis x (D update + D_drs
+    update) + one G update (reference loop: diagan-pkg/diagan/trainer/trainer.py:267-277, CLI train_mimicry_phase2.py:102-153)
+    -- at batch 64 on one GPU.  Un-scored leg after the timed region."""
+    dataset, res, desc = WORKLOADS['sngan32']
+    nets = build_models(dataset, args.loss_type, 2, device)
+    gen = torch.Generator().manual_seed(4321)
+    batches = [(torch.rand(args.batch_size, 3, res, res, generator=gen) * 2 - 1).to(device) for _ in range(4 * args.n_dis)]
+    step = make_global_step(*nets, batches, args.n_dis, num_steps=50000, device=device)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"workload": desc + " + D_drs (phase 2, ldr_conf_0.3_ratio_50 sampling is host-side and off the step)",
+            "steps": steps, "warmup": warmup, "images_per_s": round(args.batch_size * steps / el, 2),
+            "ms_per_step": round(el / steps * 1e3, 3)}
+
+
+def logit_pass_leg(device, N=50000, loader_batch=64):
+    """`_get_logit` images/s, reported separately -- the full pass of D over the dataset that fills one row of
+    the logit record (reference: trainer.py:142-156; eval mode, as train_mimicry_phase1.py's --save_eval_logits default), on
+    a CIFAR-10-sized synthetic dataset (N = 50 000, 32x32) with the training loader's batch of 64."""
+    import tempfile
+    from diagan.cli import make_loader
+    from diagan.datasets.predefined import get_predefined_dataset
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.trainer.trainer import LogTrainer
+    from diagan.utils.plot import LogitRecord
+    netG, netD, optG, optD = get_gan_model('cifar10', model='sngan', loss_type='ns')
+    ds = get_predefined_dataset('cifar10', num_data=N)
+    dl = make_loader(ds, loader_batch)
+    with tempfile.TemporaryDirectory() as tmp:
+        t = LogTrainer(output_path=tmp, netD=netD, netG=netG, optD=optD, optG=optG, dataloader=dl, num_steps=1, log_dir=tmp,
+                       device=device)
+        rec = LogitRecord(N, capacity=4, device=t.device)
+        t._get_logit(netD, eval_mode=True, record=rec, step=0)         # warm-up pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        row = t._get_logit(netD, eval_mode=True, record=rec, step=1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        finite = bool(torch.isfinite(row).all().item())
+        t.logger.close_writers()
+    return {"images_per_s": round(N / dt, 1), "seconds": round(dt, 4), "N": N, "loader_batch": loader_batch,
+            "eval_batch": t.logit_eval_batch, "mode": "eval", "record_row_finite": finite,
+            "includes": "host -> device copy of the images (dataset resident in host memory), D forward, scatter by index"}
+
+
 def cpu_model_name():
     try:
         for ln in open('/proc/cpuinfo'):
@@ -512,6 +564,15 @@ def main():
             s64_error = repr(e)
         finally:
             C.TIMER = None
+    # Extra legs (default workload, one GPU): the two SURVEY 8(d) figures the scored line does not carry -- phase 2 (+ D_drs,
+    # BASELINE configs[2]) and the logit-record pass.  Un-scored, after the timed region, exception-proof.
+    extra_legs = {}
+    if (world == 1 and args.workload == 'sngan32' and args.phase == 1 and not args.no_sngan64_leg and not args.graph):
+        for key, leg in (("phase2", lambda: phase2_leg(args, device)), ("logit_pass", lambda: logit_pass_leg(device))):
+            try:
+                extra_legs[key] = leg()
+            except Exception as e:
+                extra_legs[key] = {"error": repr(e)}
     if rank != 0:
         return
 
@@ -601,9 +662,15 @@ def main():
         line["sngan64_conv_blocks"] = s64
     elif s64_error:
         line["sngan64_conv_blocks"] = {"error": s64_error}
+    for key, val in extra_legs.items():
+        line[key] = val
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(dataset, res, args.loss_type, args.batch_size, args.n_dis)
         line["ldr_scorer"] = scorer_leg(device)
+        try:                                   # BASELINE configs[3]'s record size (CelebA: N = 162 770)
+            line["ldr_scorer_celeba"] = scorer_leg(device, N=162770)
+        except Exception as e:
+            line["ldr_scorer_celeba"] = {"error": repr(e)}
     print(json.dumps(line))
 
 

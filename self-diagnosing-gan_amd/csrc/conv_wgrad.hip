@@ -23,6 +23,8 @@ bool wgrad_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R,
                           int Kp);                                    // conv_wgrad_wino.hip
 int wgrad_wino_splits(int B, int Ho, int Wo, int Ci, int Co);
 int launch_wgrad_wino(WgradArgs a, int splits, int segments, hipStream_t st);
+int launch_wgrad_wino_batched(const WgradArgs* jobs, const int* splits, const int* segments, int n, hipStream_t st);
+int wgrad_wino_batch_max();
 
 
 // P2: Ho and Wo are powers of two -- pixel coordinates come from shifts and masks of the pixel index instead of
@@ -578,10 +580,10 @@ static void wgrad_tile(int Co, int Kp, int* bn, int* bk) {
   if (*bn == 128 && *bk == 64) *bn = 64;   // no <128,64> instantiation
 }
 
-DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int segments,
-                                 int64_t slab_stride, int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
-                                 int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
-                                 int dr, int off, int up, int Kp, void* stream) {
+// argument checks and the launch-independent part of WgradArgs (shared by the one-layer and the batched entry point)
+static int wgrad_fill_args(WgradArgs& a, const float* dy, const float* x, float* slab, int splits, int segments,
+                           int64_t slab_stride, int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
+                           int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up, int Kp) {
   DG_REQUIRE(dy && x && slab, "conv_wgrad: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && R > 0 && S > 0, "conv_wgrad: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0 && Co > 0 && (Co & 3) == 0, "conv_wgrad: Ci=%d, Co=%d must be multiples of 4", Ci, Co);
@@ -597,7 +599,6 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   DG_REQUIRE((long)Co * Kp * 4 < (1L << 31), "conv_wgrad: weight tensor must be smaller than 2 GiB");
   DG_REQUIRE((long)B * Ho * Wo * Co * 4 < (1L << 31) && (long)B * Hi * Wi * Ci * 4 < (1L << 31),
              "conv_wgrad: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-  WgradArgs a;
   a.dy = dy; a.x = x; a.slab = slab; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_mode = pro_mode;
   a.M = B * Ho * Wo;
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
@@ -614,6 +615,17 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   a.steps_per_split = cdiv(a.seg_steps, a.splits_per_seg);
   a.slab_stride = slab_stride;
   a.bias_off = bias_off;
+  return DIAGAN_OK;
+}
+
+DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, int segments,
+                                 int64_t slab_stride, int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
+                                 int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
+                                 int dr, int off, int up, int Kp, void* stream) {
+  WgradArgs a;
+  const int rc = wgrad_fill_args(a, dy, x, slab, splits, segments, slab_stride, bias_off, pro_scale, pro_shift, pro_mode, B, Hi, Wi, Ci,
+                                 Ho, Wo, Co, R, S, sy, dr, off, up, Kp);
+  if (rc != DIAGAN_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp))
     return launch_wgrad_wino(a, splits, segments, st);
@@ -647,6 +659,35 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
 #undef DG_WG
   return check_launch("conv_wgrad");
 }
+
+// see include/diagan_hip.h: the Winograd weight gradients of several layers (one prologue mode) in one launch
+struct diagan_wgrad_job {    // mirrors the typedef of the same name in include/diagan_hip.h (128 bytes)
+  const float* dy;
+  const float* x;
+  float* slab;
+  const float* pro_scale;
+  const float* pro_shift;
+  int64_t slab_stride, bias_off;
+  int32_t splits, segments, pro_mode, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, pad_;
+};
+static_assert(sizeof(diagan_wgrad_job) == 128, "diagan_wgrad_job layout");
+DIAGAN_API int diagan_conv_wgrad_batched(const diagan_wgrad_job* jobs, int n, void* stream) {
+  DG_REQUIRE(jobs && n >= 1 && n <= wgrad_wino_batch_max(), "conv_wgrad_batched: 1 .. %d jobs", wgrad_wino_batch_max());
+  WgradArgs a[16];
+  int splits[16], segments[16];
+  for (int j = 0; j < n; ++j) {
+    const diagan_wgrad_job& q = jobs[j];
+    DG_REQUIRE(diagan_conv_wgrad_uses_wino(q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.R, q.S, q.sy, q.dr, q.off, q.up, q.Kp),
+               "conv_wgrad_batched: job %d is not a layer of the Winograd weight gradient (3x3 / stride 1 / pad 1, even H and W)", j);
+    const int rc = wgrad_fill_args(a[j], q.dy, q.x, q.slab, q.splits, q.segments, q.slab_stride, q.bias_off, q.pro_scale, q.pro_shift,
+                                   q.pro_mode, q.B, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.R, q.S, q.sy, q.dr, q.off, q.up, q.Kp);
+    if (rc != DIAGAN_OK) return rc;
+    splits[j] = q.splits;
+    segments[j] = q.segments;
+  }
+  return launch_wgrad_wino_batched(a, splits, segments, n, (hipStream_t)stream);
+}
+DIAGAN_API int diagan_conv_wgrad_batch_max(void) { return wgrad_wino_batch_max(); }
 
 // The Winograd F(3x3,2x2) weight gradient (conv_wgrad_wino.hip) takes the 3x3 / stride 1 / pad 1 layers unless
 // DIAGAN_WINO=0 / diagan_conv_gemm_set_wino(0) is set.

@@ -28,13 +28,14 @@ constexpr int GW_T = 8;                        // tiles per K-step
 constexpr int GW_PLANE = GW_T * 64;            // floats of one frequency plane: 8 tiles x 64 channels
 constexpr int GW_STAGE = 2 * 16 * GW_PLANE;    // V planes + E planes
 
+// bid / nblk: this workgroup's index and the workgroup count of ITS layer (the whole grid for a one-layer launch; a contiguous
+// range of the grid in a batched launch of several layers, conv_wgrad_wino_batched_kernel below)
 template <int PRO>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 16 planes | E 16 planes] = 128 KB
+__device__ __forceinline__ void wgrad_wino_body(const WgradArgs& a, const int bid, const int nblk, float* __restrict__ smem) {
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_ci = (g.Ci + 63) / 64;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = xcd_remap(bid, nblk);
   const int split = logical / a.tiles, tile = logical - split * a.tiles;
   const int n0 = (tile / tiles_ci) * 64, c0 = (tile % tiles_ci) * 64;      // first output / input channel
   const int TW = g.Wo >> 1, TH = g.Ho >> 1;
@@ -300,6 +301,37 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
   }
 }
 
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2 stages][V 16 planes | E 16 planes] = 128 KB
+  wgrad_wino_body<PRO>(a, blockIdx.x, gridDim.x, smem);
+}
+
+// Round 5: the weight gradients of SEVERAL layers of one backward pass in ONE launch.  A layer's own launch fills the chip by
+// splitting its pixel range 256 / tiles ways, which for the small maps means 4-16 K-steps per workgroup behind ~15 us of
+// fixed cost (prologue, G^T . G, 147 KB of slab per workgroup) and 38 MB of slab per layer whatever its size; deferred to the
+// end of the pass (the host keeps dy and x alive) the layers share the 256 workgroups in proportion to their work, every
+// workgroup runs ~(sum of all K-steps) / 256 steps and a small layer writes 8 slabs instead of 64.  The layers of a launch
+// share the prologue mode; a workgroup finds its layer through the first-workgroup prefix (multiples of 8: the XCD remap
+// inside a layer's range stays a permutation of that range).
+constexpr int GW_BATCH_MAX = 8;
+struct WgradWinoBatch {
+  int n;
+  int blk0[GW_BATCH_MAX];      // first workgroup of layer j (a multiple of 8)
+  int cnt[GW_BATCH_MAX];       // its workgroups: tiles x splits
+  WgradArgs a[GW_BATCH_MAX];
+};
+template <int PRO>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_wino_batched_kernel(const WgradWinoBatch b) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int local = (int)blockIdx.x - b.blk0[j];
+  if (local >= b.cnt[j]) return;                       // (padding of a range to a multiple of 8)
+  wgrad_wino_body<PRO>(b.a[j], local, b.cnt[j], smem);
+}
+
 // the layers the Winograd weight gradient takes: 3x3 / stride 1 / pad 1 forward geometry, even H and W, channels % 4
 bool wgrad_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up,
                           int Kp) {
@@ -352,6 +384,53 @@ int launch_wgrad_wino(WgradArgs a, int splits, int segments, hipStream_t st) {
     default: launch_gw<PRO_AFFINE>(a, wgs, st); break;
   }
   return check_launch("conv_wgrad_wino");
+}
+
+// several layers in one launch: a[j] as prepared by diagan_conv_wgrad for layer j (same prologue mode), splits[j] a multiple of
+// segments[j]
+template <int PRO>
+static void launch_gw_batched(const WgradWinoBatch& b, int wgs, hipStream_t st) {
+  const size_t lds = (size_t)2 * GW_STAGE * sizeof(float);
+  auto kern = conv_wgrad_wino_batched_kernel<PRO>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, b);
+}
+int wgrad_wino_batch_max() { return GW_BATCH_MAX; }
+int launch_wgrad_wino_batched(const WgradArgs* jobs, const int* splits, const int* segments, int n, hipStream_t st) {
+  if (n < 1 || n > GW_BATCH_MAX) return set_err(DIAGAN_EINVAL, "conv_wgrad_batched: 1 .. %d layers per launch, got %d", GW_BATCH_MAX, n);
+  WgradWinoBatch b;
+  b.n = n;
+  int wgs = 0;
+  for (int j = 0; j < n; ++j) {
+    WgradArgs a = jobs[j];
+    if (a.pro_mode != jobs[0].pro_mode) return set_err(DIAGAN_EINVAL, "conv_wgrad_batched: the layers of a launch share the prologue mode");
+    const ConvGeom& g = a.g;
+    a.dWo = make_fastdiv((unsigned)(g.Wo >> 1));
+    a.dHo = make_fastdiv((unsigned)(g.Ho >> 1));
+    const int MT = g.B * (g.Ho >> 1) * (g.Wo >> 1);
+    const int total_steps = cdiv(MT, GW_T);
+    a.seg_steps = cdiv(total_steps, segments[j]);
+    a.splits_per_seg = splits[j] / segments[j];
+    a.steps_per_split = cdiv(a.seg_steps, a.splits_per_seg);
+    a.tiles = cdiv(g.Co, 64) * cdiv(g.Ci, 64);
+    b.a[j] = a;
+    b.blk0[j] = wgs;
+    b.cnt[j] = a.tiles * splits[j];
+    wgs += (b.cnt[j] + 7) & ~7;
+  }
+  for (int j = n; j < GW_BATCH_MAX; ++j) b.blk0[j] = wgs, b.cnt[j] = 0;
+  switch (jobs[0].pro_mode) {
+    case PRO_NONE: launch_gw_batched<PRO_NONE>(b, wgs, st); break;
+    case PRO_RELU: launch_gw_batched<PRO_RELU>(b, wgs, st); break;
+    case PRO_AFFINE_RELU: launch_gw_batched<PRO_AFFINE_RELU>(b, wgs, st); break;
+    case PRO_LRELU: launch_gw_batched<PRO_LRELU>(b, wgs, st); break;
+    default: launch_gw_batched<PRO_AFFINE>(b, wgs, st); break;
+  }
+  return check_launch("conv_wgrad_wino_batched");
 }
 
 }  // namespace diagan

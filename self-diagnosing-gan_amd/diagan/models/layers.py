@@ -747,12 +747,21 @@ class FlatNet(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k == '_wino_batches' else copy.deepcopy(v, memo)
+            new.__dict__[k] = {} if k == '_wino_batches' else (None if k in ('_flat', '_flat_grad') else copy.deepcopy(v, memo))
         for m in new.modules():
             if isinstance(m, ConvLayer):
                 m.__dict__.pop('_wsites', None)
                 m._wd = None
-        new.slab_generation += 1
+        # nn.Parameter.__deepcopy__ CLONES its data: the copy's parameters are no views of a slab any more.  Give the copy
+        # its own slabs (parameters and gradients re-pointed, gradient values carried over) -- otherwise its fused Adam /
+        # zero_grad / gradient exchange would act on a slab nobody reads
+        if self._flat is not None:
+            grads = [None if p.grad is None else p.grad.detach().clone() for p in new.parameters()]
+            new._build_flat()
+            for p, g in zip(new.parameters(), grads):
+                if g is not None:
+                    p.grad.copy_(g)
+        new.slab_generation = self.slab_generation + 1
         return new
 
     def _build_flat(self):

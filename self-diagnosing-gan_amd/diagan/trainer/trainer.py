@@ -144,9 +144,23 @@ class LogTrainer:
         # (145 000 images/s) once D itself was batched.
         ds = self.dataloader.dataset
         lo, hi = (shard[0], shard[1]) if shard is not None else (0, n_data)
-        ranged = group > 0 and hasattr(ds, 'fetch_range') and hi > lo and ds.fetch_range(lo, lo + 1) is not None
+        # ... only where the loader visits every index exactly once (uniform shuffling or sequential): the reference walks
+        # `self.dataloader`, and with phase 2's WeightedRandomSampler (replacement=True) the indices it never draws keep the
+        # row's initial zeros (trainer.py:142-156: np.zeros + assignment by index) -- that record is reproduced by the walk
+        complete = shard is not None or isinstance(getattr(loader, 'sampler', None),
+                                                   (torch.utils.data.RandomSampler, torch.utils.data.SequentialSampler))
+        ranged = (group > 0 and complete and hasattr(ds, 'fetch_range') and hi > lo
+                  and ds.fetch_range(lo, lo + 1) is not None)
         with torch.no_grad():
             if ranged:
+                if shard is None:
+                    # The reference WALKS the training loader here (trainer.py:143).  Starting that walk is what touches the
+                    # CPU generator -- the loader draws its base seed, a shuffling / weighted sampler its seed or its whole
+                    # multinomial sample -- and everything after the snapshot (the next epoch's order, phase-2 sampling)
+                    # sees the stream behind those draws.  Start the walk and drop it: same draws, one batch fetched.
+                    it = iter(loader)
+                    next(it, None)
+                    del it
                 for a0 in range(lo, hi, group):
                     data, idx = ds.fetch_range(a0, min(a0 + group, hi))
                     pend_x.append(data.to(self.device, non_blocking=True))

@@ -103,6 +103,49 @@ def test_logit_record_matches_direct_eval(tmp_path):
     np.testing.assert_allclose(row, direct, rtol=2e-6, atol=2e-6)
 
 
+@pytest.mark.parametrize("weighted", [False, True])
+def test_logit_pass_leaves_the_cpu_generator_where_a_loader_walk_does(tmp_path, weighted):
+    """The reference's _get_logit walks the training loader (trainer.py:142-156): starting the walk draws the loader's base seed
+    and the sampler's seed / multinomial sample from the CPU generator.  The fast path (tensor-backed dataset, slices instead
+    of a walk) must leave the generator in the same state, for the shuffling loader of phase 1 and the weighted one of phase 2."""
+    from diagan.cli import make_loader
+    from diagan.datasets.predefined import get_predefined_dataset
+    from diagan.models.predefined_models import get_gan_model
+    from diagan.trainer.trainer import LogTrainer
+    torch.manual_seed(3)
+    netG, netD, optG, optD = get_gan_model('cifar10', model='sngan', loss_type='hinge')
+    w = torch.rand(150, generator=torch.Generator().manual_seed(9)).numpy() if weighted else None
+    ds = get_predefined_dataset('cifar10', num_data=150, weights=w)
+    dl = make_loader(ds, 64, weights=w)
+    t = LogTrainer(output_path=tmp_path, netD=netD, netG=netG, optD=optD, optG=optG, dataloader=dl, num_steps=1,
+                   log_dir=str(tmp_path), device='cuda')
+    torch.manual_seed(11)
+    fast = t._get_logit(netD, eval_mode=True).clone()
+    after_fast = torch.get_rng_state()
+    torch.manual_seed(11)
+    slow = t._get_logit(netD, eval_mode=True)                                        # same call: same row ...
+    torch.manual_seed(11)
+    ds_fetch, type(ds).fetch_range = type(ds).fetch_range, lambda self, lo, hi: None      # ... and the loader walk itself
+    try:
+        walked = t._get_logit(netD, eval_mode=True)
+        after_walk = torch.get_rng_state()
+    finally:
+        type(ds).fetch_range = ds_fetch
+    assert torch.equal(after_fast, after_walk)
+    assert torch.equal(fast, slow)
+    assert (fast - walked).abs().max().item() < 1e-5
+    if weighted:
+        # phase 2's weighted loader draws WITH replacement: the slices would fill indices the reference never visits, so the
+        # pass walks the loader (no fast path) and the never-drawn indices keep the record's zeros, as in trainer.py:142-156
+        torch.manual_seed(11)
+        drawn = set()
+        for _, _, _, idx in dl:
+            drawn.update(idx.tolist())
+        missing = sorted(set(range(150)) - drawn)
+        assert missing and float(fast[missing].abs().max()) == 0.0
+        assert float(fast[sorted(drawn)].abs().min()) > 0.0
+
+
 def test_ragged_step_draws_noise_update_by_update(tmp_path):
     """A global step that contains an epoch's ragged last batch does not use the stacked generator forward (which draws
     the noise of all updates up front, i.e. in another order than the reference's update-by-update draws): the device

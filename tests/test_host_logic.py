@@ -257,6 +257,7 @@ def test_deepcopy_of_a_flat_net_drops_learned_launch_state():
     from diagan.models.predefined_models import get_gan_model
     netG, _ = get_gan_model(dataset_name='cifar10', gan_type='sngan', loss_type='ns')[:2]
     conv = next(m for m in netG.modules() if m.__class__.__name__ == 'ConvLayer')
+    netG.flat_params                                     # slabs built (as after .to(device) / a first optimizer step)
     netG._wino_batches[('f', None)] = object()           # what a first pass leaves behind
     conv.__dict__['_wsites'] = {('f', None, 0): object()}
     gen = netG.slab_generation

@@ -213,13 +213,17 @@ def test_full_batch_gradients_against_float64(dataset, res, wino4_mode):
     oracle flips it always, the HIP path with some kernel selections and not with others -- bound 1e-3 for both); G-update gradients (through D's and G's masks: a pre-activation within rounding of zero flips an O(1)
     mask element) HIP 2.2e-3 - 6.2e-3 depending on the kernel selection, fp32 oracle <= 6.0e-3; bound 1.2e-2 for both.  The fp32 oracle is run beside the HIP path and held to the same
     bounds, so the allowance is a statement about fp32, not about this engine; and over a whole network the HIP path may not
-    be systematically further from float64 than plain PyTorch fp32 (rms over the parameters within 8x: measured 0.002x -
-    0.33x on three of the four (network, update) pairs, 6.9x on SNGAN-64's generator update, whose longest accumulation
-    chains are K = 9216 products in ONE fp32 accumulator on the matrix pipe against blocked sums on the CPU)."""
+    be systematically further from float64 than plain PyTorch fp32 (rms over the parameters within a per-configuration bar,
+    see `bar` below: 2x on SNGAN-32, 1x with the F(4x4) kernel off, 7x on SNGAN-64)."""
     (oG, oD, ooptG, ooptD), (netG, netD, optG, optD) = build(dataset, "ns")
     dG, dD = copy.deepcopy(oG).double(), copy.deepcopy(oD).double()
     doptG = torch.optim.Adam(dG.parameters(), 2e-4, betas=(0.0, 0.9))
     doptD = torch.optim.Adam(dD.parameters(), 2e-4, betas=(0.0, 0.9))
+    # rms(HIP) / rms(fp32 oracle) over a network's parameters, per configuration (round 5: was 8 for all).  Measured on MI355X
+    # (profiles/r05_trajectory.md, D / G update): SNGAN-32 default 1.01 / 1.04, SNGAN-32 without F(4x4) 0.002 / 0.31, SNGAN-64
+    # default 5.1 / 4.8 (round 3: 6.9 on the G update; explained in profiles/r04_f64_parity.md -- transform rounding of the
+    # Winograd launches plus K = 9216 single-accumulator chains on the small maps -- and 300x below the contract's 1e-3)
+    bar = {("cifar10", "default"): 2.0, ("cifar10", "off"): 1.0, ("celeba", "default"): 7.0}[(dataset, wino4_mode)]
     B = 64
     g = torch.Generator().manual_seed(5)
     x = torch.rand(B, 3, res, res, generator=g) * 2 - 1
@@ -242,7 +246,8 @@ def test_full_batch_gradients_against_float64(dataset, res, wino4_mode):
         o32.append(rel(p32.grad, p64.grad))
         assert hip[-1] < 1e-3, f"D grad {k}: {hip[-1]:.2e} from float64 (fp32 oracle: {o32[-1]:.2e})"
         assert o32[-1] < 1e-3, f"(oracle fp32) D grad {k}: {o32[-1]:.2e} from float64"
-    assert rms(hip) <= 8 * rms(o32) + 1e-6, (rms(hip), rms(o32))
+    print(f"f64-parity {dataset} {wino4_mode} D update: rms hip {rms(hip):.3e} oracle32 {rms(o32):.3e} ratio {rms(hip) / rms(o32):.3f}")
+    assert rms(hip) <= bar * rms(o32) + 1e-6, (rms(hip), rms(o32))
     g32 = oG.train_step((x, None), oD, ooptG, noise=zg)
     g64 = dG.train_step((x.double(), None), dD, doptG, noise=zg.double())
     log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda', noise=zg.cuda())
@@ -258,7 +263,8 @@ def test_full_batch_gradients_against_float64(dataset, res, wino4_mode):
         o32.append(rel(p32.grad, p64.grad))
         assert hip[-1] < 1.2e-2, f"G grad {k}: {hip[-1]:.2e} from float64 (fp32 oracle: {o32[-1]:.2e})"
         assert o32[-1] < 1.2e-2, f"(oracle fp32) G grad {k}: {o32[-1]:.2e} from float64"
-    assert rms(hip) <= 8 * rms(o32) + 1e-6, (rms(hip), rms(o32))
+    print(f"f64-parity {dataset} {wino4_mode} G update: rms hip {rms(hip):.3e} oracle32 {rms(o32):.3e} ratio {rms(hip) / rms(o32):.3f}")
+    assert rms(hip) <= bar * rms(o32) + 1e-6, (rms(hip), rms(o32))
 
 
 def test_generator_backward_isolated():
@@ -641,3 +647,27 @@ def test_deep_copy_after_forwards_uses_its_own_weights():
         outs.append(y)
     relclose(outs[0], outs[1], 1e-5, "copy vs freshly loaded")
     assert (outs[0] - outs[2]).abs().max().item() > 1e-3          # and it really differs from the original's images
+
+
+def test_five_step_trajectory_drifts_no_faster_than_the_exact_fp32_build_and_the_cpu_oracle():
+    """SURVEY section 4 item 3 (the loop of trainer.py:238-299) for the headline network: five global steps (5 D + 1 G updates
+    each, Adam, batch 64) from the same weights with the same injected batches and noise -- the engine as shipped (Winograd
+    F(4x4) / F(2x2)), the engine with the implicit GEMM everywhere, the CPU oracle in fp32 -- each measured against the CPU
+    oracle in float64 (tools/sngan_trajectory.py; 20 steps: profiles/r05_trajectory.md).  With beta1 = 0 Adam's first steps are
+    lr * g / |g|: EVERY fp32 implementation is 4-7 % of the float64 run's own movement away after one step (sign flips of
+    near-zero gradient entries) and the losses decorrelate within ~10 steps, so what is asserted is relative: the default build
+    drifts no faster than 2x the exact-fp32 build and no faster than 3x plain PyTorch fp32, and the first step's losses agree
+    to the contract's 1e-3."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from sngan_trajectory import trajectories
+    r = trajectories("cifar10", steps=5)
+    d, e, c = (r[k]["dist"] for k in ("hip default", "hip exact-fp32", "cpu fp32"))
+    print("trajectory dist:", [f"{v:.3e}" for v in d], [f"{v:.3e}" for v in e], [f"{v:.3e}" for v in c])
+    for k in ("hip default", "hip exact-fp32", "cpu fp32"):
+        assert r[k]["errD"][0] < 1e-3 and r[k]["errG"][0] < 1e-3, (k, r[k]["errD"][0], r[k]["errG"][0])
+    for s in range(5):
+        assert d[s] <= 2.0 * e[s] + 0.01, (s, d[s], e[s])
+        assert d[s] <= 3.0 * c[s] + 0.01, (s, d[s], c[s])
+    assert d[-1] < 0.25                          # and it is still the same run, not a diverged one
