@@ -198,7 +198,7 @@ def executed_flop(name, flop):
         return flop * (25.0 / 144.0 if name.endswith((",1>", ",2>")) else 0.25)     # ... 25 with the 2x2 average pool folded in
     if name.endswith("[pooled gradient]"):     # weight gradient through the average pool as a strided convolution over box sums
         return flop * 0.25
-    return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel")) else flop
+    return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel", "conv_wgrad_wino_batched_kernel")) else flop
 
 
 def conv_block_excluded(name, shape):

@@ -595,6 +595,11 @@ class WgradBatch:
         self.hold = False
         self.pending = []
         self.overlapped = 0      # updates whose reduction was split (tests)
+        # Winograd weight gradients wait here until the end of the pass and then run as ONE launch per prologue mode
+        # (ops/conv.py: conv_wgrad_batched); the queue keeps dy and x alive
+        self.queue = {}          # slot -> [(layer, dy, x, pro, segments, entry)]
+        self.batch_plans = {}    # (layer ids, shapes) -> splits per layer
+        self.batched_launches = 0
 
     def _entry(self, layer, slot, M, segments=1, dy_shape=None, x_shape=None, geom=None):
         self.net.flat_grads
@@ -636,14 +641,58 @@ class WgradBatch:
             # through the same slot, e.g. MNIST_DCGAN_Discriminator): conv_wgrad_into WRITES the slab, so the first pass
             # has to be reduced into the gradient before its partials are overwritten
             self.pending.remove(slot)
+            self.flush(slot)
             self._finish_layers(slot, self.launched.pop(slot, []))
         e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape), geom)
         e['sn_ctx'] = sn_ctx
+        self.launched.setdefault(slot, []).append(layer)
+        if (C.WGRAD_BATCH and geom is None and dy.dim() == 4 and x.dim() == 4
+                and C.wgrad_uses_wino(layer.geom, x.shape[1], x.shape[2], dy.shape[1], dy.shape[2])):
+            self.queue.setdefault(slot, []).append((layer, dy, x, pro, segments, e))
+            return
         C.conv_wgrad_into(geom if geom is not None else layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'],
                           pro=pro, segments=segments, pooled=geom is not None)
-        self.launched.setdefault(slot, []).append(layer)
+
+    def flush(self, slot):
+        """launch the queued Winograd weight gradients of `slot`: one launch per prologue mode (and per wgrad_batch_max()
+        layers), every layer with the split count the group's plan gives it; a group of one runs as an ordinary launch"""
+        jobs = self.queue.pop(slot, None)
+        if not jobs:
+            return
+        groups = {}
+        for job in jobs:
+            pro = job[3]
+            groups.setdefault(int(pro[0]) if pro is not None else 0, []).append(job)
+        nmax = C.wgrad_batch_max()
+        for mode, grp in groups.items():
+            for lo in range(0, len(grp), nmax):
+                part = grp[lo: lo + nmax]
+                if len(part) == 1:
+                    layer, dy, x, pro, segments, e = part[0]
+                    C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro,
+                                      segments=segments)
+                    continue
+                key = tuple((id(j[0]), tuple(j[1].shape), j[4]) for j in part)
+                plan = self.batch_plans.get(key)
+                if plan is None:
+                    desc = []
+                    for layer, dy, x, pro, segments, e in part:
+                        g = layer.geom
+                        tiles = ((g.Co + 63) // 64) * ((g.Ci + 63) // 64)
+                        steps = (dy.shape[0] * (dy.shape[1] // 2) * (dy.shape[2] // 2) + 7) // 8
+                        desc.append((tiles, steps, segments))
+                    plan = self.batch_plans[key] = C.batched_wgrad_splits(desc)
+                for (layer, dy, x, pro, segments, e), sp in zip(part, plan):
+                    if e['splits'] != sp:                # the slab of this layer shrinks to the batch's split count
+                        e['splits'] = sp
+                        e['slab'] = torch.empty(sp * e['stride'], dtype=torch.float32, device=dy.device)
+                        self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
+                C.conv_wgrad_batched([(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro, segments)
+                                      for layer, dy, x, pro, segments, e in part], key=(key, tuple(plan), mode))
+                self.batched_launches += 1
 
     def finish(self, slot):
+        self.flush(slot)             # the partial sums are computed now, whatever happens to their reduction
         if self.hold:
             self.pending.append(slot)
             return
@@ -800,6 +849,7 @@ class FlatNet(nn.Module):
             self._build_flat()
         self._flat_grad.zero_()
         self.wgrad_batch.hold, self.wgrad_batch.pending = False, []
+        self.wgrad_batch.queue.clear()
 
     @property
     def flat_params(self):

@@ -15,6 +15,8 @@ nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
+nat.register("diagan_conv_wgrad_batched", [P, I, P])
+nat.register("diagan_conv_wgrad_batch_max", [])
 nat.register("diagan_conv_gemm_set_wino4x", [I])
 nat.register("diagan_conv_gemm_get_wino4x", [])
 nat.register("diagan_conv_wino4_pool_used", [I] * 5 + [I64])
@@ -569,6 +571,92 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
     if t0 is not None:
         px = B * Ho * Wo * (4 if pooled else 1)
         TIMER.end(kn, 2.0 * px * Co * geom.R * geom.S * Ci, t0, (px, Co, geom.R * geom.S * Ci, f"pro{mode}"))
+
+
+# ---- the Winograd weight gradients of several layers in ONE launch (include/diagan_hip.h: diagan_conv_wgrad_batched, round 5) ----
+# A layer's own launch fills the chip by cutting its pixel range 256 / tiles ways: for the small maps that is 4-16 K-steps per
+# workgroup behind ~15 us of fixed cost, and 38 MB of slab per layer whatever its size.  Deferred to the end of the backward
+# pass the layers of one prologue mode share the chip's workgroups in proportion to their work (`batched_wgrad_splits`).
+# DIAGAN_WGRAD_BATCH=0: every layer launches on its own, as before.
+WGRAD_BATCH = _os.environ.get("DIAGAN_WGRAD_BATCH", "1") != "0"
+_WG_JOB = None
+
+
+def batched_wgrad_splits(jobs, slots=256, fixed=8.0):
+    """jobs: [(tiles, steps, segments)] per layer (64x64 output tiles, K-steps of 8 Winograd tiles over the whole pixel range,
+    segments the splits may not straddle) -> split count per layer.  Model: the launch runs ceil(workgroups / slots) rounds
+    of (longest K loop of a workgroup + `fixed` K-steps of prologue / epilogue / slab write-out, ~15 us at 1.8 us per step);
+    every layer is cut so that no workgroup runs more than `per` steps (at least 4 steps per split, one split per segment,
+    workgroup ranges padded to multiples of 8), and `per` is the candidate with the cheapest launch."""
+    def plan(per):
+        out, total, longest = [], 0, 0
+        for tiles, steps, seg in jobs:
+            seg_steps = -(-steps // seg)
+            k = max(1, min(-(-seg_steps // per), max(1, seg_steps // 4)))
+            out.append(k * seg)
+            total += (tiles * k * seg + 7) // 8 * 8
+            longest = max(longest, -(-seg_steps // k))
+        return (-(-total // slots)) * (longest + fixed), out
+    best, per = None, 4.0
+    top = max(-(-steps // seg) for _, steps, seg in jobs)
+    while True:
+        cost, out = plan(int(per))
+        if best is None or cost < best[0]:
+            best = (cost, out)
+        if per > top:
+            return best[1]
+        per = max(per + 1, per * 1.08)
+
+
+_WG_TABS = {}
+
+
+def conv_wgrad_batched(jobs, key=None):
+    """jobs: [(geom, dy, x, slab, splits, stride, bias_off, pro, segments)] -- the arguments of conv_wgrad_into, every job a
+    layer of the Winograd weight gradient, all with the same prologue mode; at most wgrad_batch_max() of them.
+    key: a hashable that identifies everything but the tensors' addresses (layers, shapes, splits): the job table's constant
+    columns are then built once and only the five pointers per job are refreshed (host time matters on launch-bound nets)."""
+    global _WG_JOB
+    import numpy as np
+    if _WG_JOB is None:
+        _WG_JOB = np.dtype([('p', np.uint64, 5), ('l', np.int64, 2), ('i', np.int32, 18)])
+        assert _WG_JOB.itemsize == 128
+    cached = _WG_TABS.get(key) if key is not None else None
+    if cached is None:
+        tab = np.zeros(len(jobs), dtype=_WG_JOB)
+        flop, px, mode0 = 0.0, 0, None
+        for j, (geom, dy, x, slab, splits, stride, bias_off, pro, segments) in enumerate(jobs):
+            B, Ho, Wo, Co = dy.shape
+            _, Hi, Wi, Ci = x.shape
+            mode = _pro3(pro)[0]
+            mode0 = mode if mode0 is None else mode0
+            sy, dr, off, up = geom.fwd_params()
+            tab[j]['l'] = [stride, bias_off]
+            tab[j]['i'] = [splits, segments, mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, 0]
+            flop += 2.0 * B * Ho * Wo * Co * geom.R * geom.S * Ci
+            px += B * Ho * Wo
+        cached = (tab, flop, px, mode0)
+        if key is not None:
+            if len(_WG_TABS) > 256:
+                _WG_TABS.clear()
+            _WG_TABS[key] = cached
+    tab, flop, px, mode0 = cached
+    ptrs = []
+    for geom, dy, x, slab, splits, stride, bias_off, pro, segments in jobs:
+        scale, shift = (pro[1], pro[2]) if pro is not None and len(pro) > 2 else (None, None)
+        ptrs.append((dy.data_ptr(), x.data_ptr(), slab.data_ptr(), 0 if scale is None else scale.data_ptr(),
+                     0 if shift is None else shift.data_ptr()))
+    tab['p'] = ptrs
+    timed = TIMER is not None and TIMER.wants_any()
+    kn = f"conv_wgrad_wino_batched_kernel<{mode0}>" if timed else None
+    t0 = TIMER.begin(kn) if timed else None
+    nat.call("diagan_conv_wgrad_batched", tab.ctypes.data, len(jobs), nat.current_stream())
+    if t0 is not None:
+        TIMER.end(kn, flop, t0, (px, jobs[0][0].Co, 9 * jobs[0][0].Ci, f"pro{mode0} {len(jobs)} layers"))
+
+
+def wgrad_batch_max():
+    return nat.fn("diagan_conv_wgrad_batch_max")()
 
 
 POOLED_TAG = " [pooled gradient]"     # kernel-timer name suffix of ConvLayer.wgrad_pooled's launches

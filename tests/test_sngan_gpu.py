@@ -671,3 +671,37 @@ def test_five_step_trajectory_drifts_no_faster_than_the_exact_fp32_build_and_the
         assert d[s] <= 2.0 * e[s] + 0.01, (s, d[s], e[s])
         assert d[s] <= 3.0 * c[s] + 0.01, (s, d[s], c[s])
     assert d[-1] < 0.25                          # and it is still the same run, not a diverged one
+
+
+@pytest.mark.parametrize("dataset", ["cifar10", "celeba"])
+def test_batched_weight_gradient_launches_equal_the_per_layer_ones(dataset):
+    """Round 5: the Winograd weight gradients of a backward pass run as ONE launch per prologue mode at the end of the pass
+    (diagan_conv_wgrad_batched; the layers share the chip's workgroups, so their split counts -- the order of the fp32 sums
+    -- differ from the per-layer launches').  Same weights, images and noise with the batching on and off: losses equal,
+    gradients equal to fp32 summation-order rounding, and the batched path really ran."""
+    from diagan.ops import conv as C
+    res = 32 if dataset == "cifar10" else 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(64, 3, res, res, generator=g) * 2 - 1
+    zd, zg = torch.randn(64, 128, generator=g), torch.randn(64, 128, generator=g)
+    out = {}
+    try:
+        for on in (True, False):
+            C.WGRAD_BATCH = on
+            (_, _, _, _), (netG, netD, optG, optD) = build(dataset, "ns")
+            log = netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=zd.cuda())
+            gd, ed = netD.export_grads(), log.m['errD'].item()
+            log = netG.train_step(real_batch=(x.cuda(), None), netD=netD, optG=optG, log_data=Log(), device='cuda', noise=zg.cuda())
+            out[on] = (gd, ed, netG.export_grads(), log.m['errG'].item(),
+                       netD.wgrad_batch.batched_launches + netG.wgrad_batch.batched_launches)
+    finally:
+        C.WGRAD_BATCH = True
+    assert out[True][4] >= 2 and out[False][4] == 0
+    assert out[True][1] == out[False][1]                       # the D forward does not depend on the switch
+    for k, v in out[False][0].items():
+        relclose(out[True][0][k], v, 2e-5, f"D grad {k}")
+    # (the G update runs through a discriminator whose Adam step saw gradients that differ in the last bits: ReLU masks of
+    #  near-zero pre-activations may flip, hence the L2 form -- see l2close)
+    for k, v in out[False][2].items():
+        if not is_dead_bias(k):
+            l2close(out[True][2][k], v, 2e-3, f"G grad {k}", floor=1e-6)
