@@ -232,8 +232,8 @@ int diagan_conv_wgrad(const float* dy, const float* x, float* slab, int splits, 
                       int Wo, int Co, int R, int S, int sy, int dr, int off, int up, int Kp,
                       void* stream);
 int diagan_conv_wgrad_splits(int M, int Co, int Kp);
-/* Round 5: the weight gradients of SEVERAL layers of one backward pass (the layers diagan_conv_wgrad_uses_wino accepts, one
- * prologue mode per call, at most diagan_conv_wgrad_batch_max() of them) in ONE launch: the layers share the chip's workgroups
+/* Round 5: the weight gradients of SEVERAL layers of one backward pass (layers of one diagan_conv_wgrad_batch_class, at most
+ * diagan_conv_wgrad_batch_max() of them) in ONE launch: the layers share the chip's workgroups
  * in proportion to their work, so a small layer needs 4-8 slabs instead of the 64 its own chip-filling launch writes, and the
  * per-workgroup fixed cost is paid once per ~30 K-steps instead of once per 4.  Every job carries the arguments of a
  * diagan_conv_wgrad call (same slab layout: the deferred reduction does not change); `splits` is the caller's allocation for
@@ -249,6 +249,12 @@ typedef struct {
 } diagan_wgrad_job;
 int diagan_conv_wgrad_batched(const diagan_wgrad_job* jobs, int n, void* stream);
 int diagan_conv_wgrad_batch_max(void);
+/* The jobs of one diagan_conv_wgrad_batched call run the SAME kernel template: this is its identity for a geometry and prologue
+ * mode (0: the layer cannot be batched and launches through diagan_conv_wgrad; Winograd layers 100 + mode, the implicit-GEMM
+ * kernel 1000 for its 64 x 64 tile and 2000 + ... for the 128-column tiles with prologue none / ReLU).  Equal non-zero
+ * classes may share a call. */
+int diagan_conv_wgrad_batch_class(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up,
+                                  int Kp, int pro_mode);
 /* The Winograd F(3x3,2x2) weight gradient (csrc/conv_wgrad_wino.hip: 16/36 of the multiply-accumulates, same slab layout
  * and deferred reduction) takes the 3x3 / stride 1 / pad 1 layers inside diagan_conv_wgrad; uses_wino tells whether a
  * geometry qualifies (DIAGAN_WINO / diagan_conv_gemm_set_wino / DIAGAN_WINO_WGRAD=0 turn it off), splits_geom the split

@@ -145,6 +145,16 @@ struct WgradArgs {
   int same;                 // stride-1, un-dilated, same-size conv (Hi == Ho, Wi == Wo): linear gather offsets
 };
 
+// Several layers' weight gradients in one launch (round 5: conv_wgrad_wino_batched_kernel, conv_wgrad_batched_kernel): passed BY VALUE
+// as the kernel argument (< 4 KB); a workgroup finds its layer through the first-workgroup prefix
+constexpr int WG_BATCH_MAX = 8;
+struct WgradBatchArgs {
+  int n;
+  int blk0[WG_BATCH_MAX];      // first workgroup of layer j (a multiple of 8: the XCD remap inside a layer's range stays a permutation)
+  int cnt[WG_BATCH_MAX];       // its workgroups: tiles x splits
+  WgradArgs a[WG_BATCH_MAX];
+};
+
 // Loader of the Winograd weight-transform kernels (conv_wino.hip, conv_wino4.hip): the 3x3 taps of a block of 64 output x 32
 // input channels of the packed weights w[Co][Kp], for thread (column = tid & 63, channel quad = tid >> 6) of a 512-thread
 // workgroup.  Read with eight lanes along the input channels -- one whole 128-byte line per output channel and tap; with the

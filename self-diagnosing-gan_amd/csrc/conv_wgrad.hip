@@ -29,8 +29,10 @@ int wgrad_wino_batch_max();
 
 // P2: Ho and Wo are powers of two -- pixel coordinates come from shifts and masks of the pixel index instead of
 // the incrementally advanced (b, oy, ox) registers (the gather arithmetic is ~7 % of the kernel otherwise)
-template <int BNn, int BNk, int PRO = -1, bool P2 = false>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+// bid / nblk: this workgroup's index and the workgroup count of ITS layer (the whole grid for a one-layer launch, a range
+// of the grid in conv_wgrad_batched_kernel)
+template <int BNn, int BNk, int PRO, bool P2>
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bid, const int nblk) {
   constexpr int BK = 32;                       // pixels per K-step
   constexpr int TM = BNn / 64, TN = BNk / 64;  // 2x2 waves
   constexpr int AC = BNn / 4, BC = BNk / 4;    // 16-byte chunks per pixel row
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int tiles_k = (g.Kp + BNk - 1) / BNk;
   // 1-D grid of tiles x splits, XCD-aware: consecutive logical ids -- the tiles of ONE split, which share its dy
   // rows and re-read the same x rows tap by tap -- land on the same XCD (= the same L2)
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int logical = xcd_remap(bid, nblk);
   const int split = logical / a.tiles, tile = logical - split * a.tiles;
   const int n0 = (tile / tiles_k) * BNn, k0 = (tile % tiles_k) * BNk;
   const int seg = split / a.splits_per_seg, sub = split - seg * a.splits_per_seg;
@@ -276,6 +278,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(av), osrc, vbase, (int)(((e & 3) + 8 * (e >> 2)) * rowbytes), 0);
       }
     }
+}
+
+template <int BNn, int BNk, int PRO = -1, bool P2 = false>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  conv_wgrad_body<BNn, BNk, PRO, P2>(a, blockIdx.x, gridDim.x);
+}
+
+// Round 5: several layers of one backward pass in ONE launch (see conv_wgrad_wino.hip: conv_wgrad_wino_batched_kernel; the
+// layers of a launch share the kernel's template, i.e. tile, prologue mode and power-of-two image)
+template <int BNn, int BNk, int PRO = -1, bool P2 = false>
+__global__ __launch_bounds__(256) void conv_wgrad_batched_kernel(const WgradBatchArgs b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.blk0[j + 1]) ++j;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const int local = (int)blockIdx.x - b.blk0[j];
+  if (local >= b.cnt[j]) return;
+  conv_wgrad_body<BNn, BNk, PRO, P2>(b.a[j], local, b.cnt[j]);
 }
 
 
@@ -580,6 +599,18 @@ static void wgrad_tile(int Co, int Kp, int* bn, int* bk) {
   if (*bn == 128 && *bk == 64) *bn = 64;   // no <128,64> instantiation
 }
 
+// the implicit-GEMM kernel's own fields of WgradArgs and its template choice (tile; power-of-two image)
+static void wgrad_gemm_fields(WgradArgs& a, int* bn, int* bk, bool* p2) {
+  const ConvGeom& g = a.g;
+  wgrad_tile(g.Co, g.Kp, bn, bk);
+  a.tiles = cdiv(g.Co, *bn) * cdiv(g.Kp, *bk);
+  a.same = (g.Hi == g.Ho && g.Wi == g.Wo && g.sy == 1 && g.up == 1) ? 1 : 0;
+  *p2 = (g.Ho & (g.Ho - 1)) == 0 && (g.Wo & (g.Wo - 1)) == 0;
+  a.lgW = a.lgHW = 0;
+  while ((1 << a.lgW) < g.Wo) ++a.lgW;
+  while ((1 << a.lgHW) < g.Ho * g.Wo) ++a.lgHW;
+}
+
 // argument checks and the launch-independent part of WgradArgs (shared by the one-layer and the batched entry point)
 static int wgrad_fill_args(WgradArgs& a, const float* dy, const float* x, float* slab, int splits, int segments,
                            int64_t slab_stride, int64_t bias_off, const float* pro_scale, const float* pro_shift, int pro_mode, int B,
@@ -630,16 +661,10 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp))
     return launch_wgrad_wino(a, splits, segments, st);
   int bn, bk;
-  wgrad_tile(Co, Kp, &bn, &bk);
-  const int tiles = cdiv(Co, bn) * cdiv(Kp, bk);
-  a.tiles = tiles;
-  a.same = (Hi == Ho && Wi == Wo && sy == 1 && up == 1) ? 1 : 0;
-  const dim3 grid(tiles * splits);
+  bool p2;
+  wgrad_gemm_fields(a, &bn, &bk, &p2);
+  const dim3 grid(a.tiles * splits);
   // one straight-line kernel per prologue mode (x power-of-two image or not) for the two production tiles
-  const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
-  a.lgW = a.lgHW = 0;
-  while ((1 << a.lgW) < Wo) ++a.lgW;
-  while ((1 << a.lgHW) < Ho * Wo) ++a.lgHW;
 #define DG_WG(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_kernel<BN_, 128, PRO_, true>), grid, dim3(256), 0, st, a); \
                               else hipLaunchKernelGGL((conv_wgrad_kernel<BN_, 128, PRO_, false>), grid, dim3(256), 0, st, a); } while (0)
 #define DG_WG_ALL(BN_) switch (pro_mode) { \
@@ -671,23 +696,70 @@ struct diagan_wgrad_job {    // mirrors the typedef of the same name in include/
   int32_t splits, segments, pro_mode, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, pad_;
 };
 static_assert(sizeof(diagan_wgrad_job) == 128, "diagan_wgrad_job layout");
+// Which launches may share a batched launch: equal class = the same kernel template.  0: this layer launches on its own.
+//   100 + pro                         the Winograd F(3x3,2x2) weight gradient (conv_wgrad_wino.hip)
+//   1000                              implicit GEMM, 64 x 64 tile (prologue mode at run time)
+//   2000 + 100 (bn == 128) + 2 pro + p2   implicit GEMM, bn x 128 tile, prologue none / ReLU (the modes the networks' 1x1, strided
+//                                     and pooled layers use; the other modes are not instantiated for batches)
+DIAGAN_API int diagan_conv_wgrad_batch_class(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                                             int up, int Kp, int pro_mode) {
+  if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp)) return 100 + pro_mode;
+  int bn, bk;
+  wgrad_tile(Co, Kp, &bn, &bk);
+  if (bn == 64 && bk == 64) return 1000;
+  if (pro_mode != PRO_NONE && pro_mode != PRO_RELU) return 0;
+  const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
+  return 2000 + (bn == 128 ? 100 : 0) + 2 * pro_mode + (p2 ? 1 : 0);
+}
+
+template <int BN_, int BK_, int PRO_, bool P2_>
+static void launch_wgrad_gemm_batched(const WgradBatchArgs& b, int wgs, hipStream_t st) {
+  hipLaunchKernelGGL((conv_wgrad_batched_kernel<BN_, BK_, PRO_, P2_>), dim3(wgs), dim3(256), 0, st, b);
+}
+
 DIAGAN_API int diagan_conv_wgrad_batched(const diagan_wgrad_job* jobs, int n, void* stream) {
-  DG_REQUIRE(jobs && n >= 1 && n <= wgrad_wino_batch_max(), "conv_wgrad_batched: 1 .. %d jobs", wgrad_wino_batch_max());
-  WgradArgs a[16];
-  int splits[16], segments[16];
+  DG_REQUIRE(jobs && n >= 1 && n <= WG_BATCH_MAX, "conv_wgrad_batched: 1 .. %d jobs", WG_BATCH_MAX);
+  WgradArgs a[WG_BATCH_MAX];
+  int splits[WG_BATCH_MAX], segments[WG_BATCH_MAX], cls = -1;
   for (int j = 0; j < n; ++j) {
     const diagan_wgrad_job& q = jobs[j];
-    DG_REQUIRE(diagan_conv_wgrad_uses_wino(q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.R, q.S, q.sy, q.dr, q.off, q.up, q.Kp),
-               "conv_wgrad_batched: job %d is not a layer of the Winograd weight gradient (3x3 / stride 1 / pad 1, even H and W)", j);
+    const int c = diagan_conv_wgrad_batch_class(q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.R, q.S, q.sy, q.dr, q.off, q.up, q.Kp, q.pro_mode);
+    DG_REQUIRE(c != 0 && (cls < 0 || c == cls), "conv_wgrad_batched: job %d has batch class %d, the launch's is %d "
+               "(diagan_conv_wgrad_batch_class: equal non-zero classes share a launch)", j, c, cls);
+    cls = c;
     const int rc = wgrad_fill_args(a[j], q.dy, q.x, q.slab, q.splits, q.segments, q.slab_stride, q.bias_off, q.pro_scale, q.pro_shift,
                                    q.pro_mode, q.B, q.Hi, q.Wi, q.Ci, q.Ho, q.Wo, q.Co, q.R, q.S, q.sy, q.dr, q.off, q.up, q.Kp);
     if (rc != DIAGAN_OK) return rc;
     splits[j] = q.splits;
     segments[j] = q.segments;
   }
-  return launch_wgrad_wino_batched(a, splits, segments, n, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (cls < 1000) return launch_wgrad_wino_batched(a, splits, segments, n, st);
+  WgradBatchArgs b;
+  b.n = n;
+  int wgs = 0, bn = 0, bk = 0;
+  bool p2 = false;
+  for (int j = 0; j < n; ++j) {
+    wgrad_gemm_fields(a[j], &bn, &bk, &p2);
+    b.a[j] = a[j];
+    b.blk0[j] = wgs;
+    b.cnt[j] = a[j].tiles * splits[j];
+    wgs += (b.cnt[j] + 7) & ~7;
+  }
+  for (int j = n; j < WG_BATCH_MAX; ++j) b.blk0[j] = wgs, b.cnt[j] = 0;
+  const int pro = jobs[0].pro_mode;
+  if (cls == 1000) launch_wgrad_gemm_batched<64, 64, -1, false>(b, wgs, st);
+  else if (bn == 128 && pro == PRO_NONE && p2) launch_wgrad_gemm_batched<128, 128, PRO_NONE, true>(b, wgs, st);
+  else if (bn == 128 && pro == PRO_NONE) launch_wgrad_gemm_batched<128, 128, PRO_NONE, false>(b, wgs, st);
+  else if (bn == 128 && p2) launch_wgrad_gemm_batched<128, 128, PRO_RELU, true>(b, wgs, st);
+  else if (bn == 128) launch_wgrad_gemm_batched<128, 128, PRO_RELU, false>(b, wgs, st);
+  else if (pro == PRO_NONE && p2) launch_wgrad_gemm_batched<64, 128, PRO_NONE, true>(b, wgs, st);
+  else if (pro == PRO_NONE) launch_wgrad_gemm_batched<64, 128, PRO_NONE, false>(b, wgs, st);
+  else if (p2) launch_wgrad_gemm_batched<64, 128, PRO_RELU, true>(b, wgs, st);
+  else launch_wgrad_gemm_batched<64, 128, PRO_RELU, false>(b, wgs, st);
+  return check_launch("conv_wgrad_batched");
 }
-DIAGAN_API int diagan_conv_wgrad_batch_max(void) { return wgrad_wino_batch_max(); }
+DIAGAN_API int diagan_conv_wgrad_batch_max(void) { return WG_BATCH_MAX; }
 
 // The Winograd F(3x3,2x2) weight gradient (conv_wgrad_wino.hip) takes the 3x3 / stride 1 / pad 1 layers unless
 // DIAGAN_WINO=0 / diagan_conv_gemm_set_wino(0) is set.

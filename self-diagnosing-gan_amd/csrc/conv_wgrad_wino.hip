@@ -314,13 +314,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_kernel(const WgradArgs
 // workgroup runs ~(sum of all K-steps) / 256 steps and a small layer writes 8 slabs instead of 64.  The layers of a launch
 // share the prologue mode; a workgroup finds its layer through the first-workgroup prefix (multiples of 8: the XCD remap
 // inside a layer's range stays a permutation of that range).
-constexpr int GW_BATCH_MAX = 8;
-struct WgradWinoBatch {
-  int n;
-  int blk0[GW_BATCH_MAX];      // first workgroup of layer j (a multiple of 8)
-  int cnt[GW_BATCH_MAX];       // its workgroups: tiles x splits
-  WgradArgs a[GW_BATCH_MAX];
-};
+constexpr int GW_BATCH_MAX = WG_BATCH_MAX;
+typedef WgradBatchArgs WgradWinoBatch;
 template <int PRO>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_wino_batched_kernel(const WgradWinoBatch b) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -392,8 +392,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(up + 4 * 256),                     \
                                      (__attribute__((address_space(3))) void*)(uslot + 4 * 256), 16, ((u) - 4) * 1024, 0); \
     break;
+  f32x4 uprobe = {0.f, 0.f, 0.f, 0.f};
   auto issue_u = [&](int kk, int s) {
     const float* up = ublock + (long)kk * MD::U_FLOATS + lane * 4;
+    if (X3_ABL & 512) {        // timing probe: the unit fetched by an ordinary load into a register nobody reads (results garbage)
+      asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(uprobe) : "v"(up + s * 256) : "memory");     // ("+v": the register stays reserved)
+      return;
+    }
     switch (s) {
       W4_DMA_CASE(0) W4_DMA_CASE(1) W4_DMA_CASE(2) W4_DMA_CASE(3) W4_DMA_CASE(4) W4_DMA_CASE(5) W4_DMA_CASE(6) W4_DMA_CASE(7)
       default:
@@ -921,6 +926,10 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     return;
   }
 #endif
+  if (X3_ABL & 512) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(uprobe)::"memory");
+    if (uprobe[0] == 123.456f) a.y[0] = uprobe[1];
+  }
   // ---- epilogue ----
   const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
   // pixel-row index (of the tensor that is written: the pooled one in MODE 1) where the second sigma starts

@@ -646,49 +646,58 @@ class WgradBatch:
         e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape), geom)
         e['sn_ctx'] = sn_ctx
         self.launched.setdefault(slot, []).append(layer)
-        if (C.WGRAD_BATCH and geom is None and dy.dim() == 4 and x.dim() == 4
-                and C.wgrad_uses_wino(layer.geom, x.shape[1], x.shape[2], dy.shape[1], dy.shape[2])):
-            self.queue.setdefault(slot, []).append((layer, dy, x, pro, segments, e))
-            return
+        if C.WGRAD_BATCH and dy.dim() == 4 and x.dim() == 4:
+            g = geom if geom is not None else layer.geom
+            cls = 0 if (segments == 1 and C.small_co_wgrad(g)) else C.wgrad_batch_class(
+                g, x.shape[1], x.shape[2], dy.shape[1], dy.shape[2], int(pro[0]) if pro is not None else 0)
+            if cls:
+                self.queue.setdefault(slot, []).append((layer, dy, x, pro, segments, e, g, (cls, geom is not None)))
+                return
         C.conv_wgrad_into(geom if geom is not None else layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'],
                           pro=pro, segments=segments, pooled=geom is not None)
 
     def flush(self, slot):
-        """launch the queued Winograd weight gradients of `slot`: one launch per prologue mode (and per wgrad_batch_max()
-        layers), every layer with the split count the group's plan gives it; a group of one runs as an ordinary launch"""
+        """launch the queued weight gradients of `slot`: one launch per kernel template (batch class; the pooled layers'
+        strided form apart, for the FLOP accounting) and per wgrad_batch_max() layers, every layer with the split count the
+        group's plan gives it; a group of one runs as an ordinary launch"""
         jobs = self.queue.pop(slot, None)
         if not jobs:
             return
         groups = {}
         for job in jobs:
-            pro = job[3]
-            groups.setdefault(int(pro[0]) if pro is not None else 0, []).append(job)
+            groups.setdefault(job[7], []).append(job)
         nmax = C.wgrad_batch_max()
-        for mode, grp in groups.items():
+        for (cls, pooled), grp in groups.items():
             for lo in range(0, len(grp), nmax):
                 part = grp[lo: lo + nmax]
                 if len(part) == 1:
-                    layer, dy, x, pro, segments, e = part[0]
-                    C.conv_wgrad_into(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro,
-                                      segments=segments)
+                    layer, dy, x, pro, segments, e, g, _ = part[0]
+                    C.conv_wgrad_into(g, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro, segments=segments,
+                                      pooled=pooled)
                     continue
-                key = tuple((id(j[0]), tuple(j[1].shape), j[4]) for j in part)
+                key = (cls, pooled) + tuple((id(j[0]), tuple(j[1].shape), j[4]) for j in part)
                 plan = self.batch_plans.get(key)
                 if plan is None:
-                    desc = []
-                    for layer, dy, x, pro, segments, e in part:
-                        g = layer.geom
-                        tiles = ((g.Co + 63) // 64) * ((g.Ci + 63) // 64)
-                        steps = (dy.shape[0] * (dy.shape[1] // 2) * (dy.shape[2] // 2) + 7) // 8
+                    desc, slots, fixed = [], 256, 8.0
+                    for layer, dy, x, pro, segments, e, g, _ in part:
+                        tiles, steps, slots, fixed = C.wgrad_batch_shape(g, dy.shape[0], dy.shape[1], dy.shape[2], cls)
                         desc.append((tiles, steps, segments))
-                    plan = self.batch_plans[key] = C.batched_wgrad_splits(desc)
-                for (layer, dy, x, pro, segments, e), sp in zip(part, plan):
-                    if e['splits'] != sp:                # the slab of this layer shrinks to the batch's split count
+                    plan = self.batch_plans[key] = C.batched_wgrad_splits(desc, slots, fixed)
+                for (layer, dy, x, pro, segments, e, g, _), sp in zip(part, plan):
+                    if e['splits'] != sp:                # the slab of this layer takes the batch's split count
                         e['splits'] = sp
                         e['slab'] = torch.empty(sp * e['stride'], dtype=torch.float32, device=dy.device)
                         self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
-                C.conv_wgrad_batched([(layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro, segments)
-                                      for layer, dy, x, pro, segments, e in part], key=(key, tuple(plan), mode))
+                name = None
+                if cls >= 1000:
+                    g0, d0 = part[0][6], part[0][1]
+                    name = C._wgrad_kernel_name(g0.Co, g0.Kp, int(part[0][3][0]) if part[0][3] is not None else 0, d0.shape[1],
+                                                d0.shape[2]).replace("conv_wgrad_kernel", "conv_wgrad_batched_kernel")
+                    if pooled:
+                        name += C.POOLED_TAG
+                C.conv_wgrad_batched([(g, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro, segments)
+                                      for layer, dy, x, pro, segments, e, g, _ in part], key=(key, tuple(plan)),
+                                     kernel_name=name, flop_scale=4.0 if pooled else 1.0)
                 self.batched_launches += 1
 
     def finish(self, slot):

@@ -17,6 +17,7 @@ nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_wgrad_batched", [P, I, P])
 nat.register("diagan_conv_wgrad_batch_max", [])
+nat.register("diagan_conv_wgrad_batch_class", [I] * 14)
 nat.register("diagan_conv_gemm_set_wino4x", [I])
 nat.register("diagan_conv_gemm_get_wino4x", [])
 nat.register("diagan_conv_wino4_pool_used", [I] * 5 + [I64])
@@ -611,7 +612,7 @@ def batched_wgrad_splits(jobs, slots=256, fixed=8.0):
 _WG_TABS = {}
 
 
-def conv_wgrad_batched(jobs, key=None):
+def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0):
     """jobs: [(geom, dy, x, slab, splits, stride, bias_off, pro, segments)] -- the arguments of conv_wgrad_into, every job a
     layer of the Winograd weight gradient, all with the same prologue mode; at most wgrad_batch_max() of them.
     key: a hashable that identifies everything but the tensors' addresses (layers, shapes, splits): the job table's constant
@@ -648,15 +649,33 @@ def conv_wgrad_batched(jobs, key=None):
                      0 if shift is None else shift.data_ptr()))
     tab['p'] = ptrs
     timed = TIMER is not None and TIMER.wants_any()
-    kn = f"conv_wgrad_wino_batched_kernel<{mode0}>" if timed else None
+    kn = (kernel_name or f"conv_wgrad_wino_batched_kernel<{mode0}>") if timed else None
     t0 = TIMER.begin(kn) if timed else None
     nat.call("diagan_conv_wgrad_batched", tab.ctypes.data, len(jobs), nat.current_stream())
     if t0 is not None:
-        TIMER.end(kn, flop, t0, (px, jobs[0][0].Co, 9 * jobs[0][0].Ci, f"pro{mode0} {len(jobs)} layers"))
+        g0 = jobs[0][0]
+        TIMER.end(kn, flop * flop_scale, t0, (int(px * flop_scale), g0.Co, g0.R * g0.S * g0.Ci, f"pro{mode0} {len(jobs)} layers"))
 
 
 def wgrad_batch_max():
     return nat.fn("diagan_conv_wgrad_batch_max")()
+
+
+def wgrad_batch_class(geom, Hi, Wi, Ho, Wo, mode):
+    """identity of the kernel template a layer's weight gradient runs on (0: not batchable); equal classes share a launch"""
+    sy, dr, off, up = geom.fwd_params()
+    return nat.fn("diagan_conv_wgrad_batch_class")(Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, mode)
+
+
+def wgrad_batch_shape(geom, B, Ho, Wo, cls):
+    """(output tiles, K-steps over the whole pixel range, workgroup slots of the chip, fixed cost in K-steps) of a layer in a
+    batched launch of class `cls` -- the inputs of batched_wgrad_splits"""
+    if cls < 1000:                          # Winograd: 64 x 64 tiles, 8 tiles of 2x2 outputs per K-step, one workgroup per CU
+        return ((geom.Co + 63) // 64) * ((geom.Ci + 63) // 64), (B * (Ho // 2) * (Wo // 2) + 7) // 8, 256, 8.0
+    bn, bk = (64 if geom.Co <= 64 else 128), (64 if geom.Kp <= 64 else 128)
+    if bn == 128 and bk == 64:
+        bn = 64
+    return ((geom.Co + bn - 1) // bn) * ((geom.Kp + bk - 1) // bk), (B * Ho * Wo + 31) // 32, 512, 6.0
 
 
 POOLED_TAG = " [pooled gradient]"     # kernel-timer name suffix of ConvLayer.wgrad_pooled's launches
