@@ -53,6 +53,9 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_DMA_IMM
 #define W4_DMA_IMM 1
 #endif
+#ifndef W4_ULOAD
+#define W4_ULOAD 1            // MODE 0 / 3, fp32 build: weight units by ordinary loads into registers instead of LDS-DMA + ds_read
+#endif
 // Experiments on the arbitration between the two waves of a SIMD (profiles/r04_w4_kstep_stamps.md: waves 4-7 run ~1400 cycles per
 // step behind waves 0-3, which then wait at the barrier): W4_PRIO_B = n > 0 runs waves 4-7 at priority n for the whole kernel;
 // W4_PRIO_ALT = n > 0 alternates priority n / 0 slot by slot, in opposite phase for the two wave groups.
@@ -626,10 +629,42 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     switch (r) { X3_DMA_CASE(0) X3_DMA_CASE(1) X3_DMA_CASE(2) X3_DMA_CASE(3) X3_DMA_CASE(4) X3_DMA_CASE(5) }
   };
 #undef X3_DMA_CASE
+  // ---- ULOAD (round 5, MODE 0 / 3 of the fp32 build): the weight units by ordinary loads, straight into the MFMA's B registers ----
+  // Every unit is read by exactly one wave, once: the detour through LDS (one LDS-DMA per unit, one ds_read_b128 to get it back)
+  // buys nothing but the long look-ahead.  Three register quads per wave form a ring: the unit of slot s + 3 is requested right
+  // behind slot s's MFMAs (its register is free then) and waited for in front of slot s + 3's -- two to three slots (1 700-2 500
+  // cycles) of flight.  72 KB of the 159 KB of LDS are then unused.  Timing probe before the build: profiles/r05_bf16x6_wino.md.
+  // (nine units per step: a unit's place in the ring of three is s mod 3.  The pooled modes' seven units per step would make it
+  //  (7 step + s) mod 3 and need a three-fold unrolled loop with a run-time tail: built -- kstep_ul takes the phase -- and not used,
+  //  the accumulators spill across the tail's paths (400+ registers); they keep the LDS-DMA path)
+  constexpr bool ULOAD = W4_ULOAD && !X3 && !MD::pooled;
+  f32x4 ub[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const unsigned ulane = lane * 16;
+#define W4_UL_LOAD(u, r) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ub[r]) : "v"(ulane), "s"(ub4), "n"(((u) - 4) * 1024) : "memory")
+#define W4_UL_CASE(u)                  \
+  case u:                              \
+    if (r == 0) W4_UL_LOAD(u, 0);      \
+    else if (r == 1) W4_UL_LOAD(u, 1); \
+    else W4_UL_LOAD(u, 2);             \
+    break;
+  auto issue_ul = [&](int kk, int u, int r) __attribute__((always_inline)) {       // unit u of step kk -> ub[r]
+    // (units 0 .. 7 around one scalar base, the distance in the instruction's 13-bit offset; unit 8 from a base of its own)
+    const unsigned long long ub4 = (unsigned long long)(ublock + (long)kk * MD::U_FLOATS) + 4096;
+    const unsigned long long ub8 = ub4 + 4096;
+    switch (u) {
+      W4_UL_CASE(0) W4_UL_CASE(1) W4_UL_CASE(2) W4_UL_CASE(3) W4_UL_CASE(4) W4_UL_CASE(5) W4_UL_CASE(6) W4_UL_CASE(7)
+      default: asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ub[2]) : "v"(ulane), "s"(ub8) : "memory");      // (unit 8: nine-unit steps, ring place 2)
+    }
+  };
+#undef W4_UL_CASE
+#undef W4_UL_LOAD
   if (k_begin < k_end) {
     if (X3) {
 #pragma unroll
       for (int g = 0; g <= x3_gmax(-1); ++g) x3_issue_g(ugrp, g);
+    } else if (ULOAD) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) issue_ul(k_begin, s, s);
     } else {
 #pragma unroll
     for (int s = 0; s < NS; ++s) issue_u(k_begin, s);
@@ -749,6 +784,69 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     else if (W4_ON(128)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     W4_TICK(8);                                               // barrier
   };
+  // ---- ULOAD K-step: as kstep, the B operand from the register ring ub[] (see ULOAD above) ----
+  // vmcnt bookkeeping (in issue order: at the top of a step the NX input loads of the next one, behind slot s's MFMAs the load
+  // of unit s + 3): in front of slot s's MFMAs units s + 1 and s + 2 are younger than unit s -- and, for s < 3, the input
+  // loads issued since (unit s was requested in the previous step); the input loads are waited for behind slot ROW_AT's request
+  auto kstep_ul = [&](int kk, auto has_next, auto phase) __attribute__((always_inline)) {
+    constexpr bool HN = decltype(has_next)::value;
+    constexpr int R0 = (NS * decltype(phase)::value) % 3;     // ring place of this step's unit 0
+    constexpr int ROW_AT = W4_ROW_AT, COL_AT = W4_COL_AT;
+    constexpr int NXL = NI + (affine ? 2 : 0);
+    const int cur = (kk - k_begin) & 1;
+    W4_TICK(9);
+    const float* const fa_base = fa_lane + cur * W4_VSTAGE;
+    f32x4 fa[2];
+    fa[0] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[0]);
+    W4_TICK(0);
+    if (HN) issue_x(kk + 1);
+    static_for<0, NS>([&](auto slot) __attribute__((always_inline)) {
+      constexpr int s = decltype(slot)::value;
+      if (s + 1 < NS) fa[(s + 1) & 1] = *reinterpret_cast<const f32x4*>(fa_base + fa_off[s + 1 < NS ? s + 1 : 0]);
+      {
+        constexpr int NW = (HN ? 2 + (s < 3 ? (s == 0 ? 0 : NXL) : 0) : (NS - 1 - s < 2 ? NS - 1 - s : 2));
+        // (s == 0: the input loads of this step are issued BEHIND this wait only if the wait came first -- it does not: they
+        //  were issued above, so they count)
+        constexpr int NW0 = HN && s == 0 ? 2 + NXL : NW;
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ub[(R0 + s) % 3]) : "n"(NW0) : "memory");
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][e], ub[(R0 + s) % 3][e], acc[s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 3 < NS) issue_ul(kk, s + 3, (R0 + s) % 3);            // (the unit three slots ahead takes the register just read)
+      else if (HN) issue_ul(kk + 1, s + 3 - NS, (R0 + s) % 3);
+      if (HN) {
+        if (s == ROW_AT) {
+          W4_TICK(1);
+          constexpr int NR = ROW_AT + 1;                      // the requests behind slots 0 .. ROW_AT are younger
+          if (UPIN)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(psc2), "+v"(psh2) : "n"(NR) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(%8)"
+                         : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(psc), "+v"(psh)
+                         : "n"(NR)
+                         : "memory");
+          W4_TICK(2);
+          row_pass(cur ^ 1);
+          W4_TICK(3);
+        } else if (s == COL_AT) {
+          W4_TICK(4);
+          col_pass(cur ^ 1);
+          W4_TICK(5);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    W4_TICK(6);
+#ifdef DIAGAN_W4_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_TICK(7);
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    W4_TICK(8);
+  };
+
   // ---- X3 K-step (see the notes at X3_SP above) ----
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -893,6 +991,31 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     };
     if (std::is_same<PlA, PlB>::value || wave < 4) kloop3(PlA{});
     else kloop3(PlB{});
+  } else if constexpr (ULOAD) {
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    if (NS % 3 == 0) {
+      for (int kk = k_begin; kk + 1 < k_end; ++kk) kstep_ul(kk, std::true_type{}, P0{});
+      if (k_begin < k_end) kstep_ul(k_end - 1, std::false_type{}, P0{});
+    } else {                                   // seven units per step: the ring's phase repeats every three steps
+      int kk = k_begin;
+      for (; kk + 3 < k_end; kk += 3) {
+        kstep_ul(kk, std::true_type{}, P0{});
+        kstep_ul(kk + 1, std::true_type{}, P1{});
+        kstep_ul(kk + 2, std::true_type{}, P2{});
+      }
+      const int left = k_end - kk;             // 1 .. 3 steps (0: an empty channel range)
+      if (left == 1) kstep_ul(kk, std::false_type{}, P0{});
+      else if (left == 2) {
+        kstep_ul(kk, std::true_type{}, P0{});
+        kstep_ul(kk + 1, std::false_type{}, P1{});
+      } else if (left == 3) {
+        kstep_ul(kk, std::true_type{}, P0{});
+        kstep_ul(kk + 1, std::true_type{}, P1{});
+        kstep_ul(kk + 2, std::false_type{}, P2{});
+      }
+    }
   } else {
   using RowA = std::integral_constant<int, W4_ROW_AT>;
   using ColA = std::integral_constant<int, W4_COL_AT>;
