@@ -195,7 +195,8 @@ def executed_flop(name, flop):
     if name.startswith("conv_wino_pool_kernel"):
         return flop * WINO_POOL_MAC_RATIO
     if name.startswith("conv_wino4_kernel"):     # Winograd F(4x4,3x3): 36 products per 4x4 output tile instead of 144
-        return flop * (25.0 / 144.0 if name.endswith((",1>", ",2>")) else 0.25)     # ... 25 with the 2x2 average pool folded in
+        m = re.match(r"conv_wino4_kernel<\s*\d+\s*,\s*(\d+)", name)     # <prologue, MODE[, bf16-split build]>
+        return flop * (25.0 / 144.0 if m and m.group(1) in ("1", "2") else 0.25)     # ... 25 with the 2x2 average pool folded in
     if name.endswith("[pooled gradient]"):     # weight gradient through the average pool as a strided convolution over box sums
         return flop * 0.25
     return flop * WINO_MAC_RATIO if name.startswith(("conv_wino_kernel", "conv_wgrad_wino_kernel", "conv_wgrad_wino_batched_kernel")) else flop
@@ -636,6 +637,7 @@ def main():
                 tot += v['launches'] * 4.0 * (m_in * K / 9 + m_out * Co + Co * K)
             alg_bytes = tot / d['launches'] if tot else None
         peak = MFMA_F32_PEAK
+        x3 = name.startswith("conv_wino4_kernel") and name.endswith(",true>")     # the bf16-split build (DIAGAN_WINO4_X3=1)
         line["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak / 1e12, 1),
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4), "frac_executed": round(achieved * 1e12 / peak, 4),
@@ -644,6 +646,9 @@ def main():
             "traffic_ratio": round(traffic / alg_bytes, 3) if (traffic and alg_bytes) else None,
             "traffic_source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, "
                               "2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this run)" if traffic else None,
+            "pipe": ("bf16 MFMA with every fp32 operand split in three (six piece products per fp32 product): the dense bf16 "
+                     "peak / 6 = 416.7 TFLOP/s of fp32-equivalent products; frac is still quoted against the fp32 MFMA peak"
+                     if x3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
             "launches": d['launches'], "avg_launch_us": round(d['seconds'] / d['launches'] * 1e6, 2),
             "algorithmic_gflop_per_launch": round(d['flop'] / d['launches'] / 1e9, 3),
             "executed_gflop_per_launch": round(executed_flop(name, d['flop']) / d['launches'] / 1e9, 3),

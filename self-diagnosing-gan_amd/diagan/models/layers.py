@@ -623,7 +623,7 @@ class WgradBatch:
             if segments == 1 and dy_shape is not None and C.small_co_wgrad(g):
                 splits = C.small_co_wgrad_splits(dy_shape[0], dy_shape[1])
             dev = layer.weight.device
-            e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, bias_off=n_w if has_bias else -1,
+            e = dict(M=M, n_w=n_w, n_elem=stride, stride=stride, splits=splits, own_splits=splits, bias_off=n_w if has_bias else -1,
                      segments=segments,
                      slab=torch.empty(splits * stride, dtype=torch.float32, device=dev),
                      partials=torch.empty((segments, (stride + 1023) // 1024 + 1), dtype=torch.float64, device=dev))   # (>= blocks of any size + 1)
@@ -667,13 +667,32 @@ class WgradBatch:
         for job in jobs:
             groups.setdefault(job[7], []).append(job)
         nmax = C.wgrad_batch_max()
+
+        def alone(job, pooled):
+            layer, dy, x, pro, segments, e, g, _ = job
+            if e['splits'] != e['own_splits']:       # (it ran in a batch before: back to its own chip-filling split count)
+                e['splits'] = e['own_splits']
+                e['slab'] = torch.empty(e['splits'] * e['stride'], dtype=torch.float32, device=dy.device)
+                self.tables = {k: v for k, v in self.tables.items() if k[0] != slot}
+            C.conv_wgrad_into(g, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro, segments=segments, pooled=pooled)
+
         for (cls, pooled), grp in groups.items():
+            # (knob: a layer whose own chip-filling launch runs >= WGRAD_BATCH_MIN_STEPS K-steps per workgroup launches on its
+            #  own; default off -- ops/conv.py has the sweep: the generator's three big layers are 0.92 -> 1.03 ms slower
+            #  batched, and batching them still wins end to end through the slabs and launches it saves)
+            small = []
+            for job in grp:
+                layer, dy, x, pro, segments, e, g, _ = job
+                steps = C.wgrad_batch_shape(g, dy.shape[0], dy.shape[1], dy.shape[2], cls)[1]
+                if -(-steps // max(e['own_splits'], 1)) >= C.WGRAD_BATCH_MIN_STEPS:
+                    alone(job, pooled)
+                else:
+                    small.append(job)
+            grp = small
             for lo in range(0, len(grp), nmax):
                 part = grp[lo: lo + nmax]
                 if len(part) == 1:
-                    layer, dy, x, pro, segments, e, g, _ = part[0]
-                    C.conv_wgrad_into(g, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro=pro, segments=segments,
-                                      pooled=pooled)
+                    alone(part[0], pooled)
                     continue
                 key = (cls, pooled) + tuple((id(j[0]), tuple(j[1].shape), j[4]) for j in part)
                 plan = self.batch_plans.get(key)

@@ -60,15 +60,16 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
                7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True), 14: (64, 64, 2, 2, 32, True)}
 
 
-def gemm_kernel_name(cfg, mode, Co=128, w4pool=False):
+def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0):
+    """the kernel's name as rocprofv3 prints it (the F(4x4) kernel's third template argument: the bf16-split build, which a
+    launch takes only with the switch on and a K loop of a multiple of four steps)"""
     if cfg in (11, 12) and w4pool:            # the pooled launches on the F(4x4) kernel (MODE 1 / 2)
-        return f"conv_wino4_kernel<{mode if cfg == 11 else 0},{cfg - 10}>"
+        return f"conv_wino4_kernel<{mode if cfg == 11 else 0},{cfg - 10},false>"
     if cfg == 9:
         return f"conv_wino_kernel<{mode}>"
-    if cfg == 13:
-        return f"conv_wino4_kernel<{mode},0>"
-    if cfg == 15:
-        return f"conv_wino4_kernel<{mode},3>"
+    if cfg in (13, 15):
+        x3 = "true" if (nat.fn("diagan_conv_gemm_get_wino4x")() > 0 and Ci % 32 == 0) else "false"
+        return f"conv_wino4_kernel<{mode},{0 if cfg == 13 else 3},{x3}>"
     if cfg == 11:
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
@@ -334,14 +335,15 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         # (cached per call signature: on launch-bound workloads the name lookup itself was 6 ms of host time per step)
         key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats, group_imgs)
         kname = _NAME_CACHE.get(key)
-        if kname is None or _NAME_CACHE.get('modes') != nat.fn("diagan_conv_gemm_get_wino")():
-            if _NAME_CACHE.get('modes') != nat.fn("diagan_conv_gemm_get_wino")():
+        modes = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")())
+        if kname is None or _NAME_CACHE.get('modes') != modes:
+            if _NAME_CACHE.get('modes') != modes:
                 _NAME_CACHE.clear()
-                _NAME_CACHE['modes'] = nat.fn("diagan_conv_gemm_get_wino")()
+                _NAME_CACHE['modes'] = modes
             allow = 0 if want_stats else 1
             kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(
                 B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co,
-                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())))
+                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())), Ci=Ci)
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     _hint(wsite, wversion)
@@ -580,6 +582,11 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
 # pass the layers of one prologue mode share the chip's workgroups in proportion to their work (`batched_wgrad_splits`).
 # DIAGAN_WGRAD_BATCH=0: every layer launches on its own, as before.
 WGRAD_BATCH = _os.environ.get("DIAGAN_WGRAD_BATCH", "1") != "0"
+# a layer whose OWN launch would run at least this many K-steps per workgroup launches on its own; default: never -- sweep on
+# MI355X (tools/probe/wgrad_minsteps.sh; SNGAN-32 / SNGAN-64 images/s): 12 -> 4994 / 2876, 24 -> 5053 / 2916, 40 -> 5061 / 2920,
+# everything batched 5074 / 2949: the long layers' batched launches are a little slower than their own, the slabs and launches
+# saved are worth more
+WGRAD_BATCH_MIN_STEPS = int(_os.environ.get("DIAGAN_WGRAD_BATCH_MIN_STEPS", str(1 << 30)))
 _WG_JOB = None
 
 

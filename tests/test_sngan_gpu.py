@@ -602,7 +602,7 @@ def test_stacked_forward_folds_the_upsampling_into_c1(dataset, nup, monkeypatch)
 
     names_f, calls_f, fakes_f, g_f, sd_f = run(True)
     names_t, calls_t, fakes_t, g_t, sd_t = run(False)
-    assert names_f.count("conv_wino4_kernel<2,3>") == nup and "conv_wino4_kernel<2,3>" not in names_t
+    assert names_f.count("conv_wino4_kernel<2,3,false>") == nup and "conv_wino4_kernel<2,3,false>" not in names_t
     # fused: the stacked forward up-samples nothing; only the update's backward makes its own batch-64 copies for c1's
     # weight gradient.  Two-launch form: one stacked up-sampling per block in the forward.
     assert all(s[0] == B for s in calls_f) and len(calls_f) == nup, calls_f
