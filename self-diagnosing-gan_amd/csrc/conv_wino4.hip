@@ -53,6 +53,9 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_DMA_IMM
 #define W4_DMA_IMM 1
 #endif
+#ifndef W4_PRO_LDS
+#define W4_PRO_LDS 1          // ... and, in those modes, the BatchNorm rows from LDS instead of two vector-memory loads per step
+#endif
 #ifndef W4_ULOAD
 #define W4_ULOAD 1            // MODE 0 / 3, fp32 build: weight units by ordinary loads into registers instead of LDS-DMA + ds_read
 #endif
@@ -418,17 +421,23 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   };
 #endif
   const W4Consts kc = w4_consts();
+  // ULOAD modes (below) leave the kernel's U region of LDS unused: the BatchNorm rows of this workgroup's group (scale | shift,
+  // 2 Ci floats) are parked there once and read back per K-step by two ds_reads instead of two vector-memory loads per step
+  constexpr bool PRO_LDS = W4_ULOAD && W4_PRO_LDS && !X3 && !MD::pooled && affine;
+  float* const pls = smem + 2 * W4_VSTAGE;
+  int x_kk = 0;                                          // the K-step whose input loads are in flight / being transformed
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   f32x2 rb[4], psc2 = {1.f, 1.f}, psh2 = {0.f, 0.f};    // upin: this lane's channel PAIR of the four pixels
 #pragma unroll
   for (int c = NI; c < 6; ++c) ra[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto issue_x = [&](int kk) __attribute__((always_inline)) {
     const int soff = __builtin_amdgcn_readfirstlane(kk * (W4K * 4));
+    x_kk = kk;
     if (UPIN) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(rb[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
-      if (affine) {
+      if (affine && !PRO_LDS) {
         asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(psc2) : "v"(poff), "s"(scsrc), "s"(soff) : "memory");
         asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(psh2) : "v"(poff), "s"(shsrc), "s"(soff) : "memory");
       }
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #pragma unroll
     for (int c = 0; c < NI; ++c)
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[c]) : "v"(off[c]), "s"(xsrc), "s"(soff) : "memory");
-    if (affine) {                     // BatchNorm scale / shift of this lane's channel quad, same mechanism
+    if (affine && !PRO_LDS) {         // BatchNorm scale / shift of this lane's channel quad, same mechanism
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(psc) : "v"(poff), "s"(scsrc), "s"(soff) : "memory");
       asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(psh) : "v"(poff), "s"(shsrc), "s"(soff) : "memory");
     }
@@ -464,6 +473,16 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #undef W4_WAIT_IN
   // prologue on the loaded pixels + row transform + park in the V planes of `stage`
   auto row_pass = [&](int stage) __attribute__((always_inline)) {
+    if (PRO_LDS) {
+      const float* pr = pls + x_kk * W4K + lq * 4 + (UPIN ? uc * 2 : 0);
+      if (UPIN) {
+        psc2 = *reinterpret_cast<const f32x2*>(pr);
+        psh2 = *reinterpret_cast<const f32x2*>(pr + g.Ci);
+      } else {
+        psc = *reinterpret_cast<const f32x4*>(pr);
+        psh = *reinterpret_cast<const f32x4*>(pr + g.Ci);
+      }
+    }
     if (UPIN) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -658,6 +677,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   };
 #undef W4_UL_CASE
 #undef W4_UL_LOAD
+  if (PRO_LDS) {
+    for (int c = tid * 4; c < 2 * g.Ci; c += 2048) {
+      const float* src = c < g.Ci ? a.pro_scale + pro_group_off + c : a.pro_shift + pro_group_off + (c - g.Ci);
+      *reinterpret_cast<f32x4*>(pls + c) = *reinterpret_cast<const f32x4*>(src);
+    }
+    __syncthreads();
+  }
   if (k_begin < k_end) {
     if (X3) {
 #pragma unroll
@@ -792,7 +818,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
     constexpr bool HN = decltype(has_next)::value;
     constexpr int R0 = (NS * decltype(phase)::value) % 3;     // ring place of this step's unit 0
     constexpr int ROW_AT = W4_ROW_AT, COL_AT = W4_COL_AT;
-    constexpr int NXL = NI + (affine ? 2 : 0);
+    constexpr int NXL = NI + (affine && !PRO_LDS ? 2 : 0);
     const int cur = (kk - k_begin) & 1;
     W4_TICK(9);
     const float* const fa_base = fa_lane + cur * W4_VSTAGE;
