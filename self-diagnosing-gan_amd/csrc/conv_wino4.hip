@@ -53,6 +53,10 @@ constexpr int W4_U = 72 * 256;          // U of one K-step: 72 units (frequency,
 #ifndef W4_DMA_IMM
 #define W4_DMA_IMM 1
 #endif
+#ifndef W4_ULOAD_POOLED
+#define W4_ULOAD_POOLED 0     // ... the pooled modes too (K loops of 3 m + 1 / 3 m + 2 steps: one instantiation per remainder).  Built and
+#endif                        // measured, NOT kept: <0,2> 1.25 -> 1.22 ms but <1,1> 1.37 -> 1.49 ms per SNGAN-64 step (the unrolled loop
+                              // reloads the transform constants from scratch: vector-memory operations the counted waits then drain)
 #ifndef W4_PRO_LDS
 #define W4_PRO_LDS 1          // ... and, in those modes, the BatchNorm rows from LDS instead of two vector-memory loads per step
 #endif
@@ -273,7 +277,8 @@ __device__ __forceinline__ void w4_up(const V* d, V* t, const W4Consts& k, float
 #define W4_ON(bit) true
 #endif
 
-template <int PRO, int MODE = 0, bool X3 = false>
+// LEFT (pooled modes only): 1 / 2 = the ULOAD build for K loops of 3 m + LEFT steps (see ULOAD below); 0 = the LDS-DMA build
+template <int PRO, int MODE = 0, bool X3 = false, int LEFT = 0>
 __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, const float* __restrict__ ug) {
   using MD = W4M<MODE>;
   constexpr int NS = MD::NS, NI = MD::NI;
@@ -423,7 +428,7 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   const W4Consts kc = w4_consts();
   // ULOAD modes (below) leave the kernel's U region of LDS unused: the BatchNorm rows of this workgroup's group (scale | shift,
   // 2 Ci floats) are parked there once and read back per K-step by two ds_reads instead of two vector-memory loads per step
-  constexpr bool PRO_LDS = W4_ULOAD && W4_PRO_LDS && !X3 && !MD::pooled && affine;
+  constexpr bool PRO_LDS = W4_ULOAD && W4_PRO_LDS && !X3 && (!MD::pooled || LEFT > 0) && affine;
   float* const pls = smem + 2 * W4_VSTAGE;
   int x_kk = 0;                                          // the K-step whose input loads are in flight / being transformed
   f32x4 ra[6], psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
@@ -653,10 +658,11 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
   // buys nothing but the long look-ahead.  Three register quads per wave form a ring: the unit of slot s + 3 is requested right
   // behind slot s's MFMAs (its register is free then) and waited for in front of slot s + 3's -- two to three slots (1 700-2 500
   // cycles) of flight.  72 KB of the 159 KB of LDS are then unused.  Timing probe before the build: profiles/r05_bf16x6_wino.md.
-  // (nine units per step: a unit's place in the ring of three is s mod 3.  The pooled modes' seven units per step would make it
-  //  (7 step + s) mod 3 and need a three-fold unrolled loop with a run-time tail: built -- kstep_ul takes the phase -- and not used,
-  //  the accumulators spill across the tail's paths (400+ registers); they keep the LDS-DMA path)
-  constexpr bool ULOAD = W4_ULOAD && !X3 && !MD::pooled;
+  // (nine units per step: a unit's place in the ring of three is s mod 3.  The pooled modes' seven units per step make it
+  //  (7 step + s) mod 3: the K loop is unrolled three-fold and its tail of LEFT = 1 / 2 steps is straight-line code of a kernel
+  //  instantiated for that remainder -- a run-time tail spilled the accumulators across its paths (400+ registers); K loops
+  //  of a multiple of three steps keep the LDS-DMA path, LEFT = 0)
+  constexpr bool ULOAD = W4_ULOAD && !X3 && (!MD::pooled || LEFT > 0);
   f32x4 ub[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   const unsigned ulane = lane * 16;
 #define W4_UL_LOAD(u, r) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(ub[r]) : "v"(ulane), "s"(ub4), "n"(((u) - 4) * 1024) : "memory")
@@ -1026,20 +1032,15 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       if (k_begin < k_end) kstep_ul(k_end - 1, std::false_type{}, P0{});
     } else {                                   // seven units per step: the ring's phase repeats every three steps
       int kk = k_begin;
-      for (; kk + 3 < k_end; kk += 3) {
+      for (; kk + 3 < k_end; kk += 3) {          // (k_end - k_begin = 3 m + LEFT: the launch picks the instantiation)
         kstep_ul(kk, std::true_type{}, P0{});
         kstep_ul(kk + 1, std::true_type{}, P1{});
         kstep_ul(kk + 2, std::true_type{}, P2{});
       }
-      const int left = k_end - kk;             // 1 .. 3 steps (0: an empty channel range)
-      if (left == 1) kstep_ul(kk, std::false_type{}, P0{});
-      else if (left == 2) {
+      if (LEFT == 1) kstep_ul(kk, std::false_type{}, P0{});
+      else {
         kstep_ul(kk, std::true_type{}, P0{});
         kstep_ul(kk + 1, std::false_type{}, P1{});
-      } else if (left == 3) {
-        kstep_ul(kk, std::true_type{}, P0{});
-        kstep_ul(kk + 1, std::true_type{}, P1{});
-        kstep_ul(kk + 2, std::false_type{}, P2{});
       }
     }
   } else {
@@ -1311,13 +1312,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
 #endif
 }
 
-template <int PRO, int MODE = 0, bool X3 = false>
+template <int PRO, int MODE = 0, bool X3 = false, int LEFT = 0>
 static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t st) {
   const int MT = a.g.B * (a.g.Ho >> 2) * (a.g.Wo >> 2);
   const int wgs = cdiv(MT, W4T) * cdiv(a.g.Co, W4N);
   // [2 V stages | U]; the epilogue's exchange image (36 or 25 frequencies x 32 tiles x 32 channels) fits inside
   const size_t lds = X3 ? (size_t)X3_LDS : (size_t)(2 * W4_VSTAGE + W4M<MODE>::U_FLOATS) * sizeof(float);
-  auto kern = conv_wino4_kernel<PRO, MODE, X3>;
+  auto kern = conv_wino4_kernel<PRO, MODE, X3, LEFT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1440,6 +1441,11 @@ int launch_wino4_pool(ConvGemmArgs a, float* ws, hipStream_t st) {
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
   const float* ug = wino4_weights<1>(a, ws, 0, 1.f, (long)cdiv(g.Co, W4N) * W4N * g.Ci * 28, st);
+#if W4_ULOAD && W4_ULOAD_POOLED
+  const int left = (g.Ci / W4K) % 3;          // (no channel split in the pooled modes: the K loop is Ci / 8 steps)
+  if (left == 1) return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1, false, 1>(a, ug, st) : launch_wino4_pro<PRO_NONE, 1, false, 1>(a, ug, st);
+  if (left == 2) return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1, false, 2>(a, ug, st) : launch_wino4_pro<PRO_NONE, 1, false, 2>(a, ug, st);
+#endif
   return a.pro_mode == PRO_RELU ? launch_wino4_pro<PRO_RELU, 1>(a, ug, st) : launch_wino4_pro<PRO_NONE, 1>(a, ug, st);
 }
 
@@ -1448,6 +1454,11 @@ int launch_wino4_unpool(ConvGemmArgs a, float* ws, hipStream_t st) {
   a.dWo = make_fastdiv((unsigned)(g.Wo >> 2));
   a.dHo = make_fastdiv((unsigned)(g.Ho >> 2));
   const float* ug = wino4_weights<1>(a, ws, 1, 1.f, (long)cdiv(g.Co, W4N) * W4N * g.Ci * 28, st);
+#if W4_ULOAD && W4_ULOAD_POOLED
+  const int left = (g.Ci / W4K) % 3;
+  if (left == 1) return launch_wino4_pro<PRO_NONE, 2, false, 1>(a, ug, st);
+  if (left == 2) return launch_wino4_pro<PRO_NONE, 2, false, 2>(a, ug, st);
+#endif
   return launch_wino4_pro<PRO_NONE, 2>(a, ug, st);
 }
 
