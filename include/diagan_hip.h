@@ -368,11 +368,13 @@ int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M, int C, co
 int diagan_bn_stats_fused_splits(int tiles, int C, int groups);
 
 /* Backward of [BatchNorm -> optional (Leaky)ReLU -> optional dropout]: dx (+ residual), dgamma/dbeta (+)=.
- * relu != 0: g' = g * drop * (y > 0 ? 1 : slope), y = scale*x+shift (slope 0 = ReLU).  coef: 2*C floats.
+ * relu != 0: g' = g * drop * drop_scale * (y > 0 ? 1 : slope), y = scale*x+shift (slope 0 = ReLU).  coef: 2*C floats.
+ * drop_scale (round 5): 1 / (1 - p) for a 0 / 1 keep-mask as torch's bernoulli_ writes it (no separate scaling pass over
+ * the mask), 1 for a mask that carries the scale.
  * batch_stats = 0: eval-mode BatchNorm (running statistics): dx = scale * g'. */
 int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, const float* scale, const float* shift,
                   const float* mean, const float* invstd, int batch_stats, int relu, float slope,
-                  const float* drop, float* dgamma, float* dbeta,
+                  const float* drop, float drop_scale, float* dgamma, float* dbeta,
                   int accumulate_param_grads, const float* residual, float* dx, float* coef,
                   void* workspace, void* stream);
 
@@ -408,12 +410,12 @@ int diagan_head_bwd(const float* dlogit, const float* w, const float* inv_sigma,
                     const float* x, const float* pooled, float* gx, float* G, double* dot, float* dbias,
                     int accumulate_bias, int B, int HW, int C, void* stream);
 
-/* DCGAN discriminator activations (diagan-pkg/diagan/models/mnist.py:163-190): out = act(x*scale+shift)*drop,
- * act(v) = v > 0 ? v : slope*v (LeakyReLU 0.2), drop = dropout mask scaled by 1/(1-p) or NULL; and the
+/* DCGAN discriminator activations (diagan-pkg/diagan/models/mnist.py:163-190): out = act(x*scale+shift)*drop*drop_scale,
+ * act(v) = v > 0 ? v : slope*v (LeakyReLU 0.2), drop = dropout keep-mask or NULL, drop_scale as for diagan_bn_bwd; and the
  * backward of the un-normalised first layer. */
-int diagan_act_fwd(const float* x, const float* scale, const float* shift, float slope, const float* drop,
+int diagan_act_fwd(const float* x, const float* scale, const float* shift, float slope, const float* drop, float drop_scale,
                    float* out, int64_t M, int C, void* stream);
-int diagan_act_bwd(const float* g, const float* x, float slope, const float* drop, float* out, int64_t n,
+int diagan_act_bwd(const float* g, const float* x, float slope, const float* drop, float drop_scale, float* out, int64_t n,
                    void* stream);
 /* nn.Linear(C, 1) (mnist.py:191 out_d): logit = x.w + bias; dw += dlogit^T x, dbias += sum dlogit;
  * input gradient gx[b][j] = dlogit[b]*w[j]. */

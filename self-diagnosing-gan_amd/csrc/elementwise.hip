@@ -72,7 +72,8 @@ struct ColRedArgs {
   int rows_per_split;
   int relu;            // MODE 1: g' = g * (y > 0 ? 1 : slope) with y = scale*x+shift (ReLU: slope 0)
   float slope;
-  const float* drop;   // MODE 1: optional dropout mask (already scaled by 1/(1-p)), multiplies g
+  const float* drop;   // MODE 1: optional dropout keep-mask, multiplies g together with drop_scale (1 / (1 - p) for a 0 / 1 mask;
+  float drop_scale;    //         1 for a mask that carries the scale itself)
 };
 
 template <int MODE>
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
         } else {
           f32x4 gv = gs[k];
           const f32x4 xh = (xv - mu) * is;
-          if (a.drop) gv *= ds[k];
+          if (a.drop) gv *= ds[k] * a.drop_scale;
           if (a.relu) {
             const f32x4 y = xv * sc + sh;
 #pragma unroll
@@ -348,7 +349,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ coef, const float* __restrict__ residual,
                                     float* __restrict__ out, long M, int C, int relu, float slope,
-                                    const float* __restrict__ drop) {
+                                    const float* __restrict__ drop, float drop_scale) {
   const int C4 = C >> 2;
   const long n4 = M * C4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -360,7 +361,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __
     const f32x4 is = reinterpret_cast<const f32x4*>(invstd)[c4];
     const f32x4 k1 = reinterpret_cast<const f32x4*>(coef)[c4];
     const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + C)[c4];
-    if (drop) gv *= reinterpret_cast<const f32x4*>(drop)[i];
+    if (drop) gv *= reinterpret_cast<const f32x4*>(drop)[i] * drop_scale;
     if (relu) {
       const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
       const f32x4 y = xv * sc + sh;
@@ -609,9 +610,9 @@ __global__ __launch_bounds__(EW_T) void head_wgrad_kernel(const float* __restric
   }
 }
 
-// a = act(x*scale[c]+shift[c]) * drop ; act: v > 0 ? v : slope*v   (slope 0 ReLU, 0.2 LeakyReLU, 1 identity)
+// a = act(x*scale[c]+shift[c]) * drop * drop_scale ; act: v > 0 ? v : slope*v   (slope 0 ReLU, 0.2 LeakyReLU, 1 identity)
 __global__ void act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                               const float* __restrict__ shift, float slope, const float* __restrict__ drop,
+                               const float* __restrict__ shift, float slope, const float* __restrict__ drop, float drop_scale,
                                float* __restrict__ out, long n4, int C4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
@@ -621,18 +622,18 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, const float* __restr
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-    if (drop) v *= reinterpret_cast<const f32x4*>(drop)[i];
+    if (drop) v *= reinterpret_cast<const f32x4*>(drop)[i] * drop_scale;
     reinterpret_cast<f32x4*>(out)[i] = v;
   }
 }
 
-// backward of act(x)*drop without BatchNorm: gx = g * drop * (x > 0 ? 1 : slope)
+// backward of act(x)*drop*drop_scale without BatchNorm: gx = g * drop * drop_scale * (x > 0 ? 1 : slope)
 __global__ void act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, float slope,
-                               const float* __restrict__ drop, float* __restrict__ out, long n4) {
+                               const float* __restrict__ drop, float drop_scale, float* __restrict__ out, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
     const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-    if (drop) gv *= reinterpret_cast<const f32x4*>(drop)[i];
+    if (drop) gv *= reinterpret_cast<const f32x4*>(drop)[i] * drop_scale;
 #pragma unroll
     for (int e = 0; e < 4; ++e) gv[e] = xv[e] > 0.f ? gv[e] : gv[e] * slope;
     reinterpret_cast<f32x4*>(out)[i] = gv;
@@ -735,7 +736,7 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
   if (training) {
     DG_REQUIRE(workspace, "bn_stats: workspace required in training mode");
     colred_geometry(M, C, &splits, &rps, &grid);
-    ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr};
+    ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr, 1.f};
     hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(EW_T), 0, ST, a);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits, C,
@@ -781,7 +782,7 @@ DIAGAN_API int diagan_bn_stats_fused(const float* partials, int tiles, int64_t M
 // dx = BN_backward(relu_backward(g)); dgamma/dbeta (+)=.  coef: 2*C floats scratch.
 DIAGAN_API int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, const float* scale, const float* shift,
                              const float* mean, const float* invstd, int batch_stats, int relu, float slope,
-                             const float* drop, float* dgamma, float* dbeta,
+                             const float* drop, float drop_scale, float* dgamma, float* dbeta,
                              int accumulate_param_grads, const float* residual, float* dx, float* coef,
                              void* workspace, void* stream) {
   DG_REQUIRE(g && x && scale && shift && mean && invstd && dgamma && dbeta && dx && coef && workspace,
@@ -790,12 +791,12 @@ DIAGAN_API int diagan_bn_bwd(const float* g, const float* x, int64_t M, int C, c
   int splits, rps;
   dim3 grid;
   colred_geometry(M, C, &splits, &rps, &grid);
-  ColRedArgs a{x, g, scale, shift, mean, invstd, (double*)workspace, (long)M, C, rps, relu, slope, drop};
+  ColRedArgs a{x, g, scale, shift, mean, invstd, (double*)workspace, (long)M, C, rps, relu, slope, drop, drop_scale};
   hipLaunchKernelGGL(colred_kernel<1>, grid, dim3(EW_T), 0, ST, a);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits,
                      C, (long)M, dgamma, dbeta, coef, accumulate_param_grads, batch_stats);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(M * (C / 4))), dim3(EW_T), 0, ST, g, x, scale, shift, mean,
-                     invstd, coef, residual, dx, (long)M, C, relu, slope, drop);
+                     invstd, coef, residual, dx, (long)M, C, relu, slope, drop, drop_scale);
   return check_launch("bn_bwd");
 }
 
@@ -805,7 +806,7 @@ DIAGAN_API int diagan_colsum(const float* x, int64_t M, int C, float* out, int a
   int splits, rps;
   dim3 grid;
   colred_geometry(M, C, &splits, &rps, &grid);
-  ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr};
+  ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr, 1.f};
   hipLaunchKernelGGL(colred_kernel<2>, grid, dim3(EW_T), 0, ST, a);
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST, (const double*)workspace, splits, C,
                      out, accumulate);
@@ -887,18 +888,18 @@ DIAGAN_API int diagan_head_bwd(const float* dlogit, const float* w, const float*
 }
 
 DIAGAN_API int diagan_act_fwd(const float* x, const float* scale, const float* shift, float slope, const float* drop,
-                              float* out, int64_t M, int C, void* stream) {
+                              float drop_scale, float* out, int64_t M, int C, void* stream) {
   DG_REQUIRE(x && out && M > 0 && C > 0 && (C & 3) == 0, "act_fwd: bad args");
   DG_REQUIRE(!scale == !shift, "act_fwd: scale and shift must be given together");
   const long n4 = M * (C / 4);
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, x, scale, shift, slope, drop, out, n4, C / 4);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n4)), dim3(EW_T), 0, ST, x, scale, shift, slope, drop, drop_scale, out, n4, C / 4);
   return check_launch("act_fwd");
 }
 
-DIAGAN_API int diagan_act_bwd(const float* g, const float* x, float slope, const float* drop, float* out, int64_t n,
-                              void* stream) {
+DIAGAN_API int diagan_act_bwd(const float* g, const float* x, float slope, const float* drop, float drop_scale, float* out,
+                              int64_t n, void* stream) {
   DG_REQUIRE(g && x && out && n > 0 && (n & 3) == 0, "act_bwd: bad args");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_T), 0, ST, g, x, slope, drop, out, (long)(n / 4));
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(EW_T), 0, ST, g, x, slope, drop, drop_scale, out, (long)(n / 4));
   return check_launch("act_bwd");
 }
 

@@ -311,9 +311,9 @@ class BatchNorm(nn.Module):
         return E.bn_stats_fused(partials, tiles, M, self.weight.data, self.bias.data, self.running_mean,
                                 self.running_var, self.eps, self.momentum, groups=groups, group_imgs=group_imgs)
 
-    def bwd(self, g, x, ctx, relu, residual=None, slope=0.0, drop=None):
+    def bwd(self, g, x, ctx, relu, residual=None, slope=0.0, drop=None, drop_scale=1.0):
         return E.bn_bwd(g, x, ctx, relu, self.weight.grad, self.bias.grad, True, residual=residual, slope=slope,
-                        drop=drop)
+                        drop=drop, drop_scale=drop_scale)
 
 
 class LatentLinear(nn.Module):

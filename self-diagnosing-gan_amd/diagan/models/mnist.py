@@ -157,12 +157,14 @@ class MNIST_DCGAN_Discriminator(BaseDiscriminator):
                 y, bn = conv.fwd_bn(k, h, self.conv[bi], training)      # statistics from the GEMM epilogue
             else:
                 y, bn = conv.fwd(k, h), None
-            drop = None
-            if training:      # Dropout(0.5): keep-mask scaled by 1/(1-p); RNG is torch's (device generator)
-                drop = drop_masks[i] if drop_masks is not None else \
-                    torch.empty(y.shape, dtype=torch.float32, device=y.device).bernoulli_(0.5).mul_(2.0)
-            a = E.act_fwd(y, 0.2, bn.scale if bn else None, bn.shift if bn else None, drop)
-            saved.append((h, k, y, bn, drop))
+            drop, dsc = None, 1.0
+            if training:      # Dropout(0.5): RNG is torch's (device generator).  An injected mask carries its 1 / (1 - p); the
+                if drop_masks is not None:      # own one is the 0 / 1 keep-mask as bernoulli_ writes it, scaled inside the
+                    drop = drop_masks[i]        # kernels that multiply by it (one launch per layer and pass less: round 5)
+                else:
+                    drop, dsc = torch.empty(y.shape, dtype=torch.float32, device=y.device).bernoulli_(0.5), 2.0
+            a = E.act_fwd(y, 0.2, bn.scale if bn else None, bn.shift if bn else None, drop, dsc)
+            saved.append((h, k, y, bn, (drop, dsc)))
             h = a
         B = h.shape[0]
         flat = h.view(B, -1)
@@ -191,12 +193,12 @@ class MNIST_DCGAN_Discriminator(BaseDiscriminator):
             E.linear1_wgrad(dlogit, flat, self.out_d.weight.grad, self.out_d.bias.grad)
         g = E.linear1_bwd_input(dlogit, w, B, flat.shape[1]).view(saved[-1][2].shape)
         for i in range(len(saved) - 1, -1, -1):
-            h_in, k, y, bn, drop = saved[i]
+            h_in, k, y, bn, (drop, dsc) = saved[i]
             ci, bi = self._idx[i]
             if bn is not None:
-                g_y = self.conv[bi].bwd(g, y, bn, relu=True, slope=0.2, drop=drop)
+                g_y = self.conv[bi].bwd(g, y, bn, relu=True, slope=0.2, drop=drop, drop_scale=dsc)
             else:
-                g_y = E.act_bwd(g, y, 0.2, drop)
+                g_y = E.act_bwd(g, y, 0.2, drop, dsc)
             if need_wgrad:
                 self.conv[ci].wgrad(k, g_y, h_in)
             if i > 0 or need_gx:

@@ -14,9 +14,9 @@ nat.register("diagan_colred_workspace", [I64, I])
 nat.register("diagan_bn_stats", [P, I64, I, P, P, F, F, P, P, I, P, P, P, P, P, P])
 nat.register("diagan_bn_stats_fused", [P, I, I64, I, P, P, F, F, P, P, P, P, P, P, I, P, I64, P])
 nat.register("diagan_bn_stats_fused_splits", [I, I, I])
-nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, I, F, P, P, P, I, P, P, P, P, P])
-nat.register("diagan_act_fwd", [P, P, P, F, P, P, I64, I, P])
-nat.register("diagan_act_bwd", [P, P, F, P, P, I64, P])
+nat.register("diagan_bn_bwd", [P, P, I64, I, P, P, P, P, I, I, F, P, F, P, P, I, P, P, P, P, P])
+nat.register("diagan_act_fwd", [P, P, P, F, P, F, P, I64, I, P])
+nat.register("diagan_act_bwd", [P, P, F, P, F, P, I64, P])
 nat.register("diagan_linear1_bwd_input", [P, P, P, I, I, P])
 nat.register("diagan_linear1_fwd", [P, P, P, P, I, I, P])
 nat.register("diagan_linear1_wgrad", [P, P, P, P, I, I, P])
@@ -149,12 +149,12 @@ def bn_stats_fused(partials, tiles, M, gamma, beta, running_mean, running_var, e
     return ctx
 
 
-def bn_bwd(g, x, ctx, relu, dgamma, dbeta, accumulate, residual=None, slope=0.0, drop=None):
+def bn_bwd(g, x, ctx, relu, dgamma, dbeta, accumulate, residual=None, slope=0.0, drop=None, drop_scale=1.0):
     dx = torch.empty_like(x)
     coef = _f32((2 * ctx.C,), x.device)
     ws = _colred_ws(x.device, ctx.M, ctx.C)
     nat.call("diagan_bn_bwd", ptr(g), ptr(x), ctx.M, ctx.C, ptr(ctx.scale), ptr(ctx.shift), ptr(ctx.mean),
-             ptr(ctx.invstd), 1 if ctx.training else 0, 1 if relu else 0, slope, ptr(drop), ptr(dgamma), ptr(dbeta), 1 if accumulate else 0,
+             ptr(ctx.invstd), 1 if ctx.training else 0, 1 if relu else 0, slope, ptr(drop), drop_scale, ptr(dgamma), ptr(dbeta), 1 if accumulate else 0,
              ptr(residual),
              ptr(dx), ptr(coef), ptr(ws), st())
     return dx
@@ -226,16 +226,17 @@ def head_bwd(dlogit, w, inv_sigma, x, pooled, need_gx=True, need_wgrad=True, dbi
     return gx, G, dot
 
 
-def act_fwd(x, slope, scale=None, shift=None, drop=None):
+def act_fwd(x, slope, scale=None, shift=None, drop=None, drop_scale=1.0):
+    """drop: keep-mask; drop_scale: 1 / (1 - p) for a 0 / 1 mask (torch's bernoulli_), 1 for a mask that carries its scale"""
     C = x.shape[-1]
     out = torch.empty_like(x)
-    nat.call("diagan_act_fwd", ptr(x), ptr(scale), ptr(shift), slope, ptr(drop), ptr(out), x.numel() // C, C, st())
+    nat.call("diagan_act_fwd", ptr(x), ptr(scale), ptr(shift), slope, ptr(drop), drop_scale, ptr(out), x.numel() // C, C, st())
     return out
 
 
-def act_bwd(g, x, slope, drop=None):
+def act_bwd(g, x, slope, drop=None, drop_scale=1.0):
     out = torch.empty_like(x)
-    nat.call("diagan_act_bwd", ptr(g), ptr(x), slope, ptr(drop), ptr(out), x.numel(), st())
+    nat.call("diagan_act_bwd", ptr(g), ptr(x), slope, ptr(drop), drop_scale, ptr(out), x.numel(), st())
     return out
 
 
