@@ -150,6 +150,15 @@ class MNIST_DCGAN_Discriminator(BaseDiscriminator):
     def forward_nhwc(self, x, training, save=True, need_dgrad=True, need_in_dgrad=True, slot=0, drop_masks=None):
         x = self._pack_nhwc(x)
         h, saved = x, []
+        # the keep-masks of ALL layers of this forward from ONE bernoulli_ launch over a flat buffer (round 5: eight launches
+        # before), cut in the layers' activation sizes
+        flat_mask, moff = None, 0
+        if training and drop_masks is None:
+            total, hw = 0, tuple(x.shape[1:3])
+            for ci, _ in self._idx:
+                hw = self.conv[ci].geom.out_hw(*hw)
+                total += x.shape[0] * hw[0] * hw[1] * self.conv[ci].geom.Co
+            flat_mask = torch.empty(total, dtype=torch.float32, device=x.device).bernoulli_(0.5)
         for i, (ci, bi) in enumerate(self._idx):
             conv = self.conv[ci]
             k = conv.prepare(training, need_dgrad and (i > 0 or need_in_dgrad))
@@ -162,7 +171,8 @@ class MNIST_DCGAN_Discriminator(BaseDiscriminator):
                 if drop_masks is not None:      # own one is the 0 / 1 keep-mask as bernoulli_ writes it, scaled inside the
                     drop = drop_masks[i]        # kernels that multiply by it (one launch per layer and pass less: round 5)
                 else:
-                    drop, dsc = torch.empty(y.shape, dtype=torch.float32, device=y.device).bernoulli_(0.5), 2.0
+                    drop, dsc = flat_mask[moff: moff + y.numel()].view(y.shape), 2.0
+                    moff += y.numel()
             a = E.act_fwd(y, 0.2, bn.scale if bn else None, bn.shift if bn else None, drop, dsc)
             saved.append((h, k, y, bn, (drop, dsc)))
             h = a
