@@ -22,6 +22,10 @@ enum ProMode : int {
   PRO_AFFINE_RELU = 2,   // a = max(x*scale[c] + shift[c], 0)   (BatchNorm apply + ReLU)
   PRO_LRELU = 3,         // a = x > 0 ? x : 0.2 x
   PRO_AFFINE = 4,        // a = x*scale[c] + shift[c]
+  // weight gradient only (conv_wgrad.hip): the gathered tensor is the (H+1) x (W+1) image of 0.25 * 2x2 box sums of x / of
+  // max(x, 0) (what diagan_boxsum2 writes), summed by the LOADER from the H x W tensor itself
+  PRO_BOX = 5,
+  PRO_BOX_RELU = 6,
 };
 
 struct ConvGeom {

@@ -38,6 +38,10 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
   constexpr int AC = BNn / 4, BC = BNk / 4;    // 16-byte chunks per pixel row
   constexpr int AJ = BK * AC / 256, BJ = BK * BC / 256;
   constexpr int APR = 256 / AC, BPR = 256 / BC;  // pixel rows covered per pass
+  // BOX (round 5): the gathered image is never materialised -- g.Hi x g.Wi is the (H+1) x (W+1) grid of 2x2 box sums and every
+  // gathered 16-byte piece is the sum of FOUR loads from the H x W tensor, in diagan_boxsum2's order (bit-identical operands)
+  constexpr bool BOX = PRO == PRO_BOX || PRO == PRO_BOX_RELU;
+  constexpr int BQ = BOX ? 4 : 1;
   __shared__ __attribute__((aligned(16))) float As[2][BK * BNn];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * BNk];
 
@@ -68,7 +72,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
   const int dyo = kr * g.dr + g.off, dxo = ks * g.dr + g.off;
   const int upm = g.up - 1, ush = g.up >> 1;
   const int pstep = (g.Ci * 4) >> ush;                      // bytes per numerator unit along x (see conv_gemm.hip)
-  const int img_bytes = g.Hi * g.Wi * g.Ci * 4;
+  const int img_bytes = BOX ? (g.Hi - 1) * (g.Wi - 1) * g.Ci * 4 : g.Hi * g.Wi * g.Ci * 4;
   const unsigned ylim = (unsigned)g.Hi << ush, xlim = (unsigned)g.Wi << ush;
 
   // branch-free raw buffer loads (out-of-range -> zeros); prologue applied at LDS-store time so the
@@ -76,7 +80,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
   const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.dy), 0, (int)((unsigned)a.M * g.Co * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u), 0x00020000);
+      const_cast<float*>(a.x), 0, (int)((unsigned)g.B * (BOX ? (g.Hi - 1) * (g.Wi - 1) : g.Hi * g.Wi) * g.Ci * 4u), 0x00020000);
   const bool affine = pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE;
   f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
   if (affine && b_ok) {
@@ -104,7 +108,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
 #pragma unroll
   for (int j = 0; j < AJ; ++j) aoff[j] = (((unsigned)(step0 * BK + ap + APR * j)) * g.Co + an) * 4u;
   const unsigned astep = (unsigned)BK * g.Co * 4u;
-  f32x4 ra[AJ], rb[BJ];
+  f32x4 ra[AJ], rb[BJ * BQ];
   unsigned bmask = 0;
   // bias gradient = column sums of dy, taken by the k0 == 0 tile column from the staging REGISTERS of the dy
   // loader (every thread adds its own 16-byte pieces; one LDS reduction over the APR pixel-row groups at the end).
@@ -121,7 +125,7 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
     }
     const int j = p - AJ;
     if (j == 0) bmask = 0;
-    if (P2 && a.same) {
+    if (!BOX && P2 && a.same) {
       // same-size stride-1 conv on a power-of-two image: the gathered offset is LINEAR in the pixel index
       // (m*Ci*4 + a per-thread tap constant); only the border test needs (oy, ox), from shifts and masks
       const int m = mstep + bp + BPR * j;
@@ -144,11 +148,23 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
       pbj = pb[j]; pyj = py[j]; pxj = px[j];
     }
     const int yn = pyj * g.sy + dyo, xn = pxj * g.sy + dxo;
+    if constexpr (BOX) {
+      const int H = g.Hi - 1, W = g.Wi - 1;
+      const bool okp = b_ok && pbj < g.B;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {     // the window whose lower-right corner is (yn, xn): rows first, as boxsum2_kernel adds them
+        const int y = yn - 1 + (q >> 1), x = xn - 1 + (q & 1);
+        const bool ok = okp && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const unsigned off = (unsigned)(pbj * img_bytes + (y * W + x) * pstep + kc * 4) | (ok ? 0u : 0x80000000u);
+        rb[j * 4 + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
+      }
+    } else {
     const bool ok = b_ok && pbj < g.B && (unsigned)yn < ylim && (unsigned)xn < xlim && ((yn | xn) & upm) == 0;
     const unsigned okb = ok ? 1u : 0u;
     const unsigned off = (unsigned)(pbj * img_bytes + (yn * g.Wi + xn) * pstep + kc * 4) | ((okb ^ 1u) << 31);
     rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 0, 0));
     bmask |= okb << j;
+    }
     if (!P2) {      // advance to the same row of the next K-step
       int x = px[j] + a.adv_x, y = py[j] + a.adv_y, b = pb[j] + a.adv_b;
       const int cx = x >= g.Wo ? 1 : 0;
@@ -172,8 +188,20 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bi
       if (bias_tile) bacc += ra[p];
     } else {
       const int j = p - AJ;
-      f32x4 v = rb[j];
-      if (pro_mode != PRO_NONE) {
+      f32x4 v = rb[j * BQ];
+      if constexpr (BOX) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 t = rb[j * 4 + q];
+          if (PRO == PRO_BOX_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+          }
+          sum += t;
+        }
+        v = sum * 0.25f;
+      } else if (pro_mode != PRO_NONE) {
         if (affine) v = v * psc + psh;
         if (pro_mode == PRO_LRELU) {
 #pragma unroll
@@ -622,7 +650,9 @@ static int wgrad_fill_args(WgradArgs& a, const float* dy, const float* x, float*
   DG_REQUIRE(dr == 1 || dr == -1, "conv_wgrad: dr must be +-1");
   DG_REQUIRE(Kp % 32 == 0 && Kp >= R * S * Ci, "conv_wgrad: bad Kp=%d", Kp);
   DG_REQUIRE(splits >= 1, "conv_wgrad: splits=%d", splits);
-  DG_REQUIRE(pro_mode >= 0 && pro_mode <= 4, "conv_wgrad: bad pro_mode %d", pro_mode);
+  DG_REQUIRE(pro_mode >= 0 && pro_mode <= PRO_BOX_RELU, "conv_wgrad: bad pro_mode %d", pro_mode);
+  DG_REQUIRE(!(pro_mode == PRO_BOX || pro_mode == PRO_BOX_RELU) || (up == 1 && dr == 1 && Hi >= 2 && Wi >= 2),
+             "conv_wgrad: the box-sum loader (pro_mode 5 / 6) gathers forward geometries without up-sampling");
   DG_REQUIRE(!(pro_mode == PRO_AFFINE_RELU || pro_mode == PRO_AFFINE) || (pro_scale && pro_shift),
              "conv_wgrad: affine prologue needs scale/shift");
   DG_REQUIRE(slab_stride >= (int64_t)Co * Kp && (bias_off < 0 || bias_off + Co <= slab_stride),
@@ -672,8 +702,11 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
       case PRO_RELU: DG_WG(BN_, PRO_RELU); break; \
       case PRO_AFFINE_RELU: DG_WG(BN_, PRO_AFFINE_RELU); break; \
       case PRO_LRELU: DG_WG(BN_, PRO_LRELU); break; \
+      case PRO_BOX: DG_WG(BN_, PRO_BOX); break; \
+      case PRO_BOX_RELU: DG_WG(BN_, PRO_BOX_RELU); break; \
       default: DG_WG(BN_, PRO_AFFINE); break; }
   if (bn == 64 && bk == 64) {
+    DG_REQUIRE(pro_mode <= PRO_AFFINE, "conv_wgrad: no box-sum loader on the 64 x 64 tile (Kp <= 64)");
     hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
   } else if (bn == 64) {
     DG_WG_ALL(64)
@@ -699,15 +732,15 @@ static_assert(sizeof(diagan_wgrad_job) == 128, "diagan_wgrad_job layout");
 // Which launches may share a batched launch: equal class = the same kernel template.  0: this layer launches on its own.
 //   100 + pro                         the Winograd F(3x3,2x2) weight gradient (conv_wgrad_wino.hip)
 //   1000                              implicit GEMM, 64 x 64 tile (prologue mode at run time)
-//   2000 + 100 (bn == 128) + 2 pro + p2   implicit GEMM, bn x 128 tile, prologue none / ReLU (the modes the networks' 1x1, strided
-//                                     and pooled layers use; the other modes are not instantiated for batches)
+//   2000 + 100 (bn == 128) + 2 pro + p2   implicit GEMM, bn x 128 tile, prologue none / ReLU / box sums (the modes the networks'
+//                                     1x1, strided and pooled layers use; the other modes are not instantiated for batches)
 DIAGAN_API int diagan_conv_wgrad_batch_class(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
                                              int up, int Kp, int pro_mode) {
   if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp)) return 100 + pro_mode;
   int bn, bk;
   wgrad_tile(Co, Kp, &bn, &bk);
   if (bn == 64 && bk == 64) return 1000;
-  if (pro_mode != PRO_NONE && pro_mode != PRO_RELU) return 0;
+  if (pro_mode != PRO_NONE && pro_mode != PRO_RELU && pro_mode != PRO_BOX && pro_mode != PRO_BOX_RELU) return 0;
   const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
   return 2000 + (bn == 128 ? 100 : 0) + 2 * pro_mode + (p2 ? 1 : 0);
 }
@@ -748,15 +781,24 @@ DIAGAN_API int diagan_conv_wgrad_batched(const diagan_wgrad_job* jobs, int n, vo
   }
   for (int j = n; j < WG_BATCH_MAX; ++j) b.blk0[j] = wgs, b.cnt[j] = 0;
   const int pro = jobs[0].pro_mode;
-  if (cls == 1000) launch_wgrad_gemm_batched<64, 64, -1, false>(b, wgs, st);
-  else if (bn == 128 && pro == PRO_NONE && p2) launch_wgrad_gemm_batched<128, 128, PRO_NONE, true>(b, wgs, st);
-  else if (bn == 128 && pro == PRO_NONE) launch_wgrad_gemm_batched<128, 128, PRO_NONE, false>(b, wgs, st);
-  else if (bn == 128 && p2) launch_wgrad_gemm_batched<128, 128, PRO_RELU, true>(b, wgs, st);
-  else if (bn == 128) launch_wgrad_gemm_batched<128, 128, PRO_RELU, false>(b, wgs, st);
-  else if (pro == PRO_NONE && p2) launch_wgrad_gemm_batched<64, 128, PRO_NONE, true>(b, wgs, st);
-  else if (pro == PRO_NONE) launch_wgrad_gemm_batched<64, 128, PRO_NONE, false>(b, wgs, st);
-  else if (p2) launch_wgrad_gemm_batched<64, 128, PRO_RELU, true>(b, wgs, st);
-  else launch_wgrad_gemm_batched<64, 128, PRO_RELU, false>(b, wgs, st);
+  if (cls == 1000) {
+    launch_wgrad_gemm_batched<64, 64, -1, false>(b, wgs, st);
+    return check_launch("conv_wgrad_batched");
+  }
+#define DG_WGB(BN_, PRO_) do { if (p2) launch_wgrad_gemm_batched<BN_, 128, PRO_, true>(b, wgs, st); \
+                               else launch_wgrad_gemm_batched<BN_, 128, PRO_, false>(b, wgs, st); } while (0)
+#define DG_WGB_ALL(BN_) switch (pro) { \
+      case PRO_NONE: DG_WGB(BN_, PRO_NONE); break; \
+      case PRO_RELU: DG_WGB(BN_, PRO_RELU); break; \
+      case PRO_BOX: DG_WGB(BN_, PRO_BOX); break; \
+      default: DG_WGB(BN_, PRO_BOX_RELU); break; }
+  if (bn == 128) {
+    DG_WGB_ALL(128)
+  } else {
+    DG_WGB_ALL(64)
+  }
+#undef DG_WGB_ALL
+#undef DG_WGB
   return check_launch("conv_wgrad_batched");
 }
 DIAGAN_API int diagan_conv_wgrad_batch_max(void) { return WG_BATCH_MAX; }

@@ -15,6 +15,9 @@ import torch.nn as nn
 from diagan.ops import conv as C
 from diagan.ops import eltwise as E
 
+# the pooled layers' weight gradient sums its 2x2 boxes in the loader (DIAGAN_WGRAD_BOX=0: a boxsum2 pass in front, as before)
+WGRAD_BOX = os.environ.get("DIAGAN_WGRAD_BOX", "1") != "0"
+
 
 def _r4(n):
     return (n + 3) // 4 * 4
@@ -254,7 +257,10 @@ class ConvLayer(nn.Module):
         if getattr(self, '_geom_s2', None) is None:
             g = self.geom
             object.__setattr__(self, '_geom_s2', C.Geom('conv', g.Ci, g.Co, 3, 3, 2, 0))
-        self.wgrad(ctx, dy_pooled, E.boxsum2(x, relu_in=relu_in), pro=None, slot=slot, geom=self._geom_s2)
+        if WGRAD_BOX:      # the box sums are taken by the weight gradient's loader (round 5; same operands bit for bit)
+            self.wgrad(ctx, dy_pooled, x, pro=(C.PRO_BOX_RELU if relu_in else C.PRO_BOX, None, None), slot=slot, geom=self._geom_s2)
+        else:
+            self.wgrad(ctx, dy_pooled, E.boxsum2(x, relu_in=relu_in), pro=None, slot=slot, geom=self._geom_s2)
 
     def wgrad(self, ctx, dy, x, pro=None, slot=0, geom=None):
         """Accumulates into weight.grad / bias.grad (views of the net's flat gradient buffer).
@@ -643,13 +649,14 @@ class WgradBatch:
             self.pending.remove(slot)
             self.flush(slot)
             self._finish_layers(slot, self.launched.pop(slot, []))
-        e = self._entry(layer, slot, M, segments, tuple(dy.shape), tuple(x.shape), geom)
+        xs = C.wg_x_shape(x, pro)
+        e = self._entry(layer, slot, M, segments, tuple(dy.shape), xs, geom)
         e['sn_ctx'] = sn_ctx
         self.launched.setdefault(slot, []).append(layer)
         if C.WGRAD_BATCH and dy.dim() == 4 and x.dim() == 4:
             g = geom if geom is not None else layer.geom
             cls = 0 if (segments == 1 and C.small_co_wgrad(g)) else C.wgrad_batch_class(
-                g, x.shape[1], x.shape[2], dy.shape[1], dy.shape[2], int(pro[0]) if pro is not None else 0)
+                g, xs[1], xs[2], dy.shape[1], dy.shape[2], int(pro[0]) if pro is not None else 0)
             if cls:
                 self.queue.setdefault(slot, []).append((layer, dy, x, pro, segments, e, g, (cls, geom is not None)))
                 return

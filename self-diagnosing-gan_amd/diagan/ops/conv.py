@@ -53,6 +53,9 @@ nat.register("diagan_pack_weights", [P, P, P, P, I, I, I, I, I, P])
 nat.register("diagan_sn_grad_fix", [P, P, I, P, P, P, P, I, I, I, P])
 
 PRO_NONE, PRO_RELU, PRO_AFFINE_RELU, PRO_LRELU, PRO_AFFINE = 0, 1, 2, 3, 4
+# weight gradients only: the gathered image is the (H+1) x (W+1) grid of 0.25 * 2x2 box sums of x / relu(x) (eltwise.boxsum2), summed by
+# the kernel's loader from the H x W tensor it is handed (csrc/conv_common.h)
+PRO_BOX, PRO_BOX_RELU = 5, 6
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO; PRO = -1: run-time mode)
 # kernel names as rocprofv3 prints them (template arguments: BM, BN, WM, WN, BK, PRO, STAMP, FP; PRO = -1: run-time mode)
 TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3: (64, 64, 2, 2, 32, False),
@@ -266,6 +269,14 @@ def _pro3(pro):
     if len(pro) > 3 and pro[3]:
         raise RuntimeError("grouped BatchNorm prologues exist for the forward kernels only")
     return tuple(pro)[:3]
+
+
+def wg_x_shape(x, pro):
+    """shape of the tensor a weight gradient GATHERS from: x's own, or the box-sum grid over x for the PRO_BOX modes"""
+    B, H, W, Ci = x.shape
+    if pro is not None and int(pro[0]) >= PRO_BOX:
+        return B, H + 1, W + 1, Ci
+    return B, H, W, Ci
 
 
 def _chk(t, name):
@@ -482,7 +493,7 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
 
     sn = (W_master, u, v, state): backward through W/sigma (diagan_sn_grad_fix)."""
     B, Ho, Wo, Co = dy.shape
-    _, Hi, Wi, Ci = x.shape
+    _, Hi, Wi, Ci = wg_x_shape(x, pro)
     mode, scale, shift = _pro3(pro)
     for t, n in ((dy, 'dy'), (x, 'x'), (grad, 'grad'), (scale, 'pro_scale'), (shift, 'pro_shift')):
         _chk(t, n)
@@ -550,7 +561,7 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
     pooled: this launch is ConvLayer.wgrad_pooled's strided form of a stride-1 layer's weight gradient (the kernel timer
     then books the reference convolution's FLOP, 4x what the launch executes, under a marked kernel name)."""
     B, Ho, Wo, Co = dy.shape
-    _, Hi, Wi, Ci = x.shape
+    _, Hi, Wi, Ci = wg_x_shape(x, pro)
     mode, scale, shift = _pro3(pro)
     sy, dr, off, up = geom.fwd_params()
     if segments == 1 and small_co_wgrad(geom):
@@ -635,7 +646,7 @@ def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0):
         flop, px, mode0 = 0.0, 0, None
         for j, (geom, dy, x, slab, splits, stride, bias_off, pro, segments) in enumerate(jobs):
             B, Ho, Wo, Co = dy.shape
-            _, Hi, Wi, Ci = x.shape
+            _, Hi, Wi, Ci = wg_x_shape(x, pro)
             mode = _pro3(pro)[0]
             mode0 = mode if mode0 is None else mode0
             sy, dr, off, up = geom.fwd_params()

@@ -705,3 +705,28 @@ def test_batched_weight_gradient_launches_equal_the_per_layer_ones(dataset):
     for k, v in out[False][2].items():
         if not is_dead_bias(k):
             l2close(out[True][2][k], v, 2e-3, f"G grad {k}", floor=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dataset", ["cifar10", "celeba"])
+def test_box_sums_in_the_weight_gradients_loader_change_no_bit(dataset):
+    """Round 5: the weight gradient of a convolution + average pool layer gathers from the 2x2 box sums of its input; the sums are
+    now taken by the kernel's loader (prologue modes 5 / 6 of diagan_conv_wgrad) instead of a diagan_boxsum2 pass in front.  Same
+    operands in the same order: a D update with the switch on and off gives the same gradients bit for bit."""
+    from diagan.models import layers as L
+    res = 32 if dataset == "cifar10" else 64
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(64, 3, res, res, generator=g) * 2 - 1
+    zd = torch.randn(64, 128, generator=g)
+    out = {}
+    try:
+        for on in (True, False):
+            L.WGRAD_BOX = on
+            (_, _, _, _), (netG, netD, optG, optD) = build(dataset, "ns")
+            log = netD.train_step(real_batch=(x.cuda(), None), netG=netG, optD=optD, log_data=Log(), device='cuda', noise=zd.cuda())
+            out[on] = (netD.export_grads(), log.m['errD'].item())
+    finally:
+        L.WGRAD_BOX = True
+    assert out[True][1] == out[False][1]
+    for k, v in out[False][0].items():
+        assert torch.equal(out[True][0][k], v), k

@@ -281,6 +281,14 @@ def test_weight_gradient_through_the_average_pool_as_a_strided_convolution(case)
     close(ga, ref, tol=2e-5)
     C.conv_wgrad(geom, E.avgpool2_bwd(nhwc(gp).cuda()), nhwc(x).cuda(), gb, accumulate=False, pro=(C.PRO_RELU, None, None))
     close(ga, gb, tol=1e-5)
+    # round 5: the box sums taken by the loader itself (prologue modes 5 / 6 of diagan_conv_wgrad: four loads from x per gathered
+    # piece, added in diagan_boxsum2's order) -- the same operands, so the same gradient bit for bit
+    gc = torch.zeros(Co, geom.Kp, device="cuda")
+    C.conv_wgrad(g2, nhwc(gp).cuda(), nhwc(x).cuda(), gc, accumulate=False, pro=(C.PRO_BOX_RELU, None, None))
+    assert torch.equal(gc, ga)
+    C.conv_wgrad(g2, nhwc(gp).cuda(), E.boxsum2(nhwc(x).cuda(), relu_in=False), ga, accumulate=False)
+    C.conv_wgrad(g2, nhwc(gp).cuda(), nhwc(x).cuda(), gc, accumulate=False, pro=(C.PRO_BOX, None, None))
+    assert torch.equal(gc, ga)
 
 
 @pytest.mark.parametrize("case", [(128, 32, 32, 128, 128), (64, 64, 64, 64, 64), (128, 16, 16, 128, 256)])
@@ -320,3 +328,6 @@ def test_pooled_launches_at_the_discriminators_full_sizes(case):
     C.conv_wgrad(C.Geom("conv", Ci, Co, 3, 3, 2, 0), gp, E.boxsum2(x, relu_in=True), ga, accumulate=False)
     C.conv_wgrad(geom, E.avgpool2_bwd(gp), x, gb, accumulate=False, pro=relu)
     close(ga, gb, tol=2e-5)
+    gc = torch.zeros(Co, geom.Kp, device="cuda")
+    C.conv_wgrad(C.Geom("conv", Ci, Co, 3, 3, 2, 0), gp, x, gc, accumulate=False, pro=(C.PRO_BOX_RELU, None, None))
+    assert torch.equal(gc, ga)               # the loader's box sums: bit-identical to the boxsum2 pass + gather
