@@ -108,6 +108,16 @@ int diagan_conv3x3_co4(const float* x, const float* w, float* y, const float* bi
                        int dr, int off, int Kp, int group_imgs, void* stream);
 /* group_imgs > 0: image b reads the affine prologue of group b / group_imgs (see diagan_conv_gemm pro_group_rows). */
 
+/* 3x3 / stride 1 / pad 1 convolution FROM four input channels (RGB + pad) to 64 or 128 channels: the first layer of the
+ * discriminators (mimicry SNGANDiscriminator32 / 64 block1.c1; replaces that layer's cuDNN forward).  K = 36 leaves the
+ * implicit GEMM's tile with nothing to overlap its LDS round trip and epilogue with; here a wave keeps the weights in registers,
+ * streams 32 pixels at a time and writes 16-byte channel quads (no LDS, no barrier): bound by the output stream.
+ * y = conv(x) * scale + bias, scale = *scale0 for pixel rows < scale_split and *scale1 behind it (both null: out_scale), as
+ * diagan_conv_gemm.  DIAGAN_CONV_CI4=0 makes _supported answer 0 (A/B runs against the implicit GEMM). */
+int diagan_conv3x3_ci4_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up);
+int diagan_conv3x3_ci4(const float* x, const float* w, float* y, const float* bias, float out_scale, const float* scale0,
+                       const float* scale1, int scale_split, int B, int H, int W, int Co, int Kp, void* stream);
+
 /* Weight (+ bias) gradient of the same layer, Ci in {64,128,256}, Kp == 9*Ci: the whole [4][Kp] gradient lives in
  * each wave's accumulators; writes diagan_conv3x3_co4_wgrad_splits(B, H) partial slabs
  * slab[split][slab_stride] in the packed-weight layout (bias column sums at bias_off if >= 0), to be summed by

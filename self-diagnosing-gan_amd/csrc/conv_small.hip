@@ -18,6 +18,7 @@
 // Same gather formula / prologue / epilogue semantics as conv_gemm_kernel.  Roofline: LDS bandwidth for the
 // forward (one 16-byte A read per lane per 4 instructions), HBM / L2 for the weight gradient.
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace diagan {
 
@@ -312,6 +313,115 @@ __global__ __launch_bounds__(256) void conv3x3_co4_wgrad_kernel(const SmallCoWgr
   }
 }
 
+
+// ---- 3x3 convolution FROM four input channels (RGB + pad), stride 1, pad 1: the discriminators' first layer (round 5) ----------
+// K = 36: on the implicit GEMM's tiles the launch is one LDS round trip and one epilogue per 64 x 64 outputs with nothing to
+// overlap them -- 35 / 62 us for 67 / 134 MB of output (a plain fill of that size: 11 / 20 us; tools/probe/ci4_rate.py).
+// Here a workgroup takes 128 consecutive pixels x ALL output channels: the packed weights go through LDS once (coalesced), a wave
+// loads the nine taps of its 32 pixels once and then walks the 32-channel tiles -- 18 MFMAs, turn the tile through LDS, four
+// 1 KB stores, next tile -- without ever waiting for a store: ~16 KB per wave in flight, which is what the write stream needs
+// (one small wave per tile, retired when its 4 KB are acknowledged: 2.8 TB/s; fat persistent waves with the weights in registers:
+// bound by their own serial chain, 24 / 35 us).  The product is taken TRANSPOSED (D[channel][pixel] = W . X) so that an
+// accumulator quad is four consecutive channels of one pixel; the LDS turn makes a store instruction eight whole 128-byte lines
+// (16 bytes per lane strided by a pixel row reached a third of the store rate).  k = tap * 4 + c as in the packed weights; the
+// sums run k = 0, 1, .. 35 as the implicit GEMM's do.  Roofline: the output stream (HBM).
+struct FirstConvArgs {
+  const float* x;          // [B,H,W,4]
+  const float* w;          // packed [Co][Kp], Kp >= 36
+  float* y;                // [B,H,W,Co]
+  const float* bias;       // [Co] or null
+  const float* scale0;     // as ConvGemmArgs: rows < scale_split use *scale0, the others *scale1; null: out_scale
+  const float* scale1;
+  float out_scale;
+  int scale_split;
+  int M, H, W, Co, Kp, tiles;       // tiles = Co / 32
+  FastDiv dW, dH;
+};
+
+constexpr int FC_RS = 36;                  // floats per pixel row of a wave's exchange tile (32 channels + 16 bytes: conflict-free)
+
+__global__ __launch_bounds__(256) void conv3x3_ci4_kernel(const FirstConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];        // [Co][36] weights | [Co] bias | [4 waves][32][FC_RS]
+  float* const ws = lds;
+  float* const bs = lds + a.Co * 36;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+  float* const xt = bs + a.Co + wave * (32 * FC_RS);
+  // B operand first (the longest latency): the nine taps of pixel m (zeros outside the image and past M: out-of-range bit of
+  // the buffer offset); a lane multiplies channels (h, 2 + h) of each tap
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)((unsigned)a.M * 16u), 0x00020000);
+  const int g = blockIdx.x * 4 + wave, m = g * 32 + j;
+  float xv[18];
+  {
+    const unsigned q1 = fdiv((unsigned)m, a.dW);
+    const int ox = m - (int)q1 * a.W;
+    const unsigned b = fdiv(q1, a.dH);
+    const int oy = (int)q1 - (int)b * a.H;
+    const bool mv = m < a.M;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int yy = oy + r - 1, xx = ox + q - 1;
+        const bool ok = mv && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+        const unsigned off = (unsigned)((m + (r - 1) * a.W + (q - 1)) * 16 + 4 * h) | (ok ? 0u : 0x80000000u);
+        xv[2 * (r * 3 + q)] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, off, 0, 0));
+        xv[2 * (r * 3 + q) + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xsrc, off, 8, 0));
+      }
+  }
+  for (int i = tid; i < a.Co * 9; i += 256) {          // weight rows of 9 x 16 bytes: coalesced, once per workgroup
+    const int n = i / 9, q = i - 9 * n;
+    *reinterpret_cast<f32x4*>(ws + n * 36 + 4 * q) = *reinterpret_cast<const f32x4*>(a.w + (long)n * a.Kp + 4 * q);
+  }
+  for (int i = tid; i < a.Co; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;
+  __syncthreads();
+  const float sc0 = a.scale0 ? a.scale0[0] : a.out_scale, sc1 = a.scale1 ? a.scale1[0] : a.out_scale;
+  const __amdgpu_buffer_rsrc_t ysrc =
+      __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((unsigned)a.M * (unsigned)a.Co * 4u), 0x00020000);
+  const int prl = lane >> 3, ccl = lane & 7;           // read-back: this lane's row (of 8 per store) and channel quad
+  float scv[4];
+  unsigned yoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mm = g * 32 + i * 8 + prl;
+    scv[i] = mm < a.scale_split ? sc0 : sc1;
+    yoff[i] = (unsigned)mm * (unsigned)(a.Co * 4) + (unsigned)(ccl * 16);
+  }
+  for (int t = 0; t < a.tiles; ++t) {
+    // A operand: W[n = 32 t + j][k = 2 i + h], i = 0 .. 17 (row stride 36 words: conflict-free)
+    const float* wr = ws + (32 * t + j) * 36 + h;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[4 * q], xv[2 * q], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[4 * q + 2], xv[2 * q + 1], acc, 0, 0, 0);
+    }
+    // this lane holds pixel j, channels 8 q + 4 h + (0 .. 3) of the tile in accumulator elements 4 q .. 4 q + 3: parked in the
+    // wave's exchange tile [pixel][channel], read back by rows (8 lanes = one pixel's 128 bytes), scaled and biased there
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = acc[4 * q + e];
+      *reinterpret_cast<f32x4*>(xt + j * FC_RS + 8 * q + 4 * h) = y;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (one wave: its LDS instructions execute in order)
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(bs + 32 * t + 4 * ccl);
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(xt + (i * 8 + prl) * FC_RS + 4 * ccl);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 y = v[i] * scv[i] + bq;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y), ysrc, yoff[i],
+                                             t * 128, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the tile is read before the next one is parked
+  }
+}
+
 }  // namespace diagan
 
 using namespace diagan;
@@ -337,6 +447,34 @@ DIAGAN_API int diagan_conv3x3_co4(const float* x, const float* w, float* y, cons
   const long blocks = (long)B * a.tiles_x * a.tiles_y;
   hipLaunchKernelGGL(conv3x3_co4_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("conv3x3_co4");
+}
+
+
+// 1 if diagan_conv3x3_ci4 takes this layer: forward 3x3 / stride 1 / pad 1 from 4 input channels, Co a multiple of 32
+DIAGAN_API int diagan_conv3x3_ci4_supported(int Ci, int Co, int R, int S, int sy, int dr, int off, int up) {
+  static const int env = getenv("DIAGAN_CONV_CI4") ? atoi(getenv("DIAGAN_CONV_CI4")) : 1;
+  return env && R == 3 && S == 3 && sy == 1 && up == 1 && dr == 1 && off == -1 && Ci == 4 && Co >= 32 && Co <= 256 && (Co % 32) == 0;
+}
+
+// y = conv3x3(x) * scale + bias for such a layer (no prologue, residual, mask or statistics: the discriminators' first
+// convolution); scale = *scale0 for pixel rows < scale_split, *scale1 behind it (both null: out_scale), as diagan_conv_gemm
+DIAGAN_API int diagan_conv3x3_ci4(const float* x, const float* w, float* y, const float* bias, float out_scale, const float* scale0,
+                                  const float* scale1, int scale_split, int B, int H, int W, int Co, int Kp, void* stream) {
+  DG_REQUIRE(x && w && y, "conv3x3_ci4: null tensor");
+  DG_REQUIRE(B > 0 && H > 0 && W > 0 && Kp >= 36 && (Kp & 3) == 0, "conv3x3_ci4: bad dims");
+  DG_REQUIRE(diagan_conv3x3_ci4_supported(4, Co, 3, 3, 1, 1, -1, 1), "conv3x3_ci4: Co=%d unsupported (a multiple of 32)", Co);
+  DG_REQUIRE((scale0 == nullptr) == (scale1 == nullptr), "conv3x3_ci4: scale0 and scale1 come together");
+  DG_REQUIRE((long)B * H * W * Co * 4 < (1L << 31), "conv3x3_ci4: tensors must be smaller than 2 GiB");
+  FirstConvArgs a;
+  a.x = x; a.w = w; a.y = y; a.bias = bias; a.scale0 = scale0; a.scale1 = scale1; a.out_scale = out_scale;
+  a.scale_split = scale0 ? scale_split : 0x7fffffff;
+  a.M = B * H * W; a.H = H; a.W = W; a.Co = Co; a.Kp = Kp; a.tiles = Co / 32;
+  a.dW = make_fastdiv((unsigned)W);
+  a.dH = make_fastdiv((unsigned)H);
+  const size_t lds = (size_t)(Co * 36 + Co + 4 * 32 * FC_RS) * sizeof(float);        // 37 KB at 128 channels
+  DG_REQUIRE(lds <= 64 * 1024, "conv3x3_ci4: Co=%d needs %zu bytes of LDS", Co, lds);
+  hipLaunchKernelGGL(conv3x3_ci4_kernel, dim3(cdiv(cdiv(a.M, 32), 4)), dim3(256), lds, (hipStream_t)stream, a);
+  return check_launch("conv3x3_ci4");
 }
 
 // 1 if diagan_conv3x3_co4_wgrad supports the layer (3x3, stride 1, pad 1, 4 output channels)

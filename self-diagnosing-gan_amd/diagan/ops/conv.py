@@ -38,6 +38,8 @@ nat.register("diagan_conv_gemm_set_stamp_buffer", [P, I64])
 nat.register("diagan_conv_gemm_tune", [I, I, I])
 nat.register("diagan_conv3x3_co4_supported", [I] * 8)
 nat.register("diagan_conv3x3_co4", [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
+nat.register("diagan_conv3x3_ci4_supported", [I] * 8)
+nat.register("diagan_conv3x3_ci4", [P, P, P, P, F, P, P, I, I, I, I, I, I, P])
 nat.register("diagan_conv3x3_co4_wgrad_supported", [I] * 8)
 nat.register("diagan_conv3x3_co4_wgrad_splits", [I, I])
 nat.register("diagan_conv3x3_co4_wgrad", [P, P, P, I64, I64, P, P, I, I, I, I, I, I, P])
@@ -327,6 +329,15 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         if t0 is not None:
             TIMER.end("conv3x3_co4_kernel", 2.0 * B * Ho * Wo * Co * R * S * Ci, t0,
                       (B * Ho * Wo, Co, R * S * Ci, f"pro{mode}"))
+        return out
+    if (mode == PRO_NONE and residual is None and mask_src is None and not res_relu and tile_cfg == 0 and not want_stats
+            and nat.fn("diagan_conv3x3_ci4_supported")(Ci, Co, R, S, sy, dr, off, up)):
+        t0 = TIMER.begin("conv3x3_ci4_kernel") if TIMER is not None else None
+        nat.call("diagan_conv3x3_ci4", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), out_scale,
+                 nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
+                 (B // 2) * Ho * Wo if row_scale else 0, B, Hi, Wi, Co, Kp, nat.current_stream())
+        if t0 is not None:
+            TIMER.end("conv3x3_ci4_kernel", 2.0 * B * Ho * Wo * Co * R * S * Ci, t0, (B * Ho * Wo, Co, R * S * Ci, "pro0"))
         return out
     ws = _splitk_ws(x.device)
     if tile_cfg == 0 and not wino:        # caller keeps to the implicit GEMM (the StyleGAN2 autograd ops by default)

@@ -255,6 +255,37 @@ def test_small_co_kernel_fwd_and_dgrad(Ci, H, W, B, pro):
         close(nchw(dx)[:, :3], xi.grad)
 
 
+@pytest.mark.parametrize("B,H,W,Co", [(3, 5, 7, 64), (1, 4, 4, 128), (6, 32, 32, 128), (4, 64, 64, 64), (2, 9, 33, 128)])
+def test_first_layer_kernel_from_four_channels(B, H, W, Co):
+    """conv3x3_ci4 (round 5): the discriminators' first convolution (RGB + pad -> 64 / 128 channels) on its own kernel -- weights
+    in registers, 32 pixels x all channels per wave, no LDS.  Against float64 F.conv2d (ragged pixel counts, one image, borders),
+    with the bias, without it, with the two spectral-norm scales of a paired pass; and against the implicit GEMM (tile_cfg 7), which
+    adds the same products in the same order (the last bit of scale * sum + bias may differ: fused or not)."""
+    from diagan.ops import conv as C
+    g = torch.Generator().manual_seed(B * 1000 + H + Co)
+    x = torch.randn(B, 4, H, W, generator=g)
+    w = torch.randn(Co, 4, 3, 3, generator=g) / 6.0
+    bias = torch.randn(Co, generator=g)
+    geom = C.Geom("conv", 4, Co, 3, 3, 1, 1)
+    wp = C.pack_oihw(w, geom.Kp).cuda()
+    xc = nhwc(x).cuda()
+    assert C.nat.fn("diagan_conv3x3_ci4_supported")(4, Co, 3, 3, 1, 1, -1, 1) == 1
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    y = C.conv_fwd(geom, xc, wp, bias=bias.cuda())
+    close(nchw(y), ref + bias.double().view(1, -1, 1, 1), tol=2e-6)
+    close(y, C.conv_fwd(geom, xc, wp, bias=bias.cuda(), tile_cfg=7), tol=1e-6)
+    close(nchw(C.conv_fwd(geom, xc, wp)), ref, tol=2e-6)
+    close(nchw(C.conv_fwd(geom, xc, wp, bias=bias.cuda(), out_scale=0.37)), 0.37 * ref + bias.double().view(1, -1, 1, 1), tol=2e-6)
+    if B % 2 == 0:
+        s0, s1 = torch.tensor([0.7]).cuda(), torch.tensor([1.9]).cuda()
+        y2 = C.conv_fwd(geom, xc, wp, bias=bias.cuda(), row_scale=(s0, s1))
+        r2 = ref.clone()
+        r2[:B // 2] *= 0.7
+        r2[B // 2:] *= 1.9
+        close(nchw(y2), r2 + bias.double().view(1, -1, 1, 1), tol=2e-6)
+        close(y2, C.conv_fwd(geom, xc, wp, bias=bias.cuda(), row_scale=(s0, s1), tile_cfg=7), tol=1e-6)
+
+
 @pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
 @pytest.mark.parametrize("pro", [0, 1, 2])
 def test_small_co_kernel_wgrad(Ci, H, W, B, pro):
