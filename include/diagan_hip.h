@@ -179,6 +179,11 @@ int diagan_conv_gemm_set_wino4(int mode);
  * reference ops, arguments and results to the tolerance of tile_cfg 13.  1 on, 0 off, -1 the environment's DIAGAN_WINO4_X3. */
 int diagan_conv_gemm_set_wino4x(int mode);
 int diagan_conv_gemm_get_wino4x(void);
+/* Split-K launches of the Winograd kernels (few output tiles, long channel loops): the tile's LAST workgroup to deliver its partial
+ * sums adds the slabs (in slab order) and runs the epilogue itself instead of a second launch (round 5).  0: always the second
+ * launch; 1: in-kernel where the kernel has it (the F(2x2) kernel); -1: DIAGAN_SPLITK_FUSED, default OFF: measured neutral
+ * (csrc/conv_gemm.hip, splitk_tickets). */
+int diagan_conv_gemm_set_splitk_fused(int mode);
 /* tile_cfg 11 / 12 (convolution + 2x2 average pool, and its data gradient from the pooled gradient) run on the same F(4x4) kernel
  * in 25 products per 4x4 tile (frequency row / column 2 never reaches a pooling-window sum) where the launch has >= 192 workgroups
  * and H, W are multiples of 4; this query says whether a geometry does (kernel names, executed-FLOP accounting). */

@@ -112,7 +112,9 @@ struct ConvGemmArgs {
   const float* scale1;    // (two forwards with different spectral-norm sigmas batched into one GEMM)
   int scale_split;
   float* stat_partials;   // optional [tiles_m][2][Co]: per-tile column sums of y and y*y (fused BatchNorm statistics)
-  float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel)
+  float* slab;            // split-K: raw partial sums go to slab[split][M][Co] (epilogue applied by a 2nd kernel ...
+  int* tickets;           // ... or, where a kernel supports it and this is not null, by the tile's last-arriving workgroup:
+                          // one zero-initialised counter per output tile, left at zero)
   int ksplit;             // number of K splits (gridDim.y); 1 = no split
   int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
   int res_up;             // residual is a HALF-resolution tensor [B,Ho/2,Wo/2,Co]: its bilinear x2 up-sampling is added

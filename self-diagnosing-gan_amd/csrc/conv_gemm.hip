@@ -686,6 +686,30 @@ static thread_local WinoFormat g_hint_next = {nullptr, 0, 0, 0.f, 0}, g_hint_now
 static thread_local long g_weight_launches = 0;   // per-launch weight-transform kernels issued by this thread (tests)
 constexpr int kDefaultTune = 0;
 
+// Ticket counters of the in-kernel split-K combine (ConvGemmArgs::tickets): one int per output tile, zero between launches (the
+// last-arriving workgroup of a tile resets its counter).  Allocated on first use (outside any stream capture).
+// OFF by default (DIAGAN_SPLITK_FUSED=1 / diagan_conv_gemm_set_splitk_fused(1) turn it on): measured on the F(2x2) kernel's
+// 36 / 10 split launches per SNGAN-64 / -32 step it buys nothing -- plain partial stores + an agent-scope release per workgroup:
+// -0.5 % (the release writes the L2's dirty lines back); write-through partial stores, no release: +-0.1 % (2998-3005 vs
+// 3003-3008 images/s): draining the stores and the last arriver's serial read-back cost what the 7 us second launch costs.
+constexpr int kTicketSlots = 1 << 16;
+static int g_splitk_fused = -1;                   // -1: DIAGAN_SPLITK_FUSED / default (on); 0 / 1: diagan_conv_gemm_set_splitk_fused
+static int* splitk_tickets(hipStream_t st) {
+  static const int env = getenv("DIAGAN_SPLITK_FUSED") ? atoi(getenv("DIAGAN_SPLITK_FUSED")) : 0;
+  static int* buf = nullptr;
+  static bool tried = false;
+  if (!(g_splitk_fused >= 0 ? g_splitk_fused : env)) return nullptr;
+  if (!tried) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;   // not now: two launches
+    tried = true;
+    int* p = nullptr;
+    if (hipMalloc(&p, kTicketSlots * sizeof(int)) == hipSuccess && hipMemset(p, 0, kTicketSlots * sizeof(int)) == hipSuccess) buf = p;
+    (void)hipGetLastError();
+  }
+  return buf;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int PRO, bool STAMP = false, bool FP = false, int KG = 1>
 static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.g.Co, BN);
@@ -885,6 +909,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   DG_REQUIRE(pro_group_rows >= 0 && (pro_group_rows == 0 || (pro_group_rows % bm == 0 && a.M % pro_group_rows == 0)),
              "conv_gemm: pro_group_rows=%d must be a multiple of the %d-row tile and divide M=%d", pro_group_rows, bm, a.M);
   a.slab = splitk_ws;
+  a.tickets = nullptr;
   a.ksplit = 1;
   a.stat_partials = stat_partials;
   a.tune = g_tune_flags >= 0 ? g_tune_flags : kDefaultTune;
@@ -1005,8 +1030,9 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     }
     a.ksplit = ks;
     a.slab = splitk_ws + wfl;
+    if (ks > 1 && (long)cdiv(a.M / 4, 64) * cdiv(Co, 64) <= kTicketSlots) a.tickets = splitk_tickets(st);
     int rc = launch_wino(a, splitk_ws, st);
-    if (rc == DIAGAN_OK && ks > 1) {
+    if (rc == DIAGAN_OK && ks > 1 && !a.tickets) {
       long blocks = ((long)a.M * (Co / 4) + 255) / 256;
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)blocks), dim3(256), 0, st, a);
@@ -1165,6 +1191,11 @@ DIAGAN_API int diagan_conv_gemm_set_wino4x(int mode) {
   return DIAGAN_OK;
 }
 DIAGAN_API int diagan_conv_gemm_get_wino4x(void) { return wino4_get_x3(); }
+DIAGAN_API int diagan_conv_gemm_set_splitk_fused(int mode) {
+  DG_REQUIRE(mode >= -1 && mode <= 1, "set_splitk_fused: -1, 0 or 1");
+  g_splitk_fused = mode;
+  return DIAGAN_OK;
+}
 
 // Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.
 //  * stamp buffer: while set, diagan_conv_gemm launches the STAMP build of the kernel, which records per workgroup

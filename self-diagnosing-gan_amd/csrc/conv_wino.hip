@@ -384,6 +384,40 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
     }
   }
   __syncthreads();
+  // the epilogue proper of (tile it, its 4 output pixels): scale, bias, residual, mask, store, statistics
+  const __amdgpu_buffer_rsrc_t psrc =
+      __builtin_amdgcn_make_buffer_rsrc(ydst, 0, raw ? (int)((unsigned)a.M * (unsigned)g.Co * 4u) : 0, 0x00020000);
+  auto finish = [&](int it, const f32x4* y4, const f32x4* res, const f32x4* msk, bool wr, bool wm, bool ws) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x4 y = y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
+      if (wr) {
+        f32x4 r;
+        if (a.res_up) {
+          // upsample2x_kernel's arithmetic: (w0 * a + w1 * b) along x inside the y blend
+          const int ya = p >> 1, xa = p & 1;
+          const float wy0 = ya ? 0.75f : 0.25f, wx0 = xa ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx1 = 1.f - wx0;
+          const f32x4 top = wx0 * res[ya * 3 + xa] + wx1 * res[ya * 3 + xa + 1];
+          const f32x4 bot = wx0 * res[ya * 3 + 3 + xa] + wx1 * res[ya * 3 + 3 + xa + 1];
+          r = wy0 * top + wy1 * bot;
+        } else {
+          r = res[p];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+        }
+        y += r;
+      }
+      if (wm) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = msk[p][e] > 0.f ? y[e] : y[e] * a.mask_slope;
+      }
+      *reinterpret_cast<f32x4*>(a.y + o4[it][p]) = y;
+      if (ws) {
+        cs1 += y;
+        cs2 += y * y;
+      }
+    }
+  };
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     f32x4 y4[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -396,34 +430,73 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       if (i >= 2) { y4[2] -= sa; y4[3] -= sb; }
     }
     if (ok2[it]) {
+      if (raw && a.tickets) {
+        // write-through (sc1) stores: the partial sums go to memory as they are written, no release fence (L2 write-back) later
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        f32x4 y = raw ? y4[p] : y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
-        if (hr) {
-          f32x4 r;
+        for (int p = 0; p < 4; ++p)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y4[p]), psrc,
+                                                 (unsigned)o4[it][p] * 4u, 0, 16);
+      } else if (raw) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(ydst + o4[it][p]) = y4[p];
+      } else {
+        finish(it, y4, rres[it], rmsk[it], hr, hm, hs);
+      }
+    }
+  }
+  if (raw && a.tickets) {
+    // Round 5: the LAST workgroup of a tile to deliver its partial sums adds the slabs and runs the epilogue itself (no second
+    // launch).  Publish = write-through stores, every wave drains them, one lane draws a ticket; the last arriver acquires
+    // (invalidates this CU's L1) and every thread reads back, in slab order, the positions it wrote itself.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int tk = __hip_atomic_fetch_add(a.tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int lastwg = tk == a.ksplit - 1 ? 1 : 0;
+      if (lastwg) {
+        __hip_atomic_store(a.tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      reinterpret_cast<volatile int*>(smem)[0] = lastwg;
+    }
+    __syncthreads();
+    if (reinterpret_cast<volatile int*>(smem)[0]) {
+      const bool fr = a.residual != nullptr, fm = a.mask_src != nullptr;
+      if (a.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+      const long slab_elems = (long)a.M * g.Co;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        if (!ok2[it]) continue;
+        f32x4 y4[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) y4[p] = *reinterpret_cast<const f32x4*>(a.slab + o4[it][p]);
+        for (int k = 1; k < a.ksplit; ++k) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) y4[p] += *reinterpret_cast<const f32x4*>(a.slab + k * slab_elems + o4[it][p]);
+        }
+        f32x4 res[9], msk[4];
+        if (fr) {
           if (a.res_up) {
-            // upsample2x_kernel's arithmetic: (w0 * a + w1 * b) along x inside the y blend
-            const int ya = p >> 1, xa = p & 1;
-            const float wy0 = ya ? 0.75f : 0.25f, wx0 = xa ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx1 = 1.f - wx0;
-            const f32x4 top = wx0 * rres[it][ya * 3 + xa] + wx1 * rres[it][ya * 3 + xa + 1];
-            const f32x4 bot = wx0 * rres[it][ya * 3 + 3 + xa] + wx1 * rres[it][ya * 3 + 3 + xa + 1];
-            r = wy0 * top + wy1 * bot;
+            const int gt = t0 + it * 32 + et;
+            const unsigned q1 = fdiv((unsigned)gt, a.dWo);
+            const int tx = gt - (int)q1 * TW;
+            const unsigned b = fdiv(q1, a.dHo);
+            const int ty = (int)q1 - (int)b * TH;
+            const float* rb = a.residual + ((long)b * TH * TW) * g.Co + n;
+            const int yy[3] = {max(ty - 1, 0), ty, min(ty + 1, TH - 1)}, xx[3] = {max(tx - 1, 0), tx, min(tx + 1, TW - 1)};
+#pragma unroll
+            for (int q = 0; q < 9; ++q) res[q] = *reinterpret_cast<const f32x4*>(rb + ((long)yy[q / 3] * TW + xx[q % 3]) * g.Co);
           } else {
-            r = rres[it][p];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], rfloor);
+            for (int p = 0; p < 4; ++p) res[p] = *reinterpret_cast<const f32x4*>(a.residual + o4[it][p]);
           }
-          y += r;
         }
-        if (hm) {
+        if (fm) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) y[e] = rmsk[it][p][e] > 0.f ? y[e] : y[e] * a.mask_slope;
+          for (int p = 0; p < 4; ++p) msk[p] = *reinterpret_cast<const f32x4*>(a.mask_src + o4[it][p]);
         }
-        *reinterpret_cast<f32x4*>(ydst + o4[it][p]) = y;
-        if (hs) {
-          cs1 += y;
-          cs2 += y * y;
-        }
+        finish(it, y4, res, msk, fr, fm, false);
       }
     }
   }

@@ -15,6 +15,7 @@ nat.register("diagan_conv_wino_supported", [I] * 12)
 nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
+nat.register("diagan_conv_gemm_set_splitk_fused", [I])
 nat.register("diagan_conv_wgrad_batched", [P, I, P])
 nat.register("diagan_conv_wgrad_batch_max", [])
 nat.register("diagan_conv_wgrad_batch_class", [I] * 14)
@@ -271,6 +272,11 @@ def _pro3(pro):
     if len(pro) > 3 and pro[3]:
         raise RuntimeError("grouped BatchNorm prologues exist for the forward kernels only")
     return tuple(pro)[:3]
+
+
+def set_splitk_fused(on):
+    """True / False: the split-K launches' last-arriving workgroup runs the epilogue / a second launch does; None: the default"""
+    nat.call("diagan_conv_gemm_set_splitk_fused", -1 if on is None else (1 if on else 0))
 
 
 def wg_x_shape(x, pro):

@@ -126,6 +126,46 @@ def test_auto_selection_and_agreement_with_the_implicit_gemm():
         C.conv_fwd(g2, nhwc(x).cuda(), wp, tile_cfg=9)
 
 
+@pytest.mark.parametrize("case", [(64, 4, 4, 512, 512), (64, 8, 8, 256, 512), (128, 4, 4, 1024, 1024), (64, 8, 8, 512, 256)])
+def test_split_k_combine_by_the_last_arriving_workgroup(case):
+    """Round 5: a split-K launch's partial sums are added, in slab order, by the tile's LAST workgroup to deliver, which then
+    runs the epilogue itself (ticket counter per tile; no second launch).  Same inputs through diagan_conv_gemm_set_splitk_fused(0)
+    (the splitk_epilogue_kernel launch): the same sums in the same order -- forward with bias + residual, forward with a
+    half-resolution residual, data gradient with a mask -- equal up to the fused multiply-add of scale and bias; repeated launches
+    (the counters return to zero) give the same bits; and against float64."""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=21)
+    g = torch.Generator().manual_seed(22)
+    bias, res = torch.randn(Co, generator=g), torch.randn(B, Co, H, W, generator=g)
+    low = torch.randn(B, Co, H // 2, W // 2, generator=g)
+    xc, rc, lc = nhwc(x).cuda(), nhwc(res).cuda(), nhwc(low).cuda()
+    relu = (C.PRO_RELU, None, None)
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    gy = torch.randn(B, H, W, Co, device="cuda", generator=torch.Generator(device="cuda").manual_seed(23))
+    msk = torch.randn(B, H, W, Ci, device="cuda", generator=torch.Generator(device="cuda").manual_seed(24))
+    out = {}
+    C.set_winograd4(False)                   # these shapes: the F(2x2) kernel, split 2 - 4 ways by the automatic choice
+    try:
+        for fused in (True, False, True):
+            C.set_splitk_fused(fused)
+            cur = (C.conv_fwd(geom, xc, wp, bias=bias.cuda(), residual=rc, pro=relu),
+                   C.conv_fwd(geom, xc, wp, bias=bias.cuda(), residual=lc, res_up=True),
+                   C.conv_dgrad(geom, gy, wd, (H, W), mask_src=msk))
+            if fused in out:
+                for a, b in zip(out[fused], cur):
+                    assert torch.equal(a, b)
+            out[fused] = cur
+    finally:
+        C.set_splitk_fused(None)
+        C.set_winograd4(None)
+    for a, b in zip(out[True], out[False]):
+        close(a, b, tol=1e-6)
+    ref = F.conv2d(F.relu(x.double()), w.double(), bias.double(), padding=1) + res.double()
+    close(nchw(out[True][0]), ref, tol=2e-5)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (3, 6, 10, 16, 24), (5, 16, 16, 128, 72), (64, 4, 4, 512, 512)])
 def test_half_resolution_residual_is_upsampled_in_the_epilogue(case):
     """mimicry GBlock's shortcut is c_sc(interpolate(x, scale_factor=2, mode='bilinear')) (= interpolate(c_sc(x)), a 1x1
