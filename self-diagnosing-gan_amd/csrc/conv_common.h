@@ -117,8 +117,10 @@ struct ConvGemmArgs {
                           // one zero-initialised counter per output tile, left at zero)
   int ksplit;             // number of K splits (gridDim.y); 1 = no split
   int res_relu;           // residual is added as max(residual, 0) (DBlock identity shortcut sees relu(x))
-  int res_up;             // residual is a HALF-resolution tensor [B,Ho/2,Wo/2,Co]: its bilinear x2 up-sampling is added
-                          // (GBlock's up-sampled shortcut; Winograd kernel and its split-K epilogue only)
+  int res_up;             // residual is a HALF-resolution tensor [B,Ho/2,Wo/2,Co]: 1: its bilinear x2 up-sampling is added
+                          // (GBlock's up-sampled shortcut); 2: 0.25 * its value at (oy / 2, ox / 2) is added = the gradient of a
+                          // 2x2 average pool (DBlock's pooled shortcut in the data gradient).  Winograd kernels and the split-K
+                          // epilogue only
   int pro_mode;
   int M;                  // B*Ho*Wo
   ConvGeom g;

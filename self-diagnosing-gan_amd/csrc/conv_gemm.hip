@@ -651,9 +651,12 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvGemmArgs
     if (a.bias) s += reinterpret_cast<const f32x4*>(a.bias)[c4];
     if (a.residual) {
       f32x4 r;
-      if (a.res_up) {
+      if (a.res_up == 1) {
         const int ox = m % a.g.Wo, q = m / a.g.Wo, oy = q % a.g.Ho, b = q / a.g.Ho;
         r = residual_up2(a.residual, b, oy, ox, a.g.Ho >> 1, a.g.Wo >> 1, a.g.Co, c4 * 4);
+      } else if (a.res_up == 2) {
+        const int ox = m % a.g.Wo, q = m / a.g.Wo, oy = q % a.g.Ho, b = q / a.g.Ho;
+        r = 0.25f * *reinterpret_cast<const f32x4*>(a.residual + (((long)b * (a.g.Ho >> 1) + (oy >> 1)) * (a.g.Wo >> 1) + (ox >> 1)) * a.g.Co + c4 * 4);
       } else {
         r = reinterpret_cast<const f32x4*>(a.residual)[i];
       }
@@ -890,10 +893,13 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.scale0 = scale0; a.scale1 = scale1; a.scale_split = scale_split;
   DG_REQUIRE(!scale0 || scale1, "conv_gemm: scale0 and scale1 must be given together");
   DG_REQUIRE(!(stat_partials && mask_src), "conv_gemm: stat_partials (forward statistics) and mask_src (backward mask) are exclusive");
-  a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu & 1; a.res_up = (res_relu >> 1) & 1;
-  DG_REQUIRE((res_relu & ~3) == 0, "conv_gemm: res_relu=%d (bit 0: relu(residual), bit 1: half-resolution residual)", res_relu);
-  DG_REQUIRE(!a.res_up || (residual && !(Ho & 1) && !(Wo & 1) && !mask_src && !a.res_relu),
+  a.pro_mode = pro_mode; a.M = B * Ho * Wo; a.res_relu = res_relu & 1; a.res_up = (res_relu & 2) ? 1 : (res_relu & 4) ? 2 : 0;
+  DG_REQUIRE((res_relu & ~7) == 0 && (res_relu & 6) != 6, "conv_gemm: res_relu=%d (bit 0: relu(residual), bit 1: half-resolution residual, "
+             "up-sampled; bit 2: half-resolution residual, un-pooled)", res_relu);
+  DG_REQUIRE(a.res_up != 1 || (residual && !(Ho & 1) && !(Wo & 1) && !mask_src && !a.res_relu),
              "conv_gemm: a half-resolution residual needs the tensor, even Ho / Wo, no backward mask and no ReLU on it");
+  DG_REQUIRE(a.res_up != 2 || (residual && !(Ho & 1) && !(Wo & 1) && !a.res_relu && !stat_partials),
+             "conv_gemm: an un-pooled half-resolution residual needs the tensor, even Ho / Wo, no ReLU on it, no statistics");
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);

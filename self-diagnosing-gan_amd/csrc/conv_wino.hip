@@ -366,7 +366,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       o4[it][p] = (long)prow4[it][p] * g.Co + n;
     }
     if (hr && ok2[it]) {
-      if (a.res_up) {
+      if (a.res_up == 2) {
+        // the tile's 2x2 output pixels all take a quarter of half-resolution pixel (ty, tx)
+        rres[it][0] = *reinterpret_cast<const f32x4*>(a.residual + (((long)b * TH + ty) * TW + tx) * g.Co + n);
+      } else if (a.res_up) {
         // the tile's 2x2 output pixels blend the 3x3 neighbourhood of half-resolution pixel (ty, tx), edges clamped
         const float* rb = a.residual + ((long)b * TH * TW) * g.Co + n;
         const int yy[3] = {max(ty - 1, 0), ty, min(ty + 1, TH - 1)}, xx[3] = {max(tx - 1, 0), tx, min(tx + 1, TW - 1)};
@@ -393,7 +396,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
       f32x4 y = y4[p] * (prow4[it][p] < split ? sc0 : sc1) + bv;
       if (wr) {
         f32x4 r;
-        if (a.res_up) {
+        if (a.res_up == 2) {
+          r = 0.25f * res[0];
+        } else if (a.res_up) {
           // upsample2x_kernel's arithmetic: (w0 * a + w1 * b) along x inside the y blend
           const int ya = p >> 1, xa = p & 1;
           const float wy0 = ya ? 0.75f : 0.25f, wx0 = xa ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx1 = 1.f - wx0;
@@ -483,10 +488,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_kernel(const ConvGemmArgs a,
             const int tx = gt - (int)q1 * TW;
             const unsigned b = fdiv(q1, a.dHo);
             const int ty = (int)q1 - (int)b * TH;
+            if (a.res_up == 2) res[0] = *reinterpret_cast<const f32x4*>(a.residual + (((long)b * TH + ty) * TW + tx) * g.Co + n);
             const float* rb = a.residual + ((long)b * TH * TW) * g.Co + n;
             const int yy[3] = {max(ty - 1, 0), ty, min(ty + 1, TH - 1)}, xx[3] = {max(tx - 1, 0), tx, min(tx + 1, TW - 1)};
+            if (a.res_up == 1) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) res[q] = *reinterpret_cast<const f32x4*>(rb + ((long)yy[q / 3] * TW + xx[q % 3]) * g.Co);
+              for (int q = 0; q < 9; ++q) res[q] = *reinterpret_cast<const f32x4*>(rb + ((long)yy[q / 3] * TW + xx[q % 3]) * g.Co);
+            }
           } else {
 #pragma unroll
             for (int p = 0; p < 4; ++p) res[p] = *reinterpret_cast<const f32x4*>(a.residual + o4[it][p]);

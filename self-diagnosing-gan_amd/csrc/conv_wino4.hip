@@ -1217,7 +1217,13 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
       // (jy, jy + 1) [ar = 1], jy = oy0 / 2, and its four pixels blend columns 2 tx - 1 .. 2 tx + 2, edges clamped: eight
       // loads for the row instead of four per pixel
       f32x4 rup[8];
-      if (hr && a.res_up && ok) {
+      if (hr && a.res_up == 2 && ok) {
+        // un-pooled half-resolution residual (DBlock's pooled shortcut in the data gradient): both rows of the pair lie in
+        // half-resolution row oy0 / 2, the four pixels in its columns ox0 / 2 and ox0 / 2 + 1
+        const float* rb = a.residual + (((long)eb * (g.Ho >> 1) + (oy0 >> 1)) * (g.Wo >> 1) + (ox0 >> 1)) * g.Co + n;
+        rup[0] = 0.25f * *reinterpret_cast<const f32x4*>(rb);
+        rup[1] = 0.25f * *reinterpret_cast<const f32x4*>(rb + g.Co);
+      } else if (hr && a.res_up && ok) {
         const int Hh = g.Ho >> 1, Wh = g.Wo >> 1, jy = oy0 >> 1, jx = ox0 >> 1;
         const int y0 = ar ? jy : max(jy - 1, 0), y1 = ar ? min(jy + 1, Hh - 1) : jy;
         const int xx[4] = {max(jx - 1, 0), jx, jx + 1, min(jx + 2, Wh - 1)};
@@ -1234,7 +1240,9 @@ __global__ __launch_bounds__(512) void conv_wino4_kernel(const ConvGemmArgs a, c
         f32x4 y = raw ? (UNPOOL ? y4[bc] * 0.25f : y4[bc]) : y4[bc] * scv + bv;
         if (hr) {
           f32x4 r;
-          if (a.res_up) {
+          if (a.res_up == 2) {
+            r = rup[bc >> 1];
+          } else if (a.res_up) {
             // upsample2x_kernel's arithmetic: (w0 * a + w1 * b) along x inside the y blend
             const int c0 = bc == 0 ? 0 : (bc == 3 ? 2 : 1);
             const float wy0 = ar ? 0.75f : 0.25f, wx0 = (bc & 1) ? 0.75f : 0.25f, wy1 = 1.f - wy0, wx1 = 1.f - wx0;

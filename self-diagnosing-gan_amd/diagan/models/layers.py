@@ -238,10 +238,15 @@ class ConvLayer(nn.Module):
         return C.conv_dgrad(self.geom, dy_pooled, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
                             mask_slope=mask_slope, row_scale=ctx.row_scale, unpool=True, wsite=ws, wversion=wv)
 
-    def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0):
+    def dgrad(self, ctx, dy, in_hw, residual=None, mask_src=None, mask_slope=0.0, res_unpool=False):
+        """res_unpool: `residual` is a half-resolution tensor whose avg_pool2d_backward is added (callers check
+        dgrad_res_unpool_fused first)"""
         ws, wv = self._wsite(ctx, 'd')
         return C.conv_dgrad(self.geom, dy, ctx.wd, in_hw, residual=residual, mask_src=mask_src,
-                            mask_slope=mask_slope, row_scale=ctx.row_scale, wsite=ws, wversion=wv)
+                            mask_slope=mask_slope, row_scale=ctx.row_scale, wsite=ws, wversion=wv, res_unpool=res_unpool)
+
+    def dgrad_res_unpool_fused(self, B, in_hw):
+        return C.res_unpool_fused(self.geom, B, in_hw[0], in_hw[1])
 
     def wgrad_pooled_ok(self, dy_pooled, x):
         """The weight gradient of avg_pool2d(conv3x3(act(x)), 2) from the POOLED gradient: a 3x3 / stride 2 / pad 0 weight

@@ -187,8 +187,10 @@ class DBlock(nn.Module):
         if not need_gx:
             return None
         if xp is not None:
-            tmp = E.avgpool2_bwd(self.c_sc.dgrad(ctx['ksc'], gout, xp.shape[1:3]))
-            return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=tmp, mask_src=x)
+            g_xp = self.c_sc.dgrad(ctx['ksc'], gout, xp.shape[1:3])
+            if self.c1.dgrad_res_unpool_fused(x.shape[0], hw):      # the pooled shortcut's gradient un-pooled by c1's epilogue
+                return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=g_xp, mask_src=x, res_unpool=True)
+            return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=E.avgpool2_bwd(g_xp), mask_src=x)
         if self.learnable_sc:
             tmp = self.c_sc.dgrad(ctx['ksc'], g_full, hw)
             return self.c1.dgrad(ctx['k1'], g_h1, hw, residual=tmp, mask_src=x)

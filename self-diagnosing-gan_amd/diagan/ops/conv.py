@@ -297,7 +297,7 @@ def _chk(t, name):
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
           res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False, up_in=False,
-          wsite=None, wversion=None):
+          wsite=None, wversion=None, res_unpool=False):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
@@ -320,14 +320,14 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     if w.shape != (Co, Kp):
         raise RuntimeError(f"conv_gemm: packed weight shape {tuple(w.shape)} != ({Co}, {Kp})")
     for t, n in ((residual, 'residual'), (mask_src, 'mask_src')):
-        want = (B, Ho // 2, Wo // 2, Co) if (res_up and n == 'residual') else tuple(out.shape)
+        want = (B, Ho // 2, Wo // 2, Co) if ((res_up or res_unpool) and n == 'residual') else tuple(out.shape)
         if t is not None and tuple(t.shape) != want:
             raise RuntimeError(f"conv_gemm: {n} shape {tuple(t.shape)} != {want}")
-    if res_up and (residual is None or res_relu or not wino):
-        raise RuntimeError("conv_gemm: res_up needs a half-resolution residual, no ReLU on it, and the Winograd kernel")
+    if (res_up or res_unpool) and (residual is None or res_relu or not wino or (res_up and res_unpool)):
+        raise RuntimeError("conv_gemm: res_up / res_unpool need a half-resolution residual, no ReLU on it, and the Winograd kernel")
     sy, dr, off, up = geo_params
     stats = None
-    if (mask_src is None and row_scale is None and out_scale == 1.0 and not res_relu and tile_cfg == 0
+    if (mask_src is None and row_scale is None and out_scale == 1.0 and not res_relu and tile_cfg == 0 and not res_unpool
             and not want_stats and nat.fn("diagan_conv3x3_co4_supported")(Ci, Co, R, S, sy, dr, off, up)):
         t0 = TIMER.begin("conv3x3_co4_kernel") if TIMER is not None else None
         nat.call("diagan_conv3x3_co4", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
@@ -376,7 +376,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     t0 = TIMER.begin(kname) if TIMER is not None else None
     _hint(wsite, wversion)
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
-             (1 if res_relu else 0) | (2 if res_up else 0), nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
+             (1 if res_relu else 0) | (2 if res_up else 0) | (4 if res_unpool else 0), nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
              (B // 2) * Ho * Wo if row_scale else 0,
              B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, tile_cfg, nat.ptr(ws), ws.numel(),
@@ -462,8 +462,10 @@ def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,
-               row_scale=None, wino=True, unpool=False, wsite=None, wversion=None):
+               row_scale=None, wino=True, unpool=False, wsite=None, wversion=None, res_unpool=False):
     """dx = conv^T(dy) (+ residual) (* relu'(mask_src)).  dy [B,Ho,Wo,Co] -> dx [B,Hi,Wi,Ci].
+    res_unpool: `residual` is [B,Hi/2,Wi/2,Ci] and avg_pool2d_backward of it (a quarter of its value at (y / 2, x / 2)) is added
+    (see res_unpool_fused).
     unpool: dy is the gradient of the 2x2-average-POOLED output, [B,Ho/2,Wo/2,Co]: dx = conv^T(avg_pool2d_backward(dy))
     in one launch (see unpool_fused)."""
     B, Ho, Wo, Co = dy.shape
@@ -475,7 +477,22 @@ def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0
     if out is None:
         out = torch.empty((B, Hi, Wi, geom.Ci), dtype=torch.float32, device=dy.device)
     return _gemm(dy, wd, out, geom.dgrad_params(), geom.R, geom.S, geom.Kd, None, residual, mask_src, mask_slope,
-                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino, unpool=unpool, wsite=wsite, wversion=wversion)
+                 None, 1.0, tile_cfg, row_scale=row_scale, wino=wino, unpool=unpool, wsite=wsite, wversion=wversion,
+                 res_unpool=res_unpool)
+
+
+def res_unpool_fused(geom, B, Hi, Wi):
+    """Will conv_dgrad(geom, dy, ..., residual=r_half, res_unpool=True) run for a layer with input [B,Hi,Wi,Ci]?  The quarter of
+    a half-resolution residual (the gradient arriving through an average pool) is added by the Winograd kernels' epilogues
+    and their split-K second stage only: True iff the automatic choice for this data gradient is one of them (tile_cfg 9 / 13);
+    otherwise the caller un-pools the residual itself (diagan_avgpool2_bwd)."""
+    if Hi % 2 or Wi % 2 or _os.environ.get("DIAGAN_RES_UNPOOL", "1") == "0":
+        return False
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    sy, dr, off, up = geom.dgrad_params()
+    ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
+    return nat.fn("diagan_conv_gemm_pick_cfg_geom")(B, Ho, Wo, geom.Co, Hi, Wi, geom.Ci, geom.R, geom.S, sy, dr, off, up, geom.Kd, 1,
+                                                    ws.numel()) in (9, 13)
 
 
 def unpool_fused(geom, B, Hi, Wi):

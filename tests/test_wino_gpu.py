@@ -126,6 +126,39 @@ def test_auto_selection_and_agreement_with_the_implicit_gemm():
         C.conv_fwd(g2, nhwc(x).cuda(), wp, tile_cfg=9)
 
 
+@pytest.mark.parametrize("case", [(128, 32, 32, 128, 128), (64, 16, 16, 128, 256), (128, 8, 8, 256, 512), (64, 4, 4, 512, 512),
+                                  (3, 6, 10, 16, 24)])
+def test_data_gradient_adds_an_unpooled_half_resolution_residual(case):
+    """Round 5: DBlock's shortcut is pooled before its 1x1 convolution, so its gradient arrives at half resolution; the data
+    gradient of c1 adds avg_pool2d_backward of it (a quarter of the value at (y / 2, x / 2)) in its own epilogue (res_relu bit 2;
+    F(4x4), F(2x2) and the split-K second stage) instead of reading a tensor diagan_avgpool2_bwd wrote: the same products, so the
+    same bits as the two-launch path; and against float64."""
+    from diagan.ops import conv as C, eltwise as E
+    B, H, W, Ci, Co = case
+    geom, x, w, wp = make(*case, seed=31)
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    g = torch.Generator(device="cuda").manual_seed(32)
+    gy = torch.randn(B, H, W, Co, device="cuda", generator=g)
+    lo = torch.randn(B, H // 2, W // 2, Ci, device="cuda", generator=g)
+    msk = torch.randn(B, H, W, Ci, device="cuda", generator=g)
+    if not C.res_unpool_fused(geom, B, H, W):
+        with pytest.raises(RuntimeError, match="Winograd"):
+            C.conv_dgrad(geom, gy, wd, (H, W), residual=lo, mask_src=msk, res_unpool=True)
+        cfgs = (9,)
+    else:
+        cfgs = (0, 9)
+    for cfg in cfgs:
+        a = C.conv_dgrad(geom, gy, wd, (H, W), residual=lo, mask_src=msk, res_unpool=True, tile_cfg=cfg)
+        b = C.conv_dgrad(geom, gy, wd, (H, W), residual=E.avgpool2_bwd(lo), mask_src=msk, tile_cfg=cfg)
+        assert torch.equal(a, b)
+        a = C.conv_dgrad(geom, gy, wd, (H, W), residual=lo, res_unpool=True, tile_cfg=cfg)
+        assert torch.equal(a, C.conv_dgrad(geom, gy, wd, (H, W), residual=E.avgpool2_bwd(lo), tile_cfg=cfg))
+    ref = F.conv_transpose2d(nchw(gy).double().cpu(), w.double(), padding=1) + \
+        0.25 * F.interpolate(nchw(lo).double().cpu(), scale_factor=2, mode="nearest")
+    close(nchw(a), ref, tol=1e-4)
+
+
 @pytest.mark.parametrize("case", [(64, 4, 4, 512, 512), (64, 8, 8, 256, 512), (128, 4, 4, 1024, 1024), (64, 8, 8, 512, 256)])
 def test_split_k_combine_by_the_last_arriving_workgroup(case):
     """Round 5: a split-K launch's partial sums are added, in slab order, by the tile's LAST workgroup to deliver, which then
