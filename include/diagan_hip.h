@@ -369,6 +369,12 @@ int diagan_bn_stats(const float* x, int64_t M, int C, const float* gamma, const 
                     float momentum, float* running_mean, float* running_var, int training,
                     float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                     void* workspace, void* stream);
+/* The same for `groups` batches stacked along the rows of x[groups * M][C] (the stacked generator forward), each with its OWN
+ * batch statistics, the running statistics taking the momentum updates in group order: one reduction launch and one
+ * finalisation for all groups.  Training mode only; outputs [groups][C]; workspace: groups * diagan_colred_workspace(M, C). */
+int diagan_bn_stats_grouped(const float* x, int64_t M, int C, int groups, const float* gamma, const float* beta, float eps,
+                            float momentum, float* running_mean, float* running_var, float* mean_out, float* invstd_out,
+                            float* scale_out, float* shift_out, void* workspace, void* stream);
 
 /* BatchNorm (training mode) from the per-tile sums written by diagan_conv_gemm(stat_partials).  groups > 1: `groups`
  * independently normalised batches of M rows / `tiles` tiles each, contiguous in `partials`; finalised in order in one

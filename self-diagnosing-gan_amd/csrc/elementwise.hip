@@ -74,6 +74,7 @@ struct ColRedArgs {
   float slope;
   const float* drop;   // MODE 1: optional dropout keep-mask, multiplies g together with drop_scale (1 / (1 - p) for a 0 / 1 mask;
   float drop_scale;    //         1 for a mask that carries the scale itself)
+  int splits = 0;      // MODE 0 with gridDim.z > 1: group z reduces rows [z M, (z + 1) M) into partials + z * splits * 2 * C
 };
 
 template <int MODE>
@@ -85,8 +86,9 @@ __global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
   const int cc = threadIdx.x % CW, rl = threadIdx.x / CW;
   const int c4 = blockIdx.x * CW + cc;
   const bool col_ok = c4 < C4 && rl < RL;
-  const long r0 = (long)blockIdx.y * a.rows_per_split;
-  const long r1 = r0 + a.rows_per_split < a.M ? r0 + a.rows_per_split : a.M;
+  const long rg = (long)blockIdx.z * a.M;                                   // (stacked batches: one launch for all groups)
+  const long r0 = rg + (long)blockIdx.y * a.rows_per_split;
+  const long r1 = r0 + a.rows_per_split < rg + a.M ? r0 + a.rows_per_split : rg + a.M;
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   if (col_ok) {
     f32x4 sc, sh, mu, is;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(EW_T) void colred_kernel(const ColRedArgs a) {
     for (int k = 0; k < RL; ++k)
 #pragma unroll
       for (int e = 0; e < 4; ++e) { t1[e] += red[0][k * CW + cc][e]; t2[e] += red[1][k * CW + cc][e]; }
-    double* p = a.partials + (long)blockIdx.y * 2 * a.C;
+    double* p = a.partials + ((long)blockIdx.z * a.splits + blockIdx.y) * 2 * a.C;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { p[c4 * 4 + e] = t1[e]; p[a.C + c4 * 4 + e] = t2[e]; }
   }
@@ -674,8 +676,13 @@ static int colred_geometry(long M, int C, int* splits, int* rows_per_split, dim3
   const int C4 = C / 4;
   const int CW = C4 < 64 ? C4 : 64;
   const int gx = cdiv(C4, CW);
-  int s = cdiv(1024, gx);                       // ~4 blocks per CU in total
-  const long max_s = (M + 255) / 256;           // at least 256 rows per split
+  // a thread walks rows_per_split / (256 / columns) rows, four loads in flight: with 256 rows per split and 1024 blocks a
+  // 65536 x 256 reduction was 16 dependent iterations = 21 us; 128 / 2048: SNGAN-32 +0.8 %, SNGAN-64 +0.2 % end to end
+  // (64 / 4096: +1.0 % / -0.45 %; tools/probe/colred_sweep.sh)
+  static const int blocks = getenv("DIAGAN_COLRED_BLOCKS") ? atoi(getenv("DIAGAN_COLRED_BLOCKS")) : 2048;
+  static const int minrows = getenv("DIAGAN_COLRED_ROWS") ? atoi(getenv("DIAGAN_COLRED_ROWS")) : 128;
+  int s = cdiv(blocks, gx);                     // ~8 blocks per CU in total
+  const long max_s = (M + minrows - 1) / minrows;           // at least 128 rows per split
   if (s > max_s) s = (int)max_s;
   if (s < 1) s = 1;
   *rows_per_split = (int)((M + s - 1) / s);
@@ -743,6 +750,28 @@ DIAGAN_API int diagan_bn_stats(const float* x, int64_t M, int C, const float* ga
                      (long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out,
                      shift_out, training);
   return check_launch("bn_stats");
+}
+
+// training-mode statistics of `groups` batches stacked along the rows of x[groups * M][C], each normalised on its own, the
+// running statistics updated in group order (as diagan_bn_stats called once per group -- which cost a 20 us launch pair per
+// group for the generator's first BatchNorm): ONE column-reduction launch and ONE finalisation.  Outputs [groups][C];
+// workspace: groups * diagan_colred_workspace(M, C) bytes.
+DIAGAN_API int diagan_bn_stats_grouped(const float* x, int64_t M, int C, int groups, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var, float* mean_out,
+                                       float* invstd_out, float* scale_out, float* shift_out, void* workspace, void* stream) {
+  DG_REQUIRE(x && gamma && beta && running_mean && running_var && mean_out && invstd_out && scale_out && shift_out && workspace,
+             "bn_stats_grouped: null pointer");
+  DG_REQUIRE(M > 0 && C > 0 && (C & 3) == 0 && groups >= 1 && groups <= 65535, "bn_stats_grouped: bad dims M=%ld C=%d groups=%d", (long)M, C, groups);
+  int splits = 0, rps = 0;
+  dim3 grid;
+  colred_geometry(M, C, &splits, &rps, &grid);
+  ColRedArgs a{x, nullptr, nullptr, nullptr, nullptr, nullptr, (double*)workspace, (long)M, C, rps, 0, 0.f, nullptr, 1.f, splits};
+  grid.z = groups;
+  hipLaunchKernelGGL(colred_kernel<0>, grid, dim3(EW_T), 0, ST, a);
+  hipLaunchKernelGGL(bn_finalize_fused_kernel<double>, dim3(cdiv(C, 16)), dim3(256), 0, ST, (const double*)workspace, splits, C,
+                     (long)M, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, scale_out, shift_out,
+                     groups);
+  return check_launch("bn_stats_grouped");
 }
 
 // split count of the two-stage path (1 = single stage); the workspace must hold groups * splits * 2 * C doubles

@@ -20,6 +20,7 @@ nat.register("diagan_act_bwd", [P, P, F, P, F, P, I64, P])
 nat.register("diagan_linear1_bwd_input", [P, P, P, I, I, P])
 nat.register("diagan_linear1_fwd", [P, P, P, P, I, I, P])
 nat.register("diagan_linear1_wgrad", [P, P, P, P, I, I, P])
+nat.register("diagan_bn_stats_grouped", [P, I64, I, I, P, P, F, F, P, P, P, P, P, P, P, P])
 nat.register("diagan_colsum", [P, I64, I, P, I, P, P])
 nat.register("diagan_upsample2x", [P, P, I, I, I, I, I, P, P, I, P])
 nat.register("diagan_upsample2x_bwd", [P, P, I, I, I, I, P, P])
@@ -56,11 +57,11 @@ def _workspace(dev, nbytes):
     return w
 
 
-def _colred_ws(dev, M, C):
+def _colred_ws(dev, M, C, groups=1):
     fn = nat.lib().diagan_colred_workspace
     fn.restype = ctypes.c_int64
     fn.argtypes = [ctypes.c_int64, ctypes.c_int]
-    return _workspace(dev, fn(M, C))
+    return _workspace(dev, fn(M, C) * groups)
 
 
 def nchw_to_nhwc(x, Cp, out=None):
@@ -123,7 +124,11 @@ def bn_stats(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mome
         raise RuntimeError(f"bn_stats: batch of {x.shape[0]} does not split into {groups} groups")
     Mg, bg = M // groups, x.shape[0] // groups
     ctx = _bn_ctx(C, Mg, training, groups, bg, x.device)
-    ws = _colred_ws(x.device, Mg, C) if training else None
+    ws = _colred_ws(x.device, Mg, C, groups) if training else None
+    if training and groups > 1:
+        nat.call("diagan_bn_stats_grouped", ptr(x), Mg, C, groups, ptr(gamma), ptr(beta), eps, momentum, ptr(running_mean),
+                 ptr(running_var), ptr(ctx.mean), ptr(ctx.invstd), ptr(ctx.scale), ptr(ctx.shift), ptr(ws), st())
+        return ctx
     for g in range(groups):
         o = g * C * 4
         nat.call("diagan_bn_stats", ptr(x) + g * Mg * C * 4, Mg, C, ptr(gamma), ptr(beta), eps, momentum,

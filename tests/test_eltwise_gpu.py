@@ -98,3 +98,33 @@ def test_batchnorm_backward_column_sums(M, C, relu):
     far = (y.detach().abs() > 1e-4) if relu else torch.ones(M, C, dtype=torch.bool)
     err = ((gx.reshape(M, C).cpu() - x.grad.float()).abs() * far).max().item()
     assert err <= tol * max(1.0, x.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,C,groups", [(384, 4, 256, 6), (12, 3, 20, 3), (128, 8, 128, 2), (12, 1, 4, 6)])
+def test_grouped_batchnorm_statistics_in_one_launch(B, H, C, groups):
+    """Round 5: the statistics of `groups` stacked batches (the stacked generator forward's first BatchNorm reads the latent
+    linear layer's output: no convolution epilogue to take them from) come from ONE column-reduction launch and ONE finalisation
+    (diagan_bn_stats_grouped) instead of a launch pair per group: every group equals its own torch batch norm in float64, the
+    running statistics equal `groups` successive forwards, and a single-group call gives the same statistics."""
+    from diagan.ops import eltwise as E
+    g = torch.Generator().manual_seed(B + C)
+    x = torch.randn(B, H, H, C, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    ctx = E.bn_stats(x.cuda(), gamma.cuda(), beta.cuda(), rm, rv, True, groups=groups)
+    rm64, rv64 = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    per = B // groups
+    for k in range(groups):
+        xg = x[k * per:(k + 1) * per].double().reshape(-1, C)
+        F.batch_norm(xg, rm64, rv64, None, None, True, 0.1, 1e-5)
+        mean, var = xg.mean(0), xg.var(0, unbiased=False)
+        assert (ctx.mean[k].cpu().double() - mean).abs().max().item() <= 1e-5 * max(1.0, mean.abs().max().item())
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        assert ((ctx.invstd[k].cpu().double() - inv).abs() / inv).max().item() <= 1e-5
+        sc = gamma.double() * inv
+        assert ((ctx.scale[k].cpu().double() - sc).abs() / sc.abs()).max().item() <= 2e-5
+        one = E.bn_stats(x[k * per:(k + 1) * per].cuda().contiguous(), gamma.cuda(), beta.cuda(), torch.zeros(C, device='cuda'),
+                         torch.ones(C, device='cuda'), True)
+        assert (one.mean.reshape(-1) - ctx.mean[k]).abs().max().item() <= 1e-6 * max(1.0, mean.abs().max().item())
+    assert (rm.cpu().double() - rm64).abs().max().item() <= 1e-5 * max(1.0, rm64.abs().max().item())
+    assert ((rv.cpu().double() - rv64).abs() / rv64).max().item() <= 1e-5
