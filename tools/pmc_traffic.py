@@ -21,7 +21,9 @@ def short(name):
     m = re.match(r"(?:void )?diagan::([A-Za-z0-9_]+)(<[^>]*>)?", name)
     if not m:
         return None
-    return m.group(1) + (m.group(2) or "").replace(" ", "")
+    k = m.group(1) + (m.group(2) or "").replace(" ", "")
+    # (conv_wino4_kernel's fourth template argument LEFT is 0 in every production launch: the name bench.py's timer uses has three)
+    return re.sub(r"^(conv_wino4_kernel<\d+,\d+,(?:false|true)),0>$", r"\1>", k)
 
 
 def per_kernel(path, counter):
