@@ -460,7 +460,8 @@ __device__ __forceinline__ void fin_a(const WgFinish& L, int lb, double* red) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const f32x4 g = acc[u];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), dst, voff[u], 0, 0);
+        if (L.splits > 1)        // (one split: G_c IS split 0 of the slab already -- a fifth of this kernel's bytes on SNGAN-64)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, g), dst, voff[u], 0, 0);
         dot += (double)g[0] * wv[u][0] + (double)g[1] * wv[u][1] + (double)g[2] * wv[u][2] + (double)g[3] * wv[u][3];
         acc[u] = z4;
       }
