@@ -727,9 +727,14 @@ def wgrad_batch_shape(geom, B, Ho, Wo, cls):
     bn, bk = (64 if geom.Co <= 64 else 128), (64 if geom.Kp <= 64 else 128)
     if bn == 128 and bk == 64:
         bn = 64
-    return ((geom.Co + bn - 1) // bn) * ((geom.Kp + bk - 1) // bk), (B * Ho * Wo + 31) // 32, 512, 6.0
+    slots = _WG_SLOTS64 if (bn == 64 and bk == 64) else 512
+    return ((geom.Co + bn - 1) // bn) * ((geom.Kp + bk - 1) // bk), (B * Ho * Wo + 31) // 32, slots, 6.0
 
 
+# workgroup slots the split policy assumes for the 64 x 64 weight-gradient tile.  The chip holds four of them per CU (84
+# registers, 32 KB of LDS), but planning for 1024 / 1280 is not faster: SNGAN-32 5277-5283 / 5277-5280 / 5259-5266 images/s,
+# SNGAN-64 3033-3048 / 3030-3035 / 3010-3013 for 512 / 1024 / 1280 on one box
+_WG_SLOTS64 = int(_os.environ.get("DIAGAN_WGRAD_SLOTS64", "512"))
 POOLED_TAG = " [pooled gradient]"     # kernel-timer name suffix of ConvLayer.wgrad_pooled's launches
 
 
