@@ -184,6 +184,13 @@ int diagan_conv_gemm_get_wino4x(void);
  * launch; 1: in-kernel where the kernel has it (the F(2x2) kernel); -1: DIAGAN_SPLITK_FUSED, default OFF: measured neutral
  * (csrc/conv_gemm.hip, splitk_tickets). */
 int diagan_conv_gemm_set_splitk_fused(int mode);
+/* The lone-tile implicit-GEMM launches (at most one 64 x 64 output tile per CU, long K loop: the 8x8 maps of SNGAN-32's discriminator;
+ * tile_cfg 14) on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 pieces, six piece products accumulated
+ * in fp32 (csrc/conv_gemm_x3.hip; fp32-grade results, held to float64 by tests/test_conv_gpu.py).  tile_cfg 16 asks for that kernel
+ * by name (stride 1, Ci % 32 == 0, an even number of 32-channel K-steps, prologue none / ReLU); mode 1 / 0 / -1: automatic use
+ * on / off / DIAGAN_GEMM_X3 (default on: 25.9 -> 23.2 us per launch at M = 8192, N = 128, K = 1152; SNGAN-32 +1.5 %). */
+int diagan_conv_gemm_set_x3(int mode);
+int diagan_conv_gemm_get_x3(void);
 /* tile_cfg 11 / 12 (convolution + 2x2 average pool, and its data gradient from the pooled gradient) run on the same F(4x4) kernel
  * in 25 products per 4x4 tile (frequency row / column 2 never reaches a pooling-window sum) where the launch has >= 192 workgroups
  * and H, W are multiples of 4; this query says whether a geometry does (kernel names, executed-FLOP accounting). */

@@ -196,7 +196,8 @@ __device__ __forceinline__ bool wino_stage_taps(const float* __restrict__ w, int
 // kind 2 = F(2x2,3x3) image of wino_weight_kernel, 40 = F(4x4,3x3) MODE 0 / 3 unit order, 41 = the pooled modes' 25-frequency order;
 // flip: taps reversed (data gradient); scale: 1, or 1/16 for the up-sampled-input mode.  42 / 43 (round 5): the F(4x4,3x3) formats
 // split into three bf16 pieces per element, in the per-wave stream order of the X3 kernels (conv_wino4.hip).
-enum WinoKind : int { WK_F2 = 2, WK_F4 = 40, WK_F4_POOL = 41, WK_F4X = 42, WK_F4X_POOL = 43 };
+// 50 (round 5): not a Winograd format -- the packed GEMM operand split into three bf16 planes [piece][Co][Kp] (conv_gemm_x3.hip)
+enum WinoKind : int { WK_F2 = 2, WK_F4 = 40, WK_F4_POOL = 41, WK_F4X = 42, WK_F4X_POOL = 43, WK_GX3 = 50 };
 struct WinoJob {               // one layer of a batched transform (device table)
   const float* w;              // packed weights [Co][Kp]
   float* u;                    // transformed weights (format's own size: wino_ws_floats / wino4_ws_floats)

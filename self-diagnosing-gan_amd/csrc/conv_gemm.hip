@@ -35,6 +35,9 @@ extern "C" int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo
                                           int off, int up);
 
 namespace diagan {
+int launch_gemm_x3(const ConvGemmArgs& a, float* ws, hipStream_t st);     // conv_gemm_x3.hip: bf16 pipe, exactly split operands
+bool gemm_x3_geom_ok(const ConvGemmArgs& a);
+long gemm_x3_ws_floats(int Co, int Kp);
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
 long wino_ws_floats(int Co, int Ci);
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
@@ -695,6 +698,11 @@ constexpr int kDefaultTune = 0;
 // 36 / 10 split launches per SNGAN-64 / -32 step it buys nothing -- plain partial stores + an agent-scope release per workgroup:
 // -0.5 % (the release writes the L2's dirty lines back); write-through partial stores, no release: +-0.1 % (2998-3005 vs
 // 3003-3008 images/s): draining the stores and the last arriver's serial read-back cost what the 7 us second launch costs.
+static int g_gemm_x3 = -1;                        // -1: DIAGAN_GEMM_X3 / default; 0 / 1: diagan_conv_gemm_set_x3
+static bool gemm_x3_on() {
+  static const int env = getenv("DIAGAN_GEMM_X3") ? atoi(getenv("DIAGAN_GEMM_X3")) : 1;      // on: SNGAN-32 5270-5281 -> 5355 images/s
+  return (g_gemm_x3 >= 0 ? g_gemm_x3 : env) != 0;
+}
 constexpr int kTicketSlots = 1 << 16;
 static int g_splitk_fused = -1;                   // -1: DIAGAN_SPLITK_FUSED / default (on); 0 / 1: diagan_conv_gemm_set_splitk_fused
 static int* splitk_tickets(hipStream_t st) {
@@ -1048,6 +1056,16 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   }
   DG_REQUIRE(!a.res_up, "conv_gemm: a half-resolution residual is added by the Winograd kernel only (tile_cfg 9; ask "
              "diagan_conv_gemm_pick_cfg_geom first)");
+  // the lone-tile launches (tile_cfg 14) on the bf16 pipe with exactly split operands where the geometry qualifies (round 5;
+  // conv_gemm_x3.hip); tile_cfg 16 asks for that kernel by name
+  if (cfg == 16 || (cfg == 14 && tile_cfg == 0 && gemm_x3_on() && gemm_x3_geom_ok(a) && splitk_ws &&
+                    gemm_x3_ws_floats(Co, Kp) <= splitk_ws_floats)) {
+    DG_REQUIRE(gemm_x3_geom_ok(a) && splitk_ws && gemm_x3_ws_floats(Co, Kp) <= splitk_ws_floats,
+               "conv_gemm: tile_cfg 16 (split-operand implicit GEMM) needs stride 1, no up-sampling, Ci %% 32 == 0, an even number of "
+               "32-channel K-steps, Kp == R*S*Ci, prologue none / ReLU, no statistics, and %ld floats of workspace", gemm_x3_ws_floats(Co, Kp));
+    a.ksplit = 1;
+    return launch_gemm_x3(a, splitk_ws, st);
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);
     case 3: return launch_cfg<64, 64, 2, 2, 32, true>(a, st);
@@ -1061,10 +1079,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: return 128; case 3: case 7: case 14: return 64; case 5: case 9: case 11: case 12: return 256; case 13: case 15: return 512; default: return 0; }
+  switch (cfg) { case 1: case 8: return 128; case 3: case 7: case 14: case 16: return 64; case 5: case 9: case 11: case 12: return 256; case 13: case 15: return 512; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: case 15: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: case 15: case 16: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -1197,6 +1215,12 @@ DIAGAN_API int diagan_conv_gemm_set_wino4x(int mode) {
   return DIAGAN_OK;
 }
 DIAGAN_API int diagan_conv_gemm_get_wino4x(void) { return wino4_get_x3(); }
+DIAGAN_API int diagan_conv_gemm_set_x3(int mode) {
+  DG_REQUIRE(mode >= -1 && mode <= 1, "set_x3: -1, 0 or 1");
+  g_gemm_x3 = mode;
+  return DIAGAN_OK;
+}
+DIAGAN_API int diagan_conv_gemm_get_x3(void) { return gemm_x3_on() ? 1 : 0; }
 DIAGAN_API int diagan_conv_gemm_set_splitk_fused(int mode) {
   DG_REQUIRE(mode >= -1 && mode <= 1, "set_splitk_fused: -1, 0 or 1");
   g_splitk_fused = mode;

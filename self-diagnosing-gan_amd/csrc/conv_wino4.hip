@@ -209,7 +209,8 @@ __global__ __launch_bounds__(512) void wino_weights_batched_kernel(const WinoJob
   while (j + 1 < n && (int)blockIdx.x >= jobs[j + 1].blk0) ++j;
   const WinoJob job = jobs[j];
   const int lb = blockIdx.x - job.blk0, nbx = (job.Ci + 31) >> 5;
-  if (job.kind == WK_F4X) wino4x_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
+  if (job.kind == WK_GX3) gx3_weight_job(job.w, job.u, job.Co, job.Kp, lb, nbx * ((job.Co + 63) >> 6));
+  else if (job.kind == WK_F4X) wino4x_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
   else if (job.kind == WK_F4X_POOL) wino4x_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
   else if (job.kind == WK_F4) wino4_weight_body<0>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);
   else if (job.kind == WK_F4_POOL) wino4_weight_body<1>(job.w, job.u, job.Co, job.Ci, job.Kp, job.flip, job.scale, lb % nbx, lb / nbx, sg);

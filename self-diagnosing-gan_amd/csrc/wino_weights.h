@@ -77,6 +77,26 @@ __device__ __forceinline__ void x3_split(const f32x4& v, u32x2& p0, u32x2& p1, u
   p2[1] = __builtin_amdgcn_perm(q[3], q[2], 0x07060302u);
 }
 
+// ---- format WK_GX3 (conv_gemm_x3.hip): the packed GEMM operand itself, split -------------------------------------------
+// packed fp32 weights [Co][Kp] -> three bf16 planes [piece][Co][Kp]; quad = index of a 4-float group
+__device__ __forceinline__ void gx3_split_quad(const float* __restrict__ w, unsigned short* __restrict__ wx, long quad, long plane) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(w + quad * 4);
+  u32x2 p0, p1, p2;
+  x3_split(v, p0, p1, p2);
+  *reinterpret_cast<u32x2*>(wx + quad * 4) = p0;
+  *reinterpret_cast<u32x2*>(wx + plane + quad * 4) = p1;
+  *reinterpret_cast<u32x2*>(wx + 2 * plane + quad * 4) = p2;
+}
+
+// one job of wino_weights_batched_kernel (512 threads per workgroup, `nblk` workgroups for the layer)
+__device__ __forceinline__ void gx3_weight_job(const float* __restrict__ w, float* __restrict__ u, int Co, int Kp, int lb, int nblk) {
+  const long quads = (long)Co * Kp / 4, plane = quads * 4;
+  const long per = (quads + nblk - 1) / nblk;
+  const long q1 = min(quads, (long)(lb + 1) * per);
+  for (long i = (long)lb * per + threadIdx.x; i < q1; i += 512) gx3_split_quad(w, reinterpret_cast<unsigned short*>(u), i, plane);
+}
+
+
 // U for the X3 kernels: the same (G g G^T) as wino4_weight_body, split, in the order ONE WAVE streams it:
 // [64-column block][wave = group + 4 * column half][K-step][slot][piece][column (32)][8 channels bf16] -- a contiguous stream
 // of NS x 1536 bytes per wave and K-step, fetched by that wave in 1 KB LDS-DMA granules through a 4-unit ring.

@@ -16,6 +16,8 @@ nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_gemm_set_splitk_fused", [I])
+nat.register("diagan_conv_gemm_set_x3", [I])
+nat.register("diagan_conv_gemm_get_x3", [])
 nat.register("diagan_conv_wgrad_batched", [P, I, P])
 nat.register("diagan_conv_wgrad_batch_max", [])
 nat.register("diagan_conv_wgrad_batch_class", [I] * 14)
@@ -80,6 +82,9 @@ def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0):
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
         return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
+    if cfg == 16 or (cfg == 14 and mode in (PRO_NONE, PRO_RELU) and Ci % 32 == 0 and Ci > 0 and (9 * Ci // 32) % 2 == 0
+                     and nat.fn("diagan_conv_gemm_get_x3")() > 0):
+        return f"conv_gemm_x3_kernel<{mode}>"      # (3x3 layers: the only lone-tile launches of the networks)
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     kg = ",2" if cfg == 14 else ",1"          # K-groups per workgroup (rocprofv3 prints the defaulted template argument too)
     return f"conv_gemm_kernel<{bm},{bn},{wm},{wn},{bk},{mode},false,{'true' if fp else 'false'}{kg}>"
@@ -274,6 +279,12 @@ def _pro3(pro):
     return tuple(pro)[:3]
 
 
+def set_gemm_x3(on):
+    """True / False: the lone-tile implicit-GEMM launches (tile_cfg 14) run on the bf16 matrix pipe with exactly split operands where
+    their geometry qualifies (csrc/conv_gemm_x3.hip) / on the fp32 pipe; None: what DIAGAN_GEMM_X3 says"""
+    nat.call("diagan_conv_gemm_set_x3", -1 if on is None else (1 if on else 0))
+
+
 def set_splitk_fused(on):
     """True / False: the split-K launches' last-arriving workgroup runs the epilogue / a second launch does; None: the default"""
     nat.call("diagan_conv_gemm_set_splitk_fused", -1 if on is None else (1 if on else 0))
@@ -363,7 +374,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
         # (cached per call signature: on launch-bound workloads the name lookup itself was 6 ms of host time per step)
         key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats, group_imgs)
         kname = _NAME_CACHE.get(key)
-        modes = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")())
+        modes = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")(), nat.fn("diagan_conv_gemm_get_x3")())
         if kname is None or _NAME_CACHE.get('modes') != modes:
             if _NAME_CACHE.get('modes') != modes:
                 _NAME_CACHE.clear()

@@ -286,6 +286,59 @@ def test_first_layer_kernel_from_four_channels(B, H, W, Co):
         close(y2, C.conv_fwd(geom, xc, wp, bias=bias.cuda(), row_scale=(s0, s1), tile_cfg=7), tol=1e-6)
 
 
+@pytest.mark.parametrize("case", [(128, 8, 8, 128, 128), (64, 8, 8, 128, 128), (64, 4, 4, 256, 256), (3, 6, 10, 64, 24), (2, 5, 7, 64, 200)])
+def test_split_operand_implicit_gemm_on_the_bf16_pipe(case):
+    """conv_gemm_x3.hip (round 5, tile_cfg 16): the lone-tile 3x3 launches with every fp32 operand split exactly into three bf16
+    pieces, six piece products accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  fp32-grade: against float64 F.conv2d /
+    conv_transpose2d at the implicit GEMM's own tolerance, forward (ReLU prologue, bias, ReLU-ed residual, the two scales of a
+    paired pass) and data gradient (residual + backward mask), ragged pixel counts and channel counts that fill no tile; and the
+    automatic choice takes it exactly when the switch is on."""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co = case
+    g = torch.Generator().manual_seed(B + Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    bias, res = torch.randn(Co, generator=g), torch.randn(B, Co, H, W, generator=g)
+    geom = C.Geom("conv", Ci, Co, 3, 3, 1, 1)
+    wp = C.pack_oihw(w, geom.Kp).cuda()
+    xc, rc = nhwc(x).cuda(), nhwc(res).cuda()
+    relu = (C.PRO_RELU, None, None)
+    ref = F.conv2d(F.relu(x.double()), w.double(), bias.double(), padding=1) + F.relu(res.double())
+    y = C.conv_fwd(geom, xc, wp, bias=bias.cuda(), residual=rc, res_relu=True, pro=relu, tile_cfg=16)
+    close(nchw(y), ref, tol=2e-5)
+    close(y, C.conv_fwd(geom, xc, wp, bias=bias.cuda(), residual=rc, res_relu=True, pro=relu, tile_cfg=7), tol=2e-5)
+    close(nchw(C.conv_fwd(geom, xc, wp, tile_cfg=16)), F.conv2d(x.double(), w.double(), None, padding=1), tol=2e-5)
+    if B % 2 == 0:
+        s0, s1 = torch.tensor([0.7]).cuda(), torch.tensor([1.9]).cuda()
+        r2 = F.conv2d(x.double(), w.double(), None, padding=1)
+        r2[:B // 2] *= 0.7
+        r2[B // 2:] *= 1.9
+        close(nchw(C.conv_fwd(geom, xc, wp, bias=bias.cuda(), row_scale=(s0, s1), tile_cfg=16)), r2 + bias.double().view(1, -1, 1, 1), tol=2e-5)
+    # data gradient: gathers from dy [B,H,W,Co] with the flipped taps of the packed data-gradient operand
+    wd = torch.zeros(Ci, geom.Kd, device="cuda")
+    C.pack_weights(wp, Co, Ci, 9, geom.Kp, geom.Kd, Wd=wd)
+    gy = torch.randn(B, Co, H, W, generator=g)
+    msk, r0 = torch.randn(B, Ci, H, W, generator=g), torch.randn(B, Ci, H, W, generator=g)
+    if Co % 32 == 0 and (9 * Co // 32) % 2 == 0:
+        dx = C.conv_dgrad(geom, nhwc(gy).cuda(), wd, (H, W), residual=nhwc(r0).cuda(), mask_src=nhwc(msk).cuda(), tile_cfg=16)
+        refd = (F.conv_transpose2d(gy.double(), w.double(), padding=1) + r0.double()) * (msk.double() > 0)
+        close(nchw(dx), refd, tol=2e-5)
+    # the automatic choice: the lone-tile configuration (14) becomes this kernel with the switch on, and only then
+    if (B, H, Ci, Co) == (128, 8, 128, 128):
+        timer = C.KernelTimer()
+        try:
+            C.TIMER = timer
+            for on in (True, False):
+                C.set_gemm_x3(on)
+                y2 = C.conv_fwd(geom, xc, wp, bias=bias.cuda(), residual=rc, res_relu=True, pro=relu)
+                close(nchw(y2), ref, tol=2e-5)
+        finally:
+            C.TIMER = None
+            C.set_gemm_x3(None)
+        names = [r[0] for r in timer.records]
+        assert names[0] == "conv_gemm_x3_kernel<1>" and names[1].startswith("conv_gemm_kernel<64,64"), names
+
+
 @pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
 @pytest.mark.parametrize("pro", [0, 1, 2])
 def test_small_co_kernel_wgrad(Ci, H, W, B, pro):
