@@ -1056,9 +1056,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   }
   DG_REQUIRE(!a.res_up, "conv_gemm: a half-resolution residual is added by the Winograd kernel only (tile_cfg 9; ask "
              "diagan_conv_gemm_pick_cfg_geom first)");
-  // the lone-tile launches (tile_cfg 14) on the bf16 pipe with exactly split operands where the geometry qualifies (round 5;
-  // conv_gemm_x3.hip); tile_cfg 16 asks for that kernel by name
-  if (cfg == 16 || (cfg == 14 && tile_cfg == 0 && gemm_x3_on() && gemm_x3_geom_ok(a) && splitk_ws &&
+  // the lone-tile 3x3 launches (tile_cfg 14) on the bf16 pipe with exactly split operands where the geometry qualifies (round 5;
+  // conv_gemm_x3.hip; the 1x1 shortcuts stay: a few K-steps, and their call sites hand over no pre-split weights); tile_cfg 16
+  // asks for that kernel by name
+  if (cfg == 16 || (cfg == 14 && tile_cfg == 0 && R == 3 && S == 3 && gemm_x3_on() && gemm_x3_geom_ok(a) && splitk_ws &&
                     gemm_x3_ws_floats(Co, Kp) <= splitk_ws_floats)) {
     DG_REQUIRE(gemm_x3_geom_ok(a) && splitk_ws && gemm_x3_ws_floats(Co, Kp) <= splitk_ws_floats,
                "conv_gemm: tile_cfg 16 (split-operand implicit GEMM) needs stride 1, no up-sampling, Ci %% 32 == 0, an even number of "

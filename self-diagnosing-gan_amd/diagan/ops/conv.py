@@ -68,7 +68,7 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
                7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True), 14: (64, 64, 2, 2, 32, True)}
 
 
-def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0):
+def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0, RS=9):
     """the kernel's name as rocprofv3 prints it (the F(4x4) kernel's third template argument: the bf16-split build, which a
     launch takes only with the switch on and a K loop of a multiple of four steps)"""
     if cfg in (11, 12) and w4pool:            # the pooled launches on the F(4x4) kernel (MODE 1 / 2)
@@ -82,7 +82,7 @@ def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0):
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
         return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
-    if cfg == 16 or (cfg == 14 and mode in (PRO_NONE, PRO_RELU) and Ci % 32 == 0 and Ci > 0 and (9 * Ci // 32) % 2 == 0
+    if cfg == 16 or (cfg == 14 and RS == 9 and mode in (PRO_NONE, PRO_RELU) and Ci % 32 == 0 and Ci > 0 and (9 * Ci // 32) % 2 == 0
                      and nat.fn("diagan_conv_gemm_get_x3")() > 0):
         return f"conv_gemm_x3_kernel<{mode}>"      # (3x3 layers: the only lone-tile launches of the networks)
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
@@ -382,7 +382,7 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
             allow = 0 if want_stats else 1
             kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(
                 B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co,
-                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())), Ci=Ci)
+                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())), Ci=Ci, RS=R * S)
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     _hint(wsite, wversion)

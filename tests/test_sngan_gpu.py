@@ -193,13 +193,16 @@ def test_full_batch_updates_match_oracle_through_the_fused_kernels(dataset, res)
 
 @pytest.fixture
 def wino4_mode(request):
-    """'off': the F(4x4,3x3) kernels (tile_cfg 13 / 15 and the pooled launches on them) are not selected -- the arithmetic the
-    rounds before 3 made their parity claims with (F(2x2) + implicit GEMM); restored afterwards"""
+    """'off': the F(4x4,3x3) kernels (tile_cfg 13 / 15 and the pooled launches on them) and the split-operand implicit GEMM of
+    round 5 (tile_cfg 16) are not selected -- the arithmetic the rounds before 3 made their parity claims with (F(2x2) + the exact
+    fp32 implicit GEMM); restored afterwards"""
     from diagan.ops import conv as C
     if request.param == "off":
         C.set_winograd4(False)
+        C.set_gemm_x3(False)
     yield request.param
     C.set_winograd4(None)
+    C.set_gemm_x3(None)
 
 
 @pytest.mark.parametrize("dataset,res,wino4_mode", [("cifar10", 32, "default"), ("celeba", 64, "default"), ("cifar10", 32, "off")],

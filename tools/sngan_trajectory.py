@@ -5,7 +5,7 @@ diagan-pkg/diagan/trainer/trainer.py:238-299).  GPU box.
 N global steps (n_dis = 5 D updates + 1 G update, Adam, batch 64) from identical weights, with the SAME injected real batches and
 latent noise, four ways:
   hip default     the engine as shipped (Winograd F(4x4,3x3) / F(2x2,3x3) where they qualify)
-  hip exact-fp32  DIAGAN_WINO=0 DIAGAN_WINO4=0: the implicit GEMM everywhere (an fp32 fmaf chain per output)
+  hip exact-fp32  DIAGAN_WINO=0 DIAGAN_WINO4=0 DIAGAN_GEMM_X3=0: the fp32 implicit GEMM everywhere (an fmaf chain per output)
   cpu fp32        oracle/nets.py (plain PyTorch CPU autograd)
   cpu float64     oracle/nets.py in double: the reference trajectory
 Per step: |errD - errD64| (mean over the step's D updates), |errG - errG64|, and the distance of all parameters to the float64
@@ -71,9 +71,11 @@ def trajectories(dataset="cifar10", steps=20, B=64, n_dis=5, loss="ns", seed=1, 
     def hip_run(mode):
         C.set_winograd(None)
         C.set_winograd4(None)
+        C.set_gemm_x3(None)
         if mode == "exact-fp32":
             C.set_winograd(False)
             C.set_winograd4(False)
+            C.set_gemm_x3(False)               # (the split-operand implicit GEMM of round 5 is fp32-grade, not an fmaf chain)
         try:
             torch.manual_seed(seed)
             netG, netD, optG, optD = get_gan_model(dataset, model='sngan', loss_type=loss)
@@ -99,6 +101,7 @@ def trajectories(dataset="cifar10", steps=20, B=64, n_dis=5, loss="ns", seed=1, 
         finally:
             C.set_winograd(None)
             C.set_winograd4(None)
+            C.set_gemm_x3(None)
 
     p0 = torch.cat([_flat64(oG.named_parameters()), _flat64(oD.named_parameters())])
     runs = {"cpu float64": cpu_run(True), "cpu fp32": cpu_run(False)}
