@@ -39,6 +39,15 @@ import torch
 
 MFMA_F32_PEAK = 157.3e12      # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
 HBM_PEAK = 8.0e12
+BF16_X3_PEAK = 2.5e15 / 6     # split-operand kernels (conv_gemm_x3.hip, conv_gemm_x3b.hip, the X3 build of conv_wino4.hip): dense bf16
+                              # MFMA peak / six piece products per fp32 product = 416.7 TFLOP/s of fp32-equivalent products
+
+
+def kernel_peak(name):
+    """FLOP/s peak of the matrix pipe the kernel `name` runs its products on"""
+    if name.startswith(("conv_gemm_x3", "conv_wgrad_x3")) or (name.startswith("conv_wino4_kernel") and name.rstrip().endswith(",true>")):
+        return BF16_X3_PEAK
+    return MFMA_F32_PEAK
 
 WORKLOADS = {
     # name: (dataset key, resolution, description)
@@ -275,7 +284,9 @@ def sngan64_leg(args, device, steps=10, warmup=3):
                           "2*M*Co*R*S*Ci of SURVEY 8(d) in full / time / peak -- the work the reference's conv costs; it "
                           "exceeds 1 because the Winograd kernels skip 56-75 % of those products",
             "kernels": {k: {"launches": v[0], "algorithmic_tflops": round(v[1] / v[2] / 1e12, 2),
-                            "executed_tflops": round(executed_flop(k, v[1]) / v[2] / 1e12, 2), "ms_per_step": round(v[2] / 2 * 1e3, 3)}
+                            "executed_tflops": round(executed_flop(k, v[1]) / v[2] / 1e12, 2),
+                            "frac_of_own_pipe": round(executed_flop(k, v[1]) / v[2] / kernel_peak(k), 4),
+                            "ms_per_step": round(v[2] / 2 * 1e3, 3)}
                         for k, v in sorted(per_kernel.items())}}
 
 
@@ -299,6 +310,47 @@ def phase2_leg(args, device, steps=10, warmup=3):
     return {"workload": desc + " + D_drs (phase 2, ldr_conf_0.3_ratio_50 sampling is host-side and off the step)",
             "steps": steps, "warmup": warmup, "images_per_s": round(args.batch_size * steps / el, 2),
             "ms_per_step": round(el / steps * 1e3, 3)}
+
+
+def stylegan2_leg(device, size=256, batch=32, warmup=3, steps=8, table_iters=4):
+    """BASELINE.json configs[4] on the driver's own line: iterations of stylegan2/train_ffhq.py (D step, G step, EMA; lazy R1
+    every 16th and path-length regularisation every 4th iteration; reference loop stylegan2/train_ffhq.py:163-382, nets
+    diagan-pkg/diagan/models/stylegan2.py:224-265,274-285,597-614) at 256 x 256, batch 32, one GPU.  Un-scored leg after the timed
+    region.  Iteration 0 (warm-up) runs both regularisers; the timed iterations 3 .. 10 hold two path-length passes (the steady
+    1-in-4) and no R1 pass (steady state: 1 in 16).  gemm_*: HIP events around every convolution / weight-gradient launch of
+    `table_iters` further iterations (one path-length pass among four)."""
+    from diagan.ops import conv as C
+    step = make_stylegan2_step(size, batch, 1, device)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    C.TIMER = full = C.KernelTimer()
+    try:
+        for _ in range(table_iters):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        C.TIMER = None
+    flop = xflop = secs = 0.0
+    for name, d in full.summary().items():
+        flop += d['flop']
+        xflop += executed_flop(name, d['flop'])
+        secs += d['seconds']
+    ms_iter, gemm_ms = el / steps * 1e3, secs / table_iters * 1e3
+    return {"workload": WORKLOADS['stylegan2'][2], "steps": steps, "warmup": warmup,
+            "images_per_s": round(batch * steps / el, 2), "ms_per_iter": round(ms_iter, 3),
+            "gemm_ms_per_iter": round(gemm_ms, 3), "non_gemm_ms": round(ms_iter - gemm_ms, 3),
+            "gemm_frac_executed": round(xflop / secs / MFMA_F32_PEAK, 4),
+            "gemm_frac_algorithmic": round(flop / secs / MFMA_F32_PEAK, 4),
+            "definition": "gemm_*: convolution, data- and weight-gradient launches (implicit GEMM + Winograd kernels) by HIP events "
+                          "in 4 un-timed iterations; non_gemm_ms = ms_per_iter - gemm_ms_per_iter (FIR, activations, modulation, "
+                          "autograd glue, optimiser); frac against the 157.3 TFLOP/s fp32 MFMA peak, executed / algorithmic as in "
+                          "roofline.accounting"}
 
 
 def logit_pass_leg(device, N=50000, loader_batch=64):
@@ -569,7 +621,8 @@ def main():
     # BASELINE configs[2]) and the logit-record pass.  Un-scored, after the timed region, exception-proof.
     extra_legs = {}
     if (world == 1 and args.workload == 'sngan32' and args.phase == 1 and not args.no_sngan64_leg and not args.graph):
-        for key, leg in (("phase2", lambda: phase2_leg(args, device)), ("logit_pass", lambda: logit_pass_leg(device))):
+        for key, leg in (("phase2", lambda: phase2_leg(args, device)), ("logit_pass", lambda: logit_pass_leg(device)),
+                         ("stylegan2", lambda: stylegan2_leg(device))):
             try:
                 extra_legs[key] = leg()
             except Exception as e:
@@ -636,8 +689,8 @@ def main():
                 m_out = M / 4 if (mode == 1 or (mp is not None and not unpool)) else M
                 tot += v['launches'] * 4.0 * (m_in * K / 9 + m_out * Co + Co * K)
             alg_bytes = tot / d['launches'] if tot else None
-        peak = MFMA_F32_PEAK
-        x3 = name.startswith("conv_wino4_kernel") and name.endswith(",true>")     # the bf16-split build (DIAGAN_WINO4_X3=1)
+        peak = kernel_peak(name)                 # the pipe THIS kernel runs on (fp32 MFMA, or bf16 MFMA with split operands)
+        x3 = peak != MFMA_F32_PEAK
         line["roofline"] = {
             "kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak / 1e12, 1),
             "unit": "TFLOP/s", "frac": round(achieved * 1e12 / peak, 4), "frac_executed": round(achieved * 1e12 / peak, 4),
@@ -647,7 +700,7 @@ def main():
             "traffic_source": "profiles/pmc_traffic.json (static: separate rocprofv3 --pmc passes of this command, "
                               "2*FETCH_SIZE + WRITE_SIZE per launch; not measured by this run)" if traffic else None,
             "pipe": ("bf16 MFMA with every fp32 operand split in three (six piece products per fp32 product): the dense bf16 "
-                     "peak / 6 = 416.7 TFLOP/s of fp32-equivalent products; frac is still quoted against the fp32 MFMA peak"
+                     "peak / 6 = 416.7 TFLOP/s of fp32-equivalent products, which is the peak frac is quoted against"
                      if x3 else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"),
             "launches": d['launches'], "avg_launch_us": round(d['seconds'] / d['launches'] * 1e6, 2),
             "algorithmic_gflop_per_launch": round(d['flop'] / d['launches'] / 1e9, 3),
@@ -661,6 +714,7 @@ def main():
             "all_gemm_kernels_2_untimed_steps": {
                 k: {"launches": v['launches'], "algorithmic_tflops": round(v['flop'] / v['seconds'] / 1e12, 2),
                     "executed_tflops": round(executed_flop(k, v['flop']) / v['seconds'] / 1e12, 2),
+                    "frac_of_own_pipe": round(executed_flop(k, v['flop']) / v['seconds'] / kernel_peak(k), 4),
                     "ms_per_step": round(v['seconds'] / 2 * 1e3, 3)} for k, v in sorted(summ_all.items())},
         }
     if s64 is not None:

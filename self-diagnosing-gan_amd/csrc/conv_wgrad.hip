@@ -740,7 +740,8 @@ DIAGAN_API int diagan_conv_wgrad_batch_class(int Hi, int Wi, int Ci, int Ho, int
   if (diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp)) return 100 + pro_mode;
   int bn, bk;
   wgrad_tile(Co, Kp, &bn, &bk);
-  if (bn == 64 && bk == 64) return 1000;
+  // (the 64 x 64 tile has no box-sum loader -- the one-layer launch rejects those modes on it -- so such a layer launches alone)
+  if (bn == 64 && bk == 64) return pro_mode >= PRO_BOX ? 0 : 1000;
   if (pro_mode != PRO_NONE && pro_mode != PRO_RELU && pro_mode != PRO_BOX && pro_mode != PRO_BOX_RELU) return 0;
   const bool p2 = (Ho & (Ho - 1)) == 0 && (Wo & (Wo - 1)) == 0;
   return 2000 + (bn == 128 ? 100 : 0) + 2 * pro_mode + (p2 ? 1 : 0);

@@ -587,6 +587,7 @@ class SNBatch:
 
 
 class WgradBatch:
+    QUEUE_BYTES = int(os.environ.get("DIAGAN_WGRAD_QUEUE_BYTES", str(8 << 30)))     # early-flush threshold of a slot's queue
     """Deferred weight-gradient epilogue of one network.
 
     Every parameterised GEMM layer owns one split-K slab per context slot; conv_wgrad_kernel writes its
@@ -607,8 +608,12 @@ class WgradBatch:
         self.pending = []
         self.overlapped = 0      # updates whose reduction was split (tests)
         # Winograd weight gradients wait here until the end of the pass and then run as ONE launch per prologue mode
-        # (ops/conv.py: conv_wgrad_batched); the queue keeps dy and x alive
+        # (ops/conv.py: conv_wgrad_batched); the queue keeps dy and x alive.  Memory: every batchable layer's dy and x stay
+        # allocated until finish() instead of being freed as the backward pass moves on -- at most the activations + gradients
+        # of one pass (SNGAN-64 at batch 64: ~1.3 GB, StyleGAN2 does not use this queue), bounded by QUEUE_BYTES below: a slot
+        # whose queue passes it is flushed early (the layers so far launch as their own batch)
         self.queue = {}          # slot -> [(layer, dy, x, pro, segments, entry)]
+        self.queued_bytes = {}   # slot -> bytes of dy + x the queue keeps alive
         self.batch_plans = {}    # (layer ids, shapes) -> splits per layer
         self.batched_launches = 0
 
@@ -663,7 +668,11 @@ class WgradBatch:
             cls = 0 if (segments == 1 and C.small_co_wgrad(g)) else C.wgrad_batch_class(
                 g, xs[1], xs[2], dy.shape[1], dy.shape[2], int(pro[0]) if pro is not None else 0)
             if cls:
-                self.queue.setdefault(slot, []).append((layer, dy, x, pro, segments, e, g, (cls, geom is not None)))
+                q = self.queue.setdefault(slot, [])
+                q.append((layer, dy, x, pro, segments, e, g, (cls, geom is not None)))
+                self.queued_bytes[slot] = self.queued_bytes.get(slot, 0) + 4 * (dy.numel() + x.numel())
+                if self.queued_bytes[slot] > self.QUEUE_BYTES:
+                    self.flush(slot)
                 return
         C.conv_wgrad_into(geom if geom is not None else layer.geom, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'],
                           pro=pro, segments=segments, pooled=geom is not None)
@@ -673,6 +682,7 @@ class WgradBatch:
         strided form apart, for the FLOP accounting) and per wgrad_batch_max() layers, every layer with the split count the
         group's plan gives it; a group of one runs as an ordinary launch"""
         jobs = self.queue.pop(slot, None)
+        self.queued_bytes.pop(slot, None)
         if not jobs:
             return
         groups = {}
@@ -836,20 +846,19 @@ class FlatNet(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
+            if k == 'wgrad_batch':            # (its entries hold per-layer slabs and queued dy / x of the ORIGINAL: a fresh one)
+                continue
             new.__dict__[k] = {} if k == '_wino_batches' else (None if k in ('_flat', '_flat_grad') else copy.deepcopy(v, memo))
+        new.__dict__['wgrad_batch'] = WgradBatch(new)
         for m in new.modules():
             if isinstance(m, ConvLayer):
                 m.__dict__.pop('_wsites', None)
                 m._wd = None
-        # nn.Parameter.__deepcopy__ CLONES its data: the copy's parameters are no views of a slab any more.  Give the copy
-        # its own slabs (parameters and gradients re-pointed, gradient values carried over) -- otherwise its fused Adam /
-        # zero_grad / gradient exchange would act on a slab nobody reads
+        # nn.Parameter.__deepcopy__ CLONES its data and drops .grad: the copy's parameters are no views of a slab any more.
+        # Give the copy its own slabs (parameters re-pointed, gradients zero like a fresh network's) -- otherwise its fused
+        # Adam / zero_grad / gradient exchange would act on a slab nobody reads
         if self._flat is not None:
-            grads = [None if p.grad is None else p.grad.detach().clone() for p in new.parameters()]
             new._build_flat()
-            for p, g in zip(new.parameters(), grads):
-                if g is not None:
-                    p.grad.copy_(g)
         new.slab_generation = self.slab_generation + 1
         return new
 
@@ -890,6 +899,7 @@ class FlatNet(nn.Module):
         self._flat_grad.zero_()
         self.wgrad_batch.hold, self.wgrad_batch.pending = False, []
         self.wgrad_batch.queue.clear()
+        self.wgrad_batch.queued_bytes.clear()
 
     @property
     def flat_params(self):

@@ -685,6 +685,11 @@ def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0):
     if _WG_JOB is None:
         _WG_JOB = np.dtype([('p', np.uint64, 5), ('l', np.int64, 2), ('i', np.int32, 18)])
         assert _WG_JOB.itemsize == 128
+    if key is not None:
+        # id() values in the caller's key are recycled once a net is freed: everything the cached constant columns hold is part of
+        # the key, so that a new layer with an old id and another geometry builds its own table
+        key = (key,) + tuple((g.kind, g.Ci, g.Co, g.R, g.S, g.stride, g.pad, g.Kp, tuple(dy.shape), tuple(x.shape), sp, st, bo,
+                              _pro3(pro)[0], seg) for g, dy, x, _, sp, st, bo, pro, seg in jobs)
     cached = _WG_TABS.get(key) if key is not None else None
     if cached is None:
         tab = np.zeros(len(jobs), dtype=_WG_JOB)

@@ -147,8 +147,14 @@ class LogTrainer:
         # ... only where the loader visits every index exactly once (uniform shuffling or sequential): the reference walks
         # `self.dataloader`, and with phase 2's WeightedRandomSampler (replacement=True) the indices it never draws keep the
         # row's initial zeros (trainer.py:142-156: np.zeros + assignment by index) -- that record is reproduced by the walk
-        complete = shard is not None or isinstance(getattr(loader, 'sampler', None),
-                                                   (torch.utils.data.RandomSampler, torch.utils.data.SequentialSampler))
+        # (a RandomSampler with replacement / a num_samples of its own does NOT visit every index once: that walk is reproduced
+        #  like the weighted one.  Assumption of the sliced path, stated: fetching items consumes no global RNG -- tensor-backed
+        #  datasets have no random transforms -- so `iter(loader)` + one `next` leaves the generator where the full walk would.)
+        smp = getattr(loader, 'sampler', None)
+        once = (isinstance(smp, torch.utils.data.SequentialSampler)
+                or (isinstance(smp, torch.utils.data.RandomSampler) and not getattr(smp, 'replacement', False)
+                    and getattr(smp, '_num_samples', None) is None))
+        complete = shard is not None or once
         ranged = (group > 0 and complete and hasattr(ds, 'fetch_range') and hi > lo
                   and ds.fetch_range(lo, lo + 1) is not None)
         with torch.no_grad():
