@@ -191,6 +191,27 @@ int diagan_conv_gemm_set_splitk_fused(int mode);
  * on / off / DIAGAN_GEMM_X3 (default on: 25.9 -> 23.2 us per launch at M = 8192, N = 128, K = 1152; SNGAN-32 +1.5 %). */
 int diagan_conv_gemm_set_x3(int mode);
 int diagan_conv_gemm_get_x3(void);
+/* Round 6: the LARGE implicit-GEMM launches no Winograd kernel takes -- StyleGAN2's 3x3 / stride 2 convolutions, the 2x2 / 2x1 / 1x2 /
+ * 1x1 parity classes of its stride-2 transposed convolutions and its 1x1 convolutions (reference: F.conv2d / F.conv_transpose2d in
+ * diagan-pkg/diagan/models/stylegan2.py:224-265,553-614) -- on the bf16 matrix pipe with the same exact three-way operand split, 128 x 128
+ * output tiles, two workgroups per CU (csrc/conv_gemm_x3b.hip; fp32-grade results, held to float64 by tests/test_conv_gpu.py).
+ * tile_cfg 17 asks for that kernel by name (no up-sampling gather, Ci % 32 == 0, Kp == R*S*Ci, prologue none / ReLU / leaky ReLU,
+ * epilogue out_scale + bias + residual only); mode 1 / 0 / -1: the automatic upgrade of an implicit-GEMM pick with >= 192 tiles of
+ * 128 x 128 and >= 4 K-steps on / off / DIAGAN_GEMM_X3B (default on). */
+int diagan_conv_gemm_set_x3b(int mode);
+int diagan_conv_gemm_get_x3b(void);
+/* Output map of the NEXT diagan_conv_gemm call of the calling thread (held for exactly one call, like the weights hint): pixel
+ * (b, oy, ox) of the launch's Ho x Wo output grid is written to (b, mul*(oy-y0)+offy, mul*(ox-x0)+offx) of y[B][OH][OW][Co] (residual,
+ * if given, is read there too); pixels outside [y0,y1) x [x0,x1) are dropped.  Written by tile_cfg 17 only (the call fails otherwise:
+ * ask diagan_conv_gemm_final_cfg first).  Use: the four dense parity classes of a stride-2 transposed convolution interleave
+ * themselves (mul = 2) instead of being copied into place.  mul = 0 clears a pending map. */
+int diagan_conv_gemm_out_map(int mul, int offy, int offx, int y0, int y1, int x0, int x1, int OH, int OW);
+/* The tile configuration diagan_conv_gemm(tile_cfg = 0) ends up with, including the upgrades to the split-operand kernels (16, 17)
+ * that the pick_cfg queries do not model.  plain_epilogue: no backward mask, per-half scales, ReLU on the residual or half-resolution
+ * residual; want_stats: BatchNorm statistics from the epilogue are requested. */
+int diagan_conv_gemm_final_cfg(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off, int up,
+                               int Kp, int allow_split, int64_t ws_floats, int pro_group_rows, int pro_mode, int plain_epilogue,
+                               int want_stats);
 /* tile_cfg 11 / 12 (convolution + 2x2 average pool, and its data gradient from the pooled gradient) run on the same F(4x4) kernel
  * in 25 products per 4x4 tile (frequency row / column 2 never reaches a pooling-window sum) where the launch has >= 192 workgroups
  * and H, W are multiples of 4; this query says whether a geometry does (kernel names, executed-FLOP accounting). */

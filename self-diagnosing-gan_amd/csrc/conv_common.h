@@ -94,6 +94,13 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
   return (t + ((n - t) >> 1)) >> (f.shift - 1);
 }
 
+// Output map of a launch that writes into a LARGER tensor (conv_gemm_x3b.hip only; mul == 0: off): pixel (b, oy, ox) of the launch's
+// own Ho x Wo grid goes to (b, mul * (oy - y0) + offy, mul * (ox - x0) + offx) of y[B][OH][OW][Co]; pixels outside [y0, y1) x [x0, x1)
+// are computed and dropped.  The parity classes of a stride-2 transposed gather use it (mul = 2).
+struct OutMap {
+  int mul, offy, offx, y0, y1, x0, x1, OH, OW;
+};
+
 // Arguments of the forward / data-gradient kernels (conv_gemm.hip: implicit GEMM; conv_wino.hip: Winograd F(2x2,3x3))
 struct ConvGemmArgs {
   const float* x;         // gathered tensor, NHWC [B,Hi,Wi,Ci]
@@ -129,6 +136,7 @@ struct ConvGemmArgs {
   int tune;               // tuning sweeps: bit 0 = raised wave priority while the loader state is set up and the first
                           // tile staged, bit 1 = raised priority in the epilogue (a new / finishing wave otherwise gets
                           // the vector-issue slots its older MFMA-bound neighbours leave over)
+  OutMap map;             // see OutMap (all zero: y is [B][Ho][Wo][Co])
 };
 
 // Arguments of the weight-gradient kernels (conv_wgrad.hip: implicit GEMM; conv_wgrad_wino.hip: Winograd F(3x3,2x2))

@@ -38,6 +38,9 @@ namespace diagan {
 int launch_gemm_x3(const ConvGemmArgs& a, float* ws, hipStream_t st);     // conv_gemm_x3.hip: bf16 pipe, exactly split operands
 bool gemm_x3_geom_ok(const ConvGemmArgs& a);
 long gemm_x3_ws_floats(int Co, int Kp);
+int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st);    // conv_gemm_x3b.hip: the same arithmetic on 128 x 128 tiles
+bool gemm_x3b_geom_ok(const ConvGemmArgs& a);
+long gemm_x3b_ws_floats(int Co, int Kp);
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
 long wino_ws_floats(int Co, int Ci);
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
@@ -703,6 +706,27 @@ static bool gemm_x3_on() {
   static const int env = getenv("DIAGAN_GEMM_X3") ? atoi(getenv("DIAGAN_GEMM_X3")) : 1;      // on: SNGAN-32 5270-5281 -> 5355 images/s
   return (g_gemm_x3 >= 0 ? g_gemm_x3 : env) != 0;
 }
+// tile_cfg 17 (round 6, conv_gemm_x3b.hip): the large implicit GEMMs on the bf16 pipe with split operands.  -1: DIAGAN_GEMM_X3B /
+// default; 0 / 1: diagan_conv_gemm_set_x3b.  The automatic choice upgrades an implicit-GEMM pick (never a Winograd one) where the
+// launch has at least `kX3bMinTiles` 128 x 128 tiles (two workgroups per CU: one round of the chip) and four K-steps.
+static int g_gemm_x3b = -1;
+static bool gemm_x3b_on() {
+  static const int env = getenv("DIAGAN_GEMM_X3B") ? atoi(getenv("DIAGAN_GEMM_X3B")) : 1;
+  return (g_gemm_x3b >= 0 ? g_gemm_x3b : env) != 0;
+}
+static int x3b_min_tiles() {
+  static const int env = getenv("DIAGAN_GEMM_X3B_MIN_TILES") ? atoi(getenv("DIAGAN_GEMM_X3B_MIN_TILES")) : 192;
+  return env;
+}
+static bool x3b_takes(const ConvGemmArgs& a, int cfg, int64_t ws_floats) {
+  if (!gemm_x3b_on() || !(cfg == 1 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8)) return false;
+  const ConvGeom& g = a.g;
+  return gemm_x3b_geom_ok(a) && g.Kp >= 128 && g.Co >= 64 && (long)cdiv(a.M, 128) * cdiv(g.Co, 128) >= x3b_min_tiles() &&
+         gemm_x3b_ws_floats(g.Co, g.Kp) <= ws_floats;
+}
+// the output map of the NEXT diagan_conv_gemm call of this thread (diagan_conv_gemm_out_map); like the weights hint it holds for
+// exactly one call
+static thread_local OutMap g_map_next = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 constexpr int kTicketSlots = 1 << 16;
 static int g_splitk_fused = -1;                   // -1: DIAGAN_SPLITK_FUSED / default (on); 0 / 1: diagan_conv_gemm_set_splitk_fused
 static int* splitk_tickets(hipStream_t st) {
@@ -882,6 +906,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   g_hint_now = g_hint_next;                 // a hint holds for exactly one call, whatever path that call takes
   g_hint_next = WinoFormat{nullptr, 0, 0, 0.f, 0};
   g_fmt_last = WinoFormat{nullptr, 0, 0, 0.f, 0};
+  const OutMap map = g_map_next;            // ... and so does an output map
+  g_map_next = OutMap{0, 0, 0, 0, 0, 0, 0, 0, 0};
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
@@ -911,12 +937,25 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
-  hipStream_t st = (hipStream_t)stream;
-  const int cfg = tile_cfg != 0 ? tile_cfg
-                                : diagan_conv_gemm_pick_cfg_grouped(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp,
-                                                                    (splitk_ws && !stat_partials) ? 1 : 0,
-                                                                    splitk_ws ? splitk_ws_floats : 0, pro_group_rows);
+  a.map = map;
+  a.stat_partials = stat_partials;
   a.pro_group_rows = pro_group_rows;
+  hipStream_t st = (hipStream_t)stream;
+  int cfg = tile_cfg != 0 ? tile_cfg
+                          : diagan_conv_gemm_pick_cfg_grouped(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp,
+                                                              (splitk_ws && !stat_partials) ? 1 : 0,
+                                                              splitk_ws ? splitk_ws_floats : 0, pro_group_rows);
+  if (tile_cfg == 0 && splitk_ws && x3b_takes(a, cfg, splitk_ws_floats)) cfg = 17;
+  if (map.mul != 0) {
+    DG_REQUIRE(map.mul > 0 && map.OH > 0 && map.OW > 0 && map.y0 >= 0 && map.x0 >= 0 && map.y1 <= Ho && map.x1 <= Wo &&
+                   map.offy >= 0 && map.offx >= 0 && (map.y1 <= map.y0 || map.mul * (map.y1 - 1 - map.y0) + map.offy < map.OH) &&
+                   (map.x1 <= map.x0 || map.mul * (map.x1 - 1 - map.x0) + map.offx < map.OW) &&
+                   (long)B * map.OH * map.OW * Co * 4 < (1L << 31),
+               "conv_gemm: output map (mul %d, off %d/%d, window [%d,%d) x [%d,%d), target %d x %d) does not fit", map.mul, map.offy,
+               map.offx, map.y0, map.y1, map.x0, map.x1, map.OH, map.OW);
+    DG_REQUIRE(cfg == 17, "conv_gemm: an output map is written by the split-operand kernel only (tile_cfg 17; ask "
+               "diagan_conv_gemm_final_cfg first)");
+  }
   const int bm = diagan_conv_gemm_tile_rows(cfg);
   DG_REQUIRE(bm > 0, "conv_gemm: unknown tile_cfg %d (0 = auto, 1 = 128x128, 3 = 64x64, 5 = 256x64, 7 = 64x64 with fragment "
              "prefetch, 8 = 128x64 with fragment prefetch, 9 = Winograd F(2x2,3x3), 11 / 12 = Winograd + average pool and its data-gradient, 13 = Winograd F(4x4,3x3), 15 = the same on the bilinear x2 of a half-resolution input; 2, 4, 6, 10 were retired)", tile_cfg);
@@ -925,7 +964,6 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.slab = splitk_ws;
   a.tickets = nullptr;
   a.ksplit = 1;
-  a.stat_partials = stat_partials;
   a.tune = g_tune_flags >= 0 ? g_tune_flags : kDefaultTune;
   a.stamps = nullptr;
   if (g_stamps) {
@@ -1067,6 +1105,14 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     a.ksplit = 1;
     return launch_gemm_x3(a, splitk_ws, st);
   }
+  if (cfg == 17) {
+    DG_REQUIRE(gemm_x3b_geom_ok(a) && splitk_ws && gemm_x3b_ws_floats(Co, Kp) <= splitk_ws_floats,
+               "conv_gemm: tile_cfg 17 (split-operand implicit GEMM, 128 x 128 tiles) needs a gather without up-sampling, Ci %% 32 == 0, "
+               "Kp == R*S*Ci, prologue none / ReLU / leaky ReLU, a plain epilogue (out_scale, bias, residual) and %ld floats of workspace",
+               gemm_x3b_ws_floats(Co, Kp));
+    a.ksplit = 1;
+    return launch_gemm_x3b(a, splitk_ws, st);
+  }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);
     case 3: return launch_cfg<64, 64, 2, 2, 32, true>(a, st);
@@ -1080,10 +1126,10 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
 
 // rows / columns of a tile configuration (0 for an unknown one)
 DIAGAN_API int diagan_conv_gemm_tile_rows(int cfg) {
-  switch (cfg) { case 1: case 8: return 128; case 3: case 7: case 14: case 16: return 64; case 5: case 9: case 11: case 12: return 256; case 13: case 15: return 512; default: return 0; }
+  switch (cfg) { case 1: case 8: case 17: return 128; case 3: case 7: case 14: case 16: return 64; case 5: case 9: case 11: case 12: return 256; case 13: case 15: return 512; default: return 0; }
 }
 DIAGAN_API int diagan_conv_gemm_tile_cols(int cfg) {
-  switch (cfg) { case 1: case 11: case 12: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: case 15: case 16: return 64; default: return 0; }
+  switch (cfg) { case 1: case 11: case 12: case 17: return 128; case 3: case 5: case 7: case 8: case 9: case 13: case 14: case 15: case 16: return 64; default: return 0; }
 }
 
 // Winograd F(2x2,3x3) (tile_cfg 9, conv_wino.hip): 3x3 taps, stride 1, pad 1 (forward: dr=+1, off=-1; data-gradient of
@@ -1222,6 +1268,38 @@ DIAGAN_API int diagan_conv_gemm_set_x3(int mode) {
   return DIAGAN_OK;
 }
 DIAGAN_API int diagan_conv_gemm_get_x3(void) { return gemm_x3_on() ? 1 : 0; }
+DIAGAN_API int diagan_conv_gemm_set_x3b(int mode) {
+  DG_REQUIRE(mode >= -1 && mode <= 1, "set_x3b: -1, 0 or 1");
+  g_gemm_x3b = mode;
+  return DIAGAN_OK;
+}
+DIAGAN_API int diagan_conv_gemm_get_x3b(void) { return gemm_x3b_on() ? 1 : 0; }
+DIAGAN_API int diagan_conv_gemm_out_map(int mul, int offy, int offx, int y0, int y1, int x0, int x1, int OH, int OW) {
+  g_map_next = OutMap{mul, offy, offx, y0, y1, x0, x1, OH, OW};
+  return DIAGAN_OK;
+}
+// The tile configuration diagan_conv_gemm ends up with for tile_cfg 0, INCLUDING the upgrades to the split-operand kernels
+// (16: conv_gemm_x3.hip, 17: conv_gemm_x3b.hip) that the pick functions do not know: what a caller needs to name the kernel of a
+// launch (kernel timers) or to know whether an output map will be honoured.  plain_epilogue: no mask, no per-half scales, no ReLU on
+// the residual, no half-resolution residual; has_ws: a workspace of ws_floats floats is handed over.
+DIAGAN_API int diagan_conv_gemm_final_cfg(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
+                                          int off, int up, int Kp, int allow_split, int64_t ws_floats, int pro_group_rows,
+                                          int pro_mode, int plain_epilogue, int want_stats) {
+  int cfg = diagan_conv_gemm_pick_cfg_grouped(B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow_split, ws_floats,
+                                              pro_group_rows);
+  ConvGemmArgs a = {};
+  a.pro_mode = pro_mode;
+  a.M = B * Ho * Wo;
+  a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
+  a.pro_group_rows = pro_group_rows;
+  static float dummy;
+  a.stat_partials = want_stats ? &dummy : nullptr;
+  a.mask_src = plain_epilogue ? nullptr : &dummy;
+  if (ws_floats > 0 && x3b_takes(a, cfg, ws_floats)) return 17;
+  a.mask_src = nullptr;
+  if (cfg == 14 && R == 3 && S == 3 && gemm_x3_on() && gemm_x3_geom_ok(a) && ws_floats >= gemm_x3_ws_floats(Co, Kp)) return 16;
+  return cfg;
+}
 DIAGAN_API int diagan_conv_gemm_set_splitk_fused(int mode) {
   DG_REQUIRE(mode >= -1 && mode <= 1, "set_splitk_fused: -1, 0 or 1");
   g_splitk_fused = mode;

@@ -203,7 +203,10 @@ static __host__ __device__ __forceinline__ int ceil_div_i(int a, int b) { return
 // a lane owns 4 channels x OXT consecutive output columns and slides a (KW + OXT - 1)-wide register window down the
 // kh filter rows, so that every input element is fetched (KW + OXT - 1) / OXT times instead of KW times and as 16-byte
 // loads; lanes run along the channel quads, then along the column groups (coalesced 512 B+ segments).
-template <int KW, int OXT>
+// DOWN = 2 (round 6): the same with every second output row / column kept -- blur + stride-2 sub-sampling in one pass (the
+// discriminator's skip branch: Blur, then a 1x1 convolution that reads every second pixel; reference stylegan2.py:553-614): the
+// window is KW + (OXT - 1) * DOWN wide and a quarter of the blurred image is ever written.
+template <int KW, int OXT, int DOWN = 1>
 __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
   __shared__ float taps[64];
   if (threadIdx.x < a.kh * KW) taps[threadIdx.x] = a.k[threadIdx.x];
@@ -221,14 +224,14 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
     f32x4 acc[OXT];
 #pragma unroll
     for (int j = 0; j < OXT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int bx = ox0 - a.pad_x0;
+    const int bx = ox0 * DOWN - a.pad_x0;
     for (int dy = 0; dy < a.kh; ++dy) {
-      const int iy = oy - a.pad_y0 + dy;
+      const int iy = oy * DOWN - a.pad_y0 + dy;
       if (iy < 0 || iy >= a.in_h) continue;
       const f32x4* row = in4 + ((long)mj * a.in_h + iy) * a.in_w * q + c4;
-      f32x4 win[KW + OXT - 1];
+      f32x4 win[KW + (OXT - 1) * DOWN];
 #pragma unroll
-      for (int u = 0; u < KW + OXT - 1; ++u) {
+      for (int u = 0; u < KW + (OXT - 1) * DOWN; ++u) {
         const int ix = bx + u;
         win[u] = (ix >= 0 && ix < a.in_w) ? row[(long)ix * q] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -237,13 +240,49 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
       for (int dx = 0; dx < KW; ++dx) {
         const float w = kr[KW - 1 - dx];
 #pragma unroll
-        for (int j = 0; j < OXT; ++j) acc[j] += win[j + dx] * w;
+        for (int j = 0; j < OXT; ++j) acc[j] += win[j * DOWN + dx] * w;
       }
     }
     f32x4* dst = out4 + (((long)mj * a.out_h + oy) * a.out_w + ox0) * q + c4;
 #pragma unroll
     for (int j = 0; j < OXT; ++j)
       if (ox0 + j < a.out_w) dst[(long)j * q] = acc[j];
+  }
+}
+
+// Any up / down factors on channels-last data with minor % 4 == 0 (round 6: the adjoint of the sub-sampling blur above is an
+// up = 2 filter, the generator's RGB Upsample is one too): a lane owns one output pixel x 4 channels and walks the (at most
+// ceil(kh / up) x ceil(kw / up)) input pixels that reach it, 16-byte loads, lanes along the channel quads.
+__global__ __launch_bounds__(256) void updn_cl4_kernel(const UpFirDnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float taps[];
+  for (int i = threadIdx.x; i < a.kh * a.kw; i += 256) taps[i] = a.k[i];
+  __syncthreads();
+  const int q = a.minor >> 2;
+  const long total = (long)a.major * a.out_h * a.out_w * q;
+  const f32x4* __restrict__ in4 = reinterpret_cast<const f32x4*>(a.in);
+  f32x4* __restrict__ out4 = reinterpret_cast<f32x4*>(a.out);
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    const int c4 = (int)(o % q);
+    long t = o / q;
+    const int ox = (int)(t % a.out_w); t /= a.out_w;
+    const int oy = (int)(t % a.out_h);
+    const int mj = (int)(t / a.out_h);
+    const int by = oy * a.down_y - a.pad_y0, bx = ox * a.down_x - a.pad_x0;
+    const int iy0 = max(ceil_div_i(by, a.up_y), 0), iy1 = min(floor_div_i(by + a.kh - 1, a.up_y), a.in_h - 1);
+    const int ix0 = max(ceil_div_i(bx, a.up_x), 0), ix1 = min(floor_div_i(bx + a.kw - 1, a.up_x), a.in_w - 1);
+    const f32x4* src = in4 + (long)mj * a.in_h * a.in_w * q + c4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int iy = iy0; iy <= iy1; ++iy) {
+      const int ky = a.kh - 1 - (iy * a.up_y - by);
+      for (int ix = ix0; ix <= ix1; ++ix) {
+        const int kx = a.kw - 1 - (ix * a.up_x - bx);
+        const f32x4 xin = src[((long)iy * a.in_w + ix) * q];
+        const float w = taps[ky * a.kw + kx];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(xin[e], w, v[e]);
+      }
+    }
+    out4[o] = v;
   }
 }
 
@@ -375,6 +414,21 @@ DIAGAN_API int diagan_upfirdn2d(const float* input, const float* kernel, float* 
     long fb = (work + 255) / 256;
     if (fb > 32768) fb = 32768;
     hipLaunchKernelGGL((fir_cl4_kernel<4, 4>), dim3((int)fb), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("upfirdn2d");
+  }
+  const bool cl4 = (minor & 3) == 0 && (((uintptr_t)input | (uintptr_t)out) & 15) == 0;
+  if (cl4 && up_x == 1 && up_y == 1 && down_x == 2 && down_y == 2 && kernel_w == 4 && kernel_h <= 16) {
+    const long work = (long)major * oh * ((ow + 1) / 2) * (minor / 4);
+    long fb = (work + 255) / 256;
+    if (fb > 32768) fb = 32768;
+    hipLaunchKernelGGL((fir_cl4_kernel<4, 2, 2>), dim3((int)fb), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("upfirdn2d");
+  }
+  if (cl4) {
+    const long work = (long)major * oh * ow * (minor / 4);
+    long fb = (work + 255) / 256;
+    if (fb > 32768) fb = 32768;
+    hipLaunchKernelGGL(updn_cl4_kernel, dim3((int)fb), dim3(256), (size_t)kernel_h * kernel_w * sizeof(float), (hipStream_t)stream, a);
     return check_launch("upfirdn2d");
   }
   const long total = (long)major * oh * ow * minor;

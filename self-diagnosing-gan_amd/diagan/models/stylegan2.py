@@ -30,6 +30,8 @@ from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
 
 SQRT2 = math.sqrt(2.0)
+import os as _os
+FUSED_SKIP = _os.environ.get("DIAGAN_SG2_FUSED_SKIP", "1") == "1"      # ResBlock skip: blur + sub-sampling in one FIR pass
 
 
 def channel_table(multiplier):
@@ -125,9 +127,10 @@ class EqualConv2d(nn.Module):
         self.stride, self.padding = stride, padding
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
-    def forward(self, x, out_mul=1.0):
-        """out_mul: an extra factor on the OUTPUT, folded into the weight scale (ResBlock's 1 / sqrt 2 on its skip branch)"""
-        y = dc.conv2d(x, self.weight * (self.scale * out_mul), self.stride, self.padding)
+    def forward(self, x, out_mul=1.0, stride=None):
+        """out_mul: an extra factor on the OUTPUT, folded into the weight scale (ResBlock's 1 / sqrt 2 on its skip branch);
+        stride: override (ResBlock's skip branch hands over an already sub-sampled input)"""
+        y = dc.conv2d(x, self.weight * (self.scale * out_mul), self.stride if stride is None else stride, self.padding)
         if self.bias is not None:
             y = y + F.pad(self.bias, (0, y.shape[3] - self.bias.shape[0])) * out_mul
         return y
@@ -380,7 +383,12 @@ class ResBlock(nn.Module):
         leaky_relu(.) * sqrt 2 runs with scale 1, the skip convolution with its weight scale divided by sqrt 2."""
         blur2, conv2, act2 = self.conv2
         y = fused_leaky_relu(conv2(blur2(self.conv1(input))), act2.bias, act2.negative_slope, act2.scale / SQRT2, bias_dim=-1)
+        # skip branch (reference :553-595: Blur, then a 1x1 convolution of stride 2): the convolution reads every second pixel of the
+        # blurred image, so the blur computes only those (upfirdn2d with down = 2, same taps and padding: the same values) and the
+        # convolution runs at stride 1 on a quarter of the pixels
         blur_s, conv_s = self.skip
+        if FUSED_SKIP and conv_s.stride == 2 and conv_s.padding == 0 and conv_s.weight.shape[2] == 1:
+            return y + conv_s(upfirdn2d_nhwc(input, blur_s.kernel, down=2, pad=blur_s.pad), out_mul=1.0 / SQRT2, stride=1)
         return y + conv_s(blur_s(input), out_mul=1.0 / SQRT2)
 
 

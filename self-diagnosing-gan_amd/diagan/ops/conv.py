@@ -18,6 +18,10 @@ nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_gemm_set_splitk_fused", [I])
 nat.register("diagan_conv_gemm_set_x3", [I])
 nat.register("diagan_conv_gemm_get_x3", [])
+nat.register("diagan_conv_gemm_set_x3b", [I])
+nat.register("diagan_conv_gemm_get_x3b", [])
+nat.register("diagan_conv_gemm_out_map", [I] * 9)
+nat.register("diagan_conv_gemm_final_cfg", [I] * 15 + [I64] + [I] * 4)
 nat.register("diagan_conv_wgrad_batched", [P, I, P])
 nat.register("diagan_conv_wgrad_batch_max", [])
 nat.register("diagan_conv_wgrad_batch_class", [I] * 14)
@@ -68,7 +72,7 @@ TILE_SHAPES = {1: (128, 128, 2, 2, 32, False), 2: (128, 64, 2, 2, 32, False), 3:
                7: (64, 64, 2, 2, 32, True), 8: (128, 64, 2, 2, 32, True), 14: (64, 64, 2, 2, 32, True)}
 
 
-def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0, RS=9):
+def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0, RS=9, mapped=False):
     """the kernel's name as rocprofv3 prints it (the F(4x4) kernel's third template argument: the bf16-split build, which a
     launch takes only with the switch on and a K loop of a multiple of four steps)"""
     if cfg in (11, 12) and w4pool:            # the pooled launches on the F(4x4) kernel (MODE 1 / 2)
@@ -82,8 +86,9 @@ def gemm_kernel_name(cfg, mode, Co=128, w4pool=False, Ci=0, RS=9):
         return f"conv_wino_pool_kernel<{mode},false,{2 if Co % 128 == 0 else 1}>"
     if cfg == 12:
         return f"conv_wino_pool_kernel<0,true,{2 if Co % 128 == 0 else 1}>"
-    if cfg == 16 or (cfg == 14 and RS == 9 and mode in (PRO_NONE, PRO_RELU) and Ci % 32 == 0 and Ci > 0 and (9 * Ci // 32) % 2 == 0
-                     and nat.fn("diagan_conv_gemm_get_x3")() > 0):
+    if cfg == 17:
+        return f"conv_gemm_x3b_kernel<{mode},{'true' if mapped else 'false'}>"
+    if cfg == 16:
         return f"conv_gemm_x3_kernel<{mode}>"      # (3x3 layers: the only lone-tile launches of the networks)
     bm, bn, wm, wn, bk, fp = TILE_SHAPES[cfg]
     kg = ",2" if cfg == 14 else ",1"          # K-groups per workgroup (rocprofv3 prints the defaulted template argument too)
@@ -308,11 +313,13 @@ def _chk(t, name):
 
 def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope, pro, out_scale, tile_cfg,
           res_relu=False, row_scale=None, want_stats=False, wino=True, res_up=False, pool=False, unpool=False, up_in=False,
-          wsite=None, wversion=None, res_unpool=False):
+          wsite=None, wversion=None, res_unpool=False, out_map=None):
     """want_stats: also return (partials, tiles) -- per-tile column sums of y, y^2 from the epilogue
     (None when the problem takes the split-K / small-Co path; the caller then reduces y itself)."""
     B, Hi, Wi, Ci = x.shape
     _, Ho, Wo, Co = out.shape
+    if out_map is not None:               # `out` is the larger tensor the launch's own Ho x Wo grid is mapped into
+        Ho, Wo = out_map[9], out_map[10]
     if up_in:                             # `x` is the half-resolution input whose bilinear x2 is convolved: tile_cfg 15
         Hi, Wi, tile_cfg = 2 * Hi, 2 * Wi, 15
         if pool or unpool or mask_src is not None:
@@ -372,20 +379,28 @@ def _gemm(x, w, out, geo_params, R, S, Kp, bias, residual, mask_src, mask_slope,
     kname = None
     if TIMER is not None and TIMER.wants_any():
         # (cached per call signature: on launch-bound workloads the name lookup itself was 6 ms of host time per step)
-        key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats, group_imgs)
+        key = (tile_cfg, B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, mode, want_stats, group_imgs, out_map is not None,
+               mask_src is None, row_scale is None, res_relu, res_up, res_unpool)
         kname = _NAME_CACHE.get(key)
-        modes = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")(), nat.fn("diagan_conv_gemm_get_x3")())
+        modes = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")(), nat.fn("diagan_conv_gemm_get_x3")(),
+                 nat.fn("diagan_conv_gemm_get_x3b")())
         if kname is None or _NAME_CACHE.get('modes') != modes:
             if _NAME_CACHE.get('modes') != modes:
                 _NAME_CACHE.clear()
                 _NAME_CACHE['modes'] = modes
             allow = 0 if want_stats else 1
-            kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_pick_cfg_grouped")(
-                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo), mode, Co,
-                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())), Ci=Ci, RS=R * S)
+            # (the launch's own answer, upgrades to the split-operand kernels included: diagan_conv_gemm_final_cfg)
+            plain = mask_src is None and row_scale is None and not res_relu and not res_up and not res_unpool
+            kname = gemm_kernel_name(tile_cfg or nat.fn("diagan_conv_gemm_final_cfg")(
+                B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp, allow, ws.numel(), group_imgs * Ho * Wo, mode,
+                1 if plain else 0, 1 if want_stats else 0), mode, Co,
+                w4pool=tile_cfg in (11, 12) and bool(nat.fn("diagan_conv_wino4_pool_used")(B, Ho, Wo, Ci, Co, ws.numel())), Ci=Ci, RS=R * S,
+                mapped=out_map is not None)
             _NAME_CACHE[key] = kname
     t0 = TIMER.begin(kname) if TIMER is not None else None
     _hint(wsite, wversion)
+    if out_map is not None:
+        nat.call("diagan_conv_gemm_out_map", *out_map[:9])
     nat.call("diagan_conv_gemm", nat.ptr(x), nat.ptr(w), nat.ptr(out), nat.ptr(bias), nat.ptr(residual),
              (1 if res_relu else 0) | (2 if res_up else 0) | (4 if res_unpool else 0), nat.ptr(mask_src), mask_slope, nat.ptr(scale), nat.ptr(shift), mode, out_scale,
              nat.ptr(row_scale[0]) if row_scale else None, nat.ptr(row_scale[1]) if row_scale else None,
@@ -454,22 +469,41 @@ def pool_fused(geom, B, Hi, Wi, pro=None):
 
 
 def conv_fwd(geom, x, wf, bias=None, residual=None, pro=None, out=None, tile_cfg=0, res_relu=False, row_scale=None,
-             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False, up_in=False, wsite=None, wversion=None):
+             want_stats=False, out_scale=1.0, wino=True, res_up=False, pool=False, up_in=False, wsite=None, wversion=None,
+             out_map=None):
     """y = conv(pro(x)) + bias + residual.   x [B,Hi,Wi,Ci] -> y [B,Ho,Wo,Co].
     res_up: `residual` is [B,Ho/2,Wo/2,Co] and its bilinear x2 up-sampling is added (see res_up_fused).
     pool: y = avg_pool2d(conv(pro(x)) + bias, 2) + residual, y and residual [B,Ho/2,Wo/2,Co] (see pool_fused).
-    up_in: y = conv(bilinear_x2(pro(x))) + ..., x [B,Hi,Wi,Ci] -> y [B,2Hi,2Wi,Co] (see upin_fused)."""
+    up_in: y = conv(bilinear_x2(pro(x))) + ..., x [B,Hi,Wi,Ci] -> y [B,2Hi,2Wi,Co] (see upin_fused).
+    out_map = (mul, offy, offx, y0, y1, x0, x1): `out` [B,OH,OW,Co] must be given; pixel (oy, ox) of the convolution's own output
+    grid is written to (mul*(oy-y0)+offy, mul*(ox-x0)+offx) of it, pixels outside [y0,y1) x [x0,x1) are dropped (tile_cfg 17 only:
+    ask out_map_ok first)."""
     B, Hi, Wi, Ci = x.shape
     if Ci != geom.Ci:
         raise RuntimeError(f"conv_fwd: input has {Ci} channels, layer expects {geom.Ci}")
     Ho, Wo = geom.out_hw(2 * Hi, 2 * Wi) if up_in else geom.out_hw(Hi, Wi)
     if pool:
         Ho, Wo = Ho // 2, Wo // 2
+    if out_map is not None:
+        if out is None:
+            raise RuntimeError("conv_fwd: an output map needs the target tensor")
+        out_map = tuple(out_map) + (out.shape[1], out.shape[2], Ho, Wo)
     if out is None:
         out = torch.empty((B, Ho, Wo, geom.Co), dtype=torch.float32, device=x.device)
     return _gemm(x, wf, out, geom.fwd_params(), geom.R, geom.S, geom.Kp, bias, residual, None, 0.0, pro, out_scale,
                  tile_cfg, res_relu=res_relu, row_scale=row_scale, want_stats=want_stats, wino=wino, res_up=res_up, pool=pool,
-                 up_in=up_in, wsite=wsite, wversion=wversion)
+                 up_in=up_in, wsite=wsite, wversion=wversion, out_map=out_map)
+
+
+def out_map_ok(geom, B, Hi, Wi, pro=None):
+    """Will conv_fwd(geom, x[B,Hi,Wi,Ci], w, out=..., out_map=...) run?  True iff the automatic choice for this plain launch is
+    the split-operand kernel (tile_cfg 17), the only one that writes through an output map."""
+    Ho, Wo = geom.out_hw(Hi, Wi)
+    sy, dr, off, up = geom.fwd_params()
+    ws = _splitk_ws(torch.device('cuda', torch.cuda.current_device()))
+    mode = pro[0] if pro is not None else PRO_NONE
+    return nat.fn("diagan_conv_gemm_final_cfg")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, 1,
+                                               ws.numel(), 0, mode, 1, 0) == 17
 
 
 def conv_dgrad(geom, dy, wd, in_hw, residual=None, mask_src=None, mask_slope=0.0, out=None, tile_cfg=0,

@@ -25,6 +25,9 @@ from diagan.ops import conv as K
 # NoiseInjection strength gradients at 256 x 256 (tools/sg2_noise_grad.py); profiles/r02_sg2_winograd.md.
 # DIAGAN_SG2_WINO=0 keeps these ops on the implicit GEMM.
 SG2_WINO = os.environ.get("DIAGAN_SG2_WINO", "1") == "1"
+# the parity classes of the stride-2 transposed gathers write straight into the interleaved result where the launch runs on the
+# split-operand kernel (csrc/conv_gemm_x3b.hip, ConvGemmArgs::map); DIAGAN_SG2_OUT_MAP=0: compute each class, then copy it into place
+OUT_MAP = os.environ.get("DIAGAN_SG2_OUT_MAP", "1") == "1"
 
 
 def _c(t):
@@ -79,6 +82,12 @@ def _up2_gather(x, w, n_out, R, S, C, out_hw):
             ws = w4[:, ry][:, :, sx].reshape(n_out, ny * nx * C)
             if ws.shape[1] != sub.Kp:
                 ws = F.pad(ws, (0, sub.Kp - ws.shape[1]))
+            if OUT_MAP and K.out_map_ok(sub, B, H, W):
+                # the class interleaves itself: the split-operand kernel writes pixel (my, mx) of the class to (2 (my - ty) + cy,
+                # 2 (mx - tx) + cx) and drops the surplus border of the symmetric padding (no copy pass; round 6)
+                K.conv_fwd(sub, x, ws.contiguous(), wino=SG2_WINO, out=out,
+                           out_map=(2, cy, cx, ty, ty + H + ny - 1, tx, tx + W + nx - 1))
+                continue
             y = K.conv_fwd(sub, x, ws.contiguous(), wino=SG2_WINO)
             out[:, cy:full_h:2, cx:full_w:2] = y[:, ty: ty + H + ny - 1, tx: tx + W + nx - 1]
     return out
