@@ -200,6 +200,9 @@ int diagan_conv_gemm_get_x3(void);
  * 128 x 128 and >= 4 K-steps on / off / DIAGAN_GEMM_X3B (default on). */
 int diagan_conv_gemm_set_x3b(int mode);
 int diagan_conv_gemm_get_x3b(void);
+/* tile_cfg 17 has two forms: 1 = 128 x 128 tiles, two workgroups per CU (small launches, short K loops); 2 = 256 x 128 tiles, four MFMA waves
+ * + four loader waves in one workgroup per CU (the large launches).  Tests / diagnostics only, process-global: force one (0: automatic). */
+int diagan_conv_gemm_x3b_force_form(int form);
 /* Output map of the NEXT diagan_conv_gemm call of the calling thread (held for exactly one call, like the weights hint): pixel
  * (b, oy, ox) of the launch's Ho x Wo output grid is written to (b, mul*(oy-y0)+offy, mul*(ox-x0)+offx) of y[B][OH][OW][Co] (residual,
  * if given, is read there too); pixels outside [y0,y1) x [x0,x1) are dropped.  Written by tile_cfg 17 only (the call fails otherwise:

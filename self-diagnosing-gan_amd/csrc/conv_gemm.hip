@@ -41,6 +41,7 @@ long gemm_x3_ws_floats(int Co, int Kp);
 int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st);    // conv_gemm_x3b.hip: the same arithmetic on 128 x 128 tiles
 bool gemm_x3b_geom_ok(const ConvGemmArgs& a);
 long gemm_x3b_ws_floats(int Co, int Kp);
+void gemm_x3b_force_form(int form);
 int launch_wino(ConvGemmArgs a, float* ws, hipStream_t st);      // conv_wino.hip
 long wino_ws_floats(int Co, int Ci);
 int wino_ksplit(int B, int Ho, int Wo, int Ci, int Co, int allow_split, long ws_floats, int min_wgs);
@@ -1274,6 +1275,12 @@ DIAGAN_API int diagan_conv_gemm_set_x3b(int mode) {
   return DIAGAN_OK;
 }
 DIAGAN_API int diagan_conv_gemm_get_x3b(void) { return gemm_x3b_on() ? 1 : 0; }
+// tests / diagnostics: 1 = the 128 x 128 form (two workgroups per CU), 2 = the producer / consumer form on 256 x 128 tiles, 0 = automatic
+DIAGAN_API int diagan_conv_gemm_x3b_force_form(int form) {
+  DG_REQUIRE(form >= 0 && form <= 2, "x3b_force_form: 0, 1 or 2");
+  gemm_x3b_force_form(form);
+  return DIAGAN_OK;
+}
 DIAGAN_API int diagan_conv_gemm_out_map(int mul, int offy, int offx, int y0, int y1, int x0, int x1, int OH, int OW) {
   g_map_next = OutMap{mul, offy, offx, y0, y1, x0, x1, OH, OW};
   return DIAGAN_OK;

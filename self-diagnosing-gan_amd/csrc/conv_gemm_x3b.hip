@@ -209,19 +209,49 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
     first_step = false;
   };
 
+#ifdef XB_STAMP
+  // diagnostic build (tools/build_variant.sh stamp conv_gemm_x3b.hip "-DXB_STAMP"): cycles per wave in the phases of the K loop,
+  // written to a.stamps[(workgroup * 4 + wave) * 8 + phase]: 0 load issue, 1 MFMA phase, 2 first barrier, 3 wait for the loads,
+  // 4 split + LDS writes, 5 second barrier, 6 whole loop, 7 epilogue
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tl = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_loop0 = tl;
+#define XB_TICK(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tl; tl = now_; }
+#else
+#define XB_TICK(i)
+#endif
   load_step();
   store_step();
   __syncthreads();
+  XB_TICK(0);
   for (int kk = 0; kk < nk; ++kk) {
     const bool more = kk + 1 < nk;
     if (more) load_step();
+    XB_TICK(0);
     mfmas();
+#ifdef XB_STAMP
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    XB_TICK(1);
     if (!(XB_ABL & 32)) __syncthreads();
+    XB_TICK(2);
     if (more) {
+#ifdef XB_STAMP
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      XB_TICK(3);
       store_step();
+#ifdef XB_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      XB_TICK(4);
       if (!(XB_ABL & 32)) __syncthreads();
+      XB_TICK(5);
     }
   }
+#ifdef XB_STAMP
+  const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue ----
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).  A wave turns its 64 x 64 block, one
@@ -273,10 +303,346 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xb_u32x4, v), ysrc, voff, 0, 0);
     }
   }
+#ifdef XB_STAMP
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    o[6] = t_loop1 - t_loop0;
+    o[7] = __builtin_amdgcn_s_memtime() - t_loop1;
+  }
+#endif
 }
 
-// floats of workspace the split weights need
-long gemm_x3b_ws_floats(int Co, int Kp) { return ((long)Co * Kp * 3 + 1) / 2; }
+// ---- second form (large launches): producer / consumer waves inside ONE workgroup per CU, 256 x 128 tiles ------------------------------
+// The stamps of the kernel above (tools/probe/x3b_stamps.py, 3x3 / stride 2, 128 -> 256 at 256 x 256) read, per K-step and wave:
+// 1150 cycles to get the ten global loads accepted, 1900 in the MFMA phase (1536 of matrix pipe), 1180 for the split and the LDS writes,
+// 460 at the two barriers -- 4950 with the pipe busy 0.62 of the time.  A first producer / consumer split of the same 128 x 128 tile
+// (waves 0-3 MFMAs only, waves 4-7 loads + split + writes, two LDS stages) ran no faster, and ITS stamps said why: a vector-memory
+// instruction of 1 KB -- load or LDS-DMA, full cache lines or not -- takes a wave ~130 cycles to issue with four waves issuing, i.e.
+// the CU takes in ~31 bytes per cycle from L2, and a 128 x 128 K-step needs 48 KB (16 KB of fp32 activations + 32 KB of split
+// weights): 1550 cycles of that path for 1536 of matrix pipe.  So the second form halves the weight bytes per MFMA:
+//   * a workgroup owns 256 pixels x 128 columns as two 128-row HALVES that take turns ("sub-steps") and share a K-step's weights;
+//   * waves 0-3 (one per SIMD) only read fragments and issue MFMAs (two accumulator sets);
+//   * waves 4-7 -- their SIMD partners -- fill the other half's A buffer for the next sub-step: full-line loads (eight lanes = one
+//     pixel's 128 bytes; two register sets, so a load has a whole sub-step to land), split, 8-byte LDS writes; and copy the NEXT
+//     K-step's weights -- which the per-launch kernel below has already laid out in global memory AS the padded LDS image of every
+//     (column tile, K-step) -- by LDS-DMA, half an image per sub-step: linear 1 KB copies, no register, no LDS-write instruction;
+//   * one raw s_barrier per sub-step; the producers' waits are counted (vector-memory operations of a wave complete in order:
+//     DMA pieces are issued BEFORE the loads of the same sub-step, so `vmcnt(4)` retires them and leaves those loads in flight).
+// LDS: A buffers 2 x 30 720 (half 0 | half 1), B buffers 2 x 32 768 (K-step parity) = 126 976 bytes.
+constexpr int XB2_AIMG = 3 * XB_PLANE * 2;         // bytes of the A planes of one half (30 720)
+constexpr int XB2_BIMG = 32768;                    // bytes of a B image: 30 720 of planes + 2 KB so that every producer wave copies 8 KB
+constexpr int XB2_BOFF = 2 * XB2_AIMG;             // first B buffer
+constexpr int XB2_LDS_BYTES = XB2_BOFF + 2 * XB2_BIMG;       // 126 976
+
+// packed fp32 weights [Co][Kp] -> for every (128-column tile, K-step) the LDS image [piece][128 rows][40 bf16] (rows behind Co: zeros)
+__global__ __launch_bounds__(256) void gx3b2_weight_kernel(const float* __restrict__ w, unsigned short* __restrict__ img, int Co, int Kp,
+                                                           int nk) {
+  const int nt = blockIdx.y, ks = blockIdx.x, row = threadIdx.x >> 1, q0 = (threadIdx.x & 1) * 4;
+  const int n = nt * 128 + row;
+  unsigned short* dst = img + ((long)nt * nk + ks) * (XB2_BIMG / 2) + row * XB_ROW;
+#pragma unroll
+  for (int q = q0; q < q0 + 4; ++q) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < Co) v = *reinterpret_cast<const f32x4*>(w + (long)n * Kp + ks * 32 + q * 4);
+    u32x2 p0, p1, p2;
+    x3_split(v, p0, p1, p2);
+    *reinterpret_cast<u32x2*>(dst + q * 4) = p0;
+    *reinterpret_cast<u32x2*>(dst + XB_PLANE + q * 4) = p1;
+    *reinterpret_cast<u32x2*>(dst + 2 * XB_PLANE + q * 4) = p2;
+  }
+}
+
+#define XB2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define XB2_WAIT(n, r) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])::"memory")
+#ifdef XB_STAMP
+#define XB2_TICK(i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tl; tl = now_; }
+#else
+#define XB2_TICK(i)
+#endif
+
+template <int PRO, bool MAP>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm_x3b2_kernel(const ConvGemmArgs a, const unsigned short* __restrict__ wimg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  char* const lds8 = reinterpret_cast<char*>(lds);
+  const ConvGeom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (g.Co + 127) >> 7;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = tile % tiles_n;
+  const int m0 = (tile / tiles_n) * 256, n0 = nt * 128;
+  const int cpt = g.Ci >> 5;                       // K-steps per tap
+  const int nk = g.R * g.S * cpt, ns = 2 * nk;     // K-steps, sub-steps (K-step k, half h): s = 2 k + h
+
+  if (wave >= 4) {
+    // ================= producers =================
+    const int ptid = tid - 256, pw = wave - 4;
+    const int prow = ptid >> 3, pc = ptid & 7;                            // rows prow + 32 j of a half, 4-channel chunk
+    int iy0[2][4], ix0[2][4], pixbase[2][4];
+    bool mv[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + 128 * h + prow + 32 * j;
+        mv[h][j] = m < a.M;
+        const unsigned t = fdiv((unsigned)(mv[h][j] ? m : 0), a.dWo);
+        const int ox = (mv[h][j] ? m : 0) - (int)t * g.Wo;
+        const unsigned b = fdiv(t, a.dHo);
+        const int oy = (int)t - (int)b * g.Ho;
+        iy0[h][j] = oy * g.sy + g.off;
+        ix0[h][j] = ox * g.sy + g.off;
+        pixbase[h][j] = (((int)b * g.Hi + iy0[h][j]) * g.Wi + ix0[h][j]) * g.Ci * 4 + pc * 16;
+      }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 xsrc;
+    {
+      const unsigned long long xb = (unsigned long long)a.x;
+      xsrc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)xb);
+      xsrc[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(xb >> 32) & 0xffffu));
+      xsrc[2] = __builtin_amdgcn_readfirstlane((int)((unsigned)g.B * g.Hi * g.Wi * g.Ci * 4u));
+      xsrc[3] = 0x00020000;
+    }
+    const int soff = 0;
+    f32x4 ra0[4], ra1[4];                          // activations of half 0 / half 1 on their way to LDS
+    int l_r = 0, l_s = 0, l_c = 0;                 // (tap, channel block) of the K-step whose halves are requested next
+    // (inline assembly: the compiler's wait-count pass would put vmcnt(0) in front of the first use of a loaded register, draining the
+    //  DMA in flight too; this way the only waits are the counted ones below)
+    auto issue_a = [&](f32x4 (&r)[4], int h) __attribute__((always_inline)) {
+      const int dy = l_r * g.dr, dx = l_s * g.dr;
+      const int toff = ((dy * g.Wi + dx) * g.Ci + (l_c << 5)) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int iy = iy0[h][j] + dy, ix = ix0[h][j] + dx;
+        const bool ok = mv[h][j] && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+        const unsigned off = (unsigned)(pixbase[h][j] + toff) | (ok ? 0u : 0x80000000u);
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(r[j]) : "v"(off), "s"(xsrc), "s"(soff) : "memory");
+      }
+      if (h == 1 && ++l_c == cpt) {                // (both halves of a K-step requested: on to the next one)
+        l_c = 0;
+        if (++l_s == g.S) {
+          l_s = 0;
+          ++l_r;
+        }
+      }
+    };
+    const char* const wsrc = reinterpret_cast<const char*>(wimg) + (long)nt * nk * XB2_BIMG + pw * 8192 + lane * 16;
+    // pieces [4 part, 4 part + 4) of this wave's eight 1 KB pieces of K-step ks's image
+    auto issue_b = [&](int ks, int part) __attribute__((always_inline)) {
+      const char* src = wsrc + (long)ks * XB2_BIMG + part * 4096;
+      char* dst = lds8 + XB2_BOFF + (ks & 1) * XB2_BIMG + pw * 8192 + part * 4096;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + t * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + t * 1024), 16, 0, 0);
+    };
+    const int sto = prow * XB_ROW + pc * 4;        // bf16 elements; row j: + 32 j rows
+    auto split_store = [&](f32x4 (&r)[4], int h) __attribute__((always_inline)) {
+      unsigned short* st0 = reinterpret_cast<unsigned short*>(lds8 + h * XB2_AIMG) + sto;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned short* st = st0 + j * 32 * XB_ROW;
+        f32x4 v = r[j];
+        if (PRO == PRO_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (PRO == PRO_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.2f * v[e];
+        }
+        u32x2 p0, p1, p2;
+        x3_split(v, p0, p1, p2);
+        *reinterpret_cast<u32x2*>(st) = p0;
+        *reinterpret_cast<u32x2*>(st + XB_PLANE) = p1;
+        *reinterpret_cast<u32x2*>(st + 2 * XB_PLANE) = p2;
+      }
+    };
+#ifdef XB_STAMP
+    // diagnostic build: a.stamps[(workgroup * 8 + wave) * 8 + i]; producers: 0 DMA issue, 1 load issue, 2 wait for the loads, 3 split +
+    // LDS writes (drained), 4 wait for the DMA, 5 barrier; consumers: 0 fragment reads + MFMAs, 5 barrier, 7 epilogue
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tl = __builtin_amdgcn_s_memtime();
+#endif
+    // sub-step s = 2 k + H of the producers, k + 1 < nk: request sub-step s + 2 (same half H) into `rl`, copy half H of K-step k + 1's
+    // weight image, then write sub-step s + 1 (the other half, waiting in `rs`) into its A buffer.
+    // (No branch in here: the first build chose between counted waits inside this body, the compiler merged the two paths' common
+    //  split code and copied the still-in-flight registers of `rs` to the merged copy IN FRONT of the wait -- results wrong once in a
+    //  few launches.  The last K-step, which requests nothing, is peeled off below instead.)
+    auto fill = [&](int s, f32x4 (&rs)[4], f32x4 (&rl)[4], int H) __attribute__((always_inline)) {
+      issue_b((s >> 1) + 1, H);                    // (that B buffer was read in K-step k - 1)
+      XB2_TICK(0);
+      issue_a(rl, H);
+      XB2_TICK(1);
+      XB2_WAIT(8, rs);                             // sub-step s + 1's loads: older than the 4 DMA pieces and the 4 loads just issued
+      XB2_TICK(2);
+      split_store(rs, H ^ 1);
+#ifdef XB_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      XB2_TICK(3);
+      if (H == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // K-step k + 1's image has landed; the 4 loads stay in flight
+      XB2_TICK(4);
+      XB2_BARRIER();
+      XB2_TICK(5);
+    };
+    issue_b(0, 0);
+    issue_b(0, 1);
+    issue_a(ra0, 0);
+    issue_a(ra1, 1);
+    XB2_WAIT(4, ra0);                              // the image of K-step 0 and half 0 have landed
+    split_store(ra0, 0);
+    XB2_BARRIER();                                 // sub-step 0 is ready
+#ifdef XB_STAMP
+    tl = __builtin_amdgcn_s_memtime();
+#endif
+    for (int s = 0; s + 2 < ns; s += 2) {
+      fill(s, ra1, ra0, 0);
+      fill(s + 1, ra0, ra1, 1);
+    }
+    XB2_WAIT(0, ra1);                              // the last K-step: its second half is waiting in ra1, nothing is requested any more
+    split_store(ra1, 1);
+    XB2_BARRIER();
+    XB2_BARRIER();
+#ifdef XB_STAMP
+    if (a.stamps && lane == 0) {
+      unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      for (int i = 0; i < 6; ++i) o[i] = tacc[i];
+    }
+#endif
+    return;
+  }
+
+  // ================= consumers =================
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2][2];                             // [half][row tile][column tile]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[h][i][j][e] = 0.f;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int fa = (wm * 64 + fi) * XB_ROW, fb = XB2_BOFF / 2 + (wn * 64 + fi) * XB_ROW;
+  const int oa01 = (fh ? XB_PLANE : 0) + fa, oa02 = (fh ? 2 * XB_PLANE : 0) + fa;
+  const int ob00 = fb, ob11 = XB_PLANE + fb, ob20 = (fh ? 0 : 2) * XB_PLANE + fb;
+  xb_bf16x8 fr[2][10];
+  // slots 0, 3, 6, 9 are A fragments (buffer of the half), the others B fragments (buffer of the K-step's parity)
+  auto read_slot = [&](const unsigned short* sa, const unsigned short* sb, int buf, int sl, int c) __attribute__((always_inline)) {
+    const int t = (sl == 2 || sl == 3 || sl == 5 || sl == 8 || sl == 9) ? 32 * XB_ROW : 0;
+    const bool isa = sl == 0 || sl == 3 || sl == 6 || sl == 9;
+    const int base = (sl == 0 || sl == 3) ? oa01 : (sl == 6 || sl == 9) ? oa02 : (sl == 1 || sl == 2) ? ob00 : (sl == 4 || sl == 5) ? ob11 : ob20;
+    fr[buf][sl] = *reinterpret_cast<const xb_bf16x8*>((isa ? sa : sb) + base + t + c * 8);
+  };
+#ifdef XB_STAMP
+  unsigned long long cacc[2] = {0, 0};
+  unsigned long long ctl = 0;
+#endif
+  auto half_step = [&](int k, int H) __attribute__((always_inline)) {
+    const unsigned short* sa = lds + H * (XB2_AIMG / 2);
+    const unsigned short* sb = lds + (k & 1) * (XB2_BIMG / 2);
+#pragma unroll
+    for (int sl = 0; sl < 10; ++sl) read_slot(sa, sb, 0, sl, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cur = c & 1, nxt = cur ^ 1;
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const int p = q >> 2, i = (q >> 1) & 1, j = q & 1;
+        const int fa_ = p == 2 ? (i ? 9 : 6) : (i ? 3 : 0);
+        const int fb_ = p == 0 ? 1 + j : (p == 1 ? 4 + j : 7 + j);
+        acc[H][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[cur][fa_], fr[cur][fb_], acc[H][i][j], 0, 0, 0);
+        if (c < 3 && q < 10) read_slot(sa, sb, nxt, q, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef XB_STAMP
+    { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cacc[0] += now_ - ctl; ctl = now_; }
+#endif
+    XB2_BARRIER();
+#ifdef XB_STAMP
+    { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cacc[1] += now_ - ctl; ctl = now_; }
+#endif
+  };
+  __builtin_amdgcn_s_setprio(XB_PRIO);
+  XB2_BARRIER();                                   // sub-step 0 is ready
+#ifdef XB_STAMP
+  ctl = __builtin_amdgcn_s_memtime();
+#endif
+  for (int k = 0; k < nk; ++k) {
+    half_step(k, 0);
+    half_step(k, 1);
+  }
+  __builtin_amdgcn_s_setprio(0);
+#ifdef XB_STAMP
+  const unsigned long long t_epi0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- epilogue (as above; the four consumer waves, through their private images in the now idle A buffers) ----
+  const float sc = a.out_scale;
+  const bool hr = a.residual != nullptr;
+  const OutMap& mp = a.map;
+  const long ypix = MAP ? (long)g.B * mp.OH * mp.OW : (long)a.M;
+  const unsigned ybytes = (unsigned)(ypix * g.Co * 4);
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(hr ? a.residual : a.y), 0, hr ? (int)ybytes : 0, 0x00020000);
+  float* xim = reinterpret_cast<float*>(lds) + wave * 2048;
+  const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xim[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fi] = acc[h][i][j][e];
+      const int nc = n0 + wn * 64 + j * 32 + ec;
+      const bool col_ok = nc < g.Co;
+      f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias && col_ok) bv = *reinterpret_cast<const f32x4*>(a.bias + nc);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rl = er + 8 * k;
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(xim + rl * 32 + ec);
+        const int m = m0 + 128 * h + wm * 64 + rl;
+        unsigned voff;
+        if (MAP) {
+          const bool in = m < a.M;
+          const unsigned t = fdiv((unsigned)(in ? m : 0), a.dWo);
+          const int ox = (in ? m : 0) - (int)t * g.Wo;
+          const unsigned b = fdiv(t, a.dHo);
+          const int oy = (int)t - (int)b * g.Ho;
+          const bool ok = in && col_ok && oy >= mp.y0 && oy < mp.y1 && ox >= mp.x0 && ox < mp.x1;
+          const int py = mp.mul * (oy - mp.y0) + mp.offy, px = mp.mul * (ox - mp.x0) + mp.offx;
+          voff = ok ? (unsigned)((((int)b * mp.OH + py) * mp.OW + px) * g.Co + nc) * 4u : 0x80000000u;
+        } else {
+          voff = (col_ok && m < a.M) ? ((unsigned)m * g.Co + nc) * 4u : 0x80000000u;
+        }
+        f32x4 v = v4 * sc + bv;
+        if (hr) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(xb_u32x4, v), ysrc, voff, 0, 0);
+      }
+    }
+#ifdef XB_STAMP
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = cacc[0];
+    o[5] = cacc[1];
+    o[7] = __builtin_amdgcn_s_memtime() - t_epi0;
+  }
+#endif
+}
+
+// floats of workspace the split weights need (the larger of the two forms' formats: planes [piece][Co][Kp] / one 32 KB LDS image per
+// 128-column tile and K-step)
+long gemm_x3b_ws_floats(int Co, int Kp) {
+  const long f1 = ((long)Co * Kp * 3 + 1) / 2, f2 = (long)cdiv(Co, 128) * (Kp / 32) * (XB2_BIMG / 4);
+  return f1 > f2 ? f1 : f2;
+}
 
 // geometry this kernel takes: no up-sampling gather (any stride, dr = +-1), Ci a multiple of 32 (a K-step lies inside one tap),
 // Kp == R S Ci (no K padding), prologue none / ReLU / leaky ReLU, plain epilogue (out_scale, bias, full-resolution residual)
@@ -285,6 +651,33 @@ bool gemm_x3b_geom_ok(const ConvGemmArgs& a) {
   return g.up == 1 && (g.Ci & 31) == 0 && g.Kp == g.R * g.S * g.Ci && (g.Co & 3) == 0 &&
          (a.pro_mode == PRO_NONE || a.pro_mode == PRO_RELU || a.pro_mode == PRO_LRELU) && !a.stat_partials && a.pro_group_rows == 0 &&
          !a.res_up && !a.res_relu && !a.mask_src && !a.scale0 && (long)g.Co * g.Kp * 6 < (1L << 31);
+}
+
+// which form: 2 = producer / consumer waves on 256 x 128 tiles (one workgroup per CU), 1 = 128 x 128 tiles, two workgroups per CU.
+// DIAGAN_GEMM_X3B_FORM forces one; default: form 2 where its tiles fill the chip at least `min_tiles2` / 256 times (the one-workgroup
+// form has nothing to run under its epilogue or beside a half-empty last round)
+static int g_x3b_form = 0;                          // diagnostics / tests: 1 / 2 force a form (diagan_conv_gemm_x3b_force_form), 0: automatic
+void gemm_x3b_force_form(int form) { g_x3b_form = form; }
+static int x3b_form(long tiles2, int nk) {
+  static const int env0 = getenv("DIAGAN_GEMM_X3B_FORM") ? atoi(getenv("DIAGAN_GEMM_X3B_FORM")) : 0;
+  const int env = g_x3b_form ? g_x3b_form : env0;
+  static const int min_tiles2 = getenv("DIAGAN_GEMM_X3B_FORM2_TILES") ? atoi(getenv("DIAGAN_GEMM_X3B_FORM2_TILES")) : 512;
+  if (env == 1 || env == 2) return env;
+  // (K loops of fewer than 8 steps: 1x1 / stride 2 from 128 channels, 316 us against 288 -- the epilogue is a quarter of such a tile)
+  return tiles2 >= min_tiles2 && nk >= 8 ? 2 : 1;
+}
+
+template <int PRO, bool MAP>
+static void launch_x3b_two(const ConvGemmArgs& a, const unsigned short* wimg, int tiles, hipStream_t st) {
+  auto kern = conv_gemm_x3b2_kernel<PRO, MAP>;
+  static int attr_dev = -1;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (attr_dev != dev) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XB2_LDS_BYTES);
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), XB2_LDS_BYTES, st, a, wimg);
 }
 
 template <int PRO, bool MAP>
@@ -302,7 +695,22 @@ static void launch_x3b_one(const ConvGemmArgs& a, const unsigned short* wx, int 
 
 int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
-  const long fl = gemm_x3b_ws_floats(g.Co, g.Kp);
+  const int tiles = cdiv(a.M, 128) * cdiv(g.Co, 128);
+  const bool map = a.map.mul != 0;
+  const int nk = g.Kp / 32;
+  const long tiles2 = (long)cdiv(a.M, 256) * cdiv(g.Co, 128);
+  if (x3b_form(tiles2, nk) == 2) {
+    const int tiles = (int)tiles2;
+    unsigned short* img = reinterpret_cast<unsigned short*>(ws);
+    hipLaunchKernelGGL(gx3b2_weight_kernel, dim3(nk, cdiv(g.Co, 128)), dim3(256), 0, st, a.w, img, g.Co, g.Kp, nk);
+    switch (a.pro_mode) {
+      case PRO_RELU: map ? launch_x3b_two<PRO_RELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_RELU, false>(a, img, tiles, st); break;
+      case PRO_LRELU: map ? launch_x3b_two<PRO_LRELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_LRELU, false>(a, img, tiles, st); break;
+      default: map ? launch_x3b_two<PRO_NONE, true>(a, img, tiles, st) : launch_x3b_two<PRO_NONE, false>(a, img, tiles, st);
+    }
+    return check_launch("conv_gemm_x3b (producer / consumer form)");
+  }
+  const long fl = ((long)g.Co * g.Kp * 3 + 1) / 2;
   const float* ready = wino_weights_ready(WK_GX3, 0, 1.f, fl);
   const unsigned short* wx = reinterpret_cast<const unsigned short*>(ready);
   if (!ready) {
@@ -312,8 +720,6 @@ int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
     hipLaunchKernelGGL(gx3b_weight_kernel, dim3((int)blocks), dim3(256), 0, st, a.w, reinterpret_cast<unsigned short*>(ws), quads);
     wx = reinterpret_cast<const unsigned short*>(ws);
   }
-  const int tiles = cdiv(a.M, 128) * cdiv(g.Co, 128);
-  const bool map = a.map.mul != 0;
   switch (a.pro_mode) {
     case PRO_RELU: map ? launch_x3b_one<PRO_RELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_RELU, false>(a, wx, tiles, st); break;
     case PRO_LRELU: map ? launch_x3b_one<PRO_LRELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_LRELU, false>(a, wx, tiles, st); break;

@@ -20,6 +20,7 @@ nat.register("diagan_conv_gemm_set_x3", [I])
 nat.register("diagan_conv_gemm_get_x3", [])
 nat.register("diagan_conv_gemm_set_x3b", [I])
 nat.register("diagan_conv_gemm_get_x3b", [])
+nat.register("diagan_conv_gemm_x3b_force_form", [I])
 nat.register("diagan_conv_gemm_out_map", [I] * 9)
 nat.register("diagan_conv_gemm_final_cfg", [I] * 15 + [I64] + [I] * 4)
 nat.register("diagan_conv_wgrad_batched", [P, I, P])
