@@ -184,6 +184,26 @@ int diagan_conv_gemm_get_wino4x(void);
  * launch; 1: in-kernel where the kernel has it (the F(2x2) kernel); -1: DIAGAN_SPLITK_FUSED, default OFF: measured neutral
  * (csrc/conv_gemm.hip, splitk_tickets). */
 int diagan_conv_gemm_set_splitk_fused(int mode);
+/* The ticket buffer of that in-kernel combine is CALLER-OWNED (round 6: the library allocates no device memory): `slots` zero-initialised
+ * ints (one per 64 x 64 output tile of the largest split launch; every launch leaves them at zero), handed over per call through
+ * diagan_conv_opts or -- diagnostics, process-wide -- registered here.  Without a buffer the second launch runs, as with the switch off. */
+int diagan_conv_gemm_set_splitk_tickets(int* buf, int64_t slots);
+/* Per-call selection options (round 6).  The kernel-selection switches above (diagan_conv_gemm_set_wino / _wino4 / _wino4x / _x3 / _x3b /
+ * _splitk_fused, diagan_conv_gemm_tune) are PROCESS-GLOBAL and exist for diagnostics, A/B runs and the tests' like-with-like comparisons
+ * only; a caller that wants another selection than the defaults passes it WITH the call: diagan_conv_gemm_next_opts stores the options
+ * for the next diagan_conv_gemm call of the calling thread (thread-local; consumed by that call whatever path it takes, like the weights
+ * hint and the output map), and two threads -- or two calls of one thread -- with different options never see each other's.
+ * Every field: -1 = the process default (environment variable at first use, or the diagnostic setter), else the value the setter of the
+ * same name takes; force_ksplit: 0 = the launch policy, > 1 = that many K splits where the configuration can split;
+ * tune: ConvGemmArgs::tune bits, -1 = production default; tickets / ticket_slots: see diagan_conv_gemm_set_splitk_tickets. */
+typedef struct diagan_conv_opts {
+  int32_t wino, wino4, wino4x, gemm_x3, gemm_x3b, splitk_fused, force_ksplit, tune;
+  int32_t* tickets;
+  int64_t ticket_slots;
+} diagan_conv_opts;
+int diagan_conv_gemm_next_opts(const diagan_conv_opts* opts);
+/* The tile configuration the last diagan_conv_gemm call of the calling thread resolved to (0: it failed before choosing). */
+int diagan_conv_gemm_last_cfg(void);
 /* The lone-tile implicit-GEMM launches (at most one 64 x 64 output tile per CU, long K loop: the 8x8 maps of SNGAN-32's discriminator;
  * tile_cfg 14) on the bf16 matrix pipe with every fp32 operand split EXACTLY into three bf16 pieces, six piece products accumulated
  * in fp32 (csrc/conv_gemm_x3.hip; fp32-grade results, held to float64 by tests/test_conv_gpu.py).  tile_cfg 16 asks for that kernel
@@ -197,7 +217,7 @@ int diagan_conv_gemm_get_x3(void);
  * output tiles, two workgroups per CU (csrc/conv_gemm_x3b.hip; fp32-grade results, held to float64 by tests/test_conv_gpu.py).
  * tile_cfg 17 asks for that kernel by name (no up-sampling gather, Ci % 32 == 0, Kp == R*S*Ci, prologue none / ReLU / leaky ReLU,
  * epilogue out_scale + bias + residual only); mode 1 / 0 / -1: the automatic upgrade of an implicit-GEMM pick with >= 192 tiles of
- * 128 x 128 and >= 4 K-steps on / off / DIAGAN_GEMM_X3B (default on). */
+ * 128 x 128, >= 4 K-steps and >= 4e9 multiply-accumulates on / off / DIAGAN_GEMM_X3B (default on). */
 int diagan_conv_gemm_set_x3b(int mode);
 int diagan_conv_gemm_get_x3b(void);
 /* tile_cfg 17 has two forms: 1 = 128 x 128 tiles, two workgroups per CU (small launches, short K loops); 2 = 256 x 128 tiles, four MFMA waves

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 
 #define DIAGAN_OK 0
 #define DIAGAN_EINVAL (-1)   // bad argument (shape / alignment / null pointer)
@@ -37,6 +38,30 @@ inline int check_launch(const char* what) {
   } while (0)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): one latch object per kernel, one entry per device,
+// taken under a lock so that two host threads (or two devices of one process) launching the same kernel both find it set.
+struct FuncAttrLatch {
+  std::mutex m;
+  size_t have[64] = {};
+};
+// `kernel` may be launched with `bytes` of dynamic LDS on the CURRENT device from here on; hipSuccess or the runtime's error
+inline hipError_t ensure_dynamic_lds(FuncAttrLatch& l, const void* kernel, size_t bytes) {
+  int d = 0;
+  hipError_t e = hipGetDevice(&d);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(l.m);
+  size_t& have = l.have[d & 63];
+  if (have >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) have = bytes;
+  return e;
+}
+#define DG_LDS(latch, kern, bytes)                                                                                    \
+  do {                                                                                                                \
+    hipError_t _e = diagan::ensure_dynamic_lds(latch, (const void*)(kern), (bytes));                                  \
+    if (_e != hipSuccess) return diagan::set_err(DIAGAN_EHIP, "%s: %zu bytes of dynamic LDS: %s", #kern, (size_t)(bytes), hipGetErrorString(_e)); \
+  } while (0)
 
 // wave64 reductions by shuffles
 __device__ __forceinline__ float wave_sum(float v) {

@@ -696,54 +696,69 @@ static thread_local WinoFormat g_hint_next = {nullptr, 0, 0, 0.f, 0}, g_hint_now
 static thread_local long g_weight_launches = 0;   // per-launch weight-transform kernels issued by this thread (tests)
 constexpr int kDefaultTune = 0;
 
-// Ticket counters of the in-kernel split-K combine (ConvGemmArgs::tickets): one int per output tile, zero between launches (the
-// last-arriving workgroup of a tile resets its counter).  Allocated on first use (outside any stream capture).
-// OFF by default (DIAGAN_SPLITK_FUSED=1 / diagan_conv_gemm_set_splitk_fused(1) turn it on): measured on the F(2x2) kernel's
-// 36 / 10 split launches per SNGAN-64 / -32 step it buys nothing -- plain partial stores + an agent-scope release per workgroup:
-// -0.5 % (the release writes the L2's dirty lines back); write-through partial stores, no release: +-0.1 % (2998-3005 vs
-// 3003-3008 images/s): draining the stores and the last arriver's serial read-back cost what the 7 us second launch costs.
-static int g_gemm_x3 = -1;                        // -1: DIAGAN_GEMM_X3 / default; 0 / 1: diagan_conv_gemm_set_x3
-static bool gemm_x3_on() {
-  static const int env = getenv("DIAGAN_GEMM_X3") ? atoi(getenv("DIAGAN_GEMM_X3")) : 1;      // on: SNGAN-32 5270-5281 -> 5355 images/s
-  return (g_gemm_x3 >= 0 ? g_gemm_x3 : env) != 0;
-}
+static int g_gemm_x3 = -1;                        // -1: DIAGAN_GEMM_X3 / default; 0 / 1: diagan_conv_gemm_set_x3 (process-wide, diagnostics)
 // tile_cfg 17 (round 6, conv_gemm_x3b.hip): the large implicit GEMMs on the bf16 pipe with split operands.  -1: DIAGAN_GEMM_X3B /
 // default; 0 / 1: diagan_conv_gemm_set_x3b.  The automatic choice upgrades an implicit-GEMM pick (never a Winograd one) where the
-// launch has at least `kX3bMinTiles` 128 x 128 tiles (two workgroups per CU: one round of the chip) and four K-steps.
+// launch has at least `x3b_min_tiles()` 128 x 128 tiles and four K-steps.
 static int g_gemm_x3b = -1;
-static bool gemm_x3b_on() {
-  static const int env = getenv("DIAGAN_GEMM_X3B") ? atoi(getenv("DIAGAN_GEMM_X3B")) : 1;
-  return (g_gemm_x3b >= 0 ? g_gemm_x3b : env) != 0;
-}
 static int x3b_min_tiles() {
   static const int env = getenv("DIAGAN_GEMM_X3B_MIN_TILES") ? atoi(getenv("DIAGAN_GEMM_X3B_MIN_TILES")) : 192;
   return env;
 }
-static bool x3b_takes(const ConvGemmArgs& a, int cfg, int64_t ws_floats) {
-  if (!gemm_x3b_on() || !(cfg == 1 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8)) return false;
-  const ConvGeom& g = a.g;
-  return gemm_x3b_geom_ok(a) && g.Kp >= 128 && g.Co >= 64 && (long)cdiv(a.M, 128) * cdiv(g.Co, 128) >= x3b_min_tiles() &&
-         gemm_x3b_ws_floats(g.Co, g.Kp) <= ws_floats;
-}
 // the output map of the NEXT diagan_conv_gemm call of this thread (diagan_conv_gemm_out_map); like the weights hint it holds for
 // exactly one call
 static thread_local OutMap g_map_next = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-constexpr int kTicketSlots = 1 << 16;
-static int g_splitk_fused = -1;                   // -1: DIAGAN_SPLITK_FUSED / default (on); 0 / 1: diagan_conv_gemm_set_splitk_fused
-static int* splitk_tickets(hipStream_t st) {
+// ---- per-call selection options (round 6; include/diagan_hip.h: diagan_conv_opts) --------------------------------------------------
+// What a diagan_conv_gemm call selects with -- Winograd on / off, the split-operand kernels, a forced split-K factor, tune bits, the
+// in-kernel split-K combine and its ticket buffer -- comes from the options the CALLER handed over for that call (thread-local, held for
+// exactly one call like the weights hint and the output map); a field at -1 (0 for force_ksplit) means "the process default": the
+// environment variable latched at first use or, for diagnostics and the tests' like-with-like runs, the process-wide setters below.
+// Nothing on the product path writes a process-global.
+struct CallOpts {
+  int wino, wino4, wino4x, gemm_x3, gemm_x3b, splitk_fused, force_ksplit, tune;
+  int* tickets;
+  long ticket_slots;
+};
+static const CallOpts kNoOpts = {-1, -1, -1, -1, -1, -1, 0, -1, nullptr, 0};
+static thread_local CallOpts g_opts_next = kNoOpts, g_opts_now = kNoOpts;
+static thread_local int g_last_cfg = 0;           // tile configuration the last call of this thread resolved to
+int call_opt_wino4x() { return g_opts_now.wino4x; }          // (conv_wino4.hip: wino4_get_x3)
+static int sel_wino() {
+  static const int env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
+  return g_opts_now.wino >= 0 ? g_opts_now.wino : (g_wino >= 0 ? g_wino : env);
+}
+static int sel_wino4() { return g_opts_now.wino4 >= 0 ? g_opts_now.wino4 : g_wino4; }      // (-1: the environment's DIAGAN_WINO4 decides, at its use)
+static int sel_force_ksplit() { return g_opts_now.force_ksplit > 0 ? g_opts_now.force_ksplit : g_force_ksplit; }
+static bool gemm_x3_on() {
+  static const int env = getenv("DIAGAN_GEMM_X3") ? atoi(getenv("DIAGAN_GEMM_X3")) : 1;      // on: SNGAN-32 5270-5281 -> 5355 images/s
+  return (g_opts_now.gemm_x3 >= 0 ? g_opts_now.gemm_x3 : (g_gemm_x3 >= 0 ? g_gemm_x3 : env)) != 0;
+}
+static bool gemm_x3b_on() {
+  static const int env = getenv("DIAGAN_GEMM_X3B") ? atoi(getenv("DIAGAN_GEMM_X3B")) : 1;
+  return (g_opts_now.gemm_x3b >= 0 ? g_opts_now.gemm_x3b : (g_gemm_x3b >= 0 ? g_gemm_x3b : env)) != 0;
+}
+static bool x3b_takes(const ConvGemmArgs& a, int cfg, int64_t ws_floats) {
+  if (!gemm_x3b_on() || !(cfg == 1 || cfg == 3 || cfg == 5 || cfg == 7 || cfg == 8)) return false;
+  const ConvGeom& g = a.g;
+  // (... and enough work to carry the per-launch weight split: below ~4e9 multiply-accumulates -- the 15 us 1x1 shortcuts of the SNGAN
+  //  nets -- the 5 us split launch in front costs more than the faster pipe returns)
+  return gemm_x3b_geom_ok(a) && g.Kp >= 128 && g.Co >= 64 && (long)cdiv(a.M, 128) * cdiv(g.Co, 128) >= x3b_min_tiles() &&
+         (double)a.M * g.Co * g.Kp >= 4e9 && gemm_x3b_ws_floats(g.Co, g.Kp) <= ws_floats;
+}
+// Ticket counters of the in-kernel split-K combine (ConvGemmArgs::tickets): one int per output tile, zero between launches (the
+// last-arriving workgroup of a tile resets its counter).  CALLER-OWNED (the library allocates nothing): the call's options carry the
+// buffer, or -- diagnostics -- diagan_conv_gemm_set_splitk_tickets registers one process-wide.  OFF by default: measured on the F(2x2)
+// kernel's 36 / 10 split launches per SNGAN-64 / -32 step it buys nothing -- plain partial stores + an agent-scope release per workgroup:
+// -0.5 % (the release writes the L2's dirty lines back); write-through partial stores, no release: +-0.1 % (2998-3005 vs 3003-3008
+// images/s): draining the stores and the last arriver's serial read-back cost what the 7 us second launch costs.
+static int g_splitk_fused = -1;                   // -1: DIAGAN_SPLITK_FUSED / default (off); 0 / 1: diagan_conv_gemm_set_splitk_fused
+static int* g_tickets = nullptr;                  // diagnostics: diagan_conv_gemm_set_splitk_tickets
+static long g_ticket_slots = 0;
+static int* splitk_tickets(long tiles) {
   static const int env = getenv("DIAGAN_SPLITK_FUSED") ? atoi(getenv("DIAGAN_SPLITK_FUSED")) : 0;
-  static int* buf = nullptr;
-  static bool tried = false;
-  if (!(g_splitk_fused >= 0 ? g_splitk_fused : env)) return nullptr;
-  if (!tried) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return nullptr;   // not now: two launches
-    tried = true;
-    int* p = nullptr;
-    if (hipMalloc(&p, kTicketSlots * sizeof(int)) == hipSuccess && hipMemset(p, 0, kTicketSlots * sizeof(int)) == hipSuccess) buf = p;
-    (void)hipGetLastError();
-  }
-  return buf;
+  if (!(g_opts_now.splitk_fused >= 0 ? g_opts_now.splitk_fused : (g_splitk_fused >= 0 ? g_splitk_fused : env))) return nullptr;
+  if (g_opts_now.tickets) return tiles <= g_opts_now.ticket_slots ? g_opts_now.tickets : nullptr;
+  return (g_tickets && tiles <= g_ticket_slots) ? g_tickets : nullptr;        // (no buffer: the second launch, as with the switch off)
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int PRO, bool STAMP = false, bool FP = false, int KG = 1>
@@ -753,11 +768,8 @@ static int launch_one(const ConvGemmArgs& a, hipStream_t st) {
   //  the allocation, where LDS accesses are dropped by the hardware's range check)
   const size_t lds = (size_t)((long)((size_t)2 * KG * (BM + BN) * BK * sizeof(float)) + g_lds_delta);
   auto kern = conv_gemm_kernel<BM, BN, WM, WN, BK, PRO, STAMP, FP, KG>;
-  static size_t attr_set = 0;
-  if (attr_set < lds) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = lds;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, lds);
   hipLaunchKernelGGL(kern, dim3(tiles, a.ksplit), dim3(256 * KG), lds, st, a);
   if (a.ksplit > 1) {
     long blocks = ((long)a.M * (a.g.Co / 4) + 255) / 256;
@@ -843,7 +855,7 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg(int M, int Co, int Kp, int allow_split)
 //    over a whole training step: 2350 -> 2323 images/s.)
 DIAGAN_API int diagan_conv_gemm_pick_ksplit(int M, int Co, int Kp, int cfg) {
   static const int env_forced = getenv("DIAGAN_KSPLIT") ? atoi(getenv("DIAGAN_KSPLIT")) : 0;   // tuning experiments only
-  const int forced = g_force_ksplit > 0 ? g_force_ksplit : env_forced;
+  const int forced = sel_force_ksplit() > 0 ? sel_force_ksplit() : env_forced;
   if (forced > 0 && !(Co & 3)) return forced < Kp / 64 ? forced : (Kp / 64 > 0 ? Kp / 64 : 1);
   if (Co & 3) return 1;
   const int nk = Kp / 32;
@@ -909,6 +921,11 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   g_fmt_last = WinoFormat{nullptr, 0, 0, 0.f, 0};
   const OutMap map = g_map_next;            // ... and so does an output map
   g_map_next = OutMap{0, 0, 0, 0, 0, 0, 0, 0, 0};
+  struct OptsScope {                        // ... and the selection options: in force until this call returns, whatever path it takes
+    OptsScope() { g_opts_now = g_opts_next; g_opts_next = kNoOpts; }
+    ~OptsScope() { g_opts_now = kNoOpts; }
+  } opts_scope;
+  g_last_cfg = 0;
   DG_REQUIRE(x && w && y, "conv_gemm: null tensor");
   DG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Co > 0 && R > 0 && S > 0, "conv_gemm: bad dims");
   DG_REQUIRE(Ci > 0 && (Ci & 3) == 0, "conv_gemm: Ci=%d must be a positive multiple of 4 (pad the tensor)", Ci);
@@ -947,6 +964,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                                                               (splitk_ws && !stat_partials) ? 1 : 0,
                                                               splitk_ws ? splitk_ws_floats : 0, pro_group_rows);
   if (tile_cfg == 0 && splitk_ws && x3b_takes(a, cfg, splitk_ws_floats)) cfg = 17;
+  g_last_cfg = cfg;
   if (map.mul != 0) {
     DG_REQUIRE(map.mul > 0 && map.OH > 0 && map.OW > 0 && map.y0 >= 0 && map.x0 >= 0 && map.y1 <= Ho && map.x1 <= Wo &&
                    map.offy >= 0 && map.offx >= 0 && (map.y1 <= map.y0 || map.mul * (map.y1 - 1 - map.y0) + map.offy < map.OH) &&
@@ -965,7 +983,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.slab = splitk_ws;
   a.tickets = nullptr;
   a.ksplit = 1;
-  a.tune = g_tune_flags >= 0 ? g_tune_flags : kDefaultTune;
+  a.tune = g_opts_now.tune >= 0 ? g_opts_now.tune : (g_tune_flags >= 0 ? g_tune_flags : kDefaultTune);
   a.stamps = nullptr;
   if (g_stamps) {
     const long wgs = (long)cdiv(a.M, bm) * cdiv(Co, diagan_conv_gemm_tile_cols(cfg)) * 16;   // room for up to 16 K splits
@@ -982,7 +1000,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                    (pro_mode == PRO_NONE || pro_mode == PRO_RELU) && !mask_src && !stat_partials && !a.res_up && pro_group_rows == 0,
                "conv_gemm: tile_cfg 11 (Winograd + average pool) needs a forward 3x3 / stride 1 / pad 1 geometry with even H, W, "
                "Ci %% 8 == 0, Co %% 64 == 0, prologue none / ReLU, no mask, statistics or half-resolution residual");
-    if (g_wino4 != 0 && splitk_ws && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats, g_wino4 == 2)) {     // 25 products per 4x4 tile (conv_wino4.hip)
+    if (sel_wino4() != 0 && splitk_ws && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats, sel_wino4() == 2)) {     // 25 products per 4x4 tile (conv_wino4.hip)
       a.ksplit = 1;
       return launch_wino4_pool(a, splitk_ws, st);
     }
@@ -1011,7 +1029,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                    pro_mode == PRO_NONE && !stat_partials && !a.res_up && pro_group_rows == 0,
                "conv_gemm: tile_cfg 12 (data-gradient through an average pool, Winograd) needs the data-gradient geometry of a "
                "3x3 / stride 1 / pad 1 layer with even H, W, Ci %% 8 == 0, Co %% 64 == 0, no prologue, statistics or half-resolution residual");
-    if (g_wino4 != 0 && splitk_ws && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats, g_wino4 == 2)) {     // the same on the pooled gradient
+    if (sel_wino4() != 0 && splitk_ws && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)splitk_ws_floats, sel_wino4() == 2)) {     // the same on the pooled gradient
       a.ksplit = 1;
       return launch_wino4_unpool(a, splitk_ws, st);
     }
@@ -1052,8 +1070,8 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     if (tile_cfg == 0 && !stat_partials) {
       ks = wino4_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats);
       if (ks < 1) ks = 1;
-    } else if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats && Ci / 8 / g_force_ksplit >= 1) {
-      ks = g_force_ksplit;
+    } else if (sel_force_ksplit() > 1 && !stat_partials && wfl + (long)sel_force_ksplit() * a.M * Co <= splitk_ws_floats && Ci / 8 / sel_force_ksplit() >= 1) {
+      ks = sel_force_ksplit();
     }
     a.ksplit = ks;
     a.slab = splitk_ws + wfl;
@@ -1077,13 +1095,13 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
     if (tile_cfg == 0 && !stat_partials) {
       ks = wino_ksplit(B, Ho, Wo, Ci, Co, 1, (long)splitk_ws_floats, 192);
       if (ks < 1) ks = 1;
-    } else if (g_force_ksplit > 1 && !stat_partials && wfl + (long)g_force_ksplit * a.M * Co <= splitk_ws_floats &&
-               Ci / 16 / g_force_ksplit >= 1) {
-      ks = g_force_ksplit;
+    } else if (sel_force_ksplit() > 1 && !stat_partials && wfl + (long)sel_force_ksplit() * a.M * Co <= splitk_ws_floats &&
+               Ci / 16 / sel_force_ksplit() >= 1) {
+      ks = sel_force_ksplit();
     }
     a.ksplit = ks;
     a.slab = splitk_ws + wfl;
-    if (ks > 1 && (long)cdiv(a.M / 4, 64) * cdiv(Co, 64) <= kTicketSlots) a.tickets = splitk_tickets(st);
+    if (ks > 1) a.tickets = splitk_tickets((long)cdiv(a.M / 4, 64) * cdiv(Co, 64));
     int rc = launch_wino(a, splitk_ws, st);
     if (rc == DIAGAN_OK && ks > 1 && !a.tickets) {
       long blocks = ((long)a.M * (Co / 4) + 255) / 256;
@@ -1147,9 +1165,8 @@ DIAGAN_API int diagan_conv_wino_supported(int Hi, int Wi, int Ci, int Ho, int Wo
 // DIAGAN_WINO=0 / DIAGAN_WINO_POOL=0 switch it off.
 DIAGAN_API int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                                int dr, int off, int up, int pro_mode, int64_t ws_floats) {
-  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
   static const int pool_env = getenv("DIAGAN_WINO_POOL") ? atoi(getenv("DIAGAN_WINO_POOL")) : 1;
-  const int wino = g_wino >= 0 ? g_wino : wino_env;
+  const int wino = sel_wino();
   if (!wino || !pool_env || dr != 1 || Co % 64 != 0 || Ci < 16 || !(pro_mode == PRO_NONE || pro_mode == PRO_RELU)) return 0;
   if (!diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
   const long wfl = wino_ws_floats(Co, Ci);
@@ -1160,9 +1177,8 @@ DIAGAN_API int diagan_conv_wino_pool_supported(int B, int Hi, int Wi, int Ci, in
 // tile_cfg 12: the data-gradient of such a layer from the HALF-resolution gradient (same nine products, see conv_wino_pool.hip)
 DIAGAN_API int diagan_conv_wino_unpool_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy,
                                                  int dr, int off, int up, int64_t ws_floats) {
-  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
   static const int pool_env = getenv("DIAGAN_WINO_POOL") ? atoi(getenv("DIAGAN_WINO_POOL")) : 1;
-  const int wino = g_wino >= 0 ? g_wino : wino_env;
+  const int wino = sel_wino();
   if (!wino || !pool_env || dr != -1 || Co % 64 != 0 || Ci < 16) return 0;
   if (!diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
   const long wfl = wino_ws_floats(Co, Ci);
@@ -1181,8 +1197,7 @@ DIAGAN_API int diagan_conv_gemm_pick_cfg_geom(int B, int Hi, int Wi, int Ci, int
 }
 static int pick_cfg_geom_impl(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
                               int up, int Kp, int allow_split, int64_t ws_floats, bool allow_w4) {
-  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
-  const int wino = g_wino >= 0 ? g_wino : wino_env;
+  const int wino = sel_wino();
   // one 512-thread workgroup per CU: below ~3/4 of the chip the implicit GEMM's smaller tiles win (8x8 / 4x4 blocks at
   // batch 64: 128 workgroups, 325 vs 317 us; their data-gradients 330 vs 168 us)
   static const int min_wgs = getenv("DIAGAN_WINO_MIN_WGS") ? atoi(getenv("DIAGAN_WINO_MIN_WGS")) : 192;
@@ -1193,7 +1208,7 @@ static int pick_cfg_geom_impl(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int
     // launch-size policy (wino4_ksplit) expects it ahead of the F(2x2) kernel
     static const int w4_env = getenv("DIAGAN_WINO4") ? atoi(getenv("DIAGAN_WINO4")) : 1;
     static const int w4_min_ci = getenv("DIAGAN_WINO4_MIN_CI") ? atoi(getenv("DIAGAN_WINO4_MIN_CI")) : 64;
-    if (allow_w4 && w4_env && g_wino4 != 0 && wino4_geom_ok(Ho, Wo, Ci) && Ci >= w4_min_ci && ws_floats >= wino4_ws_floats(Co, Ci) &&
+    if (allow_w4 && w4_env && sel_wino4() != 0 && wino4_geom_ok(Ho, Wo, Ci) && Ci >= w4_min_ci && ws_floats >= wino4_ws_floats(Co, Ci) &&
         wino4_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats) > 0)
       return 13;
     if (wino_ksplit(B, Ho, Wo, Ci, Co, wsplit ? allow_split : 0, (long)ws_floats, min_wgs) > 0) return 9;
@@ -1232,18 +1247,17 @@ DIAGAN_API int diagan_conv_gemm_set_wino(int mode) {
 // Do the pooled launches of this geometry (tile_cfg 11 / 12) run on the F(4x4) kernel (25 products per 4x4 tile) rather than on
 // conv_wino_pool.hip's F(2x2) kernels (9 per 2x2 tile)?  Host-only; for kernel names / executed-FLOP accounting.
 DIAGAN_API int diagan_conv_wino4_pool_used(int B, int Ho, int Wo, int Ci, int Co, int64_t ws_floats) {
-  return g_wino4 != 0 && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, g_wino4 == 2) ? 1 : 0;
+  return sel_wino4() != 0 && wino4_pool_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, sel_wino4() == 2) ? 1 : 0;
 }
 
 // tile_cfg 15: does conv3x3(bilinear_x2(pro(x))) of this layer (Hi, Wi, Ho, Wo: the UP-SAMPLED size) run as one launch of the
 // F(4x4) kernel on the half-resolution input?  Host-only (GBlock asks before it decides whether to write the up-sampled tensor).
 DIAGAN_API int diagan_conv_wino4_upin_supported(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                                 int off, int up, int64_t ws_floats, int pro_group_rows) {
-  static const int wino_env = getenv("DIAGAN_WINO") ? atoi(getenv("DIAGAN_WINO")) : 1;
-  const int wino = g_wino >= 0 ? g_wino : wino_env;
-  if (!wino || g_wino4 == 0 || dr != 1 || !diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
+  const int wino = sel_wino();
+  if (!wino || sel_wino4() == 0 || dr != 1 || !diagan_conv_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up)) return 0;
   if (pro_group_rows > 0 && pro_group_rows % 512 != 0) return 0;
-  return wino4_upin_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, g_wino4 == 2) ? 1 : 0;
+  return wino4_upin_ok(B, Ho, Wo, Ci, Co, (long)ws_floats, sel_wino4() == 2) ? 1 : 0;
 }
 
 // Run-time form of DIAGAN_WINO4: 0 = the automatic choice never takes the F(4x4,3x3) kernel (tile_cfg 13), 1 / -1 = where it
@@ -1312,6 +1326,38 @@ DIAGAN_API int diagan_conv_gemm_set_splitk_fused(int mode) {
   g_splitk_fused = mode;
   return DIAGAN_OK;
 }
+// process-wide ticket buffer of the in-kernel split-K combine (diagnostics; the product path hands one over per call through
+// diagan_conv_opts or leaves the combine to the second launch): caller-owned, `slots` zero-initialised ints; NULL unregisters
+DIAGAN_API int diagan_conv_gemm_set_splitk_tickets(int* buf, int64_t slots) {
+  DG_REQUIRE((buf && slots > 0) || (!buf && slots == 0), "set_splitk_tickets: a buffer with its slot count, or NULL and 0");
+  g_tickets = buf;
+  g_ticket_slots = (long)slots;
+  return DIAGAN_OK;
+}
+struct diagan_conv_opts {     // mirrors the typedef of the same name in include/diagan_hip.h (48 bytes)
+  int32_t wino, wino4, wino4x, gemm_x3, gemm_x3b, splitk_fused, force_ksplit, tune;
+  int32_t* tickets;
+  int64_t ticket_slots;
+};
+static_assert(sizeof(diagan_conv_opts) == 48, "diagan_conv_opts layout");
+// Selection options of the NEXT diagan_conv_gemm call of the calling thread (thread-local, consumed by that call whatever path it takes;
+// NULL clears a pending set).  See diagan_conv_opts in include/diagan_hip.h.
+DIAGAN_API int diagan_conv_gemm_next_opts(const diagan_conv_opts* o) {
+  if (!o) {
+    g_opts_next = kNoOpts;
+    return DIAGAN_OK;
+  }
+  DG_REQUIRE(o->wino >= -1 && o->wino <= 1 && o->wino4 >= -1 && o->wino4 <= 2 && o->wino4x >= -1 && o->wino4x <= 1 && o->gemm_x3 >= -1 &&
+                 o->gemm_x3 <= 1 && o->gemm_x3b >= -1 && o->gemm_x3b <= 1 && o->splitk_fused >= -1 && o->splitk_fused <= 1 &&
+                 o->force_ksplit >= 0 && o->tune >= -1,
+             "conv_gemm_next_opts: a field out of range (-1 = process default; force_ksplit 0 = the launch policy)");
+  DG_REQUIRE(!o->tickets || o->ticket_slots > 0, "conv_gemm_next_opts: a ticket buffer needs its slot count");
+  g_opts_next = CallOpts{o->wino, o->wino4, o->wino4x, o->gemm_x3, o->gemm_x3b, o->splitk_fused, o->force_ksplit, o->tune, o->tickets,
+                         (long)o->ticket_slots};
+  return DIAGAN_OK;
+}
+// tile configuration the last diagan_conv_gemm call of the calling thread resolved to (0: it failed before choosing)
+DIAGAN_API int diagan_conv_gemm_last_cfg(void) { return g_last_cfg; }
 
 // Diagnostics / tuning sweeps (tools/stamp_report.py, tools/bench_conv.py); never called by the product path.
 //  * stamp buffer: while set, diagan_conv_gemm launches the STAMP build of the kernel, which records per workgroup

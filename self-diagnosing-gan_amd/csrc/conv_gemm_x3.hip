@@ -231,14 +231,14 @@ int launch_gemm_x3(const ConvGemmArgs& a, float* ws, hipStream_t st) {
     wx = reinterpret_cast<const unsigned short*>(ws);
   }
   const int tiles = cdiv(a.M, 64) * cdiv(g.Co, 64);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<PRO_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)conv_gemm_x3_kernel<PRO_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, GX_LDS_BYTES);
-    attr_set = true;
+  static FuncAttrLatch latch_none, latch_relu;
+  if (a.pro_mode == PRO_RELU) {
+    DG_LDS(latch_relu, conv_gemm_x3_kernel<PRO_RELU>, GX_LDS_BYTES);
+    hipLaunchKernelGGL(conv_gemm_x3_kernel<PRO_RELU>, dim3(tiles), dim3(512), GX_LDS_BYTES, st, a, wx);
+  } else {
+    DG_LDS(latch_none, conv_gemm_x3_kernel<PRO_NONE>, GX_LDS_BYTES);
+    hipLaunchKernelGGL(conv_gemm_x3_kernel<PRO_NONE>, dim3(tiles), dim3(512), GX_LDS_BYTES, st, a, wx);
   }
-  if (a.pro_mode == PRO_RELU) hipLaunchKernelGGL(conv_gemm_x3_kernel<PRO_RELU>, dim3(tiles), dim3(512), GX_LDS_BYTES, st, a, wx);
-  else hipLaunchKernelGGL(conv_gemm_x3_kernel<PRO_NONE>, dim3(tiles), dim3(512), GX_LDS_BYTES, st, a, wx);
   return check_launch("conv_gemm_x3");
 }
 

@@ -668,29 +668,21 @@ static int x3b_form(long tiles2, int nk) {
 }
 
 template <int PRO, bool MAP>
-static void launch_x3b_two(const ConvGemmArgs& a, const unsigned short* wimg, int tiles, hipStream_t st) {
+static int launch_x3b_two(const ConvGemmArgs& a, const unsigned short* wimg, int tiles, hipStream_t st) {
   auto kern = conv_gemm_x3b2_kernel<PRO, MAP>;
-  static int attr_dev = -1;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XB2_LDS_BYTES);
-    attr_dev = dev;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, XB2_LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), XB2_LDS_BYTES, st, a, wimg);
+  return DIAGAN_OK;
 }
 
 template <int PRO, bool MAP>
-static void launch_x3b_one(const ConvGemmArgs& a, const unsigned short* wx, int tiles, hipStream_t st) {
+static int launch_x3b_one(const ConvGemmArgs& a, const unsigned short* wx, int tiles, hipStream_t st) {
   auto kern = conv_gemm_x3b_kernel<PRO, MAP>;
-  static int attr_dev = -1;                          // (the attribute is per device: re-set when the current device changes)
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (attr_dev != dev) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, XB_LDS_BYTES);
-    attr_dev = dev;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, XB_LDS_BYTES);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), XB_LDS_BYTES, st, a, wx);
+  return DIAGAN_OK;
 }
 
 int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
@@ -703,11 +695,13 @@ int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
     const int tiles = (int)tiles2;
     unsigned short* img = reinterpret_cast<unsigned short*>(ws);
     hipLaunchKernelGGL(gx3b2_weight_kernel, dim3(nk, cdiv(g.Co, 128)), dim3(256), 0, st, a.w, img, g.Co, g.Kp, nk);
+    int rc;
     switch (a.pro_mode) {
-      case PRO_RELU: map ? launch_x3b_two<PRO_RELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_RELU, false>(a, img, tiles, st); break;
-      case PRO_LRELU: map ? launch_x3b_two<PRO_LRELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_LRELU, false>(a, img, tiles, st); break;
-      default: map ? launch_x3b_two<PRO_NONE, true>(a, img, tiles, st) : launch_x3b_two<PRO_NONE, false>(a, img, tiles, st);
+      case PRO_RELU: rc = map ? launch_x3b_two<PRO_RELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_RELU, false>(a, img, tiles, st); break;
+      case PRO_LRELU: rc = map ? launch_x3b_two<PRO_LRELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_LRELU, false>(a, img, tiles, st); break;
+      default: rc = map ? launch_x3b_two<PRO_NONE, true>(a, img, tiles, st) : launch_x3b_two<PRO_NONE, false>(a, img, tiles, st);
     }
+    if (rc != DIAGAN_OK) return rc;
     return check_launch("conv_gemm_x3b (producer / consumer form)");
   }
   const long fl = ((long)g.Co * g.Kp * 3 + 1) / 2;
@@ -720,11 +714,13 @@ int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
     hipLaunchKernelGGL(gx3b_weight_kernel, dim3((int)blocks), dim3(256), 0, st, a.w, reinterpret_cast<unsigned short*>(ws), quads);
     wx = reinterpret_cast<const unsigned short*>(ws);
   }
+  int rc;
   switch (a.pro_mode) {
-    case PRO_RELU: map ? launch_x3b_one<PRO_RELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_RELU, false>(a, wx, tiles, st); break;
-    case PRO_LRELU: map ? launch_x3b_one<PRO_LRELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_LRELU, false>(a, wx, tiles, st); break;
-    default: map ? launch_x3b_one<PRO_NONE, true>(a, wx, tiles, st) : launch_x3b_one<PRO_NONE, false>(a, wx, tiles, st);
+    case PRO_RELU: rc = map ? launch_x3b_one<PRO_RELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_RELU, false>(a, wx, tiles, st); break;
+    case PRO_LRELU: rc = map ? launch_x3b_one<PRO_LRELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_LRELU, false>(a, wx, tiles, st); break;
+    default: rc = map ? launch_x3b_one<PRO_NONE, true>(a, wx, tiles, st) : launch_x3b_one<PRO_NONE, false>(a, wx, tiles, st);
   }
+  if (rc != DIAGAN_OK) return rc;
   return check_launch("conv_gemm_x3b");
 }
 

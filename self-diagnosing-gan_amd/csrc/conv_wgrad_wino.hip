@@ -348,15 +348,13 @@ int wgrad_wino_splits(int B, int Ho, int Wo, int Ci, int Co) {
 }
 
 template <int PRO>
-static void launch_gw(const WgradArgs& a, int wgs, hipStream_t st) {
+static int launch_gw(const WgradArgs& a, int wgs, hipStream_t st) {
   const size_t lds = (size_t)2 * GW_STAGE * sizeof(float);
   auto kern = conv_wgrad_wino_kernel<PRO>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, lds);
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, a);
+  return DIAGAN_OK;
 }
 
 // `a` as prepared by diagan_conv_wgrad (M, g, slab, strides, prologue); the K-step bookkeeping is redone for 8-tile steps
@@ -371,28 +369,28 @@ int launch_wgrad_wino(WgradArgs a, int splits, int segments, hipStream_t st) {
   a.steps_per_split = cdiv(a.seg_steps, a.splits_per_seg);
   a.tiles = cdiv(g.Co, 64) * cdiv(g.Ci, 64);
   const int wgs = a.tiles * splits;
+  int rc;
   switch (a.pro_mode) {
-    case PRO_NONE: launch_gw<PRO_NONE>(a, wgs, st); break;
-    case PRO_RELU: launch_gw<PRO_RELU>(a, wgs, st); break;
-    case PRO_AFFINE_RELU: launch_gw<PRO_AFFINE_RELU>(a, wgs, st); break;
-    case PRO_LRELU: launch_gw<PRO_LRELU>(a, wgs, st); break;
-    default: launch_gw<PRO_AFFINE>(a, wgs, st); break;
+    case PRO_NONE: rc = launch_gw<PRO_NONE>(a, wgs, st); break;
+    case PRO_RELU: rc = launch_gw<PRO_RELU>(a, wgs, st); break;
+    case PRO_AFFINE_RELU: rc = launch_gw<PRO_AFFINE_RELU>(a, wgs, st); break;
+    case PRO_LRELU: rc = launch_gw<PRO_LRELU>(a, wgs, st); break;
+    default: rc = launch_gw<PRO_AFFINE>(a, wgs, st); break;
   }
+  if (rc != DIAGAN_OK) return rc;
   return check_launch("conv_wgrad_wino");
 }
 
 // several layers in one launch: a[j] as prepared by diagan_conv_wgrad for layer j (same prologue mode), splits[j] a multiple of
 // segments[j]
 template <int PRO>
-static void launch_gw_batched(const WgradWinoBatch& b, int wgs, hipStream_t st) {
+static int launch_gw_batched(const WgradWinoBatch& b, int wgs, hipStream_t st) {
   const size_t lds = (size_t)2 * GW_STAGE * sizeof(float);
   auto kern = conv_wgrad_wino_batched_kernel<PRO>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, lds);
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(512), lds, st, b);
+  return DIAGAN_OK;
 }
 int wgrad_wino_batch_max() { return GW_BATCH_MAX; }
 int launch_wgrad_wino_batched(const WgradArgs* jobs, const int* splits, const int* segments, int n, hipStream_t st) {
@@ -418,13 +416,15 @@ int launch_wgrad_wino_batched(const WgradArgs* jobs, const int* splits, const in
     wgs += (b.cnt[j] + 7) & ~7;
   }
   for (int j = n; j < GW_BATCH_MAX; ++j) b.blk0[j] = wgs, b.cnt[j] = 0;
+  int rc;
   switch (jobs[0].pro_mode) {
-    case PRO_NONE: launch_gw_batched<PRO_NONE>(b, wgs, st); break;
-    case PRO_RELU: launch_gw_batched<PRO_RELU>(b, wgs, st); break;
-    case PRO_AFFINE_RELU: launch_gw_batched<PRO_AFFINE_RELU>(b, wgs, st); break;
-    case PRO_LRELU: launch_gw_batched<PRO_LRELU>(b, wgs, st); break;
-    default: launch_gw_batched<PRO_AFFINE>(b, wgs, st); break;
+    case PRO_NONE: rc = launch_gw_batched<PRO_NONE>(b, wgs, st); break;
+    case PRO_RELU: rc = launch_gw_batched<PRO_RELU>(b, wgs, st); break;
+    case PRO_AFFINE_RELU: rc = launch_gw_batched<PRO_AFFINE_RELU>(b, wgs, st); break;
+    case PRO_LRELU: rc = launch_gw_batched<PRO_LRELU>(b, wgs, st); break;
+    default: rc = launch_gw_batched<PRO_AFFINE>(b, wgs, st); break;
   }
+  if (rc != DIAGAN_OK) return rc;
   return check_launch("conv_wgrad_wino_batched");
 }
 

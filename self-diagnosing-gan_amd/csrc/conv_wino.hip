@@ -540,11 +540,8 @@ static int launch_wino_pro(const ConvGemmArgs& a, const float* ug, hipStream_t s
   const int wgs = cdiv(MT, WT) * cdiv(a.g.Co, WN);
   const size_t lds = (size_t)2 * W_STAGE * sizeof(float);
   auto kern = conv_wino_kernel<PRO>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, lds);
   hipLaunchKernelGGL(kern, dim3(wgs, a.ksplit), dim3(512), lds, st, a, ug);
   return check_launch("conv_wino");
 }

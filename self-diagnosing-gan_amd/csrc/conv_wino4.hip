@@ -1328,11 +1328,8 @@ static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t 
   // [2 V stages | U]; the epilogue's exchange image (36 or 25 frequencies x 32 tiles x 32 channels) fits inside
   const size_t lds = X3 ? (size_t)X3_LDS : (size_t)(2 * W4_VSTAGE + W4M<MODE>::U_FLOATS) * sizeof(float);
   auto kern = conv_wino4_kernel<PRO, MODE, X3, LEFT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, lds);
   hipLaunchKernelGGL(kern, dim3(wgs, a.ksplit), dim3(512), lds, st, a, ug);
   return check_launch("conv_wino4");
 }
@@ -1340,9 +1337,11 @@ static int launch_wino4_pro(const ConvGemmArgs& a, const float* ug, hipStream_t 
 // X3 (bf16 x 3 operands, see X3_SP): -1 = DIAGAN_WINO4_X3 / default, 0 / 1 = diagan_conv_gemm_set_wino4x
 static int g_wino4x = -1;
 void wino4_set_x3(int mode) { g_wino4x = mode; }
+int call_opt_wino4x();                             // conv_gemm.hip: the current call's option (-1: none)
 int wino4_get_x3() {
   static const int env = getenv("DIAGAN_WINO4_X3") ? atoi(getenv("DIAGAN_WINO4_X3")) : 0;
-  return g_wino4x >= 0 ? g_wino4x : env;
+  const int c = call_opt_wino4x();
+  return c >= 0 ? c : (g_wino4x >= 0 ? g_wino4x : env);
 }
 // floats of workspace the transformed weights need (with X3 enabled: room for the split format, 6 instead of 4 bytes per element)
 static long x3_floats(long fp32_floats) { return wino4_get_x3() > 0 ? fp32_floats + fp32_floats / 2 : fp32_floats; }

@@ -339,11 +339,8 @@ static int launch_wino_pool_pro(const ConvGemmArgs& a, const float* ug, hipStrea
   // (the data-gradient's epilogue turns every wave's 16 KB of outputs through LDS: 128 KB)
   const size_t lds = UNPOOL ? (size_t)(128 << 10) + (NB == 2 ? (4 << 10) : 0) : (size_t)2 * SH::STAGE * sizeof(float);
   auto kern = conv_wino_pool_kernel<PRO, UNPOOL, NB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static FuncAttrLatch latch;
+  DG_LDS(latch, kern, lds);
   hipLaunchKernelGGL(kern, dim3(wgs, a.ksplit), dim3(512), lds, st, a, ug);
   return check_launch("conv_wino_pool");
 }

@@ -16,6 +16,9 @@ nat.register("diagan_conv_gemm_set_wino", [I])
 nat.register("diagan_conv_gemm_get_wino", [])
 nat.register("diagan_conv_gemm_set_wino4", [I])
 nat.register("diagan_conv_gemm_set_splitk_fused", [I])
+nat.register("diagan_conv_gemm_set_splitk_tickets", [P, I64])
+nat.register("diagan_conv_gemm_next_opts", [P])
+nat.register("diagan_conv_gemm_last_cfg", [])
 nat.register("diagan_conv_gemm_set_x3", [I])
 nat.register("diagan_conv_gemm_get_x3", [])
 nat.register("diagan_conv_gemm_set_x3b", [I])
@@ -291,9 +294,44 @@ def set_gemm_x3(on):
     nat.call("diagan_conv_gemm_set_x3", -1 if on is None else (1 if on else 0))
 
 
+_TICKETS = {}
+
+
 def set_splitk_fused(on):
-    """True / False: the split-K launches' last-arriving workgroup runs the epilogue / a second launch does; None: the default"""
+    """True / False: the split-K launches' last-arriving workgroup runs the epilogue / a second launch does; None: the default.
+    (Process-wide, diagnostics / tests.)  The ticket buffer of the in-kernel combine is the caller's: one is allocated here and
+    registered with the library while the switch is on."""
     nat.call("diagan_conv_gemm_set_splitk_fused", -1 if on is None else (1 if on else 0))
+    if on:
+        dev = torch.cuda.current_device()
+        if dev not in _TICKETS:
+            _TICKETS[dev] = torch.zeros(1 << 16, dtype=torch.int32, device=torch.device('cuda', dev))
+        nat.call("diagan_conv_gemm_set_splitk_tickets", _TICKETS[dev].data_ptr(), _TICKETS[dev].numel())
+    else:
+        nat.call("diagan_conv_gemm_set_splitk_tickets", None, 0)
+
+
+class ConvOpts(_ct.Structure):
+    """diagan_conv_opts (include/diagan_hip.h): the selection options of ONE call -- `with conv_opts(wino=0): conv_fwd(...)` hands them
+    to the next diagan_conv_gemm call of this thread; nothing process-wide is touched"""
+    _fields_ = [(n, _ct.c_int32) for n in ("wino", "wino4", "wino4x", "gemm_x3", "gemm_x3b", "splitk_fused", "force_ksplit", "tune")] + \
+               [("tickets", _ct.c_void_p), ("ticket_slots", _ct.c_int64)]
+
+
+def next_opts(tickets=None, **fields):
+    """options of the next convolution launch of this thread: wino / wino4 / wino4x / gemm_x3 / gemm_x3b / splitk_fused (-1 default, 0, 1),
+    force_ksplit (0 = policy), tune (-1 default); tickets: a zeroed int32 CUDA tensor for the in-kernel split-K combine"""
+    o = ConvOpts(-1, -1, -1, -1, -1, -1, 0, -1, None, 0)
+    for k, v in fields.items():
+        setattr(o, k, int(v))
+    if tickets is not None:
+        o.tickets, o.ticket_slots = tickets.data_ptr(), tickets.numel()
+    nat.call("diagan_conv_gemm_next_opts", _ct.byref(o))
+
+
+def last_cfg():
+    """tile configuration the last convolution launch of this thread resolved to"""
+    return nat.fn("diagan_conv_gemm_last_cfg")()
 
 
 def wg_x_shape(x, pro):

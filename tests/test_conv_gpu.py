@@ -339,6 +339,78 @@ def test_split_operand_implicit_gemm_on_the_bf16_pipe(case):
         assert names[0] == "conv_gemm_x3_kernel<1>" and names[1].startswith("conv_gemm_kernel<64,64"), names
 
 
+@pytest.mark.parametrize("case", [(3, 37, 41, 64, 192, 3, 3, 2, 0), (2, 40, 40, 128, 64, 2, 2, 1, 1), (5, 30, 30, 32, 128, 1, 1, 1, 0),
+                                  (2, 50, 34, 96, 320, 2, 1, 1, 1), (8, 32, 32, 256, 256, 1, 2, 1, 1)])
+@pytest.mark.parametrize("form", [1, 2])
+def test_split_operand_implicit_gemm_128_tiles(case, form):
+    """conv_gemm_x3b.hip (round 6, tile_cfg 17): the large implicit GEMMs of StyleGAN2 (3x3 / stride 2, the 2x2 / 2x1 / 1x2 / 1x1 parity
+    classes of the stride-2 transposed gathers, 1x1) on the bf16 pipe with exactly split operands, both forms (1: 128 x 128 tiles, two
+    workgroups per CU; 2: 256 x 128 tiles, MFMA waves + loader waves).  fp32-grade: against float64 F.conv2d at the implicit GEMM's own
+    tolerance, with prologue, bias and residual, ragged pixel / channel counts; the data gradient of a stride-1 layer; an output map
+    (a parity class written straight into the interleaved tensor, border trimmed); repeated launches bit-identical (the loader waves'
+    counted waits: a race would show here)."""
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co, R, S, st, pd = case
+    g = torch.Generator().manual_seed(B + Ci + Co + R)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, R, S, generator=g) / (R * S * Ci) ** 0.5
+    geom = C.Geom("conv", Ci, Co, R, S, st, pd)
+    Ho, Wo = geom.out_hw(H, W)
+    bias, res = torch.randn(Co, generator=g), torch.randn(B, Co, Ho, Wo, generator=g)
+    wp = C.pack_oihw(w, geom.Kp).cuda()
+    xc, rc = nhwc(x).cuda(), nhwc(res).cuda()
+    try:
+        nat.call("diagan_conv_gemm_x3b_force_form", form)
+        ref = F.conv2d(F.leaky_relu(x.double(), 0.2), w.double(), bias.double(), stride=st, padding=pd) + res.double()
+        y = C.conv_fwd(geom, xc, wp, bias=bias.cuda(), residual=rc, pro=(C.PRO_LRELU, None, None), tile_cfg=17)
+        close(nchw(y), ref, tol=2e-5)
+        plain = C.conv_fwd(geom, xc, wp, tile_cfg=17)
+        close(nchw(plain), F.conv2d(x.double(), w.double(), None, stride=st, padding=pd), tol=2e-5)
+        close(plain, C.conv_fwd(geom, xc, wp, tile_cfg=1, wino=False), tol=2e-5)
+        for _ in range(10):
+            assert torch.equal(C.conv_fwd(geom, xc, wp, tile_cfg=17), plain)
+        # an output map: rows [1, Ho - 1) of the launch's grid to the odd pixels of a larger tensor
+        big = torch.full((B, 2 * Ho + 1, 2 * Wo + 1, Co), float("nan"), device="cuda")
+        C.conv_fwd(geom, xc, wp, tile_cfg=17, out=big, out_map=(2, 1, 1, 1, Ho - 1, 0, Wo))
+        assert torch.equal(big[:, 1:2 * (Ho - 2):2, 1:2 * Wo + 1:2], plain[:, 1:Ho - 1])
+        keep = torch.zeros_like(big, dtype=torch.bool)
+        keep[:, 1:2 * (Ho - 2):2, 1:2 * Wo + 1:2] = True
+        assert bool(torch.isnan(big[~keep]).all()) and not bool(torch.isnan(big[keep]).any())
+        if st == 1 and Co % 32 == 0:          # data gradient (dr = -1 gather from dy)
+            wd = torch.zeros(Ci, geom.Kd, device="cuda")
+            C.pack_weights(wp, Co, Ci, R * S, geom.Kp, geom.Kd, Wd=wd)
+            gy = torch.randn(B, Co, Ho, Wo, generator=g)
+            dx = C.conv_dgrad(geom, nhwc(gy).cuda(), wd, (H, W), tile_cfg=17)
+            close(nchw(dx), F.conv_transpose2d(gy.double(), w.double(), stride=1, padding=pd), tol=2e-5)
+    finally:
+        nat.call("diagan_conv_gemm_x3b_force_form", 0)
+
+
+def test_split_operand_128_tiles_automatic_choice():
+    """the automatic choice upgrades a large implicit-GEMM pick to tile_cfg 17 exactly when the switch is on, and reports it
+    (diagan_conv_gemm_final_cfg: what the kernel timer names and what out_map_ok answers)"""
+    from diagan.ops import conv as C
+    geom = C.Geom("conv", 128, 256, 3, 3, 2, 0)
+    x = torch.randn(16, 129, 129, 128, device="cuda")
+    wp = torch.randn(256, geom.Kp, device="cuda") * (9 * 128) ** -0.5
+    timer = C.KernelTimer()
+    try:
+        C.TIMER = timer
+        for on in (True, False):
+            C.nat.call("diagan_conv_gemm_set_x3b", 1 if on else 0)
+            assert C.out_map_ok(geom, 16, 129, 129) == on
+            y = C.conv_fwd(geom, x, wp)
+            if on:
+                y_on = y
+        close(y, y_on, tol=2e-5)
+    finally:
+        C.TIMER = None
+        C.nat.call("diagan_conv_gemm_set_x3b", -1)
+    names = [r[0] for r in timer.records]
+    assert names[0].startswith("conv_gemm_x3b_kernel<0,false>") and names[1].startswith("conv_gemm_kernel<128,128"), names
+
+
 @pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
 @pytest.mark.parametrize("pro", [0, 1, 2])
 def test_small_co_kernel_wgrad(Ci, H, W, B, pro):

@@ -124,3 +124,60 @@ def test_one_hip_runtime_whatever_the_import_order():
             "assert len(libs) == 1, libs\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-800:]
+
+
+@pytest.mark.gpu
+def test_selection_options_travel_with_the_call_not_through_globals():
+    """"no global mutable state".  The kernel-selection switches are per CALL (diagan_conv_opts handed over through
+    diagan_conv_gemm_next_opts, thread-local, consumed by one call): the same launch with two option words back to back takes two
+    different kernels, the process-wide diagnostic setters are never touched, the option does not leak into the third call, and
+    two THREADS with different options do not see each other's."""
+    import threading
+    import torch
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    geom = C.Geom("conv", 128, 128, 3, 3, 1, 1)
+    x = torch.randn(64, 32, 32, 128, device="cuda")
+    wp = torch.randn(128, geom.Kp, device="cuda") * (9 * 128) ** -0.5
+    before = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")(), nat.fn("diagan_conv_gemm_get_x3")(),
+              nat.fn("diagan_conv_gemm_get_x3b")())
+    C.next_opts(wino4=0)
+    y9 = C.conv_fwd(geom, x, wp)
+    cfg9 = C.last_cfg()
+    C.next_opts(wino=0)
+    y1 = C.conv_fwd(geom, x, wp)
+    cfg1 = C.last_cfg()
+    y13 = C.conv_fwd(geom, x, wp)
+    cfg13 = C.last_cfg()
+    assert (cfg9, cfg13) == (9, 13) and cfg1 not in (9, 13), (cfg9, cfg1, cfg13)
+    ref = y1.double()
+    for y in (y9, y13):
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) < 1e-4
+    after = (nat.fn("diagan_conv_gemm_get_wino")(), nat.fn("diagan_conv_gemm_get_wino4x")(), nat.fn("diagan_conv_gemm_get_x3")(),
+             nat.fn("diagan_conv_gemm_get_x3b")())
+    assert before == after
+    # a caller-owned ticket buffer for the in-kernel split-K combine, with the call (the library allocates nothing)
+    g2 = C.Geom("conv", 256, 256, 3, 3, 1, 1)
+    x2 = torch.randn(16, 8, 8, 256, device="cuda")
+    w2 = torch.randn(256, g2.Kp, device="cuda") * (9 * 256) ** -0.5
+    tickets = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    ya = C.conv_fwd(g2, x2, w2, tile_cfg=9)
+    C.next_opts(splitk_fused=1, tickets=tickets)
+    yb = C.conv_fwd(g2, x2, w2, tile_cfg=9)
+    assert float((ya - yb).abs().max()) < 1e-4 * float(ya.abs().max()) and int(tickets.abs().sum()) == 0
+    # two threads, two option words
+    got = {}
+
+    def worker(name, **opts):
+        torch.cuda.set_device(0)
+        for _ in range(20):
+            C.next_opts(**opts)
+            C.conv_fwd(geom, x, wp)
+            got.setdefault(name, set()).add(C.last_cfg())
+    ts = [threading.Thread(target=worker, args=("a",), kwargs=dict(wino4=0)), threading.Thread(target=worker, args=("b",), kwargs=dict(wino=0))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert got["a"] == {9} and len(got["b"]) == 1 and not (got["b"] & {9, 13}), got

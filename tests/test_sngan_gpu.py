@@ -667,8 +667,12 @@ def test_five_step_trajectory_drifts_no_faster_than_the_exact_fp32_build_and_the
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import numpy as np
     from sngan_trajectory import trajectories
-    r = trajectories("cifar10", steps=5)
+    # the CPU legs (oracle/nets.py in float64 and fp32: 280 s of float64 autograd) come from tests/golden/sngan_trajectory.npz, made
+    # by tools/gen_goldens_trajectory.py from the same function: the float64 trajectory as count-sketches (distances to ~1 %)
+    golden = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sngan_trajectory.npz")))
+    r = trajectories("cifar10", steps=5, golden=golden)
     d, e, c = (r[k]["dist"] for k in ("hip default", "hip exact-fp32", "cpu fp32"))
     print("trajectory dist:", [f"{v:.3e}" for v in d], [f"{v:.3e}" for v in e], [f"{v:.3e}" for v in c])
     for k in ("hip default", "hip exact-fp32", "cpu fp32"):

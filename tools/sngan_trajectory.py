@@ -36,9 +36,25 @@ def _flat64(named):
     return torch.cat([v.detach().double().cpu().reshape(-1) for _, v in named])
 
 
-def trajectories(dataset="cifar10", steps=20, B=64, n_dis=5, loss="ns", seed=1, hip_modes=("default", "exact-fp32")):
+SKETCH_K = 16384
+
+
+def sketch(p, k=SKETCH_K, seed=1234):
+    """count-sketch of a parameter vector: E |sketch(x)|^2 = |x|^2 with a relative standard deviation of sqrt(2 / k) ~ 1.1 % -- lets a
+    committed fixture stand in for the 5.3 M-parameter float64 trajectory (tests/golden/sngan_trajectory.npz, 0.7 MB)"""
+    g = torch.Generator().manual_seed(seed)
+    n = p.numel()
+    bucket = torch.randint(0, k, (n,), generator=g)
+    sign = torch.randint(0, 2, (n,), generator=g).double() * 2 - 1
+    return torch.zeros(k, dtype=torch.float64).index_add_(0, bucket, p.double().cpu() * sign)
+
+
+def trajectories(dataset="cifar10", steps=20, B=64, n_dis=5, loss="ns", seed=1, hip_modes=("default", "exact-fp32"), golden=None):
     """-> {name: {"errD": [steps], "errG": [steps], "dist": [steps]}} with dist / errors measured against the float64 run, and
-    "moved": how far the float64 parameters are from the start after each step (norms over G and D together)"""
+    "moved": how far the float64 parameters are from the start after each step (norms over G and D together).
+    golden: a dict made by tools/gen_goldens_trajectory.py from THIS function's CPU runs (float64 trajectory as count-sketches, the
+    CPU fp32 run's distances) -- the CPU legs, minutes of float64 autograd, are then not repeated and the HIP runs are measured
+    against the sketches (distances to ~1 %)"""
     from oracle import nets as O
     from diagan.models.predefined_models import get_gan_model
     from diagan.ops import conv as C
@@ -104,12 +120,24 @@ def trajectories(dataset="cifar10", steps=20, B=64, n_dis=5, loss="ns", seed=1, 
             C.set_gemm_x3(None)
 
     p0 = torch.cat([_flat64(oG.named_parameters()), _flat64(oD.named_parameters())])
+    if golden is not None:
+        import numpy as np
+        assert int(golden["steps"]) >= steps and str(golden["dataset"]) == dataset and int(golden["n"]) == p0.numel()
+        out = {"moved": [float(v) for v in golden["moved"][:steps]], "param_norm": float(golden["param_norm"]),
+               "errD64": [float(v) for v in golden["errD64"][:steps]], "errG64": [float(v) for v in golden["errG64"][:steps]],
+               "cpu fp32": {k: [float(v) for v in golden["cpu_fp32_" + k][:steps]] for k in ("errD", "errG", "dist")}}
+        sk64 = torch.from_numpy(np.asarray(golden["sketch64"]))
+        for m in hip_modes:
+            eD, eG, params = hip_run(m)
+            out["hip " + m] = {"errD": [abs(a - b) for a, b in zip(eD, out["errD64"])], "errG": [abs(a - b) for a, b in zip(eG, out["errG64"])],
+                               "dist": [(sketch(p) - sk64[i]).norm().item() / max(out["moved"][i], 1e-30) for i, p in enumerate(params)]}
+        return out
     runs = {"cpu float64": cpu_run(True), "cpu fp32": cpu_run(False)}
     for m in hip_modes:
         runs["hip " + m] = hip_run(m)
     eD64, eG64, p64 = runs["cpu float64"]
     moved = [(p - p0).norm().item() for p in p64]
-    out = {"moved": moved, "param_norm": p0.norm().item(), "errD64": eD64, "errG64": eG64}
+    out = {"moved": moved, "param_norm": p0.norm().item(), "errD64": eD64, "errG64": eG64, "_p64": p64, "_n": p0.numel()}
     for name, (eD, eG, params) in runs.items():
         if name == "cpu float64":
             continue
@@ -123,7 +151,7 @@ def main():
     dataset = sys.argv[2] if len(sys.argv) > 2 else "cifar10"
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     r = trajectories(dataset, steps)
-    names = [k for k in r if k not in ("moved", "param_norm", "errD64", "errG64")]
+    names = [k for k in r if k not in ("moved", "param_norm", "errD64", "errG64", "_p64", "_n")]
     print(f"SNGAN {dataset}, {steps} global steps (5 D + 1 G updates, batch 64, 'ns' loss); |parameters| = {r['param_norm']:.1f}")
     print("step  errD64   errG64   moved    | " + " | ".join(f"{n:>15s}: dD      dG      dist  " for n in names))
     for s in range(steps):
