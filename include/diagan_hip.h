@@ -393,6 +393,23 @@ int diagan_pack_batched(const void* table_dev, int n_layers, int max_Co, int max
  * (data-gradient operand, row length Kd).  inv_sigma: device float* or NULL (= 1). */
 int diagan_pack_weights(const float* W, const float* inv_sigma, float* Wf, float* Wd, int Co, int Ci,
                         int RS, int Kp, int Kd, void* stream);
+/* Round 6, StyleGAN2 weight preparation (reference: `self.weight * self.scale` in front of F.conv2d / F.conv_transpose2d,
+ * diagan-pkg/diagan/models/stylegan2.py:94-129,224-265) in one launch each instead of a scalar multiply + permuted copy + pads (+ zero fill +
+ * transposed pack in the backward) per layer and pass.  diagan_pack_oihw: w[Co_src][Ci_src][R][S] * scale -> Wf[Co][Kp] (k = (r S + s) Ci + c,
+ * rows / channels / columns beyond the source zero) and / or the data-gradient operand Wd[Ci][Kd] (k = (r S + s) Co + n) of the same values.
+ * diagan_unpack_oihw: its adjoint, gw[Co_src][Ci_src][R][S] = scale * gWp[n][(r S + s) Ci + c] (pack is linear: these two are each other's
+ * backward to any order). */
+int diagan_pack_oihw(const float* w, float scale, float* Wf, float* Wd, int Co_src, int Ci_src, int R, int S, int Co, int Ci, int Kp,
+                     int Kd, void* stream);
+int diagan_unpack_oihw(const float* gWp, float scale, float* gw, int Co_src, int Ci_src, int R, int S, int Ci, int Kp, void* stream);
+/* The sub-kernels w[:, cy::2, cx::2] (taps in correlation order) of the four output-parity classes of a stride-2 transposed gather
+ * (diagan/ops/diffconv.py: the generator's up-convolutions and the data gradients of the stride-2 layers run as four dense stride-1
+ * convolutions), from the packed operand w[n][Kp] (k = (r S + s) C + c) into ONE buffer: class (cy, cx) = (cls >> 1, cls & 1) at float offset
+ * off[cls] with rows of kp[cls] floats (zero-padded).  adjoint = 1: the reverse -- the full operand's gradient gw[n][Kp] from the classes'
+ * weight gradients in `buf` (w unused).  R, S <= 4. */
+int diagan_parity_weights(const float* w, float* buf, float* gw, int n, int R, int S, int C, int Kp, const int* kp, const int* off,
+                          int adjoint, void* stream);
+
 
 /* Backward through W/sigma: grad (+)= (G - <G,W>/sigma * u^T v) / sigma. */
 int diagan_sn_grad_fix(const float* G, const double* dot_partials, int nparts, const float* u,

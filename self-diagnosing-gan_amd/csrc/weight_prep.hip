@@ -176,6 +176,150 @@ DIAGAN_API int diagan_sn_grad_fix(const float* G, const double* dot_partials, in
 }
 
 // ================================================================================================
+// StyleGAN2 weight preparation in one launch each (round 6).  The autograd ops of diagan/ops/diffconv.py take the packed operand
+// Wp[Co][Kp] of a reference-shaped OIHW parameter times the equalised-learning-rate scale (reference: `self.weight * self.scale`
+// in front of F.conv2d, diagan-pkg/diagan/models/stylegan2.py:94-129,224-265); built from torch ops that was a scalar multiply, a
+// permuted copy, up to two pads -- and in the backward a zero fill + the transposed pack for the data gradient -- per layer and pass:
+// ~1100 of a StyleGAN2 iteration's ~5200 launches, 4-8 us each.
+//   diagan_pack_oihw      w[Co'][Ci'][R][S] * scale -> Wp[Co][Kp] (k = (r S + s) Ci + c, zero-padded) and, optionally, the
+//                         data-gradient operand Wd[Ci][Kd] (k = (r S + s) Co + n) of the same values
+//   diagan_unpack_oihw    the adjoint: gw[Co'][Ci'][R][S] = scale * gWp[co][(r S + s) Ci + c]  (pack is linear: its backward, and the
+//                         backward of that, are these two kernels again)
+//   diagan_parity_weights the sub-kernels w[:, cy::2, cx::2] (taps in correlation order, diffconv._parity_taps) of the four parity
+//                         classes of a stride-2 transposed gather, each zero-padded to its own Kp, into one buffer
+//   diagan_parity_weights_adjoint   the weight gradient of the transposed convolution from the four classes' weight gradients
+// ================================================================================================
+namespace diagan {
+
+__global__ __launch_bounds__(256) void pack_oihw_kernel(const float* __restrict__ w, float scale, float* __restrict__ Wf,
+                                                        float* __restrict__ Wd, int Cos, int Cis, int R, int S, int Co, int Ci, int Kp,
+                                                        int Kd) {
+  const long total = (long)Co * Kp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / Kp), k = (int)(i - (long)n * Kp);
+    const int tap = k / Ci, c = k - tap * Ci;
+    float v = 0.f;
+    if (n < Cos && tap < R * S && c < Cis) v = w[((long)n * Cis + c) * (R * S) + tap] * scale;
+    if (Wf) Wf[i] = v;
+    if (Wd && tap < R * S) Wd[(long)c * Kd + tap * Co + n] = v;
+  }
+}
+// (the padding columns of Wd beyond R S Co are zeroed by the first Ci x (Kd - R S Co) threads)
+__global__ __launch_bounds__(256) void pack_oihw_wd_pad_kernel(float* __restrict__ Wd, int Ci, int Kd, int used) {
+  const int padw = Kd - used;
+  const long total = (long)Ci * padw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) Wd[(i / padw) * Kd + used + (i % padw)] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void unpack_oihw_kernel(const float* __restrict__ gWp, float scale, float* __restrict__ gw, int Cos,
+                                                          int Cis, int R, int S, int Ci, int Kp) {
+  const int RS = R * S;
+  const long total = (long)Cos * Cis * RS;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int tap = (int)(i % RS);
+    const long t = i / RS;
+    const int c = (int)(t % Cis), n = (int)(t / Cis);
+    gw[i] = gWp[(long)n * Kp + tap * Ci + c] * scale;
+  }
+}
+
+struct ParityGeom {
+  int n, R, S, C, Kp;          // source: w[n][Kp], k = (r S + s) C + c
+  int off[4], kp[4];           // per class (cy, cx) = (cls >> 1, cls & 1): float offset of its matrix in the buffer, its row length
+  int ny[2], nx[2];            // taps per parity: ceil((R - cy) / 2), ceil((S - cx) / 2)
+};
+// class matrix row n: k' = (u nx + v) C + c  <-  source tap (r, s) = (taps_y[u], taps_x[v]), taps = range(parity, size, 2) reversed
+__global__ __launch_bounds__(256) void parity_weights_kernel(const float* __restrict__ w, float* __restrict__ out, const ParityGeom g,
+                                                             int adjoint) {
+  const int cls = blockIdx.y, cy = cls >> 1, cx = cls & 1;
+  const int ny = g.ny[cy], nx = g.nx[cx];
+  if (ny <= 0 || nx <= 0) return;
+  const int kp = g.kp[cls];
+  const long total = (long)g.n * kp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int n = (int)(i / kp), k = (int)(i - (long)n * kp);
+    const int uv = k / g.C, c = k - uv * g.C;
+    const bool live = uv < ny * nx;
+    const int u = live ? uv / nx : 0, v = live ? uv - u * nx : 0;
+    const int r = cy + 2 * (ny - 1 - u), s = cx + 2 * (nx - 1 - v);
+    const long src = (long)n * g.Kp + (long)(r * g.S + s) * g.C + c;
+    if (!adjoint) out[g.off[cls] + i] = live ? w[src] : 0.f;
+    else if (live) out[src] = w[g.off[cls] + i];          // (`w`: the classes' buffer, `out`: the full operand's gradient)
+  }
+}
+__global__ __launch_bounds__(256) void zero_pad_cols_kernel(float* __restrict__ m, int rows, int ld, int used) {
+  const int padw = ld - used;
+  const long total = (long)rows * padw;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) m[(i / padw) * ld + used + (i % padw)] = 0.f;
+}
+
+}  // namespace diagan
+
+DIAGAN_API int diagan_pack_oihw(const float* w, float scale, float* Wf, float* Wd, int Co_src, int Ci_src, int R, int S, int Co, int Ci,
+                                int Kp, int Kd, void* stream) {
+  DG_REQUIRE(w && (Wf || Wd), "pack_oihw: null pointer");
+  DG_REQUIRE(Co_src > 0 && Ci_src > 0 && R > 0 && S > 0 && Co >= Co_src && Ci >= Ci_src && Kp >= R * S * Ci && (!Wd || Kd >= R * S * Co),
+             "pack_oihw: bad dims");
+  long blocks = ((long)Co * Kp + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_oihw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, w, scale, Wf, Wd, Co_src, Ci_src, R, S, Co, Ci,
+                     Kp, Kd);
+  if (Wd && Kd > R * S * Co) {
+    long b2 = ((long)Ci * (Kd - R * S * Co) + 255) / 256;
+    if (b2 > 1024) b2 = 1024;
+    hipLaunchKernelGGL(pack_oihw_wd_pad_kernel, dim3((int)b2), dim3(256), 0, (hipStream_t)stream, Wd, Ci, Kd, R * S * Co);
+  }
+  return check_launch("pack_oihw");
+}
+
+DIAGAN_API int diagan_unpack_oihw(const float* gWp, float scale, float* gw, int Co_src, int Ci_src, int R, int S, int Ci, int Kp,
+                                  void* stream) {
+  DG_REQUIRE(gWp && gw, "unpack_oihw: null pointer");
+  DG_REQUIRE(Co_src > 0 && Ci_src > 0 && R > 0 && S > 0 && Ci >= Ci_src && Kp >= R * S * Ci, "unpack_oihw: bad dims");
+  long blocks = ((long)Co_src * Ci_src * R * S + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpack_oihw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, gWp, scale, gw, Co_src, Ci_src, R, S, Ci, Kp);
+  return check_launch("unpack_oihw");
+}
+
+// kp[4] / off[4]: row length (a multiple of 32, >= ny nx C) and float offset of class (cy, cx) = (cls >> 1, cls & 1) in `buf`
+// (classes without taps -- R or S == 1 -- are skipped).  adjoint = 0: buf <- w;  adjoint = 1: gw <- buf (every tap of gw belongs to
+// exactly one class; its padding columns behind R S C are zeroed)
+DIAGAN_API int diagan_parity_weights(const float* w, float* buf, float* gw, int n, int R, int S, int C, int Kp, const int* kp,
+                                     const int* off, int adjoint, void* stream) {
+  DG_REQUIRE(buf && kp && off && (adjoint ? gw != nullptr : w != nullptr), "parity_weights: null pointer");
+  DG_REQUIRE(n > 0 && R > 0 && S > 0 && R <= 4 && S <= 4 && C > 0 && Kp >= R * S * C, "parity_weights: bad dims");
+  ParityGeom g;
+  g.n = n; g.R = R; g.S = S; g.C = C; g.Kp = Kp;
+  long most = 0;
+  for (int p = 0; p < 2; ++p) {
+    g.ny[p] = p < R ? (R - p + 1) / 2 : 0;
+    g.nx[p] = p < S ? (S - p + 1) / 2 : 0;
+  }
+  for (int cls = 0; cls < 4; ++cls) {
+    g.off[cls] = off[cls];
+    g.kp[cls] = kp[cls];
+    const int taps = g.ny[cls >> 1] * g.nx[cls & 1];
+    DG_REQUIRE(taps == 0 || kp[cls] >= taps * C, "parity_weights: class %d row of %d floats holds no %d taps x %d channels", cls, kp[cls], taps, C);
+    if (taps && (long)n * kp[cls] > most) most = (long)n * kp[cls];
+  }
+  long blocks = (most + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  if (adjoint) {
+    hipLaunchKernelGGL(parity_weights_kernel, dim3((int)blocks, 4), dim3(256), 0, (hipStream_t)stream, buf, gw, g, 1);
+    if (Kp > R * S * C) {
+      long b2 = ((long)n * (Kp - R * S * C) + 255) / 256;
+      if (b2 > 1024) b2 = 1024;
+      hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((int)b2), dim3(256), 0, (hipStream_t)stream, gw, n, Kp, R * S * C);
+    }
+  } else {
+    hipLaunchKernelGGL(parity_weights_kernel, dim3((int)blocks, 4), dim3(256), 0, (hipStream_t)stream, w, buf, g, 0);
+  }
+  return check_launch("parity_weights");
+}
+
+// ================================================================================================
 // Batched spectral-norm preparation: ALL SN layers of a network in 4 launches (instead of 4 per
 // layer).  blockIdx.z selects the layer through a device-resident descriptor table.
 // ================================================================================================

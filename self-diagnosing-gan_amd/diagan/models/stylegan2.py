@@ -130,7 +130,7 @@ class EqualConv2d(nn.Module):
     def forward(self, x, out_mul=1.0, stride=None):
         """out_mul: an extra factor on the OUTPUT, folded into the weight scale (ResBlock's 1 / sqrt 2 on its skip branch);
         stride: override (ResBlock's skip branch hands over an already sub-sampled input)"""
-        y = dc.conv2d(x, self.weight * (self.scale * out_mul), self.stride if stride is None else stride, self.padding)
+        y = dc.conv2d(x, self.weight, self.stride if stride is None else stride, self.padding, scale=self.scale * out_mul)
         if self.bias is not None:
             y = y + F.pad(self.bias, (0, y.shape[3] - self.bias.shape[0])) * out_mul
         return y
@@ -158,13 +158,13 @@ class EqualLinear(nn.Module):
         return out + bias if bias is not None else out
 
     def forward(self, input):
-        return self._finish(dc.linear(input, self.weight * self.scale))
+        return self._finish(dc.linear(input, self.weight, scale=self.scale))
 
     def forward_spatial(self, x):
         """The same layer applied to the reference's `x_nchw.view(batch, -1)` when x is held as [B,H,W,C]: the
         weight's columns run (c, h, w), i.e. it IS an H x W convolution without padding."""
         b, h, w, c = x.shape
-        out = dc.conv2d(x, (self.weight * self.scale).view(-1, c, h, w))
+        out = dc.conv2d(x, self.weight.view(-1, c, h, w), scale=self.scale)
         return self._finish(out.view(b, -1)[:, : self.weight.shape[0]])
 
     def __repr__(self):
@@ -197,17 +197,18 @@ class ModulatedConv2d(nn.Module):
         """(convolution of the modulated input, demodulation factors [B, Co] or None): the caller applies d -- StyledConv
         does it inside its fused noise + bias + activation pass"""
         s = self.modulation(style)                                   # [B, Ci]
-        w = self.weight[0] * self.scale
+        w = self.weight[0]                  # (the equalised-learning-rate scale rides in the packing launch: dc.*(..., scale=))
         if self.downsample:
             x = self.blur(x)
         x = scale_rows(x, s)
         if self.upsample:
-            y = self.blur(dc.conv_transpose2d(x, w, stride=2, padding=0))
+            y = self.blur(dc.conv_transpose2d(x, w, stride=2, padding=0, scale=self.scale))
         elif self.downsample:
-            y = dc.conv2d(x, w, stride=2, padding=0)
+            y = dc.conv2d(x, w, stride=2, padding=0, scale=self.scale)
         else:
-            y = dc.conv2d(x, w, stride=1, padding=self.padding)
-        d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3))) + self.eps) if self.demodulate else None
+            y = dc.conv2d(x, w, stride=1, padding=self.padding, scale=self.scale)
+        # demodulation 1 / sqrt(sum_ci s^2 sum_taps (scale w)^2 + eps) as a [B,Ci] x [Ci,Co] product
+        d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3)), scale=self.scale ** 2) + self.eps) if self.demodulate else None
         return y, d
 
     def __repr__(self):

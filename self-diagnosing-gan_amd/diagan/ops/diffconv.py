@@ -17,7 +17,18 @@ from torch.autograd import Function
 
 import os
 
+import ctypes as _ct
+
+from diagan import _native as nat
 from diagan.ops import conv as K
+
+_P, _I, _F = nat.c_void_p, nat.c_int, nat.c_f32
+nat.register("diagan_pack_oihw", [_P, _F, _P, _P] + [_I] * 8 + [_P])
+nat.register("diagan_unpack_oihw", [_P, _F, _P] + [_I] * 6 + [_P])
+nat.register("diagan_parity_weights", [_P, _P, _P] + [_I] * 5 + [_P, _P, _I, _P])
+# weight preparation in one launch each (csrc/weight_prep.hip, round 6): scale + pack (+ the data-gradient operand), and the parity
+# classes' sub-kernels / their adjoint; DIAGAN_SG2_FUSED_PREP=0: the torch-op compositions of rounds 1-5
+FUSED_PREP = os.environ.get("DIAGAN_SG2_FUSED_PREP", "1") == "1"
 
 # The 3x3 / stride-1 layers of the StyleGAN2 ops take the Winograd kernels like the SNGAN layers do (+21 % on the 256 x 256
 # iteration: 82 -> 99 images/s).  Measured against the oracle in float64 the two convolution paths are equally far from
@@ -35,7 +46,11 @@ def _c(t):
 
 
 def _wd(geom, wp):
-    """data-gradient operand Wd[Ci][Kd] of packed forward weights"""
+    """data-gradient operand Wd[Ci][Kd] of packed forward weights: the one `pack_scaled` made beside wp (same launch, same values)
+    where there is one"""
+    wd = getattr(wp, '_diagan_wd', None)
+    if wd is not None and tuple(wd.shape) == (geom.Ci, geom.Kd):
+        return wd
     wd = torch.zeros((geom.Ci, geom.Kd), dtype=torch.float32, device=wp.device)
     K.pack_weights(_c(wp), geom.Co, geom.Ci, geom.R * geom.S, geom.Kp, geom.Kd, Wd=wd)
     return wd
@@ -75,13 +90,17 @@ def _up2_gather(x, w, n_out, R, S, C, out_hw):
     exact = (full_h, full_w) == tuple(out_hw) and R > 1 and S > 1
     out = (x.new_empty if exact else x.new_zeros)((B, out_hw[0], out_hw[1], n_out))
     w4 = w[:, : R * S * C].view(n_out, R, S, C)
+    subs = _parity_buffers(w, n_out, R, S, C, adjoint=False) if FUSED_PREP and R <= 4 and S <= 4 else None
     for cy, ry in _parity_taps(R):
         for cx, sx in _parity_taps(S):
             ny, nx = len(ry), len(sx)
             sub, ty, tx = _sub_problem(C, n_out, ny, nx)
-            ws = w4[:, ry][:, :, sx].reshape(n_out, ny * nx * C)
-            if ws.shape[1] != sub.Kp:
-                ws = F.pad(ws, (0, sub.Kp - ws.shape[1]))
+            if subs is not None:
+                ws = subs[2 * cy + cx]
+            else:
+                ws = w4[:, ry][:, :, sx].reshape(n_out, ny * nx * C)
+                if ws.shape[1] != sub.Kp:
+                    ws = F.pad(ws, (0, sub.Kp - ws.shape[1]))
             if OUT_MAP and K.out_map_ok(sub, B, H, W):
                 # the class interleaves itself: the split-operand kernel writes pixel (my, mx) of the class to (2 (my - ty) + cy,
                 # 2 (mx - tx) + cx) and drops the surplus border of the symmetric padding (no copy pass; round 6)
@@ -96,26 +115,54 @@ def _up2_gather(x, w, n_out, R, S, C, out_hw):
 def _up2_wgrad(g, x, geom):
     """weight gradient of the stride-2 transposed convolution y = convT(x, w): g [B, 2(H-1)+R, 2(W-1)+S, Co]"""
     R, S, Ci, Co = geom.R, geom.S, geom.Ci, geom.Co
-    grad = g.new_zeros((Co, R, S, Ci))
+    fused = FUSED_PREP and R <= 4 and S <= 4
+    parts, buf, kp, off = _parity_buffers(None, Co, R, S, Ci, adjoint=True, device=g.device) if fused else (None, None, None, None)
+    grad = None if fused else g.new_zeros((Co, R, S, Ci))
     for cy, ry in _parity_taps(R):
         for cx, sx in _parity_taps(S):
             ny, nx = len(ry), len(sx)
             sub, ty, tx = _sub_problem(Ci, Co, ny, nx)
-            part = torch.empty((Co, sub.Kp), dtype=torch.float32, device=g.device)
+            part = parts[2 * cy + cx] if fused else torch.empty((Co, sub.Kp), dtype=torch.float32, device=g.device)
             gc = F.pad(g[:, cy::2, cx::2], (0, 0, tx, tx, ty, ty)) if (ty or tx) else g[:, cy::2, cx::2].contiguous()
             K.conv_wgrad(sub, gc, x, part, accumulate=False)
+            if fused:
+                continue
             part = part[:, : ny * nx * Ci].view(Co, ny, nx, Ci)
             for u, r in enumerate(ry):
                 for v, s in enumerate(sx):
                     grad[:, r, s] = part[:, u, v]
+    if fused:                                 # every tap of the full operand belongs to exactly one class: one gather, padding zeroed
+        full = torch.empty((Co, geom.Kp), dtype=torch.float32, device=g.device)
+        nat.call("diagan_parity_weights", None, nat.ptr(buf), nat.ptr(full), Co, R, S, Ci, geom.Kp, kp, off, 1, nat.current_stream())
+        return full
     grad = grad.view(Co, R * S * Ci)
     return F.pad(grad, (0, geom.Kp - grad.shape[1])) if grad.shape[1] != geom.Kp else grad
+
+
+def _parity_buffers(w, n, R, S, C, adjoint, device=None):
+    """One buffer for the four parity classes' operands [n][Kp_class] (class index 2 cy + cx; classes without taps: None).
+    adjoint False: filled from the packed operand w[n][>= R S C] by ONE launch (diagan_parity_weights) -> list of views;
+    adjoint True: empty, for the classes' weight gradients -> (views, buffer, kp array, off array) for the reverse launch."""
+    kp, off, total = (_ct.c_int * 4)(), (_ct.c_int * 4)(), 0
+    for cy, ry in _parity_taps(R):
+        for cx, sx in _parity_taps(S):
+            sub, _, _ = _sub_problem(C, n, len(ry), len(sx))
+            kp[2 * cy + cx], off[2 * cy + cx] = sub.Kp, total
+            total += n * sub.Kp
+    dev = w.device if w is not None else device
+    buf = torch.empty(total, dtype=torch.float32, device=dev)
+    views = [buf[off[c]: off[c] + n * kp[c]].view(n, kp[c]) if kp[c] else None for c in range(4)]
+    if adjoint:
+        return views, buf, kp, off
+    nat.call("diagan_parity_weights", nat.ptr(_c(w)), nat.ptr(buf), None, n, R, S, C, w.shape[1], kp, off, 0, nat.current_stream())
+    return views
 
 
 class _Conv(Function):
     @staticmethod
     def forward(ctx, x, wp, geom):
         ctx.geom = geom
+        ctx.wd_cache = getattr(wp, '_diagan_wd', None)       # (the data-gradient operand pack_scaled made beside wp)
         ctx.save_for_backward(x, wp)
         if _splits_stride2(geom, geom.kind == 'convT'):
             return _up2_gather(_c(x), _c(wp), geom.Co, geom.R, geom.S, geom.Ci, geom.out_hw(x.shape[1], x.shape[2]))
@@ -124,6 +171,8 @@ class _Conv(Function):
     @staticmethod
     def backward(ctx, gy):
         x, wp = ctx.saved_tensors
+        if ctx.wd_cache is not None:
+            wp._diagan_wd = ctx.wd_cache
         gx = _DataGrad.apply(gy, wp, ctx.geom, tuple(x.shape[1:3])) if ctx.needs_input_grad[0] else None
         gw = _WeightGrad.apply(gy, x, ctx.geom) if ctx.needs_input_grad[1] else None
         return gx, gw, None
@@ -164,6 +213,55 @@ class _WeightGrad(Function):
         return gg, gx, None
 
 
+class _PackScaled(Function):
+    """(Wp[Co][Kp], Wd[Ci][Kd] or None) = pack(w_oihw * scale) in ONE launch; linear in w: the backward is _UnpackScaled, whose
+    backward is this again (any order).  Wd is a by-product for the data gradients (not differentiable: they differentiate through Wp)."""
+
+    @staticmethod
+    def forward(ctx, w, scale, geom, want_wd):
+        co, ci, r, s = w.shape
+        ctx.meta = (float(scale), geom, tuple(w.shape))
+        f32 = dict(dtype=torch.float32, device=w.device)
+        wp = torch.empty((geom.Co, geom.Kp), **f32)
+        wd = torch.empty((geom.Ci, geom.Kd), **f32) if want_wd else torch.empty(0, **f32)
+        nat.call("diagan_pack_oihw", nat.ptr(_c(w)), float(scale), nat.ptr(wp), nat.ptr(wd) if want_wd else None, co, ci, r, s,
+                 geom.Co, geom.Ci, geom.Kp, geom.Kd, nat.current_stream())
+        ctx.mark_non_differentiable(wd)
+        return wp, wd
+
+    @staticmethod
+    def backward(ctx, gwp, _gwd):
+        scale, geom, shape = ctx.meta
+        return _UnpackScaled.apply(gwp, scale, geom, shape), None, None, None
+
+
+class _UnpackScaled(Function):
+    @staticmethod
+    def forward(ctx, gwp, scale, geom, shape):
+        ctx.meta = (scale, geom)
+        co, ci, r, s = shape
+        gw = torch.empty(shape, dtype=torch.float32, device=gwp.device)
+        nat.call("diagan_unpack_oihw", nat.ptr(_c(gwp)), float(scale), nat.ptr(gw), co, ci, r, s, geom.Ci, geom.Kp, nat.current_stream())
+        return gw
+
+    @staticmethod
+    def backward(ctx, ggw):
+        scale, geom = ctx.meta
+        return _PackScaled.apply(ggw, scale, geom, False)[0], None, None, None
+
+
+def pack_scaled(w_oihw, scale, geom):
+    """pack(w_oihw * scale, geom) in one launch; with gradients enabled the data-gradient operand of the same values rides along
+    (picked up by _wd through the tensor's `_diagan_wd`)"""
+    if not FUSED_PREP or not w_oihw.is_cuda:
+        return pack(w_oihw * scale if scale != 1.0 else w_oihw, geom)
+    want_wd = torch.is_grad_enabled()
+    wp, wd = _PackScaled.apply(w_oihw, scale, geom, want_wd)
+    if want_wd:
+        wp._diagan_wd = wd
+    return wp
+
+
 def pack(w_oihw, geom):
     """[Co', Ci', R, S] parameter (Co' <= geom.Co, Ci' <= geom.Ci: zero-padded) -> Wp[Co][Kp]; differentiable."""
     co, ci, r, s = w_oihw.shape
@@ -176,25 +274,25 @@ def pack(w_oihw, geom):
     return w.contiguous()
 
 
-def conv2d(x, w_oihw, stride=1, padding=0):
-    """F.conv2d on NHWC activations: x [B,H,W,Ci] (Ci % 4 == 0), w [Co', Ci', R, S] -> [B,Ho,Wo,roundup(Co',4)]"""
+def conv2d(x, w_oihw, stride=1, padding=0, scale=1.0):
+    """F.conv2d(x, w * scale) on NHWC activations: x [B,H,W,Ci] (Ci % 4 == 0), w [Co', Ci', R, S] -> [B,Ho,Wo,roundup(Co',4)]"""
     geom = K.Geom('conv', x.shape[3], K.round_up(w_oihw.shape[0], 4), w_oihw.shape[2], w_oihw.shape[3], stride, padding)
-    return _Conv.apply(x, pack(w_oihw, geom), geom)
+    return _Conv.apply(x, pack_scaled(w_oihw, scale, geom), geom)
 
 
-def conv_transpose2d(x, w_oihw, stride=2, padding=0):
-    """F.conv_transpose2d(x, w.transpose(0, 1)) on NHWC activations: w is given output-channel-major like conv2d's
+def conv_transpose2d(x, w_oihw, stride=2, padding=0, scale=1.0):
+    """F.conv_transpose2d(x, (w * scale).transpose(0, 1)) on NHWC activations: w is given output-channel-major like conv2d's
     (the modulated convolution of the reference transposes it itself, stylegan2.py:243-248)."""
     geom = K.Geom('convT', x.shape[3], K.round_up(w_oihw.shape[0], 4), w_oihw.shape[2], w_oihw.shape[3], stride, padding)
-    return _Conv.apply(x, pack(w_oihw, geom), geom)
+    return _Conv.apply(x, pack_scaled(w_oihw, scale, geom), geom)
 
 
-def linear(x, weight):
-    """F.linear(x, weight) (no bias) as a 1x1 convolution over [B,1,1,Ci]"""
+def linear(x, weight, scale=1.0):
+    """F.linear(x, weight * scale) (no bias) as a 1x1 convolution over [B,1,1,Ci]"""
     b, ci = x.shape
     cp = K.round_up(ci, 4)
     if cp != ci:
         x = F.pad(x, (0, cp - ci))
     co = weight.shape[0]
-    y = conv2d(x.view(b, 1, 1, cp), weight.view(co, ci, 1, 1))
+    y = conv2d(x.view(b, 1, 1, cp), weight.view(co, ci, 1, 1), scale=scale)
     return y.view(b, -1)[:, :co]
