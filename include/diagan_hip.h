@@ -589,6 +589,12 @@ int diagan_rowdot(const float* a, const float* b, float* out, float* workspace, 
 int diagan_styled_bias_act_bwd(const float* gy, const float* y, const float* x, const float* demod, const float* noise,
                                float* gx, float* work_d, float* work_b, float* work_s, int B, int P, int C,
                                int noise_per_image, float alpha, float scale, void* stream);
+/* ... and the reduction of its partial sums (work_d [B][chunks][C], work_b [B * chunks][C], work_s [B * chunks]; chunks =
+ * diagan_rowdot_chunks(B, P)) to gd [B][C], gb [C], gs [1] in one launch, accumulated in double in a fixed order (round 6; any of the three
+ * pairs may be NULL). */
+int diagan_styled_bias_act_bwd_finish(const float* work_d, const float* work_b, const float* work_s, float* gd, float* gb, float* gs, int B,
+                                      int P, int C, void* stream);
+
 
 /* upfirdn2d.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up, down, pads), upfirdn2d.cpp:4-22.
  * out == NULL: size query only (writes *out_h, *out_w). */

@@ -391,6 +391,60 @@ DIAGAN_API int diagan_styled_bias_act_bwd(const float* gy, const float* y, const
   return check_launch("styled_bias_act_bwd");
 }
 
+// The partial sums of diagan_styled_bias_act_bwd to their results in ONE launch (round 6; the host side summed them with torch: a
+// float64 conversion, a reduction and a conversion back per result = nine 4-10 us launches per call, ~540 per StyleGAN2 iteration):
+//   gd[b][c] = sum_chunks work_d[b][chunk][c],  gb[c] = sum_rows work_b[row][c] (rows = B * chunks),  gs = sum work_s[rows]
+// accumulated in double in a fixed order (rows interleaved four ways per column, then a fixed LDS tree): deterministic.
+namespace diagan {
+__global__ __launch_bounds__(256) void styled_act_bwd_finish_kernel(const float* __restrict__ work_d, const float* __restrict__ work_b,
+                                                                    const float* __restrict__ work_s, float* __restrict__ gd,
+                                                                    float* __restrict__ gb, float* __restrict__ gs, int B, int chunks,
+                                                                    int C, int nd, int nb) {
+  __shared__ double red[256];
+  const int bid = blockIdx.x, tid = threadIdx.x;
+  if (bid < nd) {                                   // gd: block = image b, threads over the channels
+    const float* src = work_d + (long)bid * chunks * C;
+    for (int c = tid; c < C; c += 256) {
+      double t = 0.0;
+      for (int k = 0; k < chunks; ++k) t += (double)src[(long)k * C + c];
+      gd[(long)bid * C + c] = (float)t;
+    }
+    return;
+  }
+  const int rows = B * chunks;
+  if (bid < nd + nb) {                              // gb: block = 64 columns x 4 row lanes
+    const int col = (bid - nd) * 64 + (tid & 63), lane = tid >> 6;
+    double t = 0.0;
+    if (col < C)
+      for (int r = lane; r < rows; r += 4) t += (double)work_b[(long)r * C + col];
+    red[tid] = t;
+    __syncthreads();
+    if (lane == 0 && col < C) gb[col] = (float)((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]));
+    return;
+  }
+  double t = 0.0;                                   // gs: one block
+  for (int r = tid; r < rows; r += 256) t += (double)work_s[r];
+  red[tid] = t;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) gs[0] = (float)red[0];
+}
+}  // namespace diagan
+
+DIAGAN_API int diagan_styled_bias_act_bwd_finish(const float* work_d, const float* work_b, const float* work_s, float* gd, float* gb,
+                                                 float* gs, int B, int P, int C, void* stream) {
+  DG_REQUIRE(B > 0 && P > 0 && C > 0, "styled_bias_act_bwd_finish: bad dims");
+  DG_REQUIRE(!work_d == !gd && !work_b == !gb && !work_s == !gs && (gd || gb || gs), "styled_bias_act_bwd_finish: partials and results come in pairs");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  const int nd = gd ? B : 0, nb = gb ? cdiv(C, 64) : 0, ns = gs ? 1 : 0;
+  hipLaunchKernelGGL(diagan::styled_act_bwd_finish_kernel, dim3(nd + nb + ns), dim3(256), 0, (hipStream_t)stream, work_d, work_b, work_s,
+                     gd, gb, gs, B, chunks, C, nd, nb);
+  return check_launch("styled_bias_act_bwd_finish");
+}
+
 // out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL
 DIAGAN_API int diagan_upfirdn2d(const float* input, const float* kernel, float* out, int major, int in_h, int in_w,
                                 int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y,

@@ -16,6 +16,7 @@ nat.register("diagan_rowdot_chunks", [I, I])
 nat.register("diagan_rowdot", [P, P, P, P, I, I, I, P])
 nat.register("diagan_styled_bias_act", [P, P, P, P, P, P, I, I, I, I, F32, F32, P])
 nat.register("diagan_styled_bias_act_bwd", [P, P, P, P, P, P, P, P, P, I, I, I, I, F32, F32, P])
+nat.register("diagan_styled_bias_act_bwd_finish", [P, P, P, P, P, P, I, I, I, P])
 
 import os as _os
 FUSED_BWD = _os.environ.get("DIAGAN_SG2_FUSED_BWD", "1") != "0"
@@ -45,9 +46,12 @@ def _fused_bwd(gy, y, x, demod, noise, slope, scale, need_gx=True):
              nat.ptr(demod.contiguous()) if demod is not None else None,
              nat.ptr(noise.contiguous()) if noise is not None else None, nat.ptr(gx), nat.ptr(wd), nat.ptr(wb), nat.ptr(ws),
              b, h * w, c, 1 if per_image else 0, float(slope), float(scale), nat.current_stream())
-    gd = wd.double().sum(1).float() if wd is not None else None           # (rows of a few dozen blocks: summed in double)
-    gb = wb.double().sum(0).float()
-    gs = ws.double().sum().float().reshape(1) if ws is not None else None
+    # the partial sums (rows of a few dozen blocks) to their results, in double, ONE launch (was nine torch launches per call)
+    gd = torch.empty((b, c), **f32) if wd is not None else None
+    gb = torch.empty(c, **f32)
+    gs = torch.empty(1, **f32) if ws is not None else None
+    nat.call("diagan_styled_bias_act_bwd_finish", nat.ptr(wd), nat.ptr(wb), nat.ptr(ws), nat.ptr(gd), nat.ptr(gb), nat.ptr(gs),
+             b, h * w, c, nat.current_stream())
     return gx, gd, gb, gs
 
 

@@ -33,6 +33,23 @@ def upfirdn2d_op(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_
     return out.to(input.dtype)
 
 
+_FLIPS = {}
+
+
+def _flipped(kernel):
+    """torch.flip(kernel, [0, 1]) of a FIR kernel, made once per kernel tensor and content version (every FIR call builds its plan and
+    the plan's adjoint: the flip was a launch per call, ~65 per StyleGAN2 iteration); kernels that require grad are never cached"""
+    if kernel.requires_grad:
+        return torch.flip(kernel, [0, 1])
+    key = (kernel.data_ptr(), kernel._version, tuple(kernel.shape), kernel.device)
+    f = _FLIPS.get(key)
+    if f is None:
+        if len(_FLIPS) > 64:
+            _FLIPS.clear()
+        f = _FLIPS[key] = (torch.flip(kernel, [0, 1]), kernel)          # (the source is kept alive: its data_ptr cannot be recycled)
+    return f[0]
+
+
 class _Plan:
     """Geometry of one upfirdn2d application on [batch, channel, in_h, in_w] images, linked to its adjoint."""
 
@@ -52,7 +69,7 @@ class _Plan:
         plan = cls(kernel, up, down, pad, in_hw, (out_h, out_w), channels_last=channels_last)
         adjoint_pad = (kw - px0 - 1, in_w * ux - out_w * dx + px0 - ux + 1,
                        kh - py0 - 1, in_h * uy - out_h * dy + py0 - uy + 1)
-        plan.dual = cls(torch.flip(kernel, [0, 1]), down, up, adjoint_pad, (out_h, out_w), in_hw, dual=plan,
+        plan.dual = cls(_flipped(kernel), down, up, adjoint_pad, (out_h, out_w), in_hw, dual=plan,
                         channels_last=channels_last)
         return plan
 

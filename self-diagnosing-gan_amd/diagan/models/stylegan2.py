@@ -152,7 +152,7 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def _finish(self, out):
-        bias = self.bias * self.lr_mul if self.bias is not None else None
+        bias = (self.bias * self.lr_mul if self.lr_mul != 1 else self.bias) if self.bias is not None else None
         if self.activation:
             return fused_leaky_relu(out, bias, bias_dim=-1)
         return out + bias if bias is not None else out
