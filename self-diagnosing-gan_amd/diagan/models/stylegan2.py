@@ -197,7 +197,9 @@ class ModulatedConv2d(nn.Module):
         """(convolution of the modulated input, demodulation factors [B, Co] or None): the caller applies d -- StyledConv
         does it inside its fused noise + bias + activation pass"""
         s = self.modulation(style)                                   # [B, Ci]
-        w = self.weight[0]                  # (the equalised-learning-rate scale rides in the packing launch: dc.*(..., scale=))
+        # (a VIEW, not self.weight[0]: the select's backward zero-fills a weight-sized tensor and copies into it, every pass; the
+        #  equalised-learning-rate scale rides in the packing launch: dc.*(..., scale=))
+        w = self.weight.view(self.weight.shape[1:])
         if self.downsample:
             x = self.blur(x)
         x = scale_rows(x, s)
@@ -345,13 +347,16 @@ class StyleGANGenerator(FlatNet):
             latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
 
-        out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        # the per-layer styles latent[:, i] as contiguous views of ONE transposed copy: each strided select was a copy in the forward and,
+        # in a backward that reaches the latents (path-length regularisation), a zero-filled [B, n_latent, 512] tensor + an add
+        lat = latent.transpose(0, 1).contiguous().unbind(0)
+        out = self.conv1(self.input(latent), lat[0], noise=noise[0])
+        skip = self.to_rgb1(out, lat[1])
         for level, to_rgb in enumerate(self.to_rgbs):
             i = 1 + 2 * level
-            out = self.convs[2 * level](out, latent[:, i], noise=noise[i])
-            out = self.convs[2 * level + 1](out, latent[:, i + 1], noise=noise[i + 1])
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = self.convs[2 * level](out, lat[i], noise=noise[i])
+            out = self.convs[2 * level + 1](out, lat[i + 1], noise=noise[i + 1])
+            skip = to_rgb(out, lat[i + 2], skip)
         return to_nchw(skip, 3), (latent if return_latents else None)
 
 

@@ -227,12 +227,13 @@ class _PackScaled(Function):
         nat.call("diagan_pack_oihw", nat.ptr(_c(w)), float(scale), nat.ptr(wp), nat.ptr(wd) if want_wd else None, co, ci, r, s,
                  geom.Co, geom.Ci, geom.Kp, geom.Kd, nat.current_stream())
         ctx.mark_non_differentiable(wd)
+        ctx.set_materialize_grads(False)           # (else the engine zero-fills a [Ci][Kd] "gradient" of wd for every backward)
         return wp, wd
 
     @staticmethod
     def backward(ctx, gwp, _gwd):
         scale, geom, shape = ctx.meta
-        return _UnpackScaled.apply(gwp, scale, geom, shape), None, None, None
+        return (_UnpackScaled.apply(gwp, scale, geom, shape) if gwp is not None else None), None, None, None
 
 
 class _UnpackScaled(Function):

@@ -32,6 +32,10 @@ aten = [r for r in rows if r[2].startswith("aten::")]
 print(f"aten:: operators (self device time): {sum(r[0] for r in aten):.1f} ms per iteration")
 for ms, cnt, key, shp in aten[:45]:
     print(f"{ms:8.3f} ms  {cnt:7.1f} calls  {key:28s} {shp}")
+if os.environ.get("SG2_BY_COUNT") == "1":        # the launch-count view: which small operators are called most
+    print("aten:: operators by calls per iteration:")
+    for ms, cnt, key, shp in sorted(aten, key=lambda r: -r[1])[:70]:
+        print(f"{cnt:7.1f} calls  {ms:8.3f} ms  {key:28s} {shp}")
 own = [r for r in rows if not r[2].startswith("aten::") and not r[2].startswith("void ") and "diagan::" not in r[2]]
 print("autograd Functions of this engine (self device time):")
 for ms, cnt, key, shp in own[:12]:
