@@ -396,41 +396,63 @@ DIAGAN_API int diagan_styled_bias_act_bwd(const float* gy, const float* y, const
 //   gd[b][c] = sum_chunks work_d[b][chunk][c],  gb[c] = sum_rows work_b[row][c] (rows = B * chunks),  gs = sum work_s[rows]
 // accumulated in double in a fixed order (rows interleaved four ways per column, then a fixed LDS tree): deterministic.
 namespace diagan {
-__global__ __launch_bounds__(256) void styled_act_bwd_finish_kernel(const float* __restrict__ work_d, const float* __restrict__ work_b,
-                                                                    const float* __restrict__ work_s, float* __restrict__ gd,
-                                                                    float* __restrict__ gb, float* __restrict__ gs, int B, int chunks,
-                                                                    int C, int nd, int nb) {
-  __shared__ double red[256];
-  const int bid = blockIdx.x, tid = threadIdx.x;
-  if (bid < nd) {                                   // gd: block = image b, threads over the channels
-    const float* src = work_d + (long)bid * chunks * C;
-    for (int c = tid; c < C; c += 256) {
-      double t = 0.0;
-      for (int k = 0; k < chunks; ++k) t += (double)src[(long)k * C + c];
-      gd[(long)bid * C + c] = (float)t;
+// 1024 threads = 64 columns x 16 lanes.  Blocks [0, nd): (image b, 64-column group) -> gd, the lanes take the chunks; blocks [nd, nd + nb):
+// 64-column group -> gb, the lanes take the B * chunks rows (independent loads, eight in flight); the last block -> gs.  Every sum in
+// double: a lane's rows in order, then the sixteen lanes in order (deterministic).
+__global__ __launch_bounds__(1024) void styled_act_bwd_finish_kernel(const float* __restrict__ work_d, const float* __restrict__ work_b,
+                                                                     const float* __restrict__ work_s, float* __restrict__ gd,
+                                                                     float* __restrict__ gb, float* __restrict__ gs, int B, int chunks,
+                                                                     int C, int nd, int nb) {
+  __shared__ double red[1024];
+  const int bid = blockIdx.x, tid = threadIdx.x, cl = tid & 63, lane = tid >> 6;
+  const int groups = (C + 63) >> 6;
+  double t = 0.0;
+  int col = -1;
+  float* dst = nullptr;
+  if (bid < nd) {
+    const int b = bid / groups;
+    col = (bid - b * groups) * 64 + cl;
+    if (col < C) {
+      const float* src = work_d + (long)b * chunks * C + col;
+      for (int k = lane; k < chunks; k += 16) t += (double)src[(long)k * C];
+      dst = gd + (long)b * C + col;
     }
-    return;
-  }
-  const int rows = B * chunks;
-  if (bid < nd + nb) {                              // gb: block = 64 columns x 4 row lanes
-    const int col = (bid - nd) * 64 + (tid & 63), lane = tid >> 6;
-    double t = 0.0;
-    if (col < C)
-      for (int r = lane; r < rows; r += 4) t += (double)work_b[(long)r * C + col];
+  } else if (bid < nd + nb) {
+    col = (bid - nd) * 64 + cl;
+    const int rows = B * chunks;
+    if (col < C) {
+      const float* src = work_b + col;
+      int r = lane;
+      for (; r + 7 * 16 < rows; r += 8 * 16) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(long)(r + 16 * u) * C];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += (double)v[u];
+      }
+      for (; r < rows; r += 16) t += (double)src[(long)r * C];
+      dst = gb + col;
+    }
+  } else {
+    const int rows = B * chunks;
+    for (int r = tid; r < rows; r += 1024) t += (double)work_s[r];
     red[tid] = t;
     __syncthreads();
-    if (lane == 0 && col < C) gb[col] = (float)((red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]));
+    for (int o = 512; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) gs[0] = (float)red[0];
     return;
   }
-  double t = 0.0;                                   // gs: one block
-  for (int r = tid; r < rows; r += 256) t += (double)work_s[r];
   red[tid] = t;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
+  if (lane == 0 && dst) {
+    double a = 0.0;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) a += red[l * 64 + cl];
+    *dst = (float)a;
   }
-  if (tid == 0) gs[0] = (float)red[0];
 }
 }  // namespace diagan
 
@@ -439,8 +461,9 @@ DIAGAN_API int diagan_styled_bias_act_bwd_finish(const float* work_d, const floa
   DG_REQUIRE(B > 0 && P > 0 && C > 0, "styled_bias_act_bwd_finish: bad dims");
   DG_REQUIRE(!work_d == !gd && !work_b == !gb && !work_s == !gs && (gd || gb || gs), "styled_bias_act_bwd_finish: partials and results come in pairs");
   const int chunks = diagan_rowdot_chunks(B, P);
-  const int nd = gd ? B : 0, nb = gb ? cdiv(C, 64) : 0, ns = gs ? 1 : 0;
-  hipLaunchKernelGGL(diagan::styled_act_bwd_finish_kernel, dim3(nd + nb + ns), dim3(256), 0, (hipStream_t)stream, work_d, work_b, work_s,
+  const int groups = cdiv(C, 64);
+  const int nd = gd ? B * groups : 0, nb = gb ? groups : 0, ns = gs ? 1 : 0;
+  hipLaunchKernelGGL(diagan::styled_act_bwd_finish_kernel, dim3(nd + nb + ns), dim3(1024), 0, (hipStream_t)stream, work_d, work_b, work_s,
                      gd, gb, gs, B, chunks, C, nd, nb);
   return check_launch("styled_bias_act_bwd_finish");
 }

@@ -292,6 +292,13 @@ def set_gemm_x3(on):
     """True / False: the lone-tile implicit-GEMM launches (tile_cfg 14) run on the bf16 matrix pipe with exactly split operands where
     their geometry qualifies (csrc/conv_gemm_x3.hip) / on the fp32 pipe; None: what DIAGAN_GEMM_X3 says"""
     nat.call("diagan_conv_gemm_set_x3", -1 if on is None else (1 if on else 0))
+    # ... and with it the large-launch form (csrc/conv_gemm_x3b.hip, round 6): the callers of this switch want the fp32 fmaf chain or not
+    nat.call("diagan_conv_gemm_set_x3b", -1 if on is None else (1 if on else 0))
+
+
+def set_gemm_x3b(on):
+    """the same for the 128 x 128 / 256 x 128 split-operand kernel alone (tile_cfg 17); None: what DIAGAN_GEMM_X3B says"""
+    nat.call("diagan_conv_gemm_set_x3b", -1 if on is None else (1 if on else 0))
 
 
 _TICKETS = {}
