@@ -239,6 +239,8 @@ def sngan64_leg(args, device, steps=10, warmup=3):
     step = make_global_step(*nets, batches, args.n_dis, num_steps=75000, device=device)
     for _ in range(warmup):
         step()
+    from diagan.utils.settings import quiesce_gc
+    quiesce_gc()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -301,6 +303,8 @@ def phase2_leg(args, device, steps=10, warmup=3):
     step = make_global_step(*nets, batches, args.n_dis, num_steps=50000, device=device)
     for _ in range(warmup):
         step()
+    from diagan.utils.settings import quiesce_gc
+    quiesce_gc()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -323,6 +327,8 @@ def stylegan2_leg(device, size=256, batch=32, warmup=3, steps=8, table_iters=4):
     step = make_stylegan2_step(size, batch, 1, device)
     for _ in range(warmup):
         step()
+    from diagan.utils.settings import quiesce_gc
+    quiesce_gc()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -573,6 +579,8 @@ def main():
         graphed.capture()
         step = graphed
         timer = None            # launches inside a graph carry no events; the kernel table comes from eager steps below
+    from diagan.utils.settings import quiesce_gc
+    quiesce_gc()          # as LogTrainer.train / StyleGAN2Trainer.train do after their first step (no full GC pass over the nets mid-run)
     dist.synchronize()
     torch.cuda.synchronize()
     C.TIMER = timer

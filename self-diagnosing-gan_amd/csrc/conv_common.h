@@ -136,8 +136,9 @@ struct ConvGemmArgs {
   int tune;               // tuning sweeps: bit 0 = raised wave priority while the loader state is set up and the first
                           // tile staged, bit 1 = raised priority in the epilogue (a new / finishing wave otherwise gets
                           // the vector-issue slots its older MFMA-bound neighbours leave over)
-  OutMap map;             // see OutMap (all zero: y is [B][Ho][Wo][Co])
 };
+// (OutMap travels beside ConvGemmArgs, as a kernel argument of its own: grown by its 36 bytes the argument block changed the register
+//  allocation of conv_wino4_kernel<2,0> -- 55 -> 146 spilled VGPRs, 2.04 -> 2.24 ms per SNGAN-32 step; round 6)
 
 // Arguments of the weight-gradient kernels (conv_wgrad.hip: implicit GEMM; conv_wgrad_wino.hip: Winograd F(3x3,2x2))
 struct WgradArgs {

@@ -38,7 +38,7 @@ namespace diagan {
 int launch_gemm_x3(const ConvGemmArgs& a, float* ws, hipStream_t st);     // conv_gemm_x3.hip: bf16 pipe, exactly split operands
 bool gemm_x3_geom_ok(const ConvGemmArgs& a);
 long gemm_x3_ws_floats(int Co, int Kp);
-int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st);    // conv_gemm_x3b.hip: the same arithmetic on 128 x 128 tiles
+int launch_gemm_x3b(const ConvGemmArgs& a, const OutMap& map, float* ws, hipStream_t st);    // conv_gemm_x3b.hip: the same arithmetic on 128 x 128 tiles
 bool gemm_x3b_geom_ok(const ConvGemmArgs& a);
 long gemm_x3b_ws_floats(int Co, int Kp);
 void gemm_x3b_force_form(int form);
@@ -955,7 +955,6 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
   a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
   a.dWo = make_fastdiv((unsigned)Wo);
   a.dHo = make_fastdiv((unsigned)Ho);
-  a.map = map;
   a.stat_partials = stat_partials;
   a.pro_group_rows = pro_group_rows;
   hipStream_t st = (hipStream_t)stream;
@@ -1130,7 +1129,7 @@ DIAGAN_API int diagan_conv_gemm(const float* x, const float* w, float* y, const 
                "Kp == R*S*Ci, prologue none / ReLU / leaky ReLU, a plain epilogue (out_scale, bias, residual) and %ld floats of workspace",
                gemm_x3b_ws_floats(Co, Kp));
     a.ksplit = 1;
-    return launch_gemm_x3b(a, splitk_ws, st);
+    return launch_gemm_x3b(a, map, splitk_ws, st);
   }
   switch (cfg) {
     case 1: return launch_cfg<128, 128, 2, 2, 32, true>(a, st);

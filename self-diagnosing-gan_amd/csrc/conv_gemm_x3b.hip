@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void gx3b_weight_kernel(const float* __restric
 }
 
 template <int PRO, bool MAP>
-__global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArgs a, const unsigned short* __restrict__ wx) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArgs a, const OutMap mp, const unsigned short* __restrict__ wx) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const ConvGeom& g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,7 +262,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
   // the column halves (0, 1, 1, 0) / (1, 0, 0, 1): 32-float rows put those on four disjoint quarters of the 64 banks.
   const float sc = a.out_scale;
   const bool hr = a.residual != nullptr;
-  const OutMap& mp = a.map;
   const long ypix = MAP ? (long)g.B * mp.OH * mp.OW : (long)a.M;
   const unsigned ybytes = (unsigned)(ypix * g.Co * 4);
   const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)ybytes, 0x00020000);
@@ -362,7 +361,7 @@ __global__ __launch_bounds__(256) void gx3b2_weight_kernel(const float* __restri
 #endif
 
 template <int PRO, bool MAP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm_x3b2_kernel(const ConvGemmArgs a, const unsigned short* __restrict__ wimg) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_gemm_x3b2_kernel(const ConvGemmArgs a, const OutMap mp, const unsigned short* __restrict__ wimg) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   char* const lds8 = reinterpret_cast<char*>(lds);
   const ConvGeom& g = a.g;
@@ -584,7 +583,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // ---- epilogue (as above; the four consumer waves, through their private images in the now idle A buffers) ----
   const float sc = a.out_scale;
   const bool hr = a.residual != nullptr;
-  const OutMap& mp = a.map;
   const long ypix = MAP ? (long)g.B * mp.OH * mp.OW : (long)a.M;
   const unsigned ybytes = (unsigned)(ypix * g.Co * 4);
   const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)ybytes, 0x00020000);
@@ -668,27 +666,27 @@ static int x3b_form(long tiles2, int nk) {
 }
 
 template <int PRO, bool MAP>
-static int launch_x3b_two(const ConvGemmArgs& a, const unsigned short* wimg, int tiles, hipStream_t st) {
+static int launch_x3b_two(const ConvGemmArgs& a, const OutMap& mp, const unsigned short* wimg, int tiles, hipStream_t st) {
   auto kern = conv_gemm_x3b2_kernel<PRO, MAP>;
   static FuncAttrLatch latch;
   DG_LDS(latch, kern, XB2_LDS_BYTES);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), XB2_LDS_BYTES, st, a, wimg);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), XB2_LDS_BYTES, st, a, mp, wimg);
   return DIAGAN_OK;
 }
 
 template <int PRO, bool MAP>
-static int launch_x3b_one(const ConvGemmArgs& a, const unsigned short* wx, int tiles, hipStream_t st) {
+static int launch_x3b_one(const ConvGemmArgs& a, const OutMap& mp, const unsigned short* wx, int tiles, hipStream_t st) {
   auto kern = conv_gemm_x3b_kernel<PRO, MAP>;
   static FuncAttrLatch latch;
   DG_LDS(latch, kern, XB_LDS_BYTES);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), XB_LDS_BYTES, st, a, wx);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), XB_LDS_BYTES, st, a, mp, wx);
   return DIAGAN_OK;
 }
 
-int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
+int launch_gemm_x3b(const ConvGemmArgs& a, const OutMap& mp, float* ws, hipStream_t st) {
   const ConvGeom& g = a.g;
   const int tiles = cdiv(a.M, 128) * cdiv(g.Co, 128);
-  const bool map = a.map.mul != 0;
+  const bool map = mp.mul != 0;
   const int nk = g.Kp / 32;
   const long tiles2 = (long)cdiv(a.M, 256) * cdiv(g.Co, 128);
   if (x3b_form(tiles2, nk) == 2) {
@@ -697,9 +695,9 @@ int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
     hipLaunchKernelGGL(gx3b2_weight_kernel, dim3(nk, cdiv(g.Co, 128)), dim3(256), 0, st, a.w, img, g.Co, g.Kp, nk);
     int rc;
     switch (a.pro_mode) {
-      case PRO_RELU: rc = map ? launch_x3b_two<PRO_RELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_RELU, false>(a, img, tiles, st); break;
-      case PRO_LRELU: rc = map ? launch_x3b_two<PRO_LRELU, true>(a, img, tiles, st) : launch_x3b_two<PRO_LRELU, false>(a, img, tiles, st); break;
-      default: rc = map ? launch_x3b_two<PRO_NONE, true>(a, img, tiles, st) : launch_x3b_two<PRO_NONE, false>(a, img, tiles, st);
+      case PRO_RELU: rc = map ? launch_x3b_two<PRO_RELU, true>(a, mp, img, tiles, st) : launch_x3b_two<PRO_RELU, false>(a, mp, img, tiles, st); break;
+      case PRO_LRELU: rc = map ? launch_x3b_two<PRO_LRELU, true>(a, mp, img, tiles, st) : launch_x3b_two<PRO_LRELU, false>(a, mp, img, tiles, st); break;
+      default: rc = map ? launch_x3b_two<PRO_NONE, true>(a, mp, img, tiles, st) : launch_x3b_two<PRO_NONE, false>(a, mp, img, tiles, st);
     }
     if (rc != DIAGAN_OK) return rc;
     return check_launch("conv_gemm_x3b (producer / consumer form)");
@@ -716,9 +714,9 @@ int launch_gemm_x3b(const ConvGemmArgs& a, float* ws, hipStream_t st) {
   }
   int rc;
   switch (a.pro_mode) {
-    case PRO_RELU: rc = map ? launch_x3b_one<PRO_RELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_RELU, false>(a, wx, tiles, st); break;
-    case PRO_LRELU: rc = map ? launch_x3b_one<PRO_LRELU, true>(a, wx, tiles, st) : launch_x3b_one<PRO_LRELU, false>(a, wx, tiles, st); break;
-    default: rc = map ? launch_x3b_one<PRO_NONE, true>(a, wx, tiles, st) : launch_x3b_one<PRO_NONE, false>(a, wx, tiles, st);
+    case PRO_RELU: rc = map ? launch_x3b_one<PRO_RELU, true>(a, mp, wx, tiles, st) : launch_x3b_one<PRO_RELU, false>(a, mp, wx, tiles, st); break;
+    case PRO_LRELU: rc = map ? launch_x3b_one<PRO_LRELU, true>(a, mp, wx, tiles, st) : launch_x3b_one<PRO_LRELU, false>(a, mp, wx, tiles, st); break;
+    default: rc = map ? launch_x3b_one<PRO_NONE, true>(a, mp, wx, tiles, st) : launch_x3b_one<PRO_NONE, false>(a, mp, wx, tiles, st);
   }
   if (rc != DIAGAN_OK) return rc;
   return check_launch("conv_gemm_x3b");

@@ -615,12 +615,14 @@ class WgradBatch:
         self.queue = {}          # slot -> [(layer, dy, x, pro, segments, entry)]
         self.queued_bytes = {}   # slot -> bytes of dy + x the queue keeps alive
         self.batch_plans = {}    # (layer ids, shapes) -> splits per layer
+        self.job_tables = {}     # (the same key, plan) -> constant columns of the batched launch's job table (ops/conv.py); lives and
+                                 # dies with this network, so the layer ids in its keys cannot be recycled under it
         self.batched_launches = 0
 
     def _entry(self, layer, slot, M, segments=1, dy_shape=None, x_shape=None, geom=None):
         self.net.flat_grads
         if self.slab_generation != self.net.slab_generation:          # gradient slab was re-allocated
-            self.entries.clear(), self.tables.clear()
+            self.entries.clear(), self.tables.clear(), self.job_tables.clear()
             self.slab_generation = self.net.slab_generation
         e = self.entries.get((layer, slot))
         if e is None or e['M'] != M:
@@ -738,7 +740,7 @@ class WgradBatch:
                         name += C.POOLED_TAG
                 C.conv_wgrad_batched([(g, dy, x, e['slab'], e['splits'], e['stride'], e['bias_off'], pro, segments)
                                       for layer, dy, x, pro, segments, e, g, _ in part], key=(key, tuple(plan)),
-                                     kernel_name=name, flop_scale=4.0 if pooled else 1.0)
+                                     kernel_name=name, flop_scale=4.0 if pooled else 1.0, cache=self.job_tables)
                 self.batched_launches += 1
 
     def finish(self, slot):

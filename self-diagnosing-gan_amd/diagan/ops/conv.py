@@ -169,9 +169,14 @@ class WinoWeights:
         self.fmt, self.u, self.ready, self.used = None, None, None, False
 
 
+_LWF = (_ct.c_int(), _ct.c_int(), _ct.c_float(), _ct.c_int64(), _ct.c_int64())
+_LWF_REFS = tuple(_ct.byref(v) for v in _LWF)
+
+
 def last_weight_format():
-    k, f, sc, n, cnt = _ct.c_int(), _ct.c_int(), _ct.c_float(), _ct.c_int64(), _ct.c_int64()
-    nat.call("diagan_conv_gemm_last_weight_format", _ct.byref(k), _ct.byref(f), _ct.byref(sc), _ct.byref(n), _ct.byref(cnt))
+    # (the five out-parameters are made once: this runs behind every convolution launch of a network pass)
+    nat.fn("diagan_conv_gemm_last_weight_format")(*_LWF_REFS)
+    k, f, sc, n, cnt = _LWF
     return (k.value, f.value, sc.value, n.value), cnt.value
 
 
@@ -755,7 +760,7 @@ def batched_wgrad_splits(jobs, slots=256, fixed=8.0):
 _WG_TABS = {}
 
 
-def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0):
+def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0, cache=None):
     """jobs: [(geom, dy, x, slab, splits, stride, bias_off, pro, segments)] -- the arguments of conv_wgrad_into, every job a
     layer of the Winograd weight gradient, all with the same prologue mode; at most wgrad_batch_max() of them.
     key: a hashable that identifies everything but the tensors' addresses (layers, shapes, splits): the job table's constant
@@ -765,12 +770,14 @@ def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0):
     if _WG_JOB is None:
         _WG_JOB = np.dtype([('p', np.uint64, 5), ('l', np.int64, 2), ('i', np.int32, 18)])
         assert _WG_JOB.itemsize == 128
-    if key is not None:
-        # id() values in the caller's key are recycled once a net is freed: everything the cached constant columns hold is part of
-        # the key, so that a new layer with an old id and another geometry builds its own table
+    # `cache`: the CALLER's table cache (WgradBatch keeps one per network: it dies with the net, so the layer ids in `key` cannot be
+    # recycled under it -- ADVICE r5).  Without one the module-level cache is used and everything the cached constant columns hold
+    # becomes part of the key (a new layer with an old id and another geometry then builds its own table).
+    tabs = cache if cache is not None else _WG_TABS
+    if key is not None and cache is None:
         key = (key,) + tuple((g.kind, g.Ci, g.Co, g.R, g.S, g.stride, g.pad, g.Kp, tuple(dy.shape), tuple(x.shape), sp, st, bo,
                               _pro3(pro)[0], seg) for g, dy, x, _, sp, st, bo, pro, seg in jobs)
-    cached = _WG_TABS.get(key) if key is not None else None
+    cached = tabs.get(key) if key is not None else None
     if cached is None:
         tab = np.zeros(len(jobs), dtype=_WG_JOB)
         flop, px, mode0 = 0.0, 0, None
@@ -786,9 +793,9 @@ def conv_wgrad_batched(jobs, key=None, kernel_name=None, flop_scale=1.0):
             px += B * Ho * Wo
         cached = (tab, flop, px, mode0)
         if key is not None:
-            if len(_WG_TABS) > 256:
-                _WG_TABS.clear()
-            _WG_TABS[key] = cached
+            if len(tabs) > 256:
+                tabs.clear()
+            tabs[key] = cached
     tab, flop, px, mode0 = cached
     ptrs = []
     for geom, dy, x, slab, splits, stride, bias_off, pro, segments in jobs:

@@ -28,6 +28,7 @@ from diagan.datasets.sampler import ShardedSampler
 from diagan.optim import FusedAdam
 from diagan.trainer import distributed as dist
 from diagan.trainer.distributed import get_rank, get_world_size, reduce_loss_dict, reduce_sum
+from diagan.utils.settings import quiesce_gc
 
 
 def data_sampler(dataset, shuffle, distributed, weights=None):
@@ -259,6 +260,8 @@ class StyleGAN2Trainer:
                 print("Done!")
                 break
             losses = self.train_step(i)
+            if idx == 0:
+                quiesce_gc()                          # (the first iteration built every autograd site and launch table)
             if self.D_drs is None and i % a.logit_save_steps == 0 and a.save_logit_after <= i <= a.stop_save_logit_after:
                 print(f'save logit step: {i}')
                 logit_list = get_logit(dataloader=self.loader, netD=self.D, device=self.device)

@@ -21,6 +21,7 @@ from diagan.trainer import distributed as dist
 from diagan.trainer.logger import Logger, MetricLog
 from diagan.trainer.scheduler import DRS_LRScheduler
 from diagan.utils.plot import LogitRecord
+from diagan.utils.settings import quiesce_gc
 
 
 class _Clock:
@@ -386,6 +387,7 @@ class LogTrainer:
         if self.train_drs:
             streams['drs'] = iter(self.dataloader_drs)
         clock = _Clock()
+        quiesced = False
         try:
             while step < self.num_steps:
                 if self.topk:
@@ -393,6 +395,9 @@ class LogTrainer:
                 if self.gold and step == self.gold_step:
                     self.netD.use_gold = True
                 log = self._updates(step, streams, MetricLog())
+                if not quiesced:                           # (after the first step: every launch table and workspace exists now)
+                    quiesce_gc()
+                    quiesced = True
                 step += 1                                  # the schedule and all periodic duties see the NEW step
                 log = self.scheduler.step(log_data=log, global_step=step)
                 self._report(step, log, clock)

@@ -31,3 +31,15 @@ def set_seed(seed=3):
                _device_generators)
     for apply in seeders:
         apply(seed)
+
+
+def quiesce_gc():
+    """After the networks, optimisers and their launch tables exist (a quarter of a million tracked Python objects for an SNGAN pair):
+    collect once and move everything alive to the permanent generation.  Python's cyclic collector otherwise walks all of them on
+    every full collection -- ~50 ms, in the middle of a training step whenever the allocation counters say so (measured: 12.1 -> 14.1
+    ms per SNGAN-32 step in a 30-step window that contains one).  The engine's own per-step objects are acyclic; later collections
+    only see what was made after this call."""
+    import gc
+    gc.collect()
+    gc.freeze()
+

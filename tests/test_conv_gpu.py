@@ -387,6 +387,26 @@ def test_split_operand_implicit_gemm_128_tiles(case, form):
         nat.call("diagan_conv_gemm_x3b_force_form", 0)
 
 
+def test_split_operand_256_tiles_repeatable_over_several_rounds_of_workgroups():
+    """The loader waves of form 2 wait for their in-flight loads by COUNT (inline-assembly loads, `vmcnt(N)`); a first build let the
+    compiler copy the still-in-flight registers in front of the wait and was wrong once in a few launches, only where the launch ran
+    more than one round of workgroups (profiles/r06_x3b.md).  The shape it showed on, 40 launches, each bit-identical to form 1."""
+    from diagan import _native as nat
+    from diagan.ops import conv as C
+    g = torch.Generator(device="cuda").manual_seed(3)
+    geom = C.Geom("conv", 512, 512, 2, 2, 1, 1)
+    x = torch.randn(32, 32, 32, 512, device="cuda", generator=g)
+    wp = torch.randn(512, geom.Kp, device="cuda", generator=g) * (4 * 512) ** -0.5
+    try:
+        nat.call("diagan_conv_gemm_x3b_force_form", 1)
+        ref = C.conv_fwd(geom, x, wp, tile_cfg=17)
+        nat.call("diagan_conv_gemm_x3b_force_form", 2)
+        for _ in range(40):
+            assert torch.equal(C.conv_fwd(geom, x, wp, tile_cfg=17), ref)
+    finally:
+        nat.call("diagan_conv_gemm_x3b_force_form", 0)
+
+
 def test_split_operand_128_tiles_automatic_choice():
     """the automatic choice upgrades a large implicit-GEMM pick to tile_cfg 17 exactly when the switch is on, and reports it
     (diagan_conv_gemm_final_cfg: what the kernel timer names and what out_map_ok answers)"""

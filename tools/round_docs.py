@@ -43,7 +43,7 @@ Command (GPU box, `tools/profile_round.sh`): `rocprofv3 --kernel-trace --stats -
 {b32['value']} images/s under the profiler).
 
 Un-profiled default run of the same build (`python bench.py`): **{d['value']} images/s, {d['ms_per_step']} ms/step**
-(round 3: 4636 / 13.8; round 2: 4049 / 15.8; round 1: 2421 / 26.4).  Roofline kernel `{r['kernel']}` (Winograd F(4x4,3x3) forward / data-gradient,
+(round 5: 5340 / 12.0; round 4: 4815 / 13.3; round 3: 4636 / 13.8; round 2: 4049 / 15.8; round 1: 2421 / 26.4).  Roofline kernel `{r['kernel']}` (Winograd F(4x4,3x3) forward / data-gradient,
 `csrc/conv_wino4.hip`): HIP-event average {r['avg_launch_us']} us/launch over the {r['launches']} launches of the timed region
 (the rocprof average of the same template below also covers the table steps), {r['algorithmic_gflop_per_launch']} algorithmic
 GFLOP/launch (direct convolution, 2 M Co 9 Ci) = {r['algorithmic_tflops']} TFLOP/s = {r['frac_algorithmic']} of the 157.3 TFLOP/s
