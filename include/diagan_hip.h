@@ -329,6 +329,14 @@ int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, 
                                 int up, int Kp);
 int diagan_conv_wgrad_splits_geom(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                   int off, int up, int Kp); /* host heuristic: number of splits */
+/* Round 6: inside diagan_conv_wgrad the large plain launches of the 128 x 128 tile (no prologue, no bias column, whole tiles,
+ * Ci % 32 == 0, >= 4e9 multiply-accumulates) run on the bf16 matrix pipe with both operands split exactly in three
+ * (csrc/conv_wgrad_x3.hip; same splits, slabs and second-stage sum, fp32-grade results).  uses_x3 tells whether a launch
+ * qualifies (for kernel-name bookkeeping); set_x3: 0 off, 1 on, 2 on without the work floor (tests), -1 the environment's
+ * DIAGAN_WGRAD_X3 (default on) -- a process-level diagnostic switch.  diagan_conv_gemm_set_x3b(0) (the exact-fp32 mode) turns it off as well. */
+int diagan_conv_wgrad_uses_x3(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                              int up, int Kp, int pro_mode, int64_t bias_off);
+int diagan_conv_wgrad_set_x3(int on);
 
 /* Deferred epilogue of a whole backward pass, all layers in two launches: per layer
  * G = sum_s slab[s] (fixed order); plain layers: grad += G; spectral-norm layers:

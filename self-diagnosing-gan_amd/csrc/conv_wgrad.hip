@@ -25,6 +25,9 @@ int wgrad_wino_splits(int B, int Ho, int Wo, int Ci, int Co);
 int launch_wgrad_wino(WgradArgs a, int splits, int segments, hipStream_t st);
 int launch_wgrad_wino_batched(const WgradArgs* jobs, const int* splits, const int* segments, int n, hipStream_t st);
 int wgrad_wino_batch_max();
+bool wgrad_x3_takes(const WgradArgs& a, bool x3_on);                  // conv_wgrad_x3.hip
+int launch_wgrad_x3(const WgradArgs& a, int splits, hipStream_t st);
+void wgrad_x3_set(int on);
 
 
 // P2: Ho and Wo are powers of two -- pixel coordinates come from shifts and masks of the pixel index instead of
@@ -603,6 +606,7 @@ extern "C" __attribute__((visibility("default"))) int diagan_wgrad_finish_block_
 
 using namespace diagan;
 extern "C" int diagan_conv_gemm_get_wino(void);
+extern "C" int diagan_conv_gemm_get_x3b(void);
 extern "C" int diagan_conv_wgrad_splits(int M, int Co, int Kp);
 extern "C" int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr,
                                            int off, int up, int Kp);
@@ -694,6 +698,8 @@ DIAGAN_API int diagan_conv_wgrad(const float* dy, const float* x, float* slab, i
   int bn, bk;
   bool p2;
   wgrad_gemm_fields(a, &bn, &bk, &p2);
+  // the large plain launches: the same tiles, splits and slabs on the bf16 matrix pipe with exactly split operands
+  if (bn == 128 && bk == 128 && wgrad_x3_takes(a, diagan_conv_gemm_get_x3b() != 0)) return launch_wgrad_x3(a, splits, st);
   const dim3 grid(a.tiles * splits);
   // one straight-line kernel per prologue mode (x power-of-two image or not) for the two production tiles
 #define DG_WG(BN_, PRO_) do { if (p2) hipLaunchKernelGGL((conv_wgrad_kernel<BN_, 128, PRO_, true>), grid, dim3(256), 0, st, a); \
@@ -815,6 +821,24 @@ DIAGAN_API int diagan_conv_wgrad_uses_wino(int Hi, int Wi, int Ci, int Ho, int W
   const int on = sw >= 0 ? sw : wino_env;
   return on && wg_env &&
          wgrad_wino_supported(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp);
+}
+
+// 1: diagan_conv_wgrad runs this launch on the split-operand kernel (conv_wgrad_x3.hip; for kernel-name bookkeeping)
+DIAGAN_API int diagan_conv_wgrad_uses_x3(int B, int Hi, int Wi, int Ci, int Ho, int Wo, int Co, int R, int S, int sy, int dr, int off,
+                                         int up, int Kp, int pro_mode, int64_t bias_off) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || diagan_conv_wgrad_uses_wino(Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, Kp)) return 0;
+  int bn, bk;
+  wgrad_tile(Co, Kp, &bn, &bk);
+  if (bn != 128 || bk != 128) return 0;
+  WgradArgs a;
+  a.pro_mode = pro_mode; a.bias_off = bias_off; a.M = B * Ho * Wo;
+  a.g = ConvGeom{B, Hi, Wi, Ci, Ho, Wo, Co, R, S, sy, dr, off, up, R * S * Ci, Kp};
+  return wgrad_x3_takes(a, diagan_conv_gemm_get_x3b() != 0) ? 1 : 0;
+}
+// process-level diagnostic switch of that kernel: 0 off, 1 on, -1 back to the environment's DIAGAN_WGRAD_X3 (default on)
+DIAGAN_API int diagan_conv_wgrad_set_x3(int on) {
+  wgrad_x3_set(on);
+  return DIAGAN_OK;
 }
 
 // split count for a full geometry: the Winograd kernel's own policy where it applies, else diagan_conv_wgrad_splits

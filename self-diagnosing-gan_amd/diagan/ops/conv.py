@@ -39,6 +39,8 @@ nat.register("diagan_wino_weight_blocks", [I, I])
 nat.register("diagan_wino_weights_batched", [P, I, I, P])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
+nat.register("diagan_conv_wgrad_uses_x3", [I] * 15 + [I64])
+nat.register("diagan_conv_wgrad_set_x3", [I])
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
 nat.register("diagan_conv_gemm_pick_cfg_grouped", [I] * 15 + [I64, I])
 nat.register("diagan_conv_gemm_tile_rows", [I])
@@ -304,6 +306,18 @@ def set_gemm_x3(on):
 def set_gemm_x3b(on):
     """the same for the 128 x 128 / 256 x 128 split-operand kernel alone (tile_cfg 17); None: what DIAGAN_GEMM_X3B says"""
     nat.call("diagan_conv_gemm_set_x3b", -1 if on is None else (1 if on else 0))
+
+
+def set_wgrad_x3(on):
+    """the split-operand weight-gradient kernel (csrc/conv_wgrad_x3.hip): True / False, 2 = on for every geometry it can run
+    (no work floor: tests); None: what DIAGAN_WGRAD_X3 says.  (set_gemm_x3(False), the exact-fp32 mode, turns it off too.)"""
+    nat.call("diagan_conv_wgrad_set_x3", -1 if on is None else (int(on) if on else 0))
+
+
+def wgrad_uses_x3(geom, B, Hi, Wi, Ho, Wo, mode=0, bias_off=-1):
+    sy, dr, off, up = geom.fwd_params()
+    return bool(nat.fn("diagan_conv_wgrad_uses_x3")(B, Hi, Wi, geom.Ci, Ho, Wo, geom.Co, geom.R, geom.S, sy, dr, off, up, geom.Kp,
+                                                    mode, bias_off))
 
 
 _TICKETS = {}
@@ -635,7 +649,8 @@ def conv_wgrad(geom, dy, x, grad, accumulate, pro=None, sn=None):
     sy, dr, off, up = geom.fwd_params()
     st = nat.current_stream()
     timed = TIMER is not None and TIMER.wants_any()
-    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if timed else None
+    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo),
+                            x3=wgrad_uses_x3(geom, B, Hi, Wi, Ho, Wo, mode, -1)) if timed else None
     t0 = TIMER.begin(kn) if timed else None
     nat.call("diagan_conv_wgrad", nat.ptr(dy), nat.ptr(x), nat.ptr(slab), splits, 1, n_elem, -1, nat.ptr(scale), nat.ptr(shift),
              mode, B, Hi, Wi, Ci, Ho, Wo, Co, geom.R, geom.S, sy, dr, off, up, geom.Kp, st)
@@ -705,7 +720,8 @@ def conv_wgrad_into(geom, dy, x, slab, splits, stride, bias_off, pro=None, segme
             TIMER.end("conv3x3_co4_wgrad_kernel", 2.0 * B * Ho * Wo * Co * 9 * Ci, t0, (B * Ho * Wo, Co, 9 * Ci, f"pro{mode}"))
         return
     timed = TIMER is not None and TIMER.wants_any()
-    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo)) if timed else None
+    kn = _wgrad_kernel_name(Co, geom.Kp, mode, Ho, Wo, wino=wgrad_uses_wino(geom, Hi, Wi, Ho, Wo),
+                            x3=wgrad_uses_x3(geom, B, Hi, Wi, Ho, Wo, mode, bias_off)) if timed else None
     if kn is not None and pooled:
         kn += POOLED_TAG
     t0 = TIMER.begin(kn) if timed else None
@@ -841,10 +857,12 @@ _WG_SLOTS64 = int(_os.environ.get("DIAGAN_WGRAD_SLOTS64", "512"))
 POOLED_TAG = " [pooled gradient]"     # kernel-timer name suffix of ConvLayer.wgrad_pooled's launches
 
 
-def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0, wino=False):
+def _wgrad_kernel_name(Co, Kp, mode=0, Ho=0, Wo=0, wino=False, x3=False):
     """Kernel name as rocprofv3 prints it (template arguments BNn, BNk, PRO, P2)."""
     if wino:
         return f"conv_wgrad_wino_kernel<{mode}>"
+    if x3:
+        return "conv_wgrad_x3_kernel"
     bn, bk = (64 if Co <= 64 else 128), (64 if Kp <= 64 else 128)
     if bn == 128 and bk == 64:
         bn = 64

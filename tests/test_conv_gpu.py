@@ -431,6 +431,65 @@ def test_split_operand_128_tiles_automatic_choice():
     assert names[0].startswith("conv_gemm_x3b_kernel<0,false>") and names[1].startswith("conv_gemm_kernel<128,128"), names
 
 
+@pytest.mark.parametrize("case", [(2, 33, 33, 128, 128, 3, 3, 2, 0), (3, 20, 24, 64, 128, 2, 2, 1, 1), (2, 16, 16, 128, 256, 1, 1, 1, 0),
+                                  (2, 19, 21, 64, 128, 2, 1, 1, 1), (2, 19, 21, 64, 128, 1, 2, 1, 1), (1, 5, 5, 128, 128, 1, 1, 1, 0),
+                                  (5, 3, 3, 32, 128, 2, 2, 1, 1), (2, 31, 17, 128, 128, 3, 3, 2, 1), (3, 9, 40, 32, 256, 2, 2, 1, 0),
+                                  (40, 16, 16, 128, 128, 1, 1, 1, 0)])
+def test_split_operand_weight_gradient(case):
+    """conv_wgrad_x3_kernel (both operands split exactly in three bf16 pieces in the loader, six piece products on the bf16 matrix
+    pipe): the weight gradient of strided / padded / 1x1 / 2x1 / 1x2 geometries -- pixel counts that are no multiple of the 32-pixel
+    K-step, rows narrower than a loader's 4 pixels, several splits -- against float64 autograd; its error must be fp32-grade, i.e.
+    within 4x the fp32 kernel's on the same launch."""
+    from diagan.ops import conv as C
+    B, H, W, Ci, Co, R, S, st, pd = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Ci, H, W, generator=g, dtype=torch.float64)
+    w = torch.zeros(Co, Ci, R, S, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x, w, stride=st, padding=pd)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Co, R * S * Ci)
+    geom = C.Geom("conv", Ci, Co, R, S, st, pd)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    errs = []
+    try:
+        for on in (0, 2):
+            C.set_wgrad_x3(on)
+            assert C.wgrad_uses_x3(geom, B, H, W, dyd.shape[1], dyd.shape[2]) == bool(on)
+            grad = torch.full((Co, geom.Kp), 3.0, device="cuda")
+            C.conv_wgrad(geom, dyd, xd, grad, False)
+            errs.append((grad.double().cpu() - ref).abs().max().item() / ref.abs().max().item())
+            if on:       # accumulating form, and the same bits on a second launch (fixed summation order)
+                again = torch.zeros_like(grad)
+                C.conv_wgrad(geom, dyd, xd, again, False)
+                assert torch.equal(again, grad)
+                C.conv_wgrad(geom, dyd, xd, again, True)
+                close(again, 2 * grad, tol=1e-6)
+    finally:
+        C.set_wgrad_x3(None)
+    assert errs[1] < 2e-6 and errs[1] < 4 * max(errs[0], 1e-7), errs
+
+
+def test_split_operand_weight_gradient_follows_the_exact_fp32_switch():
+    """set_gemm_x3(False) -- the exact-fp32 mode of the parity tools -- keeps the weight gradient on the fp32 pipe as well; launches
+    with a prologue or a bias column stay on the fp32 kernel"""
+    from diagan.ops import conv as C
+    geom = C.Geom("conv", 128, 256, 3, 3, 2, 0)
+    try:
+        C.set_wgrad_x3(2)
+        assert C.wgrad_uses_x3(geom, 4, 65, 65, 32, 32)
+        assert not C.wgrad_uses_x3(geom, 4, 65, 65, 32, 32, mode=1)
+        assert not C.wgrad_uses_x3(geom, 4, 65, 65, 32, 32, bias_off=256 * geom.Kp)
+        assert not C.wgrad_uses_x3(C.Geom("conv", 128, 192, 3, 3, 2, 0), 4, 65, 65, 32, 32)       # Co % 128
+        assert not C.wgrad_uses_x3(C.Geom("conv", 128, 256, 3, 3, 1, 1), 4, 64, 64, 64, 64)       # the Winograd kernel's
+        C.set_gemm_x3(False)
+        assert not C.wgrad_uses_x3(geom, 4, 65, 65, 32, 32)
+    finally:
+        C.set_gemm_x3(None)
+        C.set_wgrad_x3(None)
+
+
 @pytest.mark.parametrize("Ci,H,W,B", [(256, 32, 32, 4), (128, 16, 16, 3), (64, 12, 20, 2), (64, 64, 64, 2)])
 @pytest.mark.parametrize("pro", [0, 1, 2])
 def test_small_co_kernel_wgrad(Ci, H, W, B, pro):
