@@ -603,6 +603,30 @@ int diagan_styled_bias_act_bwd(const float* gy, const float* y, const float* x, 
 int diagan_styled_bias_act_bwd_finish(const float* work_d, const float* work_b, const float* work_s, float* gd, float* gb, float* gs, int B,
                                       int P, int C, void* stream);
 
+/* Round 6: activation passes folded into the pass next to them (reference: diagan-pkg/diagan/models/stylegan2.py:553-614, the
+ * discriminator's ConvLayer / ResBlock; :268-329 the generator's StyledConv).  Each is bit-identical to the two launches it replaces.
+ *   diagan_bias_act_fir       out = FIR(leaky_relu(x + bias[c]) * scale) on x[major][in_h][in_w][minor], zero padding of the ACTIVATED
+ *                             tensor (ConvLayer's FusedLeakyReLU followed by the Blur of the next, sub-sampling ConvLayer); 4-tap-wide
+ *                             filters, minor % 4 == 0; out is [major][in_h + pad_y0 + pad_y1 - kh + 1][in_w + pad_x0 + pad_x1 - kw + 1][minor]
+ *   diagan_bias_act_gate_bwd  its (and diagan_bias_act_add's) first-order backward gate from the PRE-activation z and the bias:
+ *                             gx = gy * scale * (z + bias[c] > 0 ? 1 : alpha), work_b as diagan_styled_bias_act_bwd (finish: ..._bwd_finish)
+ *   diagan_bias_act_add       out = leaky_relu(x + bias[c]) * scale + addend, channels-last, n elements (ResBlock: activation of conv2 + skip)
+ *   diagan_fir_styled_act     out = [post[b][c] *] leaky_relu(FIR(x) * demod[b][c] + strength * noise[b or 0][p] + bias[c]) * scale: the
+ *                             StyledConv tail (diagan_styled_bias_act) and optionally the next layer's style applied to the blurred output
+ *                             of an up-sampling convolution on its way out (demod / noise / bias / post optional; used when no graph is
+ *                             recorded: the backward needs the blurred tensor itself) */
+int diagan_bias_act_fir(const float* input, const float* bias, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
+                        int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha, float scale,
+                        void* stream);
+int diagan_bias_act_gate_bwd(const float* gy, const float* z, const float* bias, float* gx, float* work_b, int B, int P, int C,
+                             float alpha, float scale, void* stream);
+int diagan_bias_act_add(const float* x, const float* bias, const float* addend, float* out, int64_t n, int C, float alpha, float scale,
+                        void* stream);
+int diagan_fir_styled_act(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor, int kernel_h,
+                          int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* demod, const float* noise,
+                          const float* strength, const float* bias, const float* post, int noise_per_image, float alpha, float scale,
+                          void* stream);
+
 
 /* upfirdn2d.upfirdn2d(input[major,H,W,minor], kernel[kh,kw], up, down, pads), upfirdn2d.cpp:4-22.
  * out == NULL: size query only (writes *out_h, *out_w). */

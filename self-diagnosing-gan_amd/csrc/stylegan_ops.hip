@@ -21,7 +21,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // channels-last fast path: bias runs along the innermost dimension (step_b == 1), 4 channels per lane
 __global__ __launch_bounds__(256) void fused_bias_act_cl4_kernel(const f32x4* __restrict__ x, const float* __restrict__ b,
                                                                  const f32x4* __restrict__ ref, f32x4* __restrict__ out,
-                                                                 long n4, int size_b, int mode, float alpha, float scale) {
+                                                                 long n4, int size_b, int mode, float alpha, float scale,
+                                                                 const f32x4* __restrict__ addend) {
   const long stride = (long)gridDim.x * 256;
   long i = (long)blockIdx.x * 256 + threadIdx.x;
   // size_b % 4 == 0: a lane's channel quad advances by (stride * 4) % size_b per trip
@@ -43,7 +44,13 @@ __global__ __launch_bounds__(256) void fused_bias_act_cl4_kernel(const f32x4* __
     } else {
       y = v;
     }
-    out[i] = y * scale;
+    f32x4 o = y * scale;
+    if (addend) {              // (two roundings, as the activation followed by a separate add)
+      const f32x4 r = addend[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], r[e]);
+    }
+    out[i] = o;
     c += dc;
     if (c >= size_b) c -= size_b;
   }
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const f32x4* __rest
                                                              const f32x4* __restrict__ x, const float* __restrict__ demod,
                                                              const float* __restrict__ noise, f32x4* __restrict__ gx,
                                                              float* __restrict__ wd, float* __restrict__ wb, float* __restrict__ ws,
-                                                             int P, int C, int chunks, int noise_per_image, float alpha, float scale) {
+                                                             int P, int C, int chunks, int noise_per_image, float alpha, float scale,
+                                                             const float* __restrict__ ref_bias) {
   __shared__ f32x4 red_d[256];
   __shared__ f32x4 red_b[256];
   __shared__ float red_s[256];
@@ -128,10 +136,15 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const f32x4* __rest
   if (demod) dm = *reinterpret_cast<const f32x4*>(demod + (long)img * C + cq * 4);
   f32x4 accd = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
   float accs = 0.f;
+  // ref_bias (round 6): `y` is the PRE-activation without its bias (the fused bias + activation + blur / + residual ops keep only
+  // their input): the gate is the sign of y + ref_bias[c], the sum the forward took the sign of
+  f32x4 rb = {0.f, 0.f, 0.f, 0.f};
+  if (ref_bias) rb = *reinterpret_cast<const f32x4*>(ref_bias + cq * 4);
   for (int p = p0 + pl; p < p1; p += lanes) {
     const long i = base + (long)p * q;
     f32x4 g = gy[i];
-    const f32x4 r = y[i];
+    f32x4 r = y[i];
+    if (ref_bias) r += rb;
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = g[e] * (r[e] > 0.f ? scale : scale * alpha);
     if (gx) gx[i] = demod ? g * dm : g;
@@ -191,6 +204,17 @@ struct UpFirDnArgs {
   float* out;
   int major, in_h, in_w, minor, kh, kw, out_h, out_w;
   int up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+  // fused forms of fir_cl4_kernel (round 6): FUSE 1 -- every input element goes through bias + leaky ReLU * scale on its way in (the
+  // discriminator's conv1 -> FusedLeakyReLU -> Blur); FUSE 2 -- every output element goes through the StyledConv tail (demodulation,
+  // noise, bias, leaky ReLU * scale) and optionally the NEXT layer's style on its way out (the generator's up-sampling convolution ->
+  // Blur -> NoiseInjection -> FusedLeakyReLU [-> modulation] when no graph is recorded)
+  const float* f_bias;     // [minor]
+  const float* f_demod;    // [major][minor] or null
+  const float* f_noise;    // [major or 1][out_h][out_w] or null
+  const float* f_strength; // [1]
+  const float* f_post;     // [major][minor] or null
+  int f_noise_per_image;
+  float f_alpha, f_scale;
 };
 
 static __host__ __device__ __forceinline__ int floor_div_i(int a, int b) {
@@ -206,7 +230,7 @@ static __host__ __device__ __forceinline__ int ceil_div_i(int a, int b) { return
 // DOWN = 2 (round 6): the same with every second output row / column kept -- blur + stride-2 sub-sampling in one pass (the
 // discriminator's skip branch: Blur, then a 1x1 convolution that reads every second pixel; reference stylegan2.py:553-614): the
 // window is KW + (OXT - 1) * DOWN wide and a quarter of the blurred image is ever written.
-template <int KW, int OXT, int DOWN = 1>
+template <int KW, int OXT, int DOWN = 1, int FUSE = 0>
 __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
   __shared__ float taps[64];
   if (threadIdx.x < a.kh * KW) taps[threadIdx.x] = a.k[threadIdx.x];
@@ -225,6 +249,8 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
 #pragma unroll
     for (int j = 0; j < OXT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bx = ox0 * DOWN - a.pad_x0;
+    f32x4 pb = {0.f, 0.f, 0.f, 0.f};
+    if (FUSE == 1) pb = *reinterpret_cast<const f32x4*>(a.f_bias + c4 * 4);
     for (int dy = 0; dy < a.kh; ++dy) {
       const int iy = oy * DOWN - a.pad_y0 + dy;
       if (iy < 0 || iy >= a.in_h) continue;
@@ -234,6 +260,12 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
       for (int u = 0; u < KW + (OXT - 1) * DOWN; ++u) {
         const int ix = bx + u;
         win[u] = (ix >= 0 && ix < a.in_w) ? row[(long)ix * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (FUSE == 1 && ix >= 0 && ix < a.in_w) {      // (the padding is zeros of the ACTIVATED tensor; arithmetic of fused_bias_act_cl4_kernel)
+          f32x4 v = win[u] + pb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.f_alpha;
+          win[u] = v * a.f_scale;
+        }
       }
       const float* kr = taps + (a.kh - 1 - dy) * KW;
 #pragma unroll
@@ -244,6 +276,22 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
       }
     }
     f32x4* dst = out4 + (((long)mj * a.out_h + oy) * a.out_w + ox0) * q + c4;
+    if (FUSE == 2) {                                    // (arithmetic of styled_act_cl4_kernel, then scale_rows')
+      const float w = (a.f_noise && a.f_strength) ? a.f_strength[0] : 0.f;
+#pragma unroll
+      for (int j = 0; j < OXT; ++j) {
+        if (ox0 + j >= a.out_w) continue;
+        f32x4 v = acc[j];
+        if (a.f_demod) v *= *reinterpret_cast<const f32x4*>(a.f_demod + (long)mj * a.minor + c4 * 4);
+        if (a.f_noise) v += w * a.f_noise[((long)(a.f_noise_per_image ? mj : 0) * a.out_h + oy) * a.out_w + ox0 + j];
+        if (a.f_bias) v += *reinterpret_cast<const f32x4*>(a.f_bias + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * a.f_alpha) * a.f_scale;
+        if (a.f_post) v = v * *reinterpret_cast<const f32x4*>(a.f_post + (long)mj * a.minor + c4 * 4);
+        dst[(long)j * q] = v;
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < OXT; ++j)
       if (ox0 + j < a.out_w) dst[(long)j * q] = acc[j];
@@ -332,7 +380,7 @@ DIAGAN_API int diagan_fused_bias_act(const float* x, const float* bias, const fl
     if (blocks4 > 8192) blocks4 = 8192;
     hipLaunchKernelGGL(fused_bias_act_cl4_kernel, dim3((int)blocks4), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4*)x, bias, (const f32x4*)refer, (f32x4*)out, n4, bias ? size_b : 4, act * 10 + grad,
-                       alpha, scale);
+                       alpha, scale, (const f32x4*)nullptr);
     return check_launch("fused_bias_act");
   }
   long blocks = (n + 255) / 256;
@@ -340,6 +388,19 @@ DIAGAN_API int diagan_fused_bias_act(const float* x, const float* bias, const fl
   hipLaunchKernelGGL(fused_bias_act_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, bias, refer, out,
                      (long)n, (long)step_b, size_b, act * 10 + grad, alpha, scale);
   return check_launch("fused_bias_act");
+}
+
+// see include/diagan_hip.h: out = leaky_relu(x + bias[c]) * scale + addend on channels-last data in ONE pass
+DIAGAN_API int diagan_bias_act_add(const float* x, const float* bias, const float* addend, float* out, int64_t n, int C, float alpha,
+                                   float scale, void* stream) {
+  DG_REQUIRE(x && bias && addend && out && n > 0 && C > 0 && (C & 3) == 0 && n % C == 0, "bias_act_add: bad args (C must be a multiple of 4)");
+  DG_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)addend | (uintptr_t)bias) & 15) == 0, "bias_act_add: pointers must be 16-byte aligned");
+  const long n4 = n / 4;
+  long blocks4 = (n4 + 255) / 256;
+  if (blocks4 > 8192) blocks4 = 8192;
+  hipLaunchKernelGGL(fused_bias_act_cl4_kernel, dim3((int)blocks4), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, bias,
+                     (const f32x4*)nullptr, (f32x4*)out, n4, C, 30, alpha, scale, (const f32x4*)addend);
+  return check_launch("bias_act_add");
 }
 
 DIAGAN_API int diagan_styled_bias_act(const float* x, const float* demod, const float* noise, const float* strength,
@@ -387,8 +448,23 @@ DIAGAN_API int diagan_styled_bias_act_bwd(const float* gy, const float* y, const
              "styled_bias_act_bwd: pointers must be 16-byte aligned");
   const int chunks = diagan_rowdot_chunks(B, P);
   hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)y,
-                     (const f32x4*)x, demod, noise, (f32x4*)gx, work_d, work_b, work_s, P, C, chunks, noise_per_image, alpha, scale);
+                     (const f32x4*)x, demod, noise, (f32x4*)gx, work_d, work_b, work_s, P, C, chunks, noise_per_image, alpha, scale,
+                     (const float*)nullptr);
   return check_launch("styled_bias_act_bwd");
+}
+
+// see include/diagan_hip.h: the gate of bias + leaky ReLU from the PRE-activation z and the bias (sign of z + bias), bias gradient partials
+DIAGAN_API int diagan_bias_act_gate_bwd(const float* gy, const float* z, const float* bias, float* gx, float* work_b, int B, int P, int C,
+                                        float alpha, float scale, void* stream) {
+  DG_REQUIRE(gy && z && bias && gx && work_b && B > 0 && P > 0, "bias_act_gate_bwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "bias_act_gate_bwd: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE((((uintptr_t)gy | (uintptr_t)z | (uintptr_t)gx | (uintptr_t)bias | (uintptr_t)work_b) & 15) == 0,
+             "bias_act_gate_bwd: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)z,
+                     (const f32x4*)nullptr, (const float*)nullptr, (const float*)nullptr, (f32x4*)gx, (float*)nullptr, work_b,
+                     (float*)nullptr, P, C, chunks, 0, alpha, scale, bias);
+  return check_launch("bias_act_gate_bwd");
 }
 
 // The partial sums of diagan_styled_bias_act_bwd to their results in ONE launch (round 6; the host side summed them with torch: a
@@ -466,6 +542,46 @@ DIAGAN_API int diagan_styled_bias_act_bwd_finish(const float* work_d, const floa
   hipLaunchKernelGGL(diagan::styled_act_bwd_finish_kernel, dim3(nd + nb + ns), dim3(1024), 0, (hipStream_t)stream, work_d, work_b, work_s,
                      gd, gb, gs, B, chunks, C, nd, nb);
   return check_launch("styled_bias_act_bwd_finish");
+}
+
+// see include/diagan_hip.h: blur(leaky_relu(x + bias) * scale) in ONE pass over x (FUSE 1 of fir_cl4_kernel)
+DIAGAN_API int diagan_bias_act_fir(const float* input, const float* bias, const float* kernel, float* out, int major, int in_h, int in_w,
+                                   int minor, int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha,
+                                   float scale, void* stream) {
+  DG_REQUIRE(input && bias && kernel && out && major > 0 && in_h > 0 && in_w > 0 && minor > 0, "bias_act_fir: bad args");
+  DG_REQUIRE(kernel_w == 4 && kernel_h >= 1 && kernel_h <= 16 && (minor & 3) == 0, "bias_act_fir: 4-tap-wide filters on channel counts that are multiples of 4 (got %d x %d taps, %d channels)", kernel_h, kernel_w, minor);
+  DG_REQUIRE((((uintptr_t)input | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, "bias_act_fir: pointers must be 16-byte aligned");
+  const int oh = in_h + pad_y0 + pad_y1 - kernel_h + 1, ow = in_w + pad_x0 + pad_x1 - kernel_w + 1;
+  DG_REQUIRE(oh > 0 && ow > 0, "bias_act_fir: empty output (%d x %d)", oh, ow);
+  UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow, 1, 1, 1, 1, pad_x0, pad_y0};
+  a.f_bias = bias; a.f_alpha = alpha; a.f_scale = scale;
+  const long work = (long)major * oh * ((ow + 3) / 4) * (minor / 4);
+  long fb = (work + 255) / 256;
+  if (fb > 32768) fb = 32768;
+  hipLaunchKernelGGL((fir_cl4_kernel<4, 4, 1, 1>), dim3((int)fb), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("bias_act_fir");
+}
+
+// see include/diagan_hip.h: the StyledConv tail (and optionally the next layer's style) applied to blur(x) in ONE pass (FUSE 2)
+DIAGAN_API int diagan_fir_styled_act(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
+                                     int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* demod,
+                                     const float* noise, const float* strength, const float* bias, const float* post,
+                                     int noise_per_image, float alpha, float scale, void* stream) {
+  DG_REQUIRE(input && kernel && out && major > 0 && in_h > 0 && in_w > 0 && minor > 0, "fir_styled_act: bad args");
+  DG_REQUIRE(kernel_w == 4 && kernel_h >= 1 && kernel_h <= 16 && (minor & 3) == 0, "fir_styled_act: 4-tap-wide filters on channel counts that are multiples of 4 (got %d x %d taps, %d channels)", kernel_h, kernel_w, minor);
+  DG_REQUIRE(!noise || strength, "fir_styled_act: noise needs its strength");
+  DG_REQUIRE((((uintptr_t)input | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)demod | (uintptr_t)post) & 15) == 0,
+             "fir_styled_act: pointers must be 16-byte aligned");
+  const int oh = in_h + pad_y0 + pad_y1 - kernel_h + 1, ow = in_w + pad_x0 + pad_x1 - kernel_w + 1;
+  DG_REQUIRE(oh > 0 && ow > 0, "fir_styled_act: empty output (%d x %d)", oh, ow);
+  UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow, 1, 1, 1, 1, pad_x0, pad_y0};
+  a.f_bias = bias; a.f_demod = demod; a.f_noise = noise; a.f_strength = strength; a.f_post = post;
+  a.f_noise_per_image = noise_per_image; a.f_alpha = alpha; a.f_scale = scale;
+  const long work = (long)major * oh * ((ow + 3) / 4) * (minor / 4);
+  long fb = (work + 255) / 256;
+  if (fb > 32768) fb = 32768;
+  hipLaunchKernelGGL((fir_cl4_kernel<4, 4, 1, 2>), dim3((int)fb), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("fir_styled_act");
 }
 
 // out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL

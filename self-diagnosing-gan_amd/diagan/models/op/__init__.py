@@ -4,3 +4,4 @@ behaviour (first and second order), backed by csrc/stylegan_ops.hip through the 
 No JIT compilation at import (the reference runs torch.utils.cpp_extension.load here)."""
 from .fused_act import FusedLeakyReLU, fused_leaky_relu  # noqa: F401
 from .upfirdn2d import upfirdn2d  # noqa: F401
+from . import fused_tail  # noqa: F401,E402  (round 6: activation passes folded into their neighbours; registers its entry points)

@@ -1,0 +1,141 @@
+"""Activation passes folded into the pass next to them (round 6; csrc/stylegan_ops.hip: fir_cl4_kernel's fused forms).
+
+The reference's discriminator block runs conv1 -> FusedLeakyReLU -> Blur -> conv2 (stride 2) -> FusedLeakyReLU, + skip, / sqrt 2
+(diagan-pkg/diagan/models/stylegan2.py:553-614), its generator's up-sampling StyledConv conv_transpose -> Blur -> NoiseInjection ->
+FusedLeakyReLU (:268-329).  Activation and blur are one pass each over a full-resolution tensor there; here
+
+    bias_act_blur(z, bias, kernel, pad)        = blur(leaky_relu(z + bias) * scale)           one pass (the blur's)
+    bias_act_add(z, bias, r)                   = leaky_relu(z + bias) * scale + r             one pass instead of two
+    blur_styled_act(x, kernel, pad, ...)       = the StyledConv tail of blur(x) [* next style] one pass (no graph recorded only:
+                                                 the backward of the tail needs the blurred tensor itself)
+
+each bit-identical to the launches it replaces.  Autograd: the first-order backward (no graph being recorded) is the blur's adjoint
+followed by ONE gate pass that takes the sign of z + bias and the bias gradient's partial sums (diagan_bias_act_gate_bwd); when
+the backward is itself differentiated (R1 / path-length penalties, stylegan2/train_ffhq.py:74-102) it is the composition of the
+self-differentiating pieces of fused_act.py / upfirdn2d.py, with the activated tensor recomputed as the gate's reference."""
+import os
+
+import torch
+from torch.autograd import Function
+
+from diagan import _native as nat
+from diagan.models.op import fused_act as FA
+from diagan.models.op.upfirdn2d import _LinearFIR, _Plan, upfirdn2d_nhwc
+
+P, I, F32, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
+nat.register("diagan_bias_act_fir", [P, P, P, P] + [I] * 10 + [F32, F32, P])
+nat.register("diagan_bias_act_gate_bwd", [P, P, P, P, P, I, I, I, F32, F32, P])
+nat.register("diagan_bias_act_add", [P, P, P, P, I64, I, F32, F32, P])
+nat.register("diagan_fir_styled_act", [P, P, P] + [I] * 10 + [P, P, P, P, P, I, F32, F32, P])
+
+FUSED_TAILS = os.environ.get("DIAGAN_SG2_FUSED_TAILS", "1") != "0"
+
+
+def _fir_ok(x, kernel):
+    return (FUSED_TAILS and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] % 4 == 0 and kernel.dim() == 2
+            and kernel.shape[1] == 4 and kernel.shape[0] <= 16)
+
+
+def _gate_from_pre(gy, z, bias, slope, scale):
+    """(gz, d(bias)) of leaky_relu(z + bias) * scale from the incoming gradient, ONE pass: the gate is the sign of z + bias"""
+    b, h, w, c = gy.shape
+    gy = gy.contiguous()
+    chunks = nat.fn("diagan_rowdot_chunks")(b, h * w)
+    gz = torch.empty_like(gy)
+    wb = torch.empty((b * chunks, c), dtype=torch.float32, device=gy.device)
+    st = nat.current_stream()
+    nat.call("diagan_bias_act_gate_bwd", nat.ptr(gy), nat.ptr(z), nat.ptr(bias), nat.ptr(gz), nat.ptr(wb), b, h * w, c, float(slope),
+             float(scale), st)
+    gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+    nat.call("diagan_styled_bias_act_bwd_finish", None, nat.ptr(wb), None, None, nat.ptr(gb), None, b, h * w, c, st)
+    return gz, gb
+
+
+def _gate_any_order(g, z, bias, slope, scale):
+    """the same gate as differentiable pieces (fused_act._LeakyGate differentiates itself); the activated tensor is recomputed as its
+    reference -- only the penalties' double backward comes here"""
+    with torch.no_grad():
+        ref = FA.fused_bias_act(z, bias, None, 3, 0, slope, scale, -1)
+    gz = FA._LeakyGate.apply(g, ref, slope, scale)
+    return gz, gz.sum((0, 1, 2))
+
+
+class _BiasActBlur(Function):
+    @staticmethod
+    def forward(ctx, z, bias, slope, scale, plan):
+        z, bias = z.contiguous(), bias.contiguous()
+        b, h, w, c = z.shape
+        kh, kw = plan.kernel.shape
+        out = torch.empty((b, plan.out_hw[0], plan.out_hw[1], c), dtype=torch.float32, device=z.device)
+        nat.call("diagan_bias_act_fir", nat.ptr(z), nat.ptr(bias), nat.ptr(plan.kernel.contiguous()), nat.ptr(out), b, h, w, c, kh, kw,
+                 *plan.pad, float(slope), float(scale), nat.current_stream())
+        ctx.save_for_backward(z, bias)
+        ctx.hyper, ctx.plan = (slope, scale), plan
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, bias = ctx.saved_tensors
+        if FA._fused_bwd_ok(gy):
+            gz, gb = _gate_from_pre(ctx.plan.dual.run(gy.contiguous()), z, bias, *ctx.hyper)
+        else:
+            gz, gb = _gate_any_order(_LinearFIR.apply(gy.contiguous(), ctx.plan.dual), z, bias, *ctx.hyper)
+        return gz, (gb if ctx.needs_input_grad[1] else None), None, None, None
+
+
+def bias_act_blur(x, bias, kernel, pad, negative_slope=0.2, scale=2 ** 0.5):
+    """upfirdn2d_nhwc(fused_leaky_relu(x, bias, bias_dim=-1), kernel, pad=pad) on [B,H,W,C] in one pass over x"""
+    if bias is None or not _fir_ok(x, kernel) or kernel.requires_grad:
+        return upfirdn2d_nhwc(FA.fused_leaky_relu(x, bias, negative_slope, scale, bias_dim=-1), kernel, pad=pad)
+    plan = _Plan.forward_plan(kernel, (1, 1), (1, 1), (pad[0], pad[1], pad[0], pad[1]), x.shape[1:3], channels_last=True)
+    return _BiasActBlur.apply(x, bias, negative_slope, scale, plan)
+
+
+class _BiasActAdd(Function):
+    @staticmethod
+    def forward(ctx, z, bias, r, slope, scale):
+        z, bias, r = z.contiguous(), bias.contiguous(), r.contiguous()
+        out = torch.empty_like(z)
+        nat.call("diagan_bias_act_add", nat.ptr(z), nat.ptr(bias), nat.ptr(r), nat.ptr(out), z.numel(), z.shape[-1], float(slope),
+                 float(scale), nat.current_stream())
+        ctx.save_for_backward(z, bias)
+        ctx.hyper = (slope, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, bias = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        gz = gb = None
+        if need[0] or need[1]:
+            gz, gb = _gate_from_pre(gy, z, bias, *ctx.hyper) if FA._fused_bwd_ok(gy) else _gate_any_order(gy, z, bias, *ctx.hyper)
+        return gz, (gb if need[1] else None), (gy if need[2] else None), None, None
+
+
+def bias_act_add(x, bias, r, negative_slope=0.2, scale=2 ** 0.5):
+    """fused_leaky_relu(x, bias, bias_dim=-1) + r on [B,H,W,C] in one pass"""
+    if (not FUSED_TAILS or bias is None or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32 or x.shape[3] % 4
+            or r.shape != x.shape or r.dtype != torch.float32):
+        return FA.fused_leaky_relu(x, bias, negative_slope, scale, bias_dim=-1) + r
+    return _BiasActAdd.apply(x, bias, r, negative_slope, scale)
+
+
+def blur_styled_act_ok(x, kernel):
+    """the one-pass blur + StyledConv tail applies: nothing records a graph (its backward needs the blurred tensor)"""
+    return not torch.is_grad_enabled() and _fir_ok(x, kernel)
+
+
+def blur_styled_act(x, kernel, pad, demod=None, noise=None, strength=None, bias=None, negative_slope=0.2, scale=2 ** 0.5, post=None):
+    """[post[b, c] *] styled_bias_act(upfirdn2d_nhwc(x, kernel, pad=pad), demod, noise, strength, bias) in ONE pass; no autograd
+    (callers check blur_styled_act_ok)"""
+    x = x.contiguous()
+    b, h, w, c = x.shape
+    kh, kw = kernel.shape
+    oh, ow = h + pad[0] + pad[1] - kh + 1, w + pad[0] + pad[1] - kw + 1
+    out = torch.empty((b, oh, ow, c), dtype=torch.float32, device=x.device)
+    per_image = noise is not None and noise.shape[0] == b and b > 1
+    c_ = lambda t: nat.ptr(t.contiguous()) if t is not None else None           # noqa: E731
+    nat.call("diagan_fir_styled_act", nat.ptr(x), nat.ptr(kernel.contiguous()), nat.ptr(out), b, h, w, c, kh, kw, pad[0], pad[1], pad[0],
+             pad[1], c_(demod), c_(noise), nat.ptr(strength) if noise is not None else None, c_(bias), c_(post), 1 if per_image else 0,
+             float(negative_slope), float(scale), nat.current_stream())
+    return out

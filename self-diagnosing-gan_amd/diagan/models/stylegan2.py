@@ -26,6 +26,7 @@ from torch import nn
 
 from diagan.models.layers import FlatNet
 from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, scale_rows, styled_bias_act
+from diagan.models.op.fused_tail import bias_act_add, bias_act_blur, blur_styled_act, blur_styled_act_ok
 from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
 
@@ -193,18 +194,25 @@ class ModulatedConv2d(nn.Module):
         y, d = self.forward_parts(x, style)
         return scale_rows(y, d) if d is not None else y
 
-    def forward_parts(self, x, style):
+    def forward_parts(self, x, style, s=None, premodulated=False, blur=True):
         """(convolution of the modulated input, demodulation factors [B, Co] or None): the caller applies d -- StyledConv
-        does it inside its fused noise + bias + activation pass"""
-        s = self.modulation(style)                                   # [B, Ci]
+        does it inside its fused noise + bias + activation pass.
+        s: this layer's style self.modulation(style) when the caller has it already; premodulated: x arrives multiplied by it (the
+        producing layer's tail did it on its way out); blur=False: an up-sampling layer returns the transposed convolution's output
+        and leaves its Blur to the caller (StyledConv's one-pass blur + tail)"""
+        if s is None:
+            s = self.modulation(style)                               # [B, Ci]
         # (a VIEW, not self.weight[0]: the select's backward zero-fills a weight-sized tensor and copies into it, every pass; the
         #  equalised-learning-rate scale rides in the packing launch: dc.*(..., scale=))
         w = self.weight.view(self.weight.shape[1:])
         if self.downsample:
             x = self.blur(x)
-        x = scale_rows(x, s)
+        if not premodulated:
+            x = scale_rows(x, s)
         if self.upsample:
-            y = self.blur(dc.conv_transpose2d(x, w, stride=2, padding=0, scale=self.scale))
+            y = dc.conv_transpose2d(x, w, stride=2, padding=0, scale=self.scale)
+            if blur:
+                y = self.blur(y)
         elif self.downsample:
             y = dc.conv2d(x, w, stride=2, padding=0, scale=self.scale)
         else:
@@ -227,9 +235,12 @@ class NoiseInjection(nn.Module):
     def draw(image, noise=None):
         """the noise map as [B or 1, H, W, 1]: fresh N(0,1) (same draw count and order as the reference's
         [B,1,H,W]) or the given [B or 1, 1, H, W] tensor"""
-        b, h, w, _ = image.shape
+        return NoiseInjection.draw_hw(image, image.shape[0], image.shape[1], image.shape[2], noise)
+
+    @staticmethod
+    def draw_hw(like, b, h, w, noise=None):
         if noise is None:
-            return image.new_empty(b, h, w, 1).normal_()
+            return like.new_empty(b, h, w, 1).normal_()
         return noise.reshape(noise.shape[0], h, w, 1)
 
     def forward(self, image, noise=None):
@@ -254,11 +265,22 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = _ChannelsLastLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
+    def forward(self, input, style, noise=None, s=None, premodulated=False, post=None):
+        """s / premodulated: see ModulatedConv2d.forward_parts; post [B, Co]: the NEXT layer's style, applied to the output on its way
+        out (only where nothing records a graph: generator forwards of the discriminator's step)"""
         # conv -> * demod -> + strength * noise -> + bias -> leaky ReLU * sqrt(2): the last four in one launch
-        y, d = self.conv.forward_parts(input, style)
-        return styled_bias_act(y, d, self.noise.draw(y, noise), self.noise.weight, self.activate.bias,
-                               self.activate.negative_slope, self.activate.scale)
+        act = self.activate
+        if self.conv.upsample and blur_styled_act_ok(input, self.conv.blur.kernel):
+            # ... and the Blur in front of them as well (round 6)
+            y, d = self.conv.forward_parts(input, style, s, premodulated, blur=False)
+            blur = self.conv.blur
+            oh, ow = (y.shape[1] + blur.pad[0] + blur.pad[1] - blur.kernel.shape[0] + 1,
+                      y.shape[2] + blur.pad[0] + blur.pad[1] - blur.kernel.shape[1] + 1)
+            nz = self.noise.draw_hw(y, y.shape[0], oh, ow, noise)
+            return blur_styled_act(y, blur.kernel, blur.pad, d, nz, self.noise.weight, act.bias, act.negative_slope, act.scale, post)
+        y, d = self.conv.forward_parts(input, style, s, premodulated)
+        out = styled_bias_act(y, d, self.noise.draw(y, noise), self.noise.weight, act.bias, act.negative_slope, act.scale)
+        return scale_rows(out, post) if post is not None else out
 
 
 class ToRGB(nn.Module):
@@ -352,10 +374,17 @@ class StyleGANGenerator(FlatNet):
         lat = latent.transpose(0, 1).contiguous().unbind(0)
         out = self.conv1(self.input(latent), lat[0], noise=noise[0])
         skip = self.to_rgb1(out, lat[1])
+        fuse = not torch.is_grad_enabled()
         for level, to_rgb in enumerate(self.to_rgbs):
             i = 1 + 2 * level
-            out = self.convs[2 * level](out, lat[i], noise=noise[i])
-            out = self.convs[2 * level + 1](out, lat[i + 1], noise=noise[i + 1])
+            up, same = self.convs[2 * level], self.convs[2 * level + 1]
+            if fuse:     # the up-sampling layer's only consumer is `same`: its tail applies that layer's style on the way out
+                s2 = same.conv.modulation(lat[i + 1])
+                out = up(out, lat[i], noise=noise[i], post=s2)
+                out = same(out, lat[i + 1], noise=noise[i + 1], s=s2, premodulated=True)
+            else:
+                out = up(out, lat[i], noise=noise[i])
+                out = same(out, lat[i + 1], noise=noise[i + 1])
             skip = to_rgb(out, lat[i + 2], skip)
         return to_nchw(skip, 3), (latent if return_latents else None)
 
@@ -387,15 +416,19 @@ class ResBlock(nn.Module):
         """(conv2(conv1(x)) + skip(x)) / sqrt 2 (reference :597-614) without the pass over the sum that the division costs
         (and its mirror image in the backward): the factor goes into what produces the two branches -- conv2's activation
         leaky_relu(.) * sqrt 2 runs with scale 1, the skip convolution with its weight scale divided by sqrt 2."""
+        conv1, act1 = self.conv1
         blur2, conv2, act2 = self.conv2
-        y = fused_leaky_relu(conv2(blur2(self.conv1(input))), act2.bias, act2.negative_slope, act2.scale / SQRT2, bias_dim=-1)
+        # conv1's activation rides in the Blur's pass, conv2's in the pass that adds the skip branch (round 6: models/op/fused_tail.py)
+        z = conv2(bias_act_blur(conv1(input), act1.bias, blur2.kernel, blur2.pad, act1.negative_slope, act1.scale))
         # skip branch (reference :553-595: Blur, then a 1x1 convolution of stride 2): the convolution reads every second pixel of the
         # blurred image, so the blur computes only those (upfirdn2d with down = 2, same taps and padding: the same values) and the
         # convolution runs at stride 1 on a quarter of the pixels
         blur_s, conv_s = self.skip
         if FUSED_SKIP and conv_s.stride == 2 and conv_s.padding == 0 and conv_s.weight.shape[2] == 1:
-            return y + conv_s(upfirdn2d_nhwc(input, blur_s.kernel, down=2, pad=blur_s.pad), out_mul=1.0 / SQRT2, stride=1)
-        return y + conv_s(blur_s(input), out_mul=1.0 / SQRT2)
+            r = conv_s(upfirdn2d_nhwc(input, blur_s.kernel, down=2, pad=blur_s.pad), out_mul=1.0 / SQRT2, stride=1)
+        else:
+            r = conv_s(blur_s(input), out_mul=1.0 / SQRT2)
+        return bias_act_add(z, act2.bias, r, act2.negative_slope, act2.scale / SQRT2)
 
 
 class StyleGANDiscriminator(FlatNet):

@@ -235,3 +235,91 @@ def test_styled_bias_act_one_pass_first_order_backward(shape, noise_kind):
     (torch.nn.functional.leaky_relu(xr + br, 0.2) * 2 ** 0.5 * cot).sum().backward()
     assert float((x.grad.double().cpu() - xr.grad).abs().max()) <= 1e-6
     assert float((b.grad.double().cpu() - br.grad).abs().max()) <= 2e-5 * float(br.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("shape,pad", [((3, 9, 11, 8), (2, 2)), ((2, 33, 31, 128), (2, 2)), ((2, 16, 16, 512), (1, 1)), ((1, 5, 7, 4), (2, 1))])
+def test_activation_folded_into_the_blur_and_into_the_residual_add(shape, pad):
+    """round 6 (models/op/fused_tail.py): blur(leaky_relu(z + bias) * scale) in the blur's pass and leaky_relu(z + bias) * scale + r in
+    one pass are BIT-identical to the two launches each replaces -- values, first-order gradients (plain backward: the one-pass gate
+    from the pre-activation) and the gradients of a gradient penalty (create_graph: the differentiable composition)."""
+    from diagan.models.op import fused_act as FA, fused_tail as FT
+    from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    kern = (torch.outer(k1, k1) / 64).cuda()
+    z0, b0 = torch.randn(B, H, W, C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    z0[0, 0, 0, 0] = -b0[0]                      # a pre-activation of exactly zero takes the slope branch in both forms
+
+    def two(z, b):
+        return upfirdn2d_nhwc(FA.fused_leaky_relu(z, b, 0.2, 1.3, bias_dim=-1), kern, pad=pad)
+
+    def one(z, b):
+        return FT.bias_act_blur(z, b, kern, pad, 0.2, 1.3)
+
+    def run(f, second):
+        z, b = z0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = f(z, b)
+        cot = torch.cos(torch.arange(y.numel(), device="cuda", dtype=torch.float32)).view(y.shape)
+        if not second:
+            gz, gb = torch.autograd.grad((y * cot).sum(), [z, b])
+            return y.detach(), gz, gb
+        # a gradient penalty (R1's shape): the backward is differentiated with respect to the cotangent it was given
+        w = torch.ones_like(y, requires_grad=True)
+        g1, = torch.autograd.grad((y * w * cot).sum(), [z], create_graph=True)
+        gw, = torch.autograd.grad((g1 * g1).sum(), [w])
+        return y.detach(), g1.detach(), gw
+    for second in (False, True):
+        for i, (p, q) in enumerate(zip(run(one, second), run(two, second))):
+            assert torch.equal(p, q), f"bias_act_blur second={second} output {i}: max diff {(p - q).abs().max().item():.3e}"
+
+    r0 = torch.randn(B, H, W, C, generator=g).cuda()
+
+    def two_add(z, b, r):
+        return FA.fused_leaky_relu(z, b, 0.2, 0.9, bias_dim=-1) + r
+
+    def one_add(z, b, r):
+        return FT.bias_act_add(z, b, r, 0.2, 0.9)
+
+    def run_add(f, second):
+        z, b, r = (t.clone().requires_grad_(True) for t in (z0, b0, r0))
+        y = f(z, b, r)
+        cot = torch.cos(torch.arange(y.numel(), device="cuda", dtype=torch.float32)).view(y.shape)
+        if not second:
+            return (y.detach(),) + torch.autograd.grad((y * cot).sum(), [z, b, r])
+        w = torch.ones_like(y, requires_grad=True)
+        g1, = torch.autograd.grad((y * w).sum(), [z], create_graph=True)
+        gw, = torch.autograd.grad((g1 * g1 * cot).sum(), [w])
+        return y.detach(), g1.detach(), gw
+    for second in (False, True):
+        for i, (p, q) in enumerate(zip(run_add(one_add, second), run_add(two_add, second))):
+            assert torch.equal(p, q), f"bias_act_add second={second} output {i}: max diff {(p - q).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("shape", [(3, 11, 13, 8), (2, 35, 33, 128), (2, 19, 19, 512)])
+@pytest.mark.parametrize("noise_kind", ["per_image", "shared", "none"])
+@pytest.mark.parametrize("post", [False, True])
+def test_styled_tail_folded_into_the_blur_without_a_graph(shape, noise_kind, post):
+    """round 6: the generator's up-sampling StyledConv when nothing records a graph -- Blur, demodulation, noise, bias, leaky ReLU and
+    the next layer's style in ONE pass (diagan_fir_styled_act) -- bit-identical to upfirdn2d + styled_bias_act + scale_rows"""
+    from diagan.models.op import fused_act as FA, fused_tail as FT
+    from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    kern = (torch.outer(k1, k1) / 16).cuda()
+    pad = (1, 1)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    d, s, b = (torch.rand(B, C, generator=g) + 0.5).cuda(), torch.randn(1, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    ps = torch.randn(B, C, generator=g).cuda() if post else None
+    oh, ow = H + 2 - 4 + 1, W + 2 - 4 + 1
+    noise = {"per_image": torch.randn(B, oh, ow, 1, generator=g), "shared": torch.randn(1, oh, ow, 1, generator=g), "none": None}[noise_kind]
+    noise = noise.cuda() if noise is not None else None
+    with torch.no_grad():
+        assert FT.blur_styled_act_ok(x, kern)
+        want = FA.styled_bias_act(upfirdn2d_nhwc(x, kern, pad=pad), d, noise, s if noise is not None else None, b)
+        if post:
+            want = FA.scale_rows(want, ps)
+        got = FT.blur_styled_act(x, kern, pad, d, noise, s if noise is not None else None, b, post=ps)
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    assert not FT.blur_styled_act_ok(x.requires_grad_(True), kern) or not torch.is_grad_enabled()
