@@ -615,11 +615,33 @@ int diagan_styled_bias_act_bwd_finish(const float* work_d, const float* work_b, 
  *                             StyledConv tail (diagan_styled_bias_act) and optionally the next layer's style applied to the blurred output
  *                             of an up-sampling convolution on its way out (demod / noise / bias / post optional; used when no graph is
  *                             recorded: the backward needs the blurred tensor itself) */
+/* Round 6: the generator's ToRGB (reference stylegan2.py:332-351: a modulated 1x1 convolution to 3 planes, no demodulation) in ONE read
+ * of its full-resolution input instead of three passes, its first-order backward in one read + one write instead of six:
+ *   diagan_torgb_fwd   out[b][p][0..2] = sum_c w[o][c] * (x[b][p][c] * s[b][c]) + bias[o], out[b][p][3] = 0;  x [B][P][C] channels-last,
+ *                      s [B][C], w [3][C] (the scaled weight), bias [3] or NULL, out [B][P][4]; C a power of two in [4, 1024]
+ *   diagan_torgb_bwd   gx = (sum_o gy[..][o] * w[o][c]) * s[b][c]  (gx may be NULL), gs [B][C] = d(s), gw [3][C] = d(w); work: B *
+ *                      (diagan_rowdot_chunks(B, P) + 1) * 3 * C floats of scratch.  Deterministic (fixed-order sums, accumulated in double).
+ * The higher-order backward keeps the composition scale_rows + diagan_conv_gemm / diagan_conv_wgrad. */
+int diagan_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, float* out, int B, int P, int C, void* stream);
+int diagan_torgb_bwd(const float* gy, const float* x, const float* s, const float* w, float* gx, float* work, float* gs, float* gw, int B,
+                     int P, int C, void* stream);
 int diagan_bias_act_fir(const float* input, const float* bias, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
                         int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha, float scale,
                         void* stream);
 int diagan_bias_act_gate_bwd(const float* gy, const float* z, const float* bias, float* gx, float* work_b, int B, int P, int C,
                              float alpha, float scale, void* stream);
+/* ... and the whole first-order backward of diagan_bias_act_fir in ONE pass: gz = FIR'(g) * scale * (ref + bias[c] > 0 ? 1 : alpha) with
+ * FIR' the ADJOINT filter (the caller hands in flipped taps and the adjoint pads; output size = size of ref), work_b [major *
+ * diagan_rowdot_chunks(major, out_h * out_w)][minor] the bias gradient's partial sums (finish: diagan_styled_bias_act_bwd_finish). */
+int diagan_fir_gate_bwd(const float* g, const float* kernel, const float* ref, const float* bias, float* gz, float* work_b, int major,
+                        int in_h, int in_w, int minor, int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                        float alpha, float scale, void* stream);
+/* out = upfirdn2d(input, kernel, up, down, pads) + addend (addend and out [major][out_h][out_w][minor], minor % 4 == 0) in one pass: the
+ * gradient of a tensor that feeds BOTH a convolution and a resampling filter (ResBlock's input: conv1 and the skip branch's
+ * blur + sub-sampling) -- the filter's adjoint adds the other branch's gradient on its way out instead of a separate accumulation pass. */
+int diagan_upfirdn2d_add(const float* input, const float* kernel, const float* addend, float* out, int major, int in_h, int in_w, int minor,
+                         int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                         int pad_y1, void* stream);
 int diagan_bias_act_add(const float* x, const float* bias, const float* addend, float* out, int64_t n, int C, float alpha, float scale,
                         void* stream);
 int diagan_fir_styled_act(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor, int kernel_h,

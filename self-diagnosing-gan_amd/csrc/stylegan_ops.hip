@@ -213,6 +213,10 @@ struct UpFirDnArgs {
   const float* f_noise;    // [major or 1][out_h][out_w] or null
   const float* f_strength; // [1]
   const float* f_post;     // [major][minor] or null
+  // FUSE 3 -- the adjoint blur of a gradient followed by the gate of bias + leaky ReLU (first-order backward of FUSE 1): every output
+  // element is multiplied by scale * (f_ref + f_bias[c] > 0 ? 1 : alpha); the lanes' sums of what they wrote go to f_work[block][minor]
+  const float* f_ref;      // [major][out_h][out_w][minor]: the pre-activation without its bias
+  float* f_work;           // [gridDim.x][minor]
   int f_noise_per_image;
   float f_alpha, f_scale;
 };
@@ -239,6 +243,7 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
   const long total = (long)a.major * a.out_h * gx * q;
   const f32x4* __restrict__ in4 = reinterpret_cast<const f32x4*>(a.in);
   f32x4* __restrict__ out4 = reinterpret_cast<f32x4*>(a.out);
+  f32x4 gsum = {0.f, 0.f, 0.f, 0.f};          // FUSE 3: this lane's channel quad is the same on every trip (q divides the stride)
   for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
     const int c4 = (int)(o % q);
     long t = o / q;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
     for (int j = 0; j < OXT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int bx = ox0 * DOWN - a.pad_x0;
     f32x4 pb = {0.f, 0.f, 0.f, 0.f};
-    if (FUSE == 1) pb = *reinterpret_cast<const f32x4*>(a.f_bias + c4 * 4);
+    if (FUSE == 1 || FUSE == 3) pb = *reinterpret_cast<const f32x4*>(a.f_bias + c4 * 4);
     for (int dy = 0; dy < a.kh; ++dy) {
       const int iy = oy * DOWN - a.pad_y0 + dy;
       if (iy < 0 || iy >= a.in_h) continue;
@@ -292,9 +297,33 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
       }
       continue;
     }
+    if (FUSE == 3) {
+      const f32x4* ref = reinterpret_cast<const f32x4*>(a.f_ref) + (((long)mj * a.out_h + oy) * a.out_w + ox0) * q + c4;
+#pragma unroll
+      for (int j = 0; j < OXT; ++j) {
+        if (ox0 + j >= a.out_w) continue;
+        const f32x4 r = ref[(long)j * q] + pb;
+        f32x4 v = acc[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * (r[e] > 0.f ? a.f_scale : a.f_scale * a.f_alpha);     // (styled_act_bwd_kernel's gate)
+        dst[(long)j * q] = v;
+        gsum += v;
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < OXT; ++j)
       if (ox0 + j < a.out_w) dst[(long)j * q] = acc[j];
+  }
+  if (FUSE == 3) {                              // the lanes of a channel quad, in a fixed order, to f_work[block][c]
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = gsum;
+    __syncthreads();
+    if ((int)threadIdx.x < q) {
+      f32x4 sum = red[threadIdx.x];
+      for (int l = threadIdx.x + q; l < 256; l += q) sum += red[l];
+      *reinterpret_cast<f32x4*>(a.f_work + (long)blockIdx.x * a.minor + threadIdx.x * 4) = sum;
+    }
   }
 }
 
@@ -330,6 +359,7 @@ __global__ __launch_bounds__(256) void updn_cl4_kernel(const UpFirDnArgs a) {
         for (int e = 0; e < 4; ++e) v[e] = fmaf(xin[e], w, v[e]);
       }
     }
+    if (a.f_ref) v += reinterpret_cast<const f32x4*>(a.f_ref)[o];     // (round 6: the other branch's gradient, see diagan_upfirdn2d_add)
     out4[o] = v;
   }
 }
@@ -562,6 +592,44 @@ DIAGAN_API int diagan_bias_act_fir(const float* input, const float* bias, const 
   return check_launch("bias_act_fir");
 }
 
+// see include/diagan_hip.h: out = upfirdn2d(input) + addend in one pass (channels-last, minor % 4 == 0)
+DIAGAN_API int diagan_upfirdn2d_add(const float* input, const float* kernel, const float* addend, float* out, int major, int in_h, int in_w,
+                                    int minor, int kernel_h, int kernel_w, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                                    int pad_x1, int pad_y0, int pad_y1, void* stream) {
+  DG_REQUIRE(input && kernel && addend && out && major > 0 && in_h > 0 && in_w > 0 && minor > 0 && (minor & 3) == 0, "upfirdn2d_add: bad args");
+  DG_REQUIRE(up_x > 0 && up_y > 0 && down_x > 0 && down_y > 0 && kernel_h * kernel_w <= 4096, "upfirdn2d_add: bad filter geometry");
+  DG_REQUIRE((((uintptr_t)input | (uintptr_t)out | (uintptr_t)addend) & 15) == 0, "upfirdn2d_add: pointers must be 16-byte aligned");
+  const int oh = (in_h * up_y + pad_y0 + pad_y1 - kernel_h) / down_y + 1;
+  const int ow = (in_w * up_x + pad_x0 + pad_x1 - kernel_w) / down_x + 1;
+  DG_REQUIRE(oh > 0 && ow > 0, "upfirdn2d_add: empty output (%d x %d)", oh, ow);
+  UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow, up_x, up_y, down_x, down_y, pad_x0, pad_y0};
+  a.f_ref = addend;
+  const long work = (long)major * oh * ow * (minor / 4);
+  long fb = (work + 255) / 256;
+  if (fb > 32768) fb = 32768;
+  hipLaunchKernelGGL(updn_cl4_kernel, dim3((int)fb), dim3(256), (size_t)kernel_h * kernel_w * sizeof(float), (hipStream_t)stream, a);
+  return check_launch("upfirdn2d_add");
+}
+
+// see include/diagan_hip.h: gz = gate(ref + bias) * FIR(g) and the bias gradient's partial sums in ONE pass (FUSE 3): first-order
+// backward of diagan_bias_act_fir with the ADJOINT filter geometry (flipped taps, adjoint pads) handed in by the caller
+DIAGAN_API int diagan_fir_gate_bwd(const float* g, const float* kernel, const float* ref, const float* bias, float* gz, float* work_b,
+                                   int major, int in_h, int in_w, int minor, int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0,
+                                   int pad_y1, float alpha, float scale, void* stream) {
+  DG_REQUIRE(g && kernel && ref && bias && gz && work_b && major > 0 && in_h > 0 && in_w > 0, "fir_gate_bwd: bad args");
+  DG_REQUIRE(kernel_w == 4 && kernel_h >= 1 && kernel_h <= 16, "fir_gate_bwd: 4-tap-wide filters (got %d x %d taps)", kernel_h, kernel_w);
+  DG_REQUIRE(minor >= 4 && minor <= 1024 && (minor & (minor - 1)) == 0, "fir_gate_bwd: %d channels: a power of two in [4, 1024]", minor);
+  DG_REQUIRE((((uintptr_t)g | (uintptr_t)gz | (uintptr_t)ref | (uintptr_t)bias | (uintptr_t)work_b) & 15) == 0, "fir_gate_bwd: pointers must be 16-byte aligned");
+  const int oh = in_h + pad_y0 + pad_y1 - kernel_h + 1, ow = in_w + pad_x0 + pad_x1 - kernel_w + 1;
+  DG_REQUIRE(oh > 0 && ow > 0, "fir_gate_bwd: empty output (%d x %d)", oh, ow);
+  UpFirDnArgs a{g, kernel, gz, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow, 1, 1, 1, 1, pad_x0, pad_y0};
+  a.f_bias = bias; a.f_ref = ref; a.f_work = work_b; a.f_alpha = alpha; a.f_scale = scale;
+  // work_b has one row per workgroup: major * diagan_rowdot_chunks(major, oh * ow) of them (diagan_styled_bias_act_bwd_finish sums those)
+  const int blocks = major * diagan_rowdot_chunks(major, oh * ow);
+  hipLaunchKernelGGL((fir_cl4_kernel<4, 4, 1, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("fir_gate_bwd");
+}
+
 // see include/diagan_hip.h: the StyledConv tail (and optionally the next layer's style) applied to blur(x) in ONE pass (FUSE 2)
 DIAGAN_API int diagan_fir_styled_act(const float* input, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
                                      int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, const float* demod,
@@ -582,6 +650,213 @@ DIAGAN_API int diagan_fir_styled_act(const float* input, const float* kernel, fl
   if (fb > 32768) fb = 32768;
   hipLaunchKernelGGL((fir_cl4_kernel<4, 4, 1, 2>), dim3((int)fb), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("fir_styled_act");
+}
+
+// ---- ToRGB in one pass (round 6) ----------------------------------------------------------------------------------------------------
+// The generator's ToRGB (reference stylegan2.py:332-351) is a modulated 1x1 convolution to 3 planes without demodulation:
+//   out[b,p,o] = sum_c w[o][c] * (x[b,p,c] * s[b,c]) + bias[o]
+// As scale_rows + implicit GEMM it costs three passes over the layer's full-resolution input (multiply: read + write, convolution: read)
+// for 3 output planes, and its backward six more.  Here: one read of x forward; backward one read of x and one write of gx:
+//   gx[b,p,c]     = (sum_o gy[b,p,o] * w[o][c]) * s[b,c]
+//   work[b][k][o][c] = sum over the pixels of chunk k of gy[b,p,o] * x[b,p,c]       (-> d(s) and d(w) in torgb_finish_kernel)
+// Layout: 256 threads = L lanes along the channel quads (L = min(C / 4, 64): one pixel's lanes sit in one wave) x 256 / L pixels; a
+// lane owns the quads cq, cq + L, ... (NQ = C / 4 / L <= 4); blocks = (image, pixel chunk) as rowdot_partial_kernel.
+// v + (v of the lane `ctrl` points at; 0 where that lane does not exist or the row is masked out): one full-rate VALU instruction
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+// sum over each group of L consecutive lanes (L a power of two <= 64, groups aligned), valid in the group's LAST lane: the prefix-sum
+// ladder row_shr:1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 / :31 across them -- no LDS crossbar (ds_bpermute) involved
+__device__ __forceinline__ float group_sum_last(float v, int L) {
+  if (L >= 2) v = dpp_add<0x111, 0xf>(v);
+  if (L >= 4) v = dpp_add<0x112, 0xf>(v);
+  if (L >= 8) v = dpp_add<0x114, 0xf>(v);
+  if (L >= 16) v = dpp_add<0x118, 0xf>(v);
+  if (L >= 32) v = dpp_add<0x142, 0xa>(v);
+  if (L >= 64) v = dpp_add<0x143, 0xc>(v);
+  return v;
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void torgb_fwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ s, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, f32x4* __restrict__ out, int P, int C, int chunks) {
+  constexpr int U = 4;                                     // pixels per lane and trip: U independent loads in flight
+  const int q = C >> 2, L = q / NQ, ppb = 256 / L;
+  const int cq = threadIdx.x % L, pl = threadIdx.x / L;
+  const int img = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int per = (P + chunks - 1) / chunks;
+  const int p0 = ch * per, p1 = min(p0 + per, P);
+  f32x4 sq[NQ], wq[NQ][3];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = (cq + j * L) * 4;
+    sq[j] = *reinterpret_cast<const f32x4*>(s + (long)img * C + c);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) wq[j][o] = *reinterpret_cast<const f32x4*>(w + (long)o * C + c);
+  }
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) { bv[0] = bias[0]; bv[1] = bias[1]; bv[2] = bias[2]; }
+  const long base = (long)img * P * q + cq;
+  const int iters = (p1 - p0 + U * ppb - 1) / (U * ppb);   // (block-uniform trip count: the lane exchanges below need every lane)
+  for (int it = 0; it < iters; ++it) {
+    f32x4 v[U][NQ];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + (it * U + u) * ppb + pl;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) v[u][j] = p < p1 ? x[base + (long)p * q + j * L] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = p0 + (it * U + u) * ppb + pl;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const f32x4 xm = v[u][j] * sq[j];                  // (the modulated input as scale_rows rounds it)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 = fmaf(xm[e], wq[j][0][e], a0);
+          a1 = fmaf(xm[e], wq[j][1][e], a1);
+          a2 = fmaf(xm[e], wq[j][2][e], a2);
+        }
+      }
+      a0 = group_sum_last(a0, L);
+      a1 = group_sum_last(a1, L);
+      a2 = group_sum_last(a2, L);
+      if (p < p1 && cq == L - 1) out[(long)img * P + p] = f32x4{a0 + bv[0], a1 + bv[1], a2 + bv[2], 0.f};
+    }
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void torgb_bwd_kernel(const f32x4* __restrict__ gy, const f32x4* __restrict__ x, const float* __restrict__ s,
+                                                        const float* __restrict__ w, f32x4* __restrict__ gx, float* __restrict__ work,
+                                                        int P, int C, int chunks) {
+  __shared__ f32x4 red[256];
+  const int q = C >> 2, L = q / NQ, ppb = 256 / L;
+  const int cq = threadIdx.x % L, pl = threadIdx.x / L;
+  const int img = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int per = (P + chunks - 1) / chunks;
+  const int p0 = ch * per, p1 = min(p0 + per, P);
+  f32x4 sq[NQ], wq[NQ][3], acc[NQ][3];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = (cq + j * L) * 4;
+    sq[j] = *reinterpret_cast<const f32x4*>(s + (long)img * C + c);
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      wq[j][o] = *reinterpret_cast<const f32x4*>(w + (long)o * C + c);
+      acc[j][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const long base = (long)img * P * q + cq;
+  constexpr int U = 4;                                     // pixels per lane and trip (independent loads in flight)
+  for (int pp = p0 + pl; pp < p1; pp += U * ppb) {
+    f32x4 g[U], xv[U][NQ];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pp + u * ppb;
+      const bool ok = p < p1;
+      g[u] = ok ? gy[(long)img * P + p] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) xv[u][j] = ok ? x[base + (long)p * q + j * L] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = pp + u * ppb;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        f32x4 t = g[u][0] * wq[j][0];
+        t += g[u][1] * wq[j][1];
+        t += g[u][2] * wq[j][2];
+        if (gx && p < p1) gx[base + (long)p * q + j * L] = t * sq[j];
+        acc[j][0] += g[u][0] * xv[u][j];                   // (pixels past the chunk add zeros, in the same order every run)
+        acc[j][1] += g[u][1] * xv[u][j];
+        acc[j][2] += g[u][2] * xv[u][j];
+      }
+    }
+  }
+  // the pixel lanes' partial sums, in a fixed order, to work[block][o][c]
+#pragma unroll
+  for (int j = 0; j < NQ; ++j)
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      __syncthreads();
+      red[threadIdx.x] = acc[j][o];
+      __syncthreads();
+      if (pl == 0) {
+        f32x4 t = red[cq];
+        for (int l = 1; l < ppb; ++l) t += red[l * L + cq];
+        *reinterpret_cast<f32x4*>(work + ((long)blockIdx.x * 3 + o) * C + (cq + j * L) * 4) = t;
+      }
+    }
+}
+
+// T[b][o][c] = the chunks' partial sums added in double in a fixed order (one block per (b, o)); then
+// d(s)[b][c] = sum_o w[o][c] * T[b][o][c] (blocks 0 .. B-1), d(w)[o][c] = sum_b s[b][c] * T[b][o][c] (blocks B .. B+2)
+__global__ __launch_bounds__(256) void torgb_sum_kernel(const float* __restrict__ work, float* __restrict__ T, int C, int chunks) {
+  const int b = blockIdx.x / 3, o = blockIdx.x - b * 3;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double u = 0.0;
+    for (int k = 0; k < chunks; ++k) u += (double)work[(((long)b * chunks + k) * 3 + o) * C + c];
+    T[(long)blockIdx.x * C + c] = (float)u;
+  }
+}
+__global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restrict__ T, const float* __restrict__ s, const float* __restrict__ w,
+                                                           float* __restrict__ gs, float* __restrict__ gw, int B, int C) {
+  const int blk = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    if (blk < B) {
+      double t = 0.0;
+      for (int o = 0; o < 3; ++o) t += (double)w[(long)o * C + c] * (double)T[((long)blk * 3 + o) * C + c];
+      gs[(long)blk * C + c] = (float)t;
+    } else {
+      const int o = blk - B;
+      double t = 0.0;
+      for (int b = 0; b < B; ++b) t += (double)s[(long)b * C + c] * (double)T[((long)b * 3 + o) * C + c];
+      gw[(long)o * C + c] = (float)t;
+    }
+  }
+}
+
+static int torgb_nq(int C) { return C <= 256 ? 1 : C / 256; }
+
+// see include/diagan_hip.h
+DIAGAN_API int diagan_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, float* out, int B, int P, int C,
+                                void* stream) {
+  DG_REQUIRE(x && s && w && out && B > 0 && P > 0, "torgb_fwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "torgb_fwd: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE((((uintptr_t)x | (uintptr_t)s | (uintptr_t)w | (uintptr_t)out) & 15) == 0, "torgb_fwd: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  const dim3 grid(B * chunks);
+  hipStream_t st = (hipStream_t)stream;
+  switch (torgb_nq(C)) {
+    case 1: hipLaunchKernelGGL((torgb_fwd_kernel<1>), grid, dim3(256), 0, st, (const f32x4*)x, s, w, bias, (f32x4*)out, P, C, chunks); break;
+    case 2: hipLaunchKernelGGL((torgb_fwd_kernel<2>), grid, dim3(256), 0, st, (const f32x4*)x, s, w, bias, (f32x4*)out, P, C, chunks); break;
+    default: hipLaunchKernelGGL((torgb_fwd_kernel<4>), grid, dim3(256), 0, st, (const f32x4*)x, s, w, bias, (f32x4*)out, P, C, chunks); break;
+  }
+  return check_launch("torgb_fwd");
+}
+
+DIAGAN_API int diagan_torgb_bwd(const float* gy, const float* x, const float* s, const float* w, float* gx, float* work, float* gs, float* gw,
+                                int B, int P, int C, void* stream) {
+  DG_REQUIRE(gy && x && s && w && work && gs && gw && B > 0 && P > 0, "torgb_bwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "torgb_bwd: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)s | (uintptr_t)w | (uintptr_t)gx | (uintptr_t)work) & 15) == 0,
+             "torgb_bwd: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  const dim3 grid(B * chunks);
+  hipStream_t st = (hipStream_t)stream;
+  switch (torgb_nq(C)) {
+    case 1: hipLaunchKernelGGL((torgb_bwd_kernel<1>), grid, dim3(256), 0, st, (const f32x4*)gy, (const f32x4*)x, s, w, (f32x4*)gx, work, P, C, chunks); break;
+    case 2: hipLaunchKernelGGL((torgb_bwd_kernel<2>), grid, dim3(256), 0, st, (const f32x4*)gy, (const f32x4*)x, s, w, (f32x4*)gx, work, P, C, chunks); break;
+    default: hipLaunchKernelGGL((torgb_bwd_kernel<4>), grid, dim3(256), 0, st, (const f32x4*)gy, (const f32x4*)x, s, w, (f32x4*)gx, work, P, C, chunks); break;
+  }
+  float* T = work + (long)B * chunks * 3 * C;
+  hipLaunchKernelGGL(torgb_sum_kernel, dim3(B * 3), dim3(256), 0, st, work, T, C, chunks);
+  hipLaunchKernelGGL(torgb_finish_kernel, dim3(B + 3), dim3(256), 0, st, T, s, w, gs, gw, B, C);
+  return check_launch("torgb_bwd");
 }
 
 // out dims: ((in*up + pad0 + pad1 - k) / down) + 1 ; returns them through out_h/out_w when out == NULL

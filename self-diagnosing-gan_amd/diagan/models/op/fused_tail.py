@@ -26,9 +26,11 @@ P, I, F32, I64 = nat.c_void_p, nat.c_int, nat.c_f32, nat.c_i64
 nat.register("diagan_bias_act_fir", [P, P, P, P] + [I] * 10 + [F32, F32, P])
 nat.register("diagan_bias_act_gate_bwd", [P, P, P, P, P, I, I, I, F32, F32, P])
 nat.register("diagan_bias_act_add", [P, P, P, P, I64, I, F32, F32, P])
+nat.register("diagan_fir_gate_bwd", [P, P, P, P, P, P] + [I] * 10 + [F32, F32, P])
 nat.register("diagan_fir_styled_act", [P, P, P] + [I] * 10 + [P, P, P, P, P, I, F32, F32, P])
 
 FUSED_TAILS = os.environ.get("DIAGAN_SG2_FUSED_TAILS", "1") != "0"
+FUSED_GATE = os.environ.get("DIAGAN_SG2_FUSED_GATE", "1") != "0"      # the blur's adjoint + the activation's gate in one pass
 
 
 def _fir_ok(x, kernel):
@@ -49,6 +51,23 @@ def _gate_from_pre(gy, z, bias, slope, scale):
     gb = torch.empty(c, dtype=torch.float32, device=gy.device)
     nat.call("diagan_styled_bias_act_bwd_finish", None, nat.ptr(wb), None, None, nat.ptr(gb), None, b, h * w, c, st)
     return gz, gb
+
+
+def _blur_adjoint_gate(gy, dual, z, bias, slope, scale):
+    """(gz, d(bias)) of blur(leaky_relu(z + bias) * scale): the blur's adjoint and the gate in ONE pass (diagan_fir_gate_bwd)"""
+    b, h, w, c = gy.shape
+    if FUSED_GATE and dual.kernel.shape[1] == 4 and dual.kernel.shape[0] <= 16 and tuple(dual.out_hw) == tuple(z.shape[1:3]):
+        kh, kw = dual.kernel.shape
+        gz = torch.empty_like(z)
+        chunks = nat.fn("diagan_rowdot_chunks")(b, z.shape[1] * z.shape[2])
+        wb = torch.empty((b * chunks, c), dtype=torch.float32, device=gy.device)
+        st = nat.current_stream()
+        nat.call("diagan_fir_gate_bwd", nat.ptr(gy), nat.ptr(dual.kernel.contiguous()), nat.ptr(z), nat.ptr(bias), nat.ptr(gz), nat.ptr(wb),
+                 b, h, w, c, kh, kw, *dual.pad, float(slope), float(scale), st)
+        gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+        nat.call("diagan_styled_bias_act_bwd_finish", None, nat.ptr(wb), None, None, nat.ptr(gb), None, b, z.shape[1] * z.shape[2], c, st)
+        return gz, gb
+    return _gate_from_pre(dual.run(gy), z, bias, slope, scale)
 
 
 def _gate_any_order(g, z, bias, slope, scale):
@@ -77,7 +96,7 @@ class _BiasActBlur(Function):
     def backward(ctx, gy):
         z, bias = ctx.saved_tensors
         if FA._fused_bwd_ok(gy):
-            gz, gb = _gate_from_pre(ctx.plan.dual.run(gy.contiguous()), z, bias, *ctx.hyper)
+            gz, gb = _blur_adjoint_gate(gy.contiguous(), ctx.plan.dual, z, bias, *ctx.hyper)
         else:
             gz, gb = _gate_any_order(_LinearFIR.apply(gy.contiguous(), ctx.plan.dual), z, bias, *ctx.hyper)
         return gz, (gb if ctx.needs_input_grad[1] else None), None, None, None
@@ -139,3 +158,109 @@ def blur_styled_act(x, kernel, pad, demod=None, noise=None, strength=None, bias=
              pad[1], c_(demod), c_(noise), nat.ptr(strength) if noise is not None else None, c_(bias), c_(post), 1 if per_image else 0,
              float(negative_slope), float(scale), nat.current_stream())
     return out
+
+
+# ---- the generator's ToRGB in one pass over its input ---------------------------------------------------------------------------------
+nat.register("diagan_torgb_fwd", [P, P, P, P, P, I, I, I, P])
+nat.register("diagan_torgb_bwd", [P, P, P, P, P, P, P, P, I, I, I, P])
+
+
+def torgb_ok(x):
+    c = x.shape[-1] if x.dim() == 4 else 0
+    return FUSED_TAILS and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and 4 <= c <= 1024 and not (c & (c - 1))
+
+
+class _ToRGB(Function):
+    """out[b,h,w,:3] = sum_c (weight * scale)[o, c] * (x * s)[b,h,w,c] + bias[o] (4th plane zero): the reference's ToRGB
+    (stylegan2.py:332-351) in one read of x.  First-order backward: one read of x + one write of gx (diagan_torgb_bwd); when the
+    backward is itself differentiated, the composition scale_rows -> 1x1 convolution of ops/diffconv.py (any order)."""
+
+    @staticmethod
+    def forward(ctx, x, s, weight, bias, scale):
+        b, h, w, c = x.shape
+        x, s = x.contiguous(), s.contiguous()
+        ws = (weight * scale).contiguous()                                   # [3, C]
+        out = torch.empty((b, h, w, 4), dtype=torch.float32, device=x.device)
+        nat.call("diagan_torgb_fwd", nat.ptr(x), nat.ptr(s), nat.ptr(ws), nat.ptr(bias.contiguous()) if bias is not None else None,
+                 nat.ptr(out), b, h * w, c, nat.current_stream())
+        ctx.save_for_backward(x, s, weight, bias)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, s, weight, bias = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        b, h, w, c = x.shape
+        if not torch.is_grad_enabled():
+            gy = gy.contiguous()
+            ws = (weight * ctx.scale).contiguous()
+            f32 = dict(dtype=torch.float32, device=x.device)
+            gx = torch.empty_like(x) if need[0] else None
+            chunks = nat.fn("diagan_rowdot_chunks")(b, h * w)
+            work = torch.empty(b * (chunks + 1) * 3 * c, **f32)
+            gs, gw = torch.empty((b, c), **f32), torch.empty((3, c), **f32)
+            nat.call("diagan_torgb_bwd", nat.ptr(gy), nat.ptr(x), nat.ptr(s), nat.ptr(ws), nat.ptr(gx), nat.ptr(work), nat.ptr(gs),
+                     nat.ptr(gw), b, h * w, c, nat.current_stream())
+            gb = gy.sum((0, 1, 2))[:3] if (bias is not None and need[3]) else None
+            return gx, (gs if need[1] else None), (gw * ctx.scale if need[2] else None), gb, None
+        # differentiable composition on the saved (graph-connected) tensors
+        from diagan.ops import diffconv as dc
+        from diagan.ops import conv as K
+        geom = K.Geom('conv', c, 4, 1, 1, 1, 0)
+        wp = dc.pack_scaled(weight.view(3, c, 1, 1), ctx.scale, geom)
+        xm = FA.scale_rows(x, s)
+        gxm = dc._DataGrad.apply(gy, wp, geom, (h, w)) if (need[0] or need[1]) else None
+        gx = FA.scale_rows(gxm, s) if need[0] else None
+        gs = FA.rowdot(gxm, x) if need[1] else None
+        gw = None
+        if need[2]:
+            gwp = dc._WeightGrad.apply(gy, xm, geom)
+            gw = dc._UnpackScaled.apply(gwp, ctx.scale, geom, (3, c, 1, 1)).view(3, c)
+        gb = gy.sum((0, 1, 2))[:3] if (bias is not None and need[3]) else None
+        return gx, gs, gw, gb, None
+
+
+def torgb(x, s, weight, bias, scale):
+    """x [B,H,W,C], s [B,C], weight [3,C], bias [3] or None -> [B,H,W,4]"""
+    return _ToRGB.apply(x, s, weight, bias, scale)
+
+
+# ---- a tensor that feeds a convolution AND a resampling filter: the filter's adjoint adds the other gradient on its way out -------------
+nat.register("diagan_upfirdn2d_add", [P, P, P, P] + [I] * 14 + [P])
+
+
+class _ForkFIR(Function):
+    """(x, upfirdn2d(x)): autograd hands this node BOTH consumers' gradients at once, so the plain backward is ONE pass --
+    adjoint filter + the other branch's gradient (diagan_upfirdn2d_add) -- instead of the adjoint and a separate accumulation over a
+    full-resolution tensor.  Differentiated backward: the sum of the differentiable pieces."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        ctx.plan = plan
+        return x.view_as(x), plan.run(x)
+
+    @staticmethod
+    def backward(ctx, ga, gf):
+        dual = ctx.plan.dual
+        if gf is None:
+            return ga, None
+        if ga is None:
+            return _LinearFIR.apply(gf.contiguous(), dual), None
+        if torch.is_grad_enabled() or not (gf.is_cuda and gf.shape[3] % 4 == 0 and dual.channels_last):
+            return ga + _LinearFIR.apply(gf.contiguous(), dual), None
+        gf, ga = gf.contiguous(), ga.contiguous()
+        b, h, w, c = gf.shape
+        kh, kw = dual.kernel.shape
+        out = torch.empty_like(ga)
+        nat.call("diagan_upfirdn2d_add", nat.ptr(gf), nat.ptr(dual.kernel.contiguous()), nat.ptr(ga), nat.ptr(out), b, h, w, c, kh, kw,
+                 dual.up[0], dual.up[1], dual.down[0], dual.down[1], *dual.pad, nat.current_stream())
+        return out, None
+
+
+def fork_fir(x, kernel, up=1, down=1, pad=(0, 0)):
+    """(x, upfirdn2d_nhwc(x, kernel, up, down, pad)) for a tensor with one more consumer besides the filter"""
+    if not (FUSED_TAILS and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] % 4 == 0) or kernel.requires_grad:
+        return x, upfirdn2d_nhwc(x, kernel, up=up, down=down, pad=pad)
+    plan = _Plan.forward_plan(kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]), x.shape[1:3], channels_last=True)
+    return _ForkFIR.apply(x, plan)

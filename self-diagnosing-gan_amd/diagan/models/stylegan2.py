@@ -26,7 +26,7 @@ from torch import nn
 
 from diagan.models.layers import FlatNet
 from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, scale_rows, styled_bias_act
-from diagan.models.op.fused_tail import bias_act_add, bias_act_blur, blur_styled_act, blur_styled_act_ok
+from diagan.models.op.fused_tail import bias_act_add, bias_act_blur, blur_styled_act, blur_styled_act_ok, fork_fir, torgb, torgb_ok
 from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
 
@@ -294,8 +294,12 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, input, style, skip=None):
-        out = self.conv(input, style)
-        out = out + F.pad(self.bias.view(3), (0, out.shape[3] - 3))
+        if torgb_ok(input) and self.conv.kernel_size == 1 and not self.conv.demodulate:
+            # modulation, 1x1 convolution and bias in ONE read of the layer's input (round 6: models/op/fused_tail.py)
+            out = torgb(input, self.conv.modulation(style), self.conv.weight.view(3, -1), self.bias.view(3), self.conv.scale)
+        else:
+            out = self.conv(input, style)
+            out = out + F.pad(self.bias.view(3), (0, out.shape[3] - 3))
         if skip is not None:
             out = out + self.upsample(skip)
         return out
@@ -418,14 +422,17 @@ class ResBlock(nn.Module):
         leaky_relu(.) * sqrt 2 runs with scale 1, the skip convolution with its weight scale divided by sqrt 2."""
         conv1, act1 = self.conv1
         blur2, conv2, act2 = self.conv2
+        blur_s, conv_s = self.skip
+        fused_skip = FUSED_SKIP and conv_s.stride == 2 and conv_s.padding == 0 and conv_s.weight.shape[2] == 1
+        if fused_skip:     # (the input's two consumers as ONE autograd node: its backward adds their gradients in the filter's pass)
+            input, down = fork_fir(input, blur_s.kernel, down=2, pad=blur_s.pad)
         # conv1's activation rides in the Blur's pass, conv2's in the pass that adds the skip branch (round 6: models/op/fused_tail.py)
         z = conv2(bias_act_blur(conv1(input), act1.bias, blur2.kernel, blur2.pad, act1.negative_slope, act1.scale))
         # skip branch (reference :553-595: Blur, then a 1x1 convolution of stride 2): the convolution reads every second pixel of the
         # blurred image, so the blur computes only those (upfirdn2d with down = 2, same taps and padding: the same values) and the
         # convolution runs at stride 1 on a quarter of the pixels
-        blur_s, conv_s = self.skip
-        if FUSED_SKIP and conv_s.stride == 2 and conv_s.padding == 0 and conv_s.weight.shape[2] == 1:
-            r = conv_s(upfirdn2d_nhwc(input, blur_s.kernel, down=2, pad=blur_s.pad), out_mul=1.0 / SQRT2, stride=1)
+        if fused_skip:
+            r = conv_s(down, out_mul=1.0 / SQRT2, stride=1)
         else:
             r = conv_s(blur_s(input), out_mul=1.0 / SQRT2)
         return bias_act_add(z, act2.bias, r, act2.negative_slope, act2.scale / SQRT2)

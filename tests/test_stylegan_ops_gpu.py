@@ -271,7 +271,12 @@ def test_activation_folded_into_the_blur_and_into_the_residual_add(shape, pad):
         return y.detach(), g1.detach(), gw
     for second in (False, True):
         for i, (p, q) in enumerate(zip(run(one, second), run(two, second))):
+            if not second and i == 2:      # the bias gradient: the same numbers added block by block in another (fixed) order
+                assert float((p - q).abs().max()) <= 2e-6 * float(q.abs().max()) + 1e-6
+                continue
             assert torch.equal(p, q), f"bias_act_blur second={second} output {i}: max diff {(p - q).abs().max().item():.3e}"
+    a1, a2 = run(one, False), run(one, False)
+    assert all(torch.equal(u, v) for u, v in zip(a1, a2)), "the one-pass backward must repeat bit for bit"
 
     r0 = torch.randn(B, H, W, C, generator=g).cuda()
 
@@ -323,3 +328,78 @@ def test_styled_tail_folded_into_the_blur_without_a_graph(shape, noise_kind, pos
         got = FT.blur_styled_act(x, kern, pad, d, noise, s if noise is not None else None, b, post=ps)
     assert torch.equal(got, want), (got - want).abs().max().item()
     assert not FT.blur_styled_act_ok(x.requires_grad_(True), kern) or not torch.is_grad_enabled()
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 33, 31, 128), (2, 16, 16, 512), (2, 9, 7, 256), (1, 3, 3, 1024), (2, 4, 4, 4)])
+def test_torgb_in_one_pass(shape):
+    """round 6: ToRGB (modulation, 1x1 convolution to 3 planes, bias) as ONE read of its input; the plain backward as one read + one
+    write (diagan_torgb_bwd); a differentiated backward (create_graph) as the composition of the convolution ops -- all against float64"""
+    from diagan.models.op import fused_tail as FT
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    vals = dict(x=torch.randn(B, H, W, C, generator=g), s=torch.randn(B, C, generator=g) + 1.0, w=torch.randn(3, C, generator=g),
+                b=torch.randn(3, generator=g))
+    scale = C ** -0.5
+    cot = torch.sin(torch.arange(B * H * W * 3, dtype=torch.float64).view(B, H, W, 3))
+    pen_w = torch.cos(torch.arange(B * H * W * C, dtype=torch.float64).view(B, H, W, C))
+
+    def ref(second):
+        t = {k: v.double().requires_grad_(True) for k, v in vals.items()}
+        y = torch.einsum('bhwc,oc->bhwo', t['x'] * t['s'][:, None, None, :], t['w'] * scale) + t['b']
+        if not second:
+            return [y.detach()] + list(torch.autograd.grad((y * cot).sum(), [t[k] for k in 'xswb']))
+        gx, = torch.autograd.grad((y * cot).sum(), [t['x']], create_graph=True)
+        return [y.detach()] + list(torch.autograd.grad((gx.square() * pen_w).sum(), [t['s'], t['w']]))
+
+    def ours(second):
+        t = {k: v.cuda().requires_grad_(True) for k, v in vals.items()}
+        y = FT.torgb(t['x'], t['s'], t['w'], t['b'], scale)
+        assert y.shape == (B, H, W, 4) and float(y.detach()[..., 3].abs().max()) == 0.0
+        c4 = torch.nn.functional.pad(cot, (0, 1)).float().cuda()
+        if not second:
+            gr = torch.autograd.grad((y * c4).sum(), [t[k] for k in 'xswb'])
+        else:
+            gx, = torch.autograd.grad((y * c4).sum(), [t['x']], create_graph=True)
+            gr = torch.autograd.grad((gx.square() * pen_w.float().cuda()).sum(), [t['s'], t['w']])
+        return [y[..., :3].detach().double().cpu()] + [v.detach().double().cpu() for v in gr]
+
+    for second in (False, True):
+        for i, (a, b) in enumerate(zip(ours(second), ref(second))):
+            sc = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 3e-5 * sc + 1e-6, f"second={second} output {i}: {float((a - b).abs().max()):.3e} of {sc:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, 8), (2, 33, 31, 128), (1, 10, 12, 512)])
+def test_fork_into_a_filter_accumulates_in_the_filters_pass(shape):
+    """round 6: a tensor with two consumers, one of them a resampling filter (ResBlock's input): the node's plain backward adds the other
+    consumer's gradient inside the adjoint filter's pass -- bit-identical to the adjoint followed by autograd's accumulation; the
+    differentiated backward stays the differentiable sum"""
+    from diagan.models.op import fused_tail as FT
+    from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    kern = (torch.outer(k1, k1) / 64).cuda()
+    x0 = torch.randn(B, H, W, C, generator=g).cuda()
+
+    def two(x):
+        return x, upfirdn2d_nhwc(x, kern, down=2, pad=(1, 1))
+
+    def one(x):
+        return FT.fork_fir(x, kern, down=2, pad=(1, 1))
+
+    def run(f, second):
+        x = x0.clone().requires_grad_(True)
+        a, d = f(x * 1.0)
+        ca = torch.cos(torch.arange(a.numel(), device="cuda", dtype=torch.float32)).view(a.shape)
+        cd = torch.sin(torch.arange(d.numel(), device="cuda", dtype=torch.float32)).view(d.shape)
+        if not second:
+            gx, = torch.autograd.grad((a.square() * ca).sum() + (d * cd).sum(), [x])
+            return a.detach(), d.detach(), gx
+        wd = torch.ones_like(d, requires_grad=True)
+        g1, = torch.autograd.grad((a * ca).sum() + (d * wd * cd).sum(), [x], create_graph=True)
+        gw, = torch.autograd.grad(g1.square().sum(), [wd])
+        return a.detach(), d.detach(), g1.detach(), gw
+    for second in (False, True):
+        for i, (p, q) in enumerate(zip(run(one, second), run(two, second))):
+            assert torch.equal(p, q), f"second={second} output {i}: max diff {(p - q).abs().max().item():.3e}"
