@@ -603,6 +603,17 @@ int diagan_styled_bias_act_bwd(const float* gy, const float* y, const float* x, 
 int diagan_styled_bias_act_bwd_finish(const float* work_d, const float* work_b, const float* work_s, float* gd, float* gb, float* gs, int B,
                                       int P, int C, void* stream);
 
+/* Round 6: the StyledConv tail that also leaves the NEXT layer's modulated input (out_mod = out * post[b][c]: that layer's
+ * scale_rows) in the same pass, and its first-order backward: the incoming gradient is gy (may be NULL: out has no other consumer)
+ * + gmod * post; everything diagan_styled_bias_act_bwd computes from it, plus work_p[blk][c] = sum_p gmod * y -> d(post) (finish:
+ * diagan_styled_bias_act_bwd_finish with work_p in the place of work_d). */
+int diagan_styled_bias_act_mod(const float* x, const float* demod, const float* noise, const float* strength, const float* bias,
+                               const float* post, float* out, float* out_mod, int B, int P, int C, int noise_per_image, float alpha,
+                               float scale, void* stream);
+int diagan_styled_bias_act_mod_bwd(const float* gy, const float* gmod, const float* post, const float* y, const float* x,
+                                   const float* demod, const float* noise, float* gx, float* work_d, float* work_b, float* work_s,
+                                   float* work_p, int B, int P, int C, int noise_per_image, float alpha, float scale, void* stream);
+
 /* Round 6: activation passes folded into the pass next to them (reference: diagan-pkg/diagan/models/stylegan2.py:553-614, the
  * discriminator's ConvLayer / ResBlock; :268-329 the generator's StyledConv).  Each is bit-identical to the two launches it replaces.
  *   diagan_bias_act_fir       out = FIR(leaky_relu(x + bias[c]) * scale) on x[major][in_h][in_w][minor], zero padding of the ACTIVATED

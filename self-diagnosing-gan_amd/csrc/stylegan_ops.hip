@@ -44,11 +44,11 @@ __global__ __launch_bounds__(256) void fused_bias_act_cl4_kernel(const f32x4* __
     } else {
       y = v;
     }
-    f32x4 o = y * scale;
-    if (addend) {              // (two roundings, as the activation followed by a separate add)
-      const f32x4 r = addend[i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(o[e], r[e]);
+    f32x4 o;
+    {                          // (two roundings, as the activation followed by a separate add: no fused multiply-add)
+#pragma clang fp contract(off)
+      o = y * scale;
+      if (addend) o += addend[i];
     }
     out[i] = o;
     c += dc;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void styled_act_cl4_kernel(const f32x4* __rest
                                                              const float* __restrict__ noise, const float* __restrict__ strength,
                                                              const float* __restrict__ bias, f32x4* __restrict__ out,
                                                              long n4, int P, int C, int noise_per_image, float alpha,
-                                                             float scale) {
+                                                             float scale, const float* __restrict__ post, f32x4* __restrict__ out2) {
   const int q = C >> 2;
   const float w = (noise && strength) ? strength[0] : 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -77,6 +77,8 @@ __global__ __launch_bounds__(256) void styled_act_cl4_kernel(const f32x4* __rest
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * alpha) * scale;
     out[i] = v;
+    // (round 6) the NEXT layer's modulated input in the same pass: out2 = out * post[b][c]
+    if (out2) out2[i] = v * *reinterpret_cast<const f32x4*>(post + (long)b * C + c);
   }
 }
 
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const f32x4* __rest
                                                              const float* __restrict__ noise, f32x4* __restrict__ gx,
                                                              float* __restrict__ wd, float* __restrict__ wb, float* __restrict__ ws,
                                                              int P, int C, int chunks, int noise_per_image, float alpha, float scale,
-                                                             const float* __restrict__ ref_bias) {
+                                                             const float* __restrict__ ref_bias, const f32x4* __restrict__ g2,
+                                                             const float* __restrict__ post, float* __restrict__ wp) {
   __shared__ f32x4 red_d[256];
   __shared__ f32x4 red_b[256];
   __shared__ float red_s[256];
@@ -140,10 +143,23 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const f32x4* __rest
   // their input): the gate is the sign of y + ref_bias[c], the sum the forward took the sign of
   f32x4 rb = {0.f, 0.f, 0.f, 0.f};
   if (ref_bias) rb = *reinterpret_cast<const f32x4*>(ref_bias + cq * 4);
+  // g2 / post / wp (round 6): y also left the forward as y * post[b][c] (the next layer's modulated input, diagan_styled_bias_act_mod);
+  // g2 is that output's gradient: the incoming gradient is gy (may be null) + g2 * post, and wp[blk][c] = sum_p g2 * y -> d(post)
+  f32x4 pm = {0.f, 0.f, 0.f, 0.f}, accp = {0.f, 0.f, 0.f, 0.f};
+  if (g2) pm = *reinterpret_cast<const f32x4*>(post + (long)img * C + cq * 4);
   for (int p = p0 + pl; p < p1; p += lanes) {
     const long i = base + (long)p * q;
-    f32x4 g = gy[i];
+    f32x4 g = gy ? gy[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 r = y[i];
+    if (g2) {
+      const f32x4 h = g2[i];
+      accp += h * r;
+      {                                 // (two roundings, as scale_rows' backward followed by the accumulation: no fused multiply-add)
+#pragma clang fp contract(off)
+        const f32x4 hm = h * pm;
+        g = gy ? g + hm : hm;
+      }
+    }
     if (ref_bias) r += rb;
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = g[e] * (r[e] > 0.f ? scale : scale * alpha);
@@ -161,6 +177,16 @@ __global__ __launch_bounds__(256) void styled_act_bwd_kernel(const f32x4* __rest
     for (int l = 1; l < lanes; ++l) { sd += red_d[l * q + cq]; sb += red_b[l * q + cq]; }
     if (wd) *reinterpret_cast<f32x4*>(wd + ((long)blockIdx.x * C) + cq * 4) = sd;
     *reinterpret_cast<f32x4*>(wb + ((long)blockIdx.x * C) + cq * 4) = sb;
+  }
+  if (wp) {                                         // (block-uniform)
+    __syncthreads();
+    red_d[threadIdx.x] = accp;
+    __syncthreads();
+    if (pl == 0) {
+      f32x4 sp = red_d[cq];
+      for (int l = 1; l < lanes; ++l) sp += red_d[l * q + cq];
+      *reinterpret_cast<f32x4*>(wp + ((long)blockIdx.x * C) + cq * 4) = sp;
+    }
   }
   if (ws && threadIdx.x < 64) {                    // fixed-order sum of the 256 per-thread scalars
     float t = (red_s[threadIdx.x] + red_s[threadIdx.x + 64]) + (red_s[threadIdx.x + 128] + red_s[threadIdx.x + 192]);
@@ -444,8 +470,24 @@ DIAGAN_API int diagan_styled_bias_act(const float* x, const float* demod, const 
   long blocks = (n4 + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(styled_act_cl4_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, demod,
-                     noise, strength, bias, (f32x4*)out, n4, P, C, noise_per_image, alpha, scale);
+                     noise, strength, bias, (f32x4*)out, n4, P, C, noise_per_image, alpha, scale, (const float*)nullptr, (f32x4*)nullptr);
   return check_launch("styled_bias_act");
+}
+
+// see include/diagan_hip.h: the tail and the next layer's modulated input in one pass
+DIAGAN_API int diagan_styled_bias_act_mod(const float* x, const float* demod, const float* noise, const float* strength, const float* bias,
+                                          const float* post, float* out, float* out_mod, int B, int P, int C, int noise_per_image,
+                                          float alpha, float scale, void* stream) {
+  DG_REQUIRE(x && out && post && out_mod && B > 0 && P > 0 && C > 0 && (C & 3) == 0, "styled_bias_act_mod: bad args (C must be a multiple of 4)");
+  DG_REQUIRE(!noise || strength, "styled_bias_act_mod: noise needs its strength");
+  DG_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)out_mod | (uintptr_t)demod | (uintptr_t)bias | (uintptr_t)post) & 15) == 0,
+             "styled_bias_act_mod: pointers must be 16-byte aligned");
+  const long n4 = (long)B * P * (C / 4);
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(styled_act_cl4_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, demod,
+                     noise, strength, bias, (f32x4*)out, n4, P, C, noise_per_image, alpha, scale, post, (f32x4*)out_mod);
+  return check_launch("styled_bias_act_mod");
 }
 
 DIAGAN_API int diagan_rowdot_chunks(int B, int P) {
@@ -479,8 +521,24 @@ DIAGAN_API int diagan_styled_bias_act_bwd(const float* gy, const float* y, const
   const int chunks = diagan_rowdot_chunks(B, P);
   hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)y,
                      (const f32x4*)x, demod, noise, (f32x4*)gx, work_d, work_b, work_s, P, C, chunks, noise_per_image, alpha, scale,
-                     (const float*)nullptr);
+                     (const float*)nullptr, (const f32x4*)nullptr, (const float*)nullptr, (float*)nullptr);
   return check_launch("styled_bias_act_bwd");
+}
+
+// see include/diagan_hip.h: first-order backward of diagan_styled_bias_act_mod in one pass
+DIAGAN_API int diagan_styled_bias_act_mod_bwd(const float* gy, const float* gmod, const float* post, const float* y, const float* x,
+                                              const float* demod, const float* noise, float* gx, float* work_d, float* work_b, float* work_s,
+                                              float* work_p, int B, int P, int C, int noise_per_image, float alpha, float scale, void* stream) {
+  DG_REQUIRE(gmod && post && y && work_b && work_p && B > 0 && P > 0, "styled_bias_act_mod_bwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "styled_bias_act_mod_bwd: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE(!x == !work_d && !noise == !work_s, "styled_bias_act_mod_bwd: x / work_d and noise / work_s come in pairs");
+  DG_REQUIRE((((uintptr_t)gy | (uintptr_t)gmod | (uintptr_t)y | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)demod | (uintptr_t)post |
+               (uintptr_t)work_d | (uintptr_t)work_b | (uintptr_t)work_p) & 15) == 0, "styled_bias_act_mod_bwd: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)y,
+                     (const f32x4*)x, demod, noise, (f32x4*)gx, work_d, work_b, work_s, P, C, chunks, noise_per_image, alpha, scale,
+                     (const float*)nullptr, (const f32x4*)gmod, post, work_p);
+  return check_launch("styled_bias_act_mod_bwd");
 }
 
 // see include/diagan_hip.h: the gate of bias + leaky ReLU from the PRE-activation z and the bias (sign of z + bias), bias gradient partials
@@ -493,7 +551,7 @@ DIAGAN_API int diagan_bias_act_gate_bwd(const float* gy, const float* z, const f
   const int chunks = diagan_rowdot_chunks(B, P);
   hipLaunchKernelGGL(styled_act_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)z,
                      (const f32x4*)nullptr, (const float*)nullptr, (const float*)nullptr, (f32x4*)gx, (float*)nullptr, work_b,
-                     (float*)nullptr, P, C, chunks, 0, alpha, scale, bias);
+                     (float*)nullptr, P, C, chunks, 0, alpha, scale, bias, (const f32x4*)nullptr, (const float*)nullptr, (float*)nullptr);
   return check_launch("bias_act_gate_bwd");
 }
 

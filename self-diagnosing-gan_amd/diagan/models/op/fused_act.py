@@ -198,6 +198,86 @@ class _StyledAct(Function):
         return gx, gd, None, gs, gb, None, None
 
 
+nat.register("diagan_styled_bias_act_mod", [P, P, P, P, P, P, P, P, I, I, I, I, F32, F32, P])
+nat.register("diagan_styled_bias_act_mod_bwd", [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, F32, F32, P])
+
+
+class _StyledActMod(Function):
+    """(y, y * post[b, c]) with y the StyledConv tail of x (see _StyledAct) in ONE launch: the next layer's modulated input leaves in
+    the pass that makes y (round 6).  First-order backward: ONE pass over gy (None when y has no other consumer) + g_mod * post --
+    gate, demodulated gradient, d(demod), d(bias), d(strength), d(post); otherwise the differentiable composition."""
+
+    @staticmethod
+    def forward(ctx, x, demod, noise, strength, bias, post, slope, scale):
+        b, h, w, c = x.shape
+        x, post = x.contiguous(), post.contiguous()
+        y, ym = torch.empty_like(x), torch.empty_like(x)
+        per_image = noise is not None and noise.shape[0] == b and b > 1
+        nat.call("diagan_styled_bias_act_mod", nat.ptr(x), nat.ptr(demod.contiguous()) if demod is not None else None,
+                 nat.ptr(noise.contiguous()) if noise is not None else None, nat.ptr(strength) if noise is not None else None,
+                 nat.ptr(bias) if bias is not None else None, nat.ptr(post), nat.ptr(y), nat.ptr(ym), b, h * w, c, 1 if per_image else 0,
+                 float(slope), float(scale), nat.current_stream())
+        ctx.save_for_backward(x, demod, noise, y, post)
+        ctx.hyper = (slope, scale)
+        ctx.set_materialize_grads(False)
+        return y, ym
+
+    @staticmethod
+    def backward(ctx, gy, gm):
+        x, demod, noise, y, post = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        slope, scale = ctx.hyper
+        if gm is None:                                     # only y was used: the plain tail's backward
+            if gy is None:
+                return (None,) * 8
+            gm_total, gp = gy, None
+        elif _fused_bwd_ok(gm):
+            b, h, w, c = gm.shape
+            gm = gm.contiguous()
+            gy = gy.contiguous() if gy is not None else None
+            chunks = nat.fn("diagan_rowdot_chunks")(b, h * w)
+            f32 = dict(dtype=torch.float32, device=gm.device)
+            want_d, want_s = demod is not None and need[1], noise is not None and need[3]
+            gx = torch.empty_like(gm) if need[0] else None
+            wd = torch.empty((b, chunks, c), **f32) if want_d else None
+            wb, wp = torch.empty((b * chunks, c), **f32), torch.empty((b, chunks, c), **f32)
+            per_image = noise is not None and noise.shape[0] == b and b > 1
+            ws = torch.empty(b * chunks, **f32) if want_s else None
+            st = nat.current_stream()
+            nat.call("diagan_styled_bias_act_mod_bwd", nat.ptr(gy), nat.ptr(gm), nat.ptr(post), nat.ptr(y),
+                     nat.ptr(x) if want_d else None, nat.ptr(demod.contiguous()) if demod is not None else None,
+                     nat.ptr(noise.contiguous()) if want_s else None, nat.ptr(gx), nat.ptr(wd), nat.ptr(wb), nat.ptr(ws), nat.ptr(wp),
+                     b, h * w, c, 1 if per_image else 0, float(slope), float(scale), st)
+            gd = torch.empty((b, c), **f32) if want_d else None
+            gb = torch.empty(c, **f32)
+            gs = torch.empty(1, **f32) if want_s else None
+            gp = torch.empty((b, c), **f32)
+            nat.call("diagan_styled_bias_act_bwd_finish", nat.ptr(wd), nat.ptr(wb), nat.ptr(ws), nat.ptr(gd), nat.ptr(gb), nat.ptr(gs),
+                     b, h * w, c, st)
+            nat.call("diagan_styled_bias_act_bwd_finish", nat.ptr(wp), None, None, nat.ptr(gp), None, None, b, h * w, c, st)
+            return gx, gd, None, gs, (gb if need[4] else None), (gp if need[5] else None), None, None
+        else:
+            gp = rowdot(gm, y) if need[5] else None
+            gm_total = scale_rows(gm, post)
+            if gy is not None:
+                gm_total = gm_total + gy
+        if _fused_bwd_ok(gm_total):
+            gx, gd, gb, gs = _fused_bwd(gm_total, y, x if (demod is not None and need[1]) else None, demod,
+                                        noise if need[3] else None, slope, scale, need_gx=need[0])
+            return gx, gd, None, gs, (gb if need[4] else None), gp, None, None
+        gpre = _LeakyGate.apply(gm_total, y, slope, scale)
+        gx = (scale_rows(gpre, demod) if demod is not None else gpre) if need[0] else None
+        gd = rowdot(gpre, x) if demod is not None and need[1] else None
+        gs = (gpre * noise).sum().reshape(1) if noise is not None and need[3] else None
+        gb = gpre.sum((0, 1, 2)) if need[4] else None
+        return gx, gd, None, gs, gb, gp, None, None
+
+
+def styled_bias_act_mod(x, demod, noise, strength, bias, post, negative_slope=0.2, scale=2 ** 0.5):
+    """(y, y * post[:, None, None, :]) with y = styled_bias_act(x, demod, noise, strength, bias); x [B,H,W,C] with C a multiple of 4"""
+    return _StyledActMod.apply(x, demod, noise, strength, bias, post, negative_slope, scale)
+
+
 def styled_bias_act(x, demod=None, noise=None, strength=None, bias=None, negative_slope=0.2, scale=2 ** 0.5):
     """x [B,H,W,C]; demod [B,C]; noise [B or 1, H, W, 1] with its scalar `strength` [1]; bias [C]"""
     return _StyledAct.apply(x, demod, noise, strength, bias, negative_slope, scale)

@@ -25,7 +25,8 @@ import torch.nn.functional as F
 from torch import nn
 
 from diagan.models.layers import FlatNet
-from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, scale_rows, styled_bias_act
+from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, scale_rows, styled_bias_act, styled_bias_act_mod
+from diagan.models.op import fused_tail as _tails
 from diagan.models.op.fused_tail import bias_act_add, bias_act_blur, blur_styled_act, blur_styled_act_ok, fork_fir, torgb, torgb_ok
 from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
@@ -266,8 +267,9 @@ class StyledConv(nn.Module):
         self.activate = _ChannelsLastLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None, s=None, premodulated=False, post=None):
-        """s / premodulated: see ModulatedConv2d.forward_parts; post [B, Co]: the NEXT layer's style, applied to the output on its way
-        out (only where nothing records a graph: generator forwards of the discriminator's step)"""
+        """s / premodulated: see ModulatedConv2d.forward_parts; post [B, Co]: the NEXT layer's style -- the result is then the pair
+        (y, y * post): that layer's modulated input leaves in this layer's tail pass (y is None where nothing needs it: no graph
+        recorded, and the caller of an up-sampling layer only wants the modulated output)"""
         # conv -> * demod -> + strength * noise -> + bias -> leaky ReLU * sqrt(2): the last four in one launch
         act = self.activate
         if self.conv.upsample and blur_styled_act_ok(input, self.conv.blur.kernel):
@@ -277,10 +279,16 @@ class StyledConv(nn.Module):
             oh, ow = (y.shape[1] + blur.pad[0] + blur.pad[1] - blur.kernel.shape[0] + 1,
                       y.shape[2] + blur.pad[0] + blur.pad[1] - blur.kernel.shape[1] + 1)
             nz = self.noise.draw_hw(y, y.shape[0], oh, ow, noise)
-            return blur_styled_act(y, blur.kernel, blur.pad, d, nz, self.noise.weight, act.bias, act.negative_slope, act.scale, post)
+            out = blur_styled_act(y, blur.kernel, blur.pad, d, nz, self.noise.weight, act.bias, act.negative_slope, act.scale, post)
+            return (None, out) if post is not None else out
         y, d = self.conv.forward_parts(input, style, s, premodulated)
-        out = styled_bias_act(y, d, self.noise.draw(y, noise), self.noise.weight, act.bias, act.negative_slope, act.scale)
-        return scale_rows(out, post) if post is not None else out
+        nz = self.noise.draw(y, noise)
+        if post is None:
+            return styled_bias_act(y, d, nz, self.noise.weight, act.bias, act.negative_slope, act.scale)
+        if y.is_cuda and y.shape[3] % 4 == 0:
+            return styled_bias_act_mod(y, d, nz, self.noise.weight, act.bias, post, act.negative_slope, act.scale)
+        out = styled_bias_act(y, d, nz, self.noise.weight, act.bias, act.negative_slope, act.scale)
+        return out, scale_rows(out, post)
 
 
 class ToRGB(nn.Module):
@@ -376,20 +384,33 @@ class StyleGANGenerator(FlatNet):
         # the per-layer styles latent[:, i] as contiguous views of ONE transposed copy: each strided select was a copy in the forward and,
         # in a backward that reaches the latents (path-length regularisation), a zero-filled [B, n_latent, 512] tensor + an add
         lat = latent.transpose(0, 1).contiguous().unbind(0)
-        out = self.conv1(self.input(latent), lat[0], noise=noise[0])
-        skip = self.to_rgb1(out, lat[1])
-        fuse = not torch.is_grad_enabled()
+        if not (_tails.FUSED_TAILS and len(self.to_rgbs)):
+            out = self.conv1(self.input(latent), lat[0], noise=noise[0])
+            skip = self.to_rgb1(out, lat[1])
+            for level, to_rgb in enumerate(self.to_rgbs):
+                i = 1 + 2 * level
+                out = self.convs[2 * level](out, lat[i], noise=noise[i])
+                out = self.convs[2 * level + 1](out, lat[i + 1], noise=noise[i + 1])
+                skip = to_rgb(out, lat[i + 2], skip)
+            return to_nchw(skip, 3), (latent if return_latents else None)
+        # Round 6: every styled layer hands its successor's style to its own tail, so the successor's modulated input leaves in the pass
+        # that makes the activation (and comes back, in the backward, as ONE pass: models/op/fused_act.py: _StyledActMod); ToRGB reads the
+        # un-modulated activation with its own style inside its kernel.  Same values, same order of random draws.
+        s_next = self.convs[0].conv.modulation(lat[1])
+        y, ym = self.conv1(self.input(latent), lat[0], noise=noise[0], post=s_next)
+        skip = self.to_rgb1(y, lat[1])
+        last = len(self.to_rgbs) - 1
         for level, to_rgb in enumerate(self.to_rgbs):
             i = 1 + 2 * level
             up, same = self.convs[2 * level], self.convs[2 * level + 1]
-            if fuse:     # the up-sampling layer's only consumer is `same`: its tail applies that layer's style on the way out
-                s2 = same.conv.modulation(lat[i + 1])
-                out = up(out, lat[i], noise=noise[i], post=s2)
-                out = same(out, lat[i + 1], noise=noise[i + 1], s=s2, premodulated=True)
+            s_up, s_same = s_next, same.conv.modulation(lat[i + 1])
+            _, xm = up(ym, lat[i], noise=noise[i], s=s_up, premodulated=True, post=s_same)
+            if level == last:
+                y = same(xm, lat[i + 1], noise=noise[i + 1], s=s_same, premodulated=True)
             else:
-                out = up(out, lat[i], noise=noise[i])
-                out = same(out, lat[i + 1], noise=noise[i + 1])
-            skip = to_rgb(out, lat[i + 2], skip)
+                s_next = self.convs[2 * level + 2].conv.modulation(lat[i + 2])
+                y, ym = same(xm, lat[i + 1], noise=noise[i + 1], s=s_same, premodulated=True, post=s_next)
+            skip = to_rgb(y, lat[i + 2], skip)
         return to_nchw(skip, 3), (latent if return_latents else None)
 
 

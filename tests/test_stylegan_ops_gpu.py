@@ -403,3 +403,44 @@ def test_fork_into_a_filter_accumulates_in_the_filters_pass(shape):
     for second in (False, True):
         for i, (p, q) in enumerate(zip(run(one, second), run(two, second))):
             assert torch.equal(p, q), f"second={second} output {i}: max diff {(p - q).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 33, 31, 128), (2, 16, 16, 512)])
+@pytest.mark.parametrize("noise_kind", ["per_image", "shared", "none"])
+@pytest.mark.parametrize("both", [True, False])
+def test_styled_tail_that_leaves_the_next_layers_modulated_input(shape, noise_kind, both):
+    """round 6: (y, y * post) from one launch and, in a plain backward, ONE pass for gate, gradient, d(demod), d(bias), d(strength),
+    d(post) from the two incoming gradients (`both` False: y has no consumer of its own) -- element-wise results bit-identical to
+    styled_bias_act followed by scale_rows, the per-channel sums to rounding; the differentiated backward against the same"""
+    from diagan.models.op import fused_act as FA
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape) + both)
+    vals = dict(x=torch.randn(B, H, W, C, generator=g), d=torch.rand(B, C, generator=g) + 0.5, s=torch.randn(1, generator=g),
+                b=torch.randn(C, generator=g), p=torch.randn(B, C, generator=g) + 1.0)
+    noise = {"per_image": torch.randn(B, H, W, 1, generator=g), "shared": torch.randn(1, H, W, 1, generator=g), "none": None}[noise_kind]
+    noise = noise.cuda() if noise is not None else None
+    c1 = torch.sin(torch.arange(B * H * W * C, dtype=torch.float32)).view(B, H, W, C).cuda()
+    c2 = torch.cos(torch.arange(B * H * W * C, dtype=torch.float32) * 0.7).view(B, H, W, C).cuda()
+    keys = ['x', 'd', 'b', 'p'] + (['s'] if noise is not None else [])
+
+    def run(fused, second):
+        t = {k: v.cuda().requires_grad_(True) for k, v in vals.items()}
+        st = t['s'] if noise is not None else None
+        if fused:
+            y, ym = FA.styled_bias_act_mod(t['x'], t['d'], noise, st, t['b'], t['p'])
+        else:
+            y = FA.styled_bias_act(t['x'], t['d'], noise, st, t['b'])
+            ym = FA.scale_rows(y, t['p'])
+        loss = (ym * c2).sum() + ((y * c1).sum() if both else 0.0)
+        if not second:
+            return [y.detach(), ym.detach()] + list(torch.autograd.grad(loss, [t[k] for k in keys]))
+        gx, = torch.autograd.grad(loss, [t['x']], create_graph=True)
+        return [gx.detach()] + list(torch.autograd.grad((gx.square() * c1).sum(), [t['d'], t['p']]))
+
+    for second in (False, True):
+        for i, (a, b) in enumerate(zip(run(True, second), run(False, second))):
+            exact = (not second and i < 3) or (second and i == 0)          # y, ym, gx: element-wise
+            if exact:
+                assert torch.equal(a, b), f"second={second} output {i}: {(a - b).abs().max().item():.3e}"
+            else:
+                assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-5, f"second={second} output {i}"
