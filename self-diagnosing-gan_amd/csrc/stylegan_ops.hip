@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
   const long total = (long)a.major * a.out_h * gx * q;
   const f32x4* __restrict__ in4 = reinterpret_cast<const f32x4*>(a.in);
   f32x4* __restrict__ out4 = reinterpret_cast<f32x4*>(a.out);
+  const bool slope01 = a.f_alpha > 0.f && a.f_alpha < 1.f;
   f32x4 gsum = {0.f, 0.f, 0.f, 0.f};          // FUSE 3: this lane's channel quad is the same on every trip (q divides the stride)
   for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
     const int c4 = (int)(o % q);
@@ -291,11 +292,25 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
       for (int u = 0; u < KW + (OXT - 1) * DOWN; ++u) {
         const int ix = bx + u;
         win[u] = (ix >= 0 && ix < a.in_w) ? row[(long)ix * q] : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (FUSE == 1 && ix >= 0 && ix < a.in_w) {      // (the padding is zeros of the ACTIVATED tensor; arithmetic of fused_bias_act_cl4_kernel)
-          f32x4 v = win[u] + pb;
+      }
+      if (FUSE == 1) {          // (a loop of its own, branch-free: the window's loads above stay back to back; the padding is zeros of the
+                                //  ACTIVATED tensor; values of fused_bias_act_cl4_kernel)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.f_alpha;
-          win[u] = v * a.f_scale;
+        for (int u = 0; u < KW + (OXT - 1) * DOWN; ++u) {
+          const int ix = bx + u;
+          f32x4 v = win[u] + pb;
+          if (slope01) {        // 0 < slope < 1: v > 0 ? v : v * slope == max(v, v * slope)
+            const f32x4 vs = v * a.f_alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], vs[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.f_alpha;
+          }
+          v = v * a.f_scale;
+          const bool in = ix >= 0 && ix < a.in_w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) win[u][e] = in ? v[e] : 0.f;
         }
       }
       const float* kr = taps + (a.kh - 1 - dy) * KW;
