@@ -636,6 +636,17 @@ int diagan_styled_bias_act_mod_bwd(const float* gy, const float* gmod, const flo
 int diagan_torgb_fwd(const float* x, const float* s, const float* w, const float* bias, float* out, int B, int P, int C, void* stream);
 int diagan_torgb_bwd(const float* gy, const float* x, const float* s, const float* w, float* gx, float* work, float* gs, float* gw, int B,
                      int P, int C, void* stream);
+/* Round 6: the discriminator's first ConvLayer (reference stylegan2.py:553-595: EqualConv2d 3 -> C, 1x1, + FusedLeakyReLU) as ONE write
+ * of its output, and its first-order backward as one read of gy and y:
+ *   diagan_fromrgb_fwd   y[b][p][c] = leaky_relu(wscale * sum_{i<3} w[c][i] * x[b][p][i] + bias[c]) * scale;  x [B][P][4] (RGB + a zero
+ *                        plane), w [C][3] (the raw parameter), bias [C] or NULL; C a power of two in [4, 1024]
+ *   diagan_fromrgb_bwd   gz = gy * scale * (y > 0 ? 1 : alpha); work[blk][i][c] = sum_p gz * x[..][i] (i < 3) and sum_p gz (i = 3) for the
+ *                        B * diagan_rowdot_chunks(B, P) blocks (finish: diagan_styled_bias_act_bwd_finish over 4 * C columns);
+ *                        gx[b][p][0..2] = wscale * sum_c gz * w[c][i] when gx is not NULL; C <= 256 */
+int diagan_fromrgb_fwd(const float* x, const float* w, const float* bias, float* y, int B, int P, int C, float wscale, float alpha,
+                       float scale, void* stream);
+int diagan_fromrgb_bwd(const float* gy, const float* y, const float* x, const float* w, float* gx, float* work, int B, int P, int C,
+                       float wscale, float alpha, float scale, void* stream);
 int diagan_bias_act_fir(const float* input, const float* bias, const float* kernel, float* out, int major, int in_h, int in_w, int minor,
                         int kernel_h, int kernel_w, int pad_x0, int pad_x1, int pad_y0, int pad_y1, float alpha, float scale,
                         void* stream);

@@ -893,6 +893,124 @@ __global__ __launch_bounds__(256) void torgb_finish_kernel(const float* __restri
   }
 }
 
+// ---- FromRGB in one pass (round 6) ----------------------------------------------------------------------------------------------------
+// The discriminator's first ConvLayer (reference stylegan2.py:553-595, :616-640: EqualConv2d 3 -> C, 1x1, then FusedLeakyReLU):
+//   y[b,p,c] = leaky_relu(sum_{i<3} w[c][i] * wscale * x[b,p,i] + bias[c]) * scale
+// As implicit GEMM (K = 4) + activation pass it writes the full-resolution C-channel tensor, reads it and writes it again; the backward
+// reads gy and y, writes the gated gradient, and reads that again for the weight gradient.  Here: ONE write forward; backward one read of gy
+// and y:  gz = gy * scale * (y > 0 ? 1 : alpha);  work[blk][i][c] = sum_p gz * x[.,i] (i < 3: d(w) / wscale), work[blk][3][c] = sum_p gz
+// (d(bias));  gx[b,p,i] = wscale * sum_c gz[c] * w[c][i] (only when the images need a gradient: the generator's step).
+__global__ __launch_bounds__(256) void fromrgb_fwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                          f32x4* __restrict__ y, long npix, int C, float wscale, float alpha, float scale) {
+  const int q = C >> 2;
+  const long total = npix * q, stride = (long)gridDim.x * 256;
+  long o = (long)blockIdx.x * 256 + threadIdx.x;
+  const int cq = (int)(o % q);                     // (q divides the stride: the lane's channel quad never changes)
+  f32x4 wr[3], bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[i][e] = w[(cq * 4 + e) * 3 + i] * wscale;
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+  for (; o < total; o += stride) {
+    const f32x4 xv = x[o / q];
+    f32x4 v = xv[0] * wr[0];
+    v += xv[1] * wr[1];
+    v += xv[2] * wr[2];
+    v += bv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * alpha) * scale;
+    y[o] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void fromrgb_bwd_kernel(const f32x4* __restrict__ gy, const f32x4* __restrict__ y, const f32x4* __restrict__ x,
+                                                          const float* __restrict__ w, f32x4* __restrict__ gx, float* __restrict__ work,
+                                                          int P, int C, int chunks, float wscale, float alpha, float scale) {
+  __shared__ f32x4 red[256];
+  const int q = C >> 2, lanes = 256 / q;
+  const int cq = threadIdx.x % q, pl = threadIdx.x / q;
+  const int img = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+  const int per = (P + chunks - 1) / chunks;
+  const int p0 = ch * per, p1 = min(p0 + per, P);
+  f32x4 wr[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wr[i][e] = w[(cq * 4 + e) * 3 + i] * wscale;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long base = (long)img * P * q + cq;
+  const int iters = (p1 - p0 + lanes - 1) / lanes;       // (block-uniform trip count: the lane exchange below needs every lane of a pixel)
+  for (int it = 0; it < iters; ++it) {
+    const int p = p0 + it * lanes + pl;
+    const bool ok = p < p1;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, xv = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const long i = base + (long)p * q;
+      g = gy[i];
+      const f32x4 r = y[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = g[e] * (r[e] > 0.f ? scale : scale * alpha);
+      xv = x[(long)img * P + p];
+    }
+    acc[0] += g * xv[0];
+    acc[1] += g * xv[1];
+    acc[2] += g * xv[2];
+    acc[3] += g;
+    if (gx) {                                            // (block-uniform; q <= 64: one pixel's lanes sit in one wave)
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        t0 = fmaf(g[e], wr[0][e], t0);
+        t1 = fmaf(g[e], wr[1][e], t1);
+        t2 = fmaf(g[e], wr[2][e], t2);
+      }
+      t0 = group_sum_last(t0, q);
+      t1 = group_sum_last(t1, q);
+      t2 = group_sum_last(t2, q);
+      if (ok && cq == q - 1) gx[(long)img * P + p] = f32x4{t0, t1, t2, 0.f};
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __syncthreads();
+    red[threadIdx.x] = acc[i];
+    __syncthreads();
+    if (pl == 0) {
+      f32x4 t = red[cq];
+      for (int l = 1; l < lanes; ++l) t += red[l * q + cq];
+      *reinterpret_cast<f32x4*>(work + ((long)blockIdx.x * 4 + i) * C + cq * 4) = t;
+    }
+  }
+}
+
+// see include/diagan_hip.h
+DIAGAN_API int diagan_fromrgb_fwd(const float* x, const float* w, const float* bias, float* y, int B, int P, int C, float wscale, float alpha,
+                                  float scale, void* stream) {
+  DG_REQUIRE(x && w && y && B > 0 && P > 0, "fromrgb_fwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 1024 && (C & (C - 1)) == 0, "fromrgb_fwd: C=%d must be a power of two in [4, 1024]", C);
+  DG_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) & 15) == 0, "fromrgb_fwd: pointers must be 16-byte aligned");
+  const long npix = (long)B * P, total = npix * (C / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(fromrgb_fwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)x, w, bias, (f32x4*)y, npix, C,
+                     wscale, alpha, scale);
+  return check_launch("fromrgb_fwd");
+}
+
+DIAGAN_API int diagan_fromrgb_bwd(const float* gy, const float* y, const float* x, const float* w, float* gx, float* work, int B, int P, int C,
+                                  float wscale, float alpha, float scale, void* stream) {
+  DG_REQUIRE(gy && y && x && w && work && B > 0 && P > 0, "fromrgb_bwd: bad args");
+  DG_REQUIRE(C >= 4 && C <= 256 && (C & (C - 1)) == 0, "fromrgb_bwd: C=%d must be a power of two in [4, 256]", C);
+  DG_REQUIRE((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)x | (uintptr_t)gx | (uintptr_t)work) & 15) == 0, "fromrgb_bwd: pointers must be 16-byte aligned");
+  const int chunks = diagan_rowdot_chunks(B, P);
+  hipLaunchKernelGGL(fromrgb_bwd_kernel, dim3(B * chunks), dim3(256), 0, (hipStream_t)stream, (const f32x4*)gy, (const f32x4*)y, (const f32x4*)x,
+                     w, (f32x4*)gx, work, P, C, chunks, wscale, alpha, scale);
+  return check_launch("fromrgb_bwd");
+}
+
 static int torgb_nq(int C) { return C <= 256 ? 1 : C / 256; }
 
 // see include/diagan_hip.h

@@ -264,3 +264,67 @@ def fork_fir(x, kernel, up=1, down=1, pad=(0, 0)):
         return x, upfirdn2d_nhwc(x, kernel, up=up, down=down, pad=pad)
     plan = _Plan.forward_plan(kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]), x.shape[1:3], channels_last=True)
     return _ForkFIR.apply(x, plan)
+
+
+# ---- the discriminator's first layer (1x1 convolution from RGB + bias + leaky ReLU) in one write of its output --------------------------
+nat.register("diagan_fromrgb_fwd", [P, P, P, P, I, I, I, F32, F32, F32, P])
+nat.register("diagan_fromrgb_bwd", [P, P, P, P, P, P, I, I, I, F32, F32, F32, P])
+
+
+def fromrgb_ok(x, weight, bias):
+    c = weight.shape[0]
+    return (FUSED_TAILS and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[3] == 4 and bias is not None
+            and tuple(weight.shape[1:]) == (3, 1, 1) and 4 <= c <= 256 and not (c & (c - 1)))
+
+
+class _FromRGB(Function):
+    """y = leaky_relu(conv1x1(x[..., :3], weight * wscale) + bias) * scale on x [B,H,W,4] (RGB + zero plane): the reference's first
+    ConvLayer (stylegan2.py:553-595) in one write of y.  Plain backward: ONE read of gy and y for the gate, d(weight), d(bias) and -- when
+    the images need it -- d(x); differentiated backward: gate + convolution ops of ops/diffconv.py (any order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wscale, slope, scale):
+        b, h, w, _ = x.shape
+        c = weight.shape[0]
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        y = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+        nat.call("diagan_fromrgb_fwd", nat.ptr(x), nat.ptr(weight), nat.ptr(bias), nat.ptr(y), b, h * w, c, float(wscale), float(slope),
+                 float(scale), nat.current_stream())
+        ctx.save_for_backward(x, weight, y)
+        ctx.hyper = (wscale, slope, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        wscale, slope, scale = ctx.hyper
+        need = ctx.needs_input_grad
+        b, h, w, c = gy.shape
+        if not torch.is_grad_enabled():
+            gy = gy.contiguous()
+            f32 = dict(dtype=torch.float32, device=gy.device)
+            chunks = nat.fn("diagan_rowdot_chunks")(b, h * w)
+            work = torch.empty((b * chunks, 4 * c), **f32)
+            gx = torch.empty_like(x) if need[0] else None
+            st = nat.current_stream()
+            nat.call("diagan_fromrgb_bwd", nat.ptr(gy), nat.ptr(y), nat.ptr(x), nat.ptr(weight), nat.ptr(gx), nat.ptr(work), b, h * w, c,
+                     float(wscale), float(slope), float(scale), st)
+            sums = torch.empty(4 * c, **f32)
+            nat.call("diagan_styled_bias_act_bwd_finish", None, nat.ptr(work), None, None, nat.ptr(sums), None, b, h * w, 4 * c, st)
+            sums = sums.view(4, c)
+            gw = (sums[:3].t() * wscale).reshape(c, 3, 1, 1) if need[1] else None
+            return gx, gw, (sums[3] if need[2] else None), None, None, None
+        from diagan.ops import diffconv as dc
+        from diagan.ops import conv as K
+        geom = K.Geom('conv', 4, c, 1, 1, 1, 0)
+        gz = FA._LeakyGate.apply(gy, y, slope, scale)
+        wp = dc.pack_scaled(weight, wscale, geom)
+        gx = dc._DataGrad.apply(gz, wp, geom, (h, w)) if need[0] else None
+        gw = dc._UnpackScaled.apply(dc._WeightGrad.apply(gz, x, geom), wscale, geom, tuple(weight.shape)) if need[1] else None
+        gb = gz.sum((0, 1, 2)) if need[2] else None
+        return gx, gw, gb, None, None, None
+
+
+def fromrgb(x, weight, bias, wscale, negative_slope=0.2, scale=2 ** 0.5):
+    """x [B,H,W,4], weight [C,3,1,1], bias [C] -> [B,H,W,C]"""
+    return _FromRGB.apply(x, weight, bias, wscale, negative_slope, scale)

@@ -27,7 +27,8 @@ from torch import nn
 from diagan.models.layers import FlatNet
 from diagan.models.op.fused_act import FusedLeakyReLU, fused_leaky_relu, scale_rows, styled_bias_act, styled_bias_act_mod
 from diagan.models.op import fused_tail as _tails
-from diagan.models.op.fused_tail import bias_act_add, bias_act_blur, blur_styled_act, blur_styled_act_ok, fork_fir, torgb, torgb_ok
+from diagan.models.op.fused_tail import (bias_act_add, bias_act_blur, blur_styled_act, blur_styled_act_ok, fork_fir, fromrgb, fromrgb_ok,
+                                         torgb, torgb_ok)
 from diagan.models.op.upfirdn2d import upfirdn2d_nhwc
 from diagan.ops import diffconv as dc
 
@@ -486,7 +487,15 @@ class StyleGANDiscriminator(FlatNet):
         return torch.cat([x, sd] + ([x.new_zeros(b, h, w, pad)] if pad else []), 3)
 
     def forward(self, input):
-        out = self.convs(to_nhwc(input))
+        out = to_nhwc(input)
+        blocks = list(self.convs)
+        first = blocks[0]
+        if len(first) == 2 and isinstance(first[0], EqualConv2d) and first[0].bias is None and fromrgb_ok(out, first[0].weight, first[1].bias):
+            # the 1x1 convolution from RGB, its bias and activation as ONE write of the full-resolution tensor (round 6)
+            out = fromrgb(out, first[0].weight, first[1].bias, first[0].scale, first[1].negative_slope, first[1].scale)
+            blocks = blocks[1:]
+        for blk in blocks:
+            out = blk(out)
         out = self.final_conv(self.minibatch_stddev(out))
         out = self.final_linear[0].forward_spatial(out)
         return self.final_linear[1](out)

@@ -444,3 +444,44 @@ def test_styled_tail_that_leaves_the_next_layers_modulated_input(shape, noise_ki
                 assert torch.equal(a, b), f"second={second} output {i}: {(a - b).abs().max().item():.3e}"
             else:
                 assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max()) + 1e-5, f"second={second} output {i}"
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 6, 8), (2, 33, 31, 128), (2, 16, 16, 256), (1, 7, 9, 4)])
+@pytest.mark.parametrize("need_gx", [True, False])
+def test_fromrgb_in_one_pass(shape, need_gx):
+    """round 6: the discriminator's first ConvLayer (1x1 convolution from RGB, bias, leaky ReLU * sqrt 2) as one write of its output; the
+    plain backward as one read of gy and y; a differentiated backward (R1: gradient with respect to the images, then through it) as
+    gate + convolution ops -- against float64"""
+    from diagan.models.op import fused_tail as FT
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    vals = dict(x=torch.nn.functional.pad(torch.randn(B, H, W, 3, generator=g), (0, 1)), w=torch.randn(C, 3, 1, 1, generator=g),
+                b=torch.randn(C, generator=g))
+    wscale = 3 ** -0.5
+    cot = torch.sin(torch.arange(B * H * W * C, dtype=torch.float64).view(B, H, W, C))
+
+    def ref(second):
+        t = {k: v.double().requires_grad_(True) for k, v in vals.items()}
+        y = torch.nn.functional.leaky_relu(torch.einsum('bhwi,ci->bhwc', t['x'][..., :3], t['w'].view(C, 3) * wscale) + t['b'], 0.2) * 2 ** 0.5
+        if not second:
+            gr = torch.autograd.grad((y * cot).sum(), [t['w'], t['b']] + ([t['x']] if need_gx else []))
+            return [y.detach()] + [v if v.shape[-1] != 4 or v.dim() != 4 else v[..., :3] for v in gr]
+        gx, = torch.autograd.grad((y * cot).sum(), [t['x']], create_graph=True)
+        return [y.detach()] + list(torch.autograd.grad(gx[..., :3].square().sum(), [t['w']]))
+
+    def ours(second):
+        t = {k: v.cuda().requires_grad_(k != 'x' or need_gx or second) for k, v in vals.items()}
+        assert FT.fromrgb_ok(t['x'], t['w'], t['b'])
+        y = FT.fromrgb(t['x'], t['w'], t['b'], wscale)
+        if not second:
+            gr = torch.autograd.grad((y * cot.float().cuda()).sum(), [t['w'], t['b']] + ([t['x']] if need_gx else []))
+            gr = [v if v.dim() != 4 or v.shape[-1] != 4 else v[..., :3] for v in gr]
+        else:
+            gx, = torch.autograd.grad((y * cot.float().cuda()).sum(), [t['x']], create_graph=True)
+            gr = torch.autograd.grad(gx[..., :3].square().sum(), [t['w']])
+        return [y.detach().double().cpu()] + [v.detach().double().cpu() for v in gr]
+
+    for second in (False, True):
+        for i, (a, b) in enumerate(zip(ours(second), ref(second))):
+            sc = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 3e-5 * sc + 1e-6, f"second={second} output {i}: {float((a - b).abs().max()):.3e} of {sc:.3e}"
