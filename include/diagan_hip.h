@@ -603,6 +603,21 @@ int diagan_styled_bias_act_bwd(const float* gy, const float* y, const float* x, 
 int diagan_styled_bias_act_bwd_finish(const float* work_d, const float* work_b, const float* work_s, float* gd, float* gb, float* gs, int B,
                                       int P, int C, void* stream);
 
+/* Round 6: the small dense pieces of the modulated convolution as single launches (csrc/stylegan_dense.hip; reference stylegan2.py:132-166
+ * EqualLinear, :236-238 the demodulation), each with its first-order backward:
+ *   diagan_small_linear_fwd  out[b][c] = scale * sum_k W[c][k] * x[b][k] + bias[c] * bias_mul   (x [B][K], W [C][K], K % 4 == 0; bias may be NULL)
+ *   diagan_small_linear_bwd  gW [C][K], gbias [C] (may be NULL), gx [B][K] (may be NULL) from g [B][C]
+ *   diagan_demod_fwd         wsq[co][ci] = sum_taps w[co][ci][tap]^2;  d[b][co] = rsqrt(scale2 * sum_ci s[b][ci]^2 * wsq[co][ci] + eps)
+ *   diagan_demod_bwd         gw (shape of w) and gs [B][Ci] (may be NULL) from gd [B][Co]; B <= 64 */
+int diagan_small_linear_fwd(const float* x, const float* W, const float* bias, float* out, int B, int K, int C, float scale, float bias_mul,
+                            void* stream);
+int diagan_small_linear_bwd(const float* g, const float* x, const float* W, float* gW, float* gbias, float* gx, int B, int K, int C,
+                            float scale, float bias_mul, void* stream);
+int diagan_demod_fwd(const float* s, const float* w, float* d, float* wsq, int B, int Ci, int Co, int taps, float scale2, float eps,
+                     void* stream);
+int diagan_demod_bwd(const float* gd, const float* d, const float* s, const float* w, const float* wsq, float* gw, float* gs, int B, int Ci,
+                     int Co, int taps, float scale2, void* stream);
+
 /* Round 6: the StyledConv tail that also leaves the NEXT layer's modulated input (out_mod = out * post[b][c]: that layer's
  * scale_rows) in the same pass, and its first-order backward: the incoming gradient is gy (may be NULL: out has no other consumer)
  * + gmod * post; everything diagan_styled_bias_act_bwd computes from it, plus work_p[blk][c] = sum_p gmod * y -> d(post) (finish:

@@ -328,3 +328,110 @@ class _FromRGB(Function):
 def fromrgb(x, weight, bias, wscale, negative_slope=0.2, scale=2 ** 0.5):
     """x [B,H,W,4], weight [C,3,1,1], bias [C] -> [B,H,W,C]"""
     return _FromRGB.apply(x, weight, bias, wscale, negative_slope, scale)
+
+
+# ---- the small dense pieces of the modulated convolution as single launches (csrc/stylegan_dense.hip) ----------------------------------
+nat.register("diagan_small_linear_fwd", [P, P, P, P, I, I, I, F32, F32, P])
+nat.register("diagan_small_linear_bwd", [P, P, P, P, P, P, I, I, I, F32, F32, P])
+nat.register("diagan_demod_fwd", [P, P, P, P, I, I, I, I, F32, F32, P])
+nat.register("diagan_demod_bwd", [P, P, P, P, P, P, P, I, I, I, I, F32, P])
+
+FUSED_DENSE = os.environ.get("DIAGAN_SG2_FUSED_DENSE", "1") != "0"
+
+
+def _vjp_any_order(fn, inputs, cotangent, need):
+    """gradients of fn(*inputs) for a backward that is itself being differentiated: fn is recomputed from the saved (graph-connected)
+    tensors with differentiable ops and differentiated with create_graph"""
+    with torch.enable_grad():
+        out = fn(*inputs)
+        wanted = [t for t, n in zip(inputs, need) if n and t is not None and t.requires_grad]
+        grads = iter(torch.autograd.grad(out, wanted, cotangent, create_graph=True, allow_unused=True)) if wanted else iter(())
+    return [next(grads) if (n and t is not None and t.requires_grad) else None for t, n in zip(inputs, need)]
+
+
+class _ModLinear(Function):
+    """EqualLinear without activation (reference stylegan2.py:132-166): x @ (W * scale).T + bias * lr_mul in one launch; plain backward
+    in one launch (d(W), d(bias), d(x))"""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, scale, lr_mul):
+        x, W = x.contiguous(), W.contiguous()
+        b, k = x.shape
+        c = W.shape[0]
+        out = torch.empty((b, c), dtype=torch.float32, device=x.device)
+        nat.call("diagan_small_linear_fwd", nat.ptr(x), nat.ptr(W), nat.ptr(bias.contiguous()) if bias is not None else None, nat.ptr(out),
+                 b, k, c, float(scale), float(lr_mul), nat.current_stream())
+        ctx.save_for_backward(x, W, bias)
+        ctx.hyper = (scale, lr_mul)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, bias = ctx.saved_tensors
+        scale, lr_mul = ctx.hyper
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            from diagan.ops import diffconv as dc
+            fn = lambda x_, W_, b_: dc.linear(x_, W_, scale=scale) + (b_ * lr_mul if b_ is not None else 0.0)       # noqa: E731
+            return tuple(_vjp_any_order(fn, (x, W, bias), g, need[:3])) + (None, None)
+        b, k = x.shape
+        c = W.shape[0]
+        g = g.contiguous()
+        f32 = dict(dtype=torch.float32, device=g.device)
+        gW = torch.empty_like(W)
+        gb = torch.empty(c, **f32) if (bias is not None and need[2]) else None
+        gx = torch.empty_like(x) if need[0] else None
+        nat.call("diagan_small_linear_bwd", nat.ptr(g), nat.ptr(x), nat.ptr(W), nat.ptr(gW), nat.ptr(gb), nat.ptr(gx), b, k, c, float(scale),
+                 float(lr_mul), nat.current_stream())
+        return gx, (gW if need[1] else None), gb, None, None
+
+
+def mod_linear_ok(x, W):
+    return FUSED_DENSE and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[1] % 4 == 0 and W.dim() == 2
+
+
+def mod_linear(x, W, bias, scale, lr_mul=1.0):
+    return _ModLinear.apply(x, W, bias, scale, lr_mul)
+
+
+class _Demod(Function):
+    """d[b, co] = rsqrt(scale^2 * sum_ci s[b, ci]^2 * sum_taps w[co, ci, :, :]^2 + eps) (reference stylegan2.py:236-238, as a [B,Ci] x [Ci,Co]
+    product) in one launch; plain backward (d(s), d(w)) in one launch"""
+
+    @staticmethod
+    def forward(ctx, s, w, scale2, eps):
+        s, w = s.contiguous(), w.contiguous()
+        b, ci = s.shape
+        co, taps = w.shape[0], w.shape[2] * w.shape[3]
+        f32 = dict(dtype=torch.float32, device=s.device)
+        d, wsq = torch.empty((b, co), **f32), torch.empty((co, ci), **f32)
+        nat.call("diagan_demod_fwd", nat.ptr(s), nat.ptr(w), nat.ptr(d), nat.ptr(wsq), b, ci, co, taps, float(scale2), float(eps),
+                 nat.current_stream())
+        ctx.save_for_backward(s, w, d, wsq)
+        ctx.hyper = (scale2, eps)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        s, w, d, wsq = ctx.saved_tensors
+        scale2, eps = ctx.hyper
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled() or s.shape[0] > 64:
+            from diagan.ops import diffconv as dc
+            fn = lambda s_, w_: torch.rsqrt(dc.linear(s_.square(), w_.square().sum((2, 3)), scale=scale2) + eps)       # noqa: E731
+            return tuple(_vjp_any_order(fn, (s, w), gd, need[:2])) + (None, None)
+        b, ci = s.shape
+        co, taps = w.shape[0], w.shape[2] * w.shape[3]
+        gw = torch.empty_like(w)
+        gs = torch.empty_like(s) if need[0] else None
+        nat.call("diagan_demod_bwd", nat.ptr(gd.contiguous()), nat.ptr(d), nat.ptr(s), nat.ptr(w), nat.ptr(wsq), nat.ptr(gw), nat.ptr(gs),
+                 b, ci, co, taps, float(scale2), nat.current_stream())
+        return gs, (gw if need[1] else None), None, None
+
+
+def demod_ok(s, w):
+    return FUSED_DENSE and s.is_cuda and s.dtype == torch.float32 and w.dim() == 4 and s.dim() == 2 and w.shape[1] == s.shape[1]
+
+
+def demod(s, w, scale2, eps):
+    return _Demod.apply(s, w, scale2, eps)

@@ -161,6 +161,9 @@ class EqualLinear(nn.Module):
         return out + bias if bias is not None else out
 
     def forward(self, input):
+        if not self.activation and _tails.mod_linear_ok(input, self.weight):
+            # product, equalised-learning-rate scale and bias in one launch (round 6; the styles' modulation layers come here)
+            return _tails.mod_linear(input, self.weight, self.bias, self.scale, self.lr_mul)
         return self._finish(dc.linear(input, self.weight, scale=self.scale))
 
     def forward_spatial(self, x):
@@ -220,7 +223,12 @@ class ModulatedConv2d(nn.Module):
         else:
             y = dc.conv2d(x, w, stride=1, padding=self.padding, scale=self.scale)
         # demodulation 1 / sqrt(sum_ci s^2 sum_taps (scale w)^2 + eps) as a [B,Ci] x [Ci,Co] product
-        d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3)), scale=self.scale ** 2) + self.eps) if self.demodulate else None
+        if not self.demodulate:
+            d = None
+        elif _tails.demod_ok(s, w):
+            d = _tails.demod(s, w, self.scale ** 2, self.eps)                                   # (one launch: models/op/fused_tail.py)
+        else:
+            d = torch.rsqrt(dc.linear(s.square(), w.square().sum((2, 3)), scale=self.scale ** 2) + self.eps)
         return y, d
 
     def __repr__(self):

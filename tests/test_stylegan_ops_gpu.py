@@ -485,3 +485,58 @@ def test_fromrgb_in_one_pass(shape, need_gx):
         for i, (a, b) in enumerate(zip(ours(second), ref(second))):
             sc = float(b.abs().max()) + 1e-12
             assert float((a - b).abs().max()) <= 3e-5 * sc + 1e-6, f"second={second} output {i}: {float((a - b).abs().max()):.3e} of {sc:.3e}"
+
+
+@pytest.mark.parametrize("B,K,C,lr_mul", [(32, 512, 512, 1.0), (16, 512, 128, 1.0), (5, 64, 3, 0.01), (40, 512, 1, 1.0)])
+def test_small_linear_in_one_launch(B, K, C, lr_mul):
+    """round 6: EqualLinear without activation (the styles' modulation layers) as one launch, plain backward one launch, a differentiated
+    backward through the recomputed differentiable form -- against float64"""
+    from diagan.models.op import fused_tail as FT
+    g = torch.Generator().manual_seed(B + K + C)
+    vals = dict(x=torch.randn(B, K, generator=g), w=torch.randn(C, K, generator=g), b=torch.randn(C, generator=g))
+    scale = K ** -0.5 * lr_mul
+    cot = torch.sin(torch.arange(B * C, dtype=torch.float64).view(B, C))
+
+    def run(dev, dt, second):
+        t = {k: v.to(dev, dt).requires_grad_(True) for k, v in vals.items()}
+        if dev == "cuda":
+            y = FT.mod_linear(t['x'], t['w'], t['b'], scale, lr_mul)
+        else:
+            y = t['x'] @ (t['w'] * scale).t() + t['b'] * lr_mul
+        c = cot.to(dev, dt)
+        if not second:
+            return [y.detach()] + list(torch.autograd.grad((y * c).sum(), [t['x'], t['w'], t['b']]))
+        gx, = torch.autograd.grad((y * c).sum(), [t['x']], create_graph=True)
+        return [y.detach()] + list(torch.autograd.grad(gx.square().sum(), [t['w']]))
+    for second in (False, True):
+        for i, (a, b) in enumerate(zip(run("cuda", torch.float32, second), run("cpu", torch.float64, second))):
+            sc = float(b.abs().max()) + 1e-12
+            assert float((a.double().cpu() - b).abs().max()) <= 2e-5 * sc + 1e-6, f"second={second} output {i}"
+
+
+@pytest.mark.parametrize("B,Ci,Co,k", [(32, 512, 512, 3), (16, 256, 128, 3), (3, 8, 12, 1), (7, 64, 4, 3)])
+def test_demodulation_in_one_launch(B, Ci, Co, k):
+    """round 6: d = rsqrt(scale^2 * (s^2) @ (sum_taps w^2).T + eps) as one launch forward, one backward (d(s), d(w)); the differentiated
+    backward through the recomputed differentiable form -- against float64"""
+    from diagan.models.op import fused_tail as FT
+    g = torch.Generator().manual_seed(B + Ci + Co)
+    vals = dict(s=torch.randn(B, Ci, generator=g) + 1.0, w=torch.randn(Co, Ci, k, k, generator=g))
+    scale2, eps = 1.0 / (Ci * k * k), 1e-8
+    cot = torch.sin(torch.arange(B * Co, dtype=torch.float64).view(B, Co))
+
+    def run(dev, dt, second):
+        t = {kk: v.to(dev, dt).requires_grad_(True) for kk, v in vals.items()}
+        if dev == "cuda":
+            assert FT.demod_ok(t['s'], t['w'])
+            d = FT.demod(t['s'], t['w'], scale2, eps)
+        else:
+            d = torch.rsqrt(t['s'].square() @ t['w'].square().sum((2, 3)).t() * scale2 + eps)
+        c = cot.to(dev, dt)
+        if not second:
+            return [d.detach()] + list(torch.autograd.grad((d * c).sum(), [t['s'], t['w']]))
+        gs, = torch.autograd.grad((d * c).sum(), [t['s']], create_graph=True)
+        return [d.detach()] + list(torch.autograd.grad(gs.square().sum(), [t['w'], t['s']]))
+    for second in (False, True):
+        for i, (a, b) in enumerate(zip(run("cuda", torch.float32, second), run("cpu", torch.float64, second))):
+            sc = float(b.abs().max()) + 1e-12
+            assert float((a.double().cpu() - b).abs().max()) <= 5e-5 * sc + 1e-6, f"second={second} output {i}: {float((a.double().cpu() - b).abs().max()):.3e} of {sc:.3e}"
