@@ -6,6 +6,9 @@ What is restated and from where:
     files diagan-pkg/diagan/models/mnist.py:47-80,155-223, gold_reweight_models.py:10-61,
     topk_models.py:15-38.  PINNED: tests/golden/dcgan.npz + losses.npz were produced by running
     those reference classes (torch_mimicry stubbed) and this file reproduces them.
+    The base generator STEP (_BaseG.train_step below) has a second witness since round 6: dcgan.npz's
+    `gstep_*` entries were written with the reference's own in-tree restatement of the step executing
+    (mnist.py:82-152; tools/gen_goldens_models.py), and tests/test_oracle_models.py holds this file's step to them.
   * SNGAN generators / discriminators (32, 64), GBlock / DBlock / DBlockOptimized, SNConv2d /
     SNLinear, base losses, base train steps: these live in torch-mimicry==0.1.16
     (requirements.txt:72), which is NOT in /root/reference and not installable here.  They are

@@ -96,3 +96,37 @@ def test_gold_losses_and_topk(golden_dir):
         t.decay_topk_rate(int(s), epoch_steps=782)
         got.append(t.topk_rate)
     assert got == list(g["topk_rates"])
+
+
+def test_generator_train_step_against_the_references_own_step(golden_dir):
+    """Second, independent witness for the base generator step: the fixture's `gstep_*` entries were written with the
+    reference's OWN in-tree restatement of the step executing (`diagan-pkg/diagan/models/mnist.py:82-152`: zero_grad, generate_images,
+    netD, get_topk, compute_gan_loss, backward, optG.step, log -- tools/gen_goldens_models.py), top-k rate 0.75 (4 of 6 logits selected),
+    Adam(2e-4, (0, 0.9)).  The oracle's hand-written step (oracle/nets.py: _BaseG.train_step) must give the same loss, gradients and
+    post-Adam parameters from the same seeds."""
+    g = np.load(os.path.join(golden_dir, "dcgan.npz"))
+    torch.manual_seed(11)
+    netG = O.MNIST_DCGAN_Generator(loss_type='ns', topk=True)
+    netD = O.MNIST_DCGAN_Discriminator(loss_type='ns')
+    O.MNIST_DCGAN_Discriminator(loss_type='hinge', num_pack=2)          # (the fixture's third network: same consumption of the seed)
+    gen = torch.Generator().manual_seed(5)
+    torch.randn(6, 100, generator=gen)
+    x = torch.rand(6, 3, 32, 32, generator=gen) * 2 - 1
+    netG.train(), netD.eval()
+    optG = torch.optim.Adam(netG.parameters(), 2e-4, betas=(0.0, 0.9))
+    torch.manual_seed(77)
+    errG = netG.train_step((x,), netD, optG, topk_rate=0.75)
+    assert abs(errG - float(g["gstep_errG"])) < 1e-6
+    expand_check(netG.fc.weight.grad.numpy(), g["gstep_grad_fc"], 1e-5)
+    expand_check(netG.tconv[3].weight.grad.numpy(), g["gstep_grad_tconv3"], 1e-5)
+    expand_check(netG.tconv[9].weight.grad.numpy(), g["gstep_grad_tconv9"], 1e-5)
+    expand_check(netG.tconv[4].bias.grad.numpy(), g["gstep_grad_bn4_bias"], 1e-5)
+    n = 0
+    for k, v in netG.state_dict().items():
+        if 'running' in k or 'num_batches' in k:
+            continue
+        ck = g[f"gstep_post_{k}"]
+        assert abs(v.double().sum().item() - ck[0]) <= 1e-6 * ck[1] + 1e-9, k
+        assert abs(v.double().abs().sum().item() - ck[1]) <= 1e-6 * ck[1], k
+        n += 1
+    assert n == 12

@@ -37,6 +37,17 @@ def install_stubs():
             super().__init__()
             self.nz, self.ngf, self.bottom_width, self.loss_type = nz, ngf, bottom_width, loss_type
 
+        # The two base-class methods the reference's in-tree train_step (mnist.py:82-152) calls.  They belong to torch_mimicry 0.1.16
+        # (nets/gan/gan.py: generate_images draws torch.randn((num_images, nz)) and runs forward; compute_gan_loss with loss_type 'ns' is
+        # modules/losses.py: ns_loss_gen = BCE-with-logits against ones) -- restated here because the package is absent; the STEP that
+        # the second witness pins (gen_gstep below) is the reference's own code.
+        def generate_images(self, num_images, device=None):
+            return self.forward(torch.randn((num_images, self.nz), device=device))
+
+        def compute_gan_loss(self, output):
+            assert self.loss_type == 'ns'
+            return F.binary_cross_entropy_with_logits(output, torch.ones_like(output))
+
     class BaseDiscriminator(nn.Module):
         def __init__(self, ndf, loss_type, **kw):
             super().__init__()
@@ -124,6 +135,28 @@ def main():
     out["gD_conv0"] = compact(netD.conv[0].weight.grad.numpy().copy())
     out["gD_conv19"] = compact(netD.conv[19].weight.grad.numpy().copy())
     out["gD_out_d"] = compact(netD.out_d.weight.grad.numpy().copy())
+    # ---- second witness for the generator's train step: the reference's OWN in-tree restatement of the step
+    # (mnist.py:82-152: zero_grad, generate_images, netD, get_topk, compute_gan_loss, backward, optG.step, log) executes on the pair
+    # above -- G in train mode, D in eval mode (no dropout draw), top-k rate 0.75 so that get_topk really selects (4 of 6 logits)
+    class Log:
+        def __init__(self):
+            self.m = {}
+
+        def add_metric(self, name, value, group=None, **kw):
+            self.m[name] = float(value)
+
+    netG.train(), netD.eval()
+    netG.topk_rate = 0.75
+    optG = torch.optim.Adam(netG.parameters(), 2e-4, betas=(0.0, 0.9))
+    torch.manual_seed(77)                  # the noise generate_images draws
+    log = netG.train_step(real_batch=(x,), netD=netD, optG=optG, log_data=Log(), device=torch.device('cpu'))
+    out["gstep_errG"] = np.array(log.m['errG'])
+    out["gstep_grad_fc"] = compact(netG.fc.weight.grad.numpy().copy())
+    out["gstep_grad_tconv3"] = compact(netG.tconv[3].weight.grad.numpy().copy())
+    out["gstep_grad_tconv9"] = compact(netG.tconv[9].weight.grad.numpy().copy())
+    out["gstep_grad_bn4_bias"] = compact(netG.tconv[4].bias.grad.numpy().copy())
+    for k, v in checksums({k: v for k, v in netG.state_dict().items() if 'running' not in k and 'num_batches' not in k}).items():
+        out[f"gstep_post_{k}"] = v
     np.savez_compressed(os.path.join(OUT, "dcgan.npz"), **out)
 
     # GOLD losses + top-k
