@@ -13,6 +13,7 @@
 // over the (iy, ix) whose kernel index is in range; the filter taps sit in LDS, lanes run along ox
 // (then minor) so global reads are coalesced.  Roofline: HBM (in read ~once through L2, out written once).
 #include "common.h"
+#include <stdlib.h>
 
 namespace diagan {
 
@@ -247,6 +248,12 @@ struct UpFirDnArgs {
   float f_alpha, f_scale;
 };
 
+// DIAGAN_FIR_ROWS=0: the one-output-row-per-lane form of the blur kernels (A/B; default: four rows per lane)
+static bool fir_rows() {
+  static const int env = getenv("DIAGAN_FIR_ROWS") ? atoi(getenv("DIAGAN_FIR_ROWS")) : 1;
+  return env != 0;
+}
+
 static __host__ __device__ __forceinline__ int floor_div_i(int a, int b) {
   int q = a / b;
   return (q * b > a) ? q - 1 : q;
@@ -355,6 +362,119 @@ __global__ __launch_bounds__(256) void fir_cl4_kernel(const UpFirDnArgs a) {
 #pragma unroll
     for (int j = 0; j < OXT; ++j)
       if (ox0 + j < a.out_w) dst[(long)j * q] = acc[j];
+  }
+  if (FUSE == 3) {                              // the lanes of a channel quad, in a fixed order, to f_work[block][c]
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = gsum;
+    __syncthreads();
+    if ((int)threadIdx.x < q) {
+      f32x4 sum = red[threadIdx.x];
+      for (int l = threadIdx.x + q; l < 256; l += q) sum += red[l];
+      *reinterpret_cast<f32x4*>(a.f_work + (long)blockIdx.x * a.minor + threadIdx.x * 4) = sum;
+    }
+  }
+}
+
+// The same filter (no resampling) with OYT output ROWS per lane as well: every loaded window row serves the up to min(kh, OYT) output
+// rows it reaches, so an input element is fetched (KW + OXT - 1)(kh + OYT - 1) / (OXT * OYT) = 3.06 times (4 x 4 outputs, 4 x 4 taps) instead
+// of 7 -- the one-row form above runs at 3.5 TB/s of its bytes where a plain elementwise pass reaches 4.7 (tools/probe/fir_fused_time.py):
+// the re-reads come from L1 / L2 / the memory-side cache, but they are not free.  Same order of additions per output (tap rows ascending,
+// taps ascending within a row): bit-identical results.  FUSE as above.
+template <int KW, int OXT, int OYT, int FUSE>
+__global__ __launch_bounds__(256) void fir_cl4_rows_kernel(const UpFirDnArgs a) {
+  __shared__ float taps[64];
+  if (threadIdx.x < a.kh * KW) taps[threadIdx.x] = a.k[threadIdx.x];
+  __syncthreads();
+  const int q = a.minor >> 2, gx = (a.out_w + OXT - 1) / OXT, gy = (a.out_h + OYT - 1) / OYT;
+  const long total = (long)a.major * gy * gx * q;
+  const f32x4* __restrict__ in4 = reinterpret_cast<const f32x4*>(a.in);
+  f32x4* __restrict__ out4 = reinterpret_cast<f32x4*>(a.out);
+  const bool slope01 = a.f_alpha > 0.f && a.f_alpha < 1.f;
+  f32x4 gsum = {0.f, 0.f, 0.f, 0.f};
+  for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+    const int c4 = (int)(o % q);
+    long t = o / q;
+    const int ox0 = (int)(t % gx) * OXT; t /= gx;
+    const int oy0 = (int)(t % gy) * OYT;
+    const int mj = (int)(t / gy);
+    f32x4 acc[OYT][OXT];
+#pragma unroll
+    for (int r = 0; r < OYT; ++r)
+#pragma unroll
+      for (int j = 0; j < OXT; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int bx = ox0 - a.pad_x0;
+    f32x4 pb = {0.f, 0.f, 0.f, 0.f};
+    if (FUSE == 1 || FUSE == 3) pb = *reinterpret_cast<const f32x4*>(a.f_bias + c4 * 4);
+    for (int ry = 0; ry < OYT + a.kh - 1; ++ry) {
+      const int iy = oy0 - a.pad_y0 + ry;
+      if (iy < 0 || iy >= a.in_h) continue;
+      const f32x4* row = in4 + ((long)mj * a.in_h + iy) * a.in_w * q + c4;
+      f32x4 win[KW + OXT - 1];
+#pragma unroll
+      for (int u = 0; u < KW + OXT - 1; ++u) {
+        const int ix = bx + u;
+        win[u] = (ix >= 0 && ix < a.in_w) ? row[(long)ix * q] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (FUSE == 1) {
+#pragma unroll
+        for (int u = 0; u < KW + OXT - 1; ++u) {
+          const int ix = bx + u;
+          f32x4 v = win[u] + pb;
+          if (slope01) {
+            const f32x4 vs = v * a.f_alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], vs[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.f_alpha;
+          }
+          v = v * a.f_scale;
+          const bool in = ix >= 0 && ix < a.in_w;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) win[u][e] = in ? v[e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < OYT; ++r) {
+        const int dy = ry - r;                       // (block-uniform)
+        if (dy < 0 || dy >= a.kh) continue;
+        const float* kr = taps + (a.kh - 1 - dy) * KW;
+#pragma unroll
+        for (int dx = 0; dx < KW; ++dx) {
+          const float w = kr[KW - 1 - dx];
+#pragma unroll
+          for (int j = 0; j < OXT; ++j) acc[r][j] += win[j + dx] * w;
+        }
+      }
+    }
+    const float nw = (FUSE == 2 && a.f_noise && a.f_strength) ? a.f_strength[0] : 0.f;
+#pragma unroll
+    for (int r = 0; r < OYT; ++r) {
+      const int oy = oy0 + r;
+      if (oy >= a.out_h) continue;
+      const long pix0 = ((long)mj * a.out_h + oy) * a.out_w + ox0;
+      f32x4* dst = out4 + pix0 * q + c4;
+#pragma unroll
+      for (int j = 0; j < OXT; ++j) {
+        if (ox0 + j >= a.out_w) continue;
+        f32x4 v = acc[r][j];
+        if (FUSE == 2) {                             // (arithmetic of styled_act_cl4_kernel, then scale_rows')
+          if (a.f_demod) v *= *reinterpret_cast<const f32x4*>(a.f_demod + (long)mj * a.minor + c4 * 4);
+          if (a.f_noise) v += nw * a.f_noise[((long)(a.f_noise_per_image ? mj : 0) * a.out_h + oy) * a.out_w + ox0 + j];
+          if (a.f_bias) v += *reinterpret_cast<const f32x4*>(a.f_bias + c4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] > 0.f ? v[e] : v[e] * a.f_alpha) * a.f_scale;
+          if (a.f_post) v = v * *reinterpret_cast<const f32x4*>(a.f_post + (long)mj * a.minor + c4 * 4);
+        }
+        if (FUSE == 3) {                             // (styled_act_bwd_kernel's gate)
+          const f32x4 rf = reinterpret_cast<const f32x4*>(a.f_ref)[(pix0 + j) * q + c4] + pb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * (rf[e] > 0.f ? a.f_scale : a.f_scale * a.f_alpha);
+          gsum += v;
+        }
+        dst[(long)j * q] = v;
+      }
+    }
   }
   if (FUSE == 3) {                              // the lanes of a channel quad, in a fixed order, to f_work[block][c]
     __shared__ f32x4 red[256];
@@ -658,6 +778,13 @@ DIAGAN_API int diagan_bias_act_fir(const float* input, const float* bias, const 
   DG_REQUIRE(oh > 0 && ow > 0, "bias_act_fir: empty output (%d x %d)", oh, ow);
   UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow, 1, 1, 1, 1, pad_x0, pad_y0};
   a.f_bias = bias; a.f_alpha = alpha; a.f_scale = scale;
+  if (fir_rows()) {
+    const long work4 = (long)major * ((oh + 3) / 4) * ((ow + 3) / 4) * (minor / 4);
+    long fb4 = (work4 + 255) / 256;
+    if (fb4 > 32768) fb4 = 32768;
+    hipLaunchKernelGGL((fir_cl4_rows_kernel<4, 4, 4, 1>), dim3((int)fb4), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("bias_act_fir");
+  }
   const long work = (long)major * oh * ((ow + 3) / 4) * (minor / 4);
   long fb = (work + 255) / 256;
   if (fb > 32768) fb = 32768;
@@ -699,7 +826,8 @@ DIAGAN_API int diagan_fir_gate_bwd(const float* g, const float* kernel, const fl
   a.f_bias = bias; a.f_ref = ref; a.f_work = work_b; a.f_alpha = alpha; a.f_scale = scale;
   // work_b has one row per workgroup: major * diagan_rowdot_chunks(major, oh * ow) of them (diagan_styled_bias_act_bwd_finish sums those)
   const int blocks = major * diagan_rowdot_chunks(major, oh * ow);
-  hipLaunchKernelGGL((fir_cl4_kernel<4, 4, 1, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  if (fir_rows()) hipLaunchKernelGGL((fir_cl4_rows_kernel<4, 4, 4, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((fir_cl4_kernel<4, 4, 1, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("fir_gate_bwd");
 }
 
@@ -718,6 +846,13 @@ DIAGAN_API int diagan_fir_styled_act(const float* input, const float* kernel, fl
   UpFirDnArgs a{input, kernel, out, major, in_h, in_w, minor, kernel_h, kernel_w, oh, ow, 1, 1, 1, 1, pad_x0, pad_y0};
   a.f_bias = bias; a.f_demod = demod; a.f_noise = noise; a.f_strength = strength; a.f_post = post;
   a.f_noise_per_image = noise_per_image; a.f_alpha = alpha; a.f_scale = scale;
+  if (fir_rows()) {
+    const long work4 = (long)major * ((oh + 3) / 4) * ((ow + 3) / 4) * (minor / 4);
+    long fb4 = (work4 + 255) / 256;
+    if (fb4 > 32768) fb4 = 32768;
+    hipLaunchKernelGGL((fir_cl4_rows_kernel<4, 4, 4, 2>), dim3((int)fb4), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("fir_styled_act");
+  }
   const long work = (long)major * oh * ((ow + 3) / 4) * (minor / 4);
   long fb = (work + 255) / 256;
   if (fb > 32768) fb = 32768;
@@ -1069,6 +1204,13 @@ DIAGAN_API int diagan_upfirdn2d(const float* input, const float* kernel, float* 
                 up_x, up_y, down_x, down_y, pad_x0, pad_y0};
   if (up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kernel_w == 4 && kernel_h <= 16 && (minor & 3) == 0 &&
       (((uintptr_t)input | (uintptr_t)out) & 15) == 0) {
+    if (fir_rows()) {
+      const long work4 = (long)major * ((oh + 3) / 4) * ((ow + 3) / 4) * (minor / 4);
+      long fb4 = (work4 + 255) / 256;
+      if (fb4 > 32768) fb4 = 32768;
+      hipLaunchKernelGGL((fir_cl4_rows_kernel<4, 4, 4, 0>), dim3((int)fb4), dim3(256), 0, (hipStream_t)stream, a);
+      return check_launch("upfirdn2d");
+    }
     const long work = (long)major * oh * ((ow + 3) / 4) * (minor / 4);
     long fb = (work + 255) / 256;
     if (fb > 32768) fb = 32768;
