@@ -655,7 +655,8 @@ bool gemm_x3b_geom_ok(const ConvGemmArgs& a) {
 // DIAGAN_GEMM_X3B_FORM forces one; default: form 2 where its tiles fill the chip at least `min_tiles2` / 256 times (the one-workgroup
 // form has nothing to run under its epilogue or beside a half-empty last round).  Form 2's launches are 5-14 % shorter one by one
 // (profiles/r06_x3b.md); what that is worth to the StyleGAN2 iteration depends on the box: same-box pairs of the final build read
-// form 1 everywhere +0.8 % and +1.6 % on two boxes, -1.8 % on a third (profiles/r06_raw/sg2_ab*.txt) -- inside the spread of this pool.
+// form 1 everywhere +0.8 % and +1.6 % on two boxes, -1.8 % and -1.3 ... -2.4 % on two others (profiles/r06_raw/sg2_ab*.txt) -- inside the
+// spread of this pool.
 static int g_x3b_form = 0;                          // diagnostics / tests: 1 / 2 force a form (diagan_conv_gemm_x3b_force_form), 0: automatic
 void gemm_x3b_force_form(int form) { g_x3b_form = form; }
 static int x3b_form(long tiles2, int nk) {
