@@ -220,6 +220,13 @@ int diagan_conv_gemm_get_x3(void);
  * 128 x 128, >= 4 K-steps and >= 4e9 multiply-accumulates on / off / DIAGAN_GEMM_X3B (default on). */
 int diagan_conv_gemm_set_x3b(int mode);
 int diagan_conv_gemm_get_x3b(void);
+/* Pieces per operand of the LARGE split-operand kernels (tile_cfg 17 and the weight gradient of csrc/conv_wgrad_x3.hip): 3 (default) =
+ * six piece products, fp32-grade results; 2 = OPT-IN: (a0 + a1)(b0 + b1) in two MFMAs per 8 channels, operands at ~2^-16, 1.5e-5-2e-5 of
+ * the output scale per layer against float64 (the class of the F(4x4) Winograd layers) for 1.4-1.5x shorter launches; tile_cfg 17 then
+ * runs its first form.  0: back to the environment's DIAGAN_X3_PIECES.  Process-level switch (diagnostics / an explicit user choice);
+ * the lone-tile kernel (tile_cfg 16) always uses three. */
+int diagan_conv_gemm_set_x3_pieces(int n);
+int diagan_conv_gemm_get_x3_pieces(void);
 /* tile_cfg 17 has two forms: 1 = 128 x 128 tiles, two workgroups per CU (small launches, short K loops); 2 = 256 x 128 tiles, four MFMA waves
  * + four loader waves in one workgroup per CU (the large launches).  Tests / diagnostics only, process-global: force one (0: automatic). */
 int diagan_conv_gemm_x3b_force_form(int form);

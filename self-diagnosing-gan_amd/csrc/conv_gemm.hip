@@ -1288,6 +1288,13 @@ DIAGAN_API int diagan_conv_gemm_set_x3b(int mode) {
   return DIAGAN_OK;
 }
 DIAGAN_API int diagan_conv_gemm_get_x3b(void) { return gemm_x3b_on() ? 1 : 0; }
+namespace diagan { void x3_set_pieces(int n); int x3_pieces(); }
+// see include/diagan_hip.h: pieces per operand of the large split-operand kernels (process-level diagnostic / opt-in switch)
+DIAGAN_API int diagan_conv_gemm_set_x3_pieces(int n) {
+  diagan::x3_set_pieces(n);
+  return DIAGAN_OK;
+}
+DIAGAN_API int diagan_conv_gemm_get_x3_pieces(void) { return diagan::x3_pieces(); }
 // tests / diagnostics: 1 = the 128 x 128 form (two workgroups per CU), 2 = the producer / consumer form on 256 x 128 tiles, 0 = automatic
 DIAGAN_API int diagan_conv_gemm_x3b_force_form(int form) {
   DG_REQUIRE(form >= 0 && form <= 2, "x3b_force_form: 0, 1 or 2");

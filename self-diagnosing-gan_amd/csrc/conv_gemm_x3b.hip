@@ -39,7 +39,9 @@ typedef __bf16 xb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned xb_u32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic builds only (tools/build_variant.sh <name> conv_gemm_x3b.hip "-DXB_ABL=<bits>"; results are then garbage): parts of the K
 // loop removed at compile time so that their cost can be read off the launch time -- 1 MFMAs, 2 fragment reads, 4 global loads,
-// 8 the split's arithmetic, 16 LDS writes, 32 barriers
+// 8 the split's arithmetic, 16 LDS writes, 32 barriers; 64 (first form only; results stay VALID at two-piece accuracy): the third piece
+// pair dropped everywhere -- its plane loads, LDS writes, fragment reads and MFMAs -- i.e. (a0 + a1)(b0 + b1) in two MFMAs per 8 channels,
+// to price that trade (profiles/r06_x3b.md)
 #ifndef XB_ABL
 #define XB_ABL 0
 #endif
@@ -52,7 +54,10 @@ __global__ __launch_bounds__(256) void gx3b_weight_kernel(const float* __restric
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long)gridDim.x * 256) gx3_split_quad(w, wx, i, plane);
 }
 
-template <int PRO, bool MAP>
+// TWO (round 6, opt-in: DIAGAN_X3_PIECES=2 / diagan_conv_gemm_set_x3_pieces): the third piece pair dropped everywhere -- its plane loads, LDS
+// writes, fragment reads and MFMAs -- i.e. (a0 + a1)(b0 + b1) in two MFMAs per 8 channels: ~2^-16 operands, 1.5e-5-2e-5 of the output scale
+// per layer (the F(4x4) Winograd layers' class) for 1.46x shorter launches.  NOT the default: the default stays fp32-grade.
+template <int PRO, bool MAP, bool TWO = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArgs a, const OutMap mp, const unsigned short* __restrict__ wx) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const ConvGeom& g = a.g;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
       sr.a[h][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, off, 16, 0));
       const unsigned wo = wrow[h] + (unsigned)l_k * 64u;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) sr.b[h][p] = __builtin_bit_cast(xb_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wo + p * wpl, 0, 0));
+      for (int p = 0; p < ((TWO || (XB_ABL & 64)) ? 2 : 3); ++p) sr.b[h][p] = __builtin_bit_cast(xb_u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, wo + p * wpl, 0, 0));
     }
     ++l_k;
     if (++l_c == cpt) {
@@ -150,9 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
       }
       *reinterpret_cast<xb_u32x4*>(st) = xb_u32x4{a0[0], a0[1], b0[0], b0[1]};
       *reinterpret_cast<xb_u32x4*>(st + XB_PLANE) = xb_u32x4{a1[0], a1[1], b1[0], b1[1]};
-      *reinterpret_cast<xb_u32x4*>(st + 2 * XB_PLANE) = xb_u32x4{a2[0], a2[1], b2[0], b2[1]};
+      if (!(TWO || (XB_ABL & 64))) *reinterpret_cast<xb_u32x4*>(st + 2 * XB_PLANE) = xb_u32x4{a2[0], a2[1], b2[0], b2[1]};
 #pragma unroll
-      for (int p = 0; p < 3; ++p) *reinterpret_cast<xb_u32x4*>(st + (3 + p) * XB_PLANE) = sr.b[h][p];
+      for (int p = 0; p < ((TWO || (XB_ABL & 64)) ? 2 : 3); ++p) *reinterpret_cast<xb_u32x4*>(st + (3 + p) * XB_PLANE) = sr.b[h][p];
     }
   };
 
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
   auto mfmas = [&]() __attribute__((always_inline)) {
     if (!(XB_ABL & 2) || first_step) {
 #pragma unroll
-      for (int sl = 0; sl < 10; ++sl) read_slot(0, sl, 0);
+      for (int sl = 0; sl < ((TWO || (XB_ABL & 64)) ? 6 : 10); ++sl) read_slot(0, sl, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(XB_PRIO);
@@ -195,8 +200,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_x3b_kernel(const ConvGemmArg
         const int p = q >> 2, i = (q >> 1) & 1, j = q & 1;
         const int sa = p == 2 ? (i ? 9 : 6) : (i ? 3 : 0);
         const int sb = p == 0 ? 1 + j : (p == 1 ? 4 + j : 7 + j);
+        if ((TWO || (XB_ABL & 64)) && p == 2) continue;
         if (!(XB_ABL & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[cur][sa], fr[cur][sb], acc[i][j], 0, 0, 0);
-        if (c < 3 && q < 10 && (!(XB_ABL & 2) || first_step)) read_slot(nxt, q, c + 1);
+        if (c < 3 && q < ((TWO || (XB_ABL & 64)) ? 6 : 10) && (!(XB_ABL & 2) || first_step)) read_slot(nxt, q, c + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -657,12 +663,21 @@ bool gemm_x3b_geom_ok(const ConvGemmArgs& a) {
 // (profiles/r06_x3b.md); what that is worth to the StyleGAN2 iteration depends on the box: same-box pairs of the final build read
 // form 1 everywhere +0.8 % and +1.6 % on two boxes, -1.8 % and -1.3 ... -2.4 % on two others (profiles/r06_raw/sg2_ab*.txt) -- inside the
 // spread of this pool.
+// pieces per operand of the LARGE split-operand kernels (this file's first form, conv_wgrad_x3.hip): 3 = fp32-grade (default), 2 = opt-in
+static int g_x3_pieces = 0;                        // 0: the environment's DIAGAN_X3_PIECES (default 3)
+void x3_set_pieces(int n) { g_x3_pieces = (n == 2 || n == 3) ? n : 0; }
+int x3_pieces() {
+  static const int env = getenv("DIAGAN_X3_PIECES") ? atoi(getenv("DIAGAN_X3_PIECES")) : 3;
+  const int n = g_x3_pieces ? g_x3_pieces : env;
+  return n == 2 ? 2 : 3;
+}
 static int g_x3b_form = 0;                          // diagnostics / tests: 1 / 2 force a form (diagan_conv_gemm_x3b_force_form), 0: automatic
 void gemm_x3b_force_form(int form) { g_x3b_form = form; }
 static int x3b_form(long tiles2, int nk) {
   static const int env0 = getenv("DIAGAN_GEMM_X3B_FORM") ? atoi(getenv("DIAGAN_GEMM_X3B_FORM")) : 0;
   const int env = g_x3b_form ? g_x3b_form : env0;
   static const int min_tiles2 = getenv("DIAGAN_GEMM_X3B_FORM2_TILES") ? atoi(getenv("DIAGAN_GEMM_X3B_FORM2_TILES")) : 512;
+  if (x3_pieces() == 2) return 1;                    // (the two-piece mode exists in the first form only)
   if (env == 1 || env == 2) return env;
   // (K loops of fewer than 8 steps: 1x1 / stride 2 from 128 channels, 316 us against 288 -- the epilogue is a quarter of such a tile)
   return tiles2 >= min_tiles2 && nk >= 8 ? 2 : 1;
@@ -679,6 +694,13 @@ static int launch_x3b_two(const ConvGemmArgs& a, const OutMap& mp, const unsigne
 
 template <int PRO, bool MAP>
 static int launch_x3b_one(const ConvGemmArgs& a, const OutMap& mp, const unsigned short* wx, int tiles, hipStream_t st) {
+  if (x3_pieces() == 2) {
+    auto kern2 = conv_gemm_x3b_kernel<PRO, MAP, true>;
+    static FuncAttrLatch latch2;
+    DG_LDS(latch2, kern2, XB_LDS_BYTES);
+    hipLaunchKernelGGL(kern2, dim3(tiles), dim3(256), XB_LDS_BYTES, st, a, mp, wx);
+    return DIAGAN_OK;
+  }
   auto kern = conv_gemm_x3b_kernel<PRO, MAP>;
   static FuncAttrLatch latch;
   DG_LDS(latch, kern, XB_LDS_BYTES);

@@ -34,7 +34,8 @@ typedef __bf16 wx_bf16x8 __attribute__((ext_vector_type(8)));
 
 // NOPAD: every gathered coordinate of every pixel is inside the image (no padding, e.g. the 3x3 / stride 2 / pad 0 convolutions behind
 // the blur): the loader skips the border tests
-template <bool NOPAD>
+// TWO: the opt-in two-piece mode of conv_gemm_x3b.hip (DIAGAN_X3_PIECES=2): third plane, its fragment reads and MFMAs dropped
+template <bool NOPAD, bool TWO = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const ConvGeom& g = a.g;
@@ -117,11 +118,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs a
       unsigned short* st = lds + sto + e * WX_ROW;
       *reinterpret_cast<u32x2*>(st) = p0;
       *reinterpret_cast<u32x2*>(st + WX_PLANE) = p1;
-      *reinterpret_cast<u32x2*>(st + 2 * WX_PLANE) = p2;
+      if (!TWO) *reinterpret_cast<u32x2*>(st + 2 * WX_PLANE) = p2;
       x3_split(f32x4{rb[0][e], rb[1][e], rb[2][e], rb[3][e]}, p0, p1, p2);
       *reinterpret_cast<u32x2*>(st + 3 * WX_PLANE) = p0;
       *reinterpret_cast<u32x2*>(st + 4 * WX_PLANE) = p1;
-      *reinterpret_cast<u32x2*>(st + 5 * WX_PLANE) = p2;
+      if (!TWO) *reinterpret_cast<u32x2*>(st + 5 * WX_PLANE) = p2;
     }
   };
 
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs a
   };
   auto mfmas = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int sl = 0; sl < 10; ++sl) read_slot(0, sl, 0);
+    for (int sl = 0; sl < (TWO ? 6 : 10); ++sl) read_slot(0, sl, 0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -159,8 +160,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_x3_kernel(const WgradArgs a
         const int p = q >> 2, i = (q >> 1) & 1, j = q & 1;
         const int sa = p == 2 ? (i ? 9 : 6) : (i ? 3 : 0);
         const int sb = p == 0 ? 1 + j : (p == 1 ? 4 + j : 7 + j);
+        if (TWO && p == 2) continue;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[cur][sa], fr[cur][sb], acc[i][j], 0, 0, 0);
-        if (c < 3 && q < 10) read_slot(nxt, q, c + 1);
+        if (c < 3 && q < (TWO ? 6 : 10)) read_slot(nxt, q, c + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -226,9 +228,21 @@ static bool wgrad_x3_nopad(const ConvGeom& g) {
   return lo >= 0 && lo_x >= 0 && hi_y < g.Hi && hi_x < g.Wi;
 }
 
+int x3_pieces();                                     // conv_gemm_x3b.hip
+
 int launch_wgrad_x3(const WgradArgs& a, int splits, hipStream_t st) {
-  static FuncAttrLatch l0, l1;
+  static FuncAttrLatch l0, l1, m0, m1;
   const dim3 grid(a.tiles * splits);
+  if (x3_pieces() == 2) {
+    if (wgrad_x3_nopad(a.g)) {
+      DG_LDS(m1, (conv_wgrad_x3_kernel<true, true>), WX_LDS_BYTES);
+      hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, true>), grid, dim3(256), WX_LDS_BYTES, st, a);
+    } else {
+      DG_LDS(m0, (conv_wgrad_x3_kernel<false, true>), WX_LDS_BYTES);
+      hipLaunchKernelGGL((conv_wgrad_x3_kernel<false, true>), grid, dim3(256), WX_LDS_BYTES, st, a);
+    }
+    return check_launch("conv_wgrad_x3 (two pieces)");
+  }
   if (wgrad_x3_nopad(a.g)) {
     DG_LDS(l1, conv_wgrad_x3_kernel<true>, WX_LDS_BYTES);
     hipLaunchKernelGGL((conv_wgrad_x3_kernel<true>), grid, dim3(256), WX_LDS_BYTES, st, a);

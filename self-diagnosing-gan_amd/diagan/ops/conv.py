@@ -39,6 +39,8 @@ nat.register("diagan_wino_weight_blocks", [I, I])
 nat.register("diagan_wino_weights_batched", [P, I, I, P])
 nat.register("diagan_conv_wgrad_uses_wino", [I] * 13)
 nat.register("diagan_conv_wgrad_splits_geom", [I] * 14)
+nat.register("diagan_conv_gemm_set_x3_pieces", [I])
+nat.register("diagan_conv_gemm_get_x3_pieces", [])
 nat.register("diagan_conv_wgrad_uses_x3", [I] * 15 + [I64])
 nat.register("diagan_conv_wgrad_set_x3", [I])
 nat.register("diagan_conv_gemm_pick_cfg_geom", [I] * 15 + [I64])
@@ -306,6 +308,12 @@ def set_gemm_x3(on):
 def set_gemm_x3b(on):
     """the same for the 128 x 128 / 256 x 128 split-operand kernel alone (tile_cfg 17); None: what DIAGAN_GEMM_X3B says"""
     nat.call("diagan_conv_gemm_set_x3b", -1 if on is None else (1 if on else 0))
+
+
+def set_x3_pieces(n):
+    """pieces per operand of the large split-operand kernels: 3 = fp32-grade (default), 2 = opt-in (operands at ~2^-16, 1.5e-5-2e-5 of the
+    output scale per layer, 1.4-1.5x shorter launches); None: what DIAGAN_X3_PIECES says"""
+    nat.call("diagan_conv_gemm_set_x3_pieces", 0 if n is None else int(n))
 
 
 def set_wgrad_x3(on):

@@ -471,6 +471,43 @@ def test_split_operand_weight_gradient(case):
     assert errs[1] < 2e-6 and errs[1] < 4 * max(errs[0], 1e-7), errs
 
 
+def test_two_piece_mode_is_opt_in_and_priced():
+    """round 6: DIAGAN_X3_PIECES=2 / set_x3_pieces(2) drops the third piece pair of the large split-operand kernels (forward / data gradient,
+    weight gradient): operands at ~2^-16.  The default is three pieces (fp32-grade); the opt-in mode's error against float64 is the
+    class of the F(4x4) Winograd layers (1e-5 of the output scale), far from bf16's 4e-3."""
+    from diagan.ops import conv as C
+    assert C.nat.fn("diagan_conv_gemm_get_x3_pieces")() == 3
+    g = torch.Generator().manual_seed(7)
+    B, H, Ci, Co = 4, 33, 128, 128
+    x = torch.randn(B, Ci, H, H, generator=g, dtype=torch.float64)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64) * (9 * Ci) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    geom = C.Geom("conv", Ci, Co, 3, 3, 2, 0)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().cuda()
+    wp = C.pack_oihw(w.detach().float().cuda(), geom.Kp)
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    yref = y.detach().permute(0, 2, 3, 1)
+    gref = w.grad.permute(0, 2, 3, 1).reshape(Co, 9 * Ci)
+    errs = {}
+    try:
+        C.set_wgrad_x3(2)
+        for n in (3, 2):
+            C.set_x3_pieces(n)
+            assert C.nat.fn("diagan_conv_gemm_get_x3_pieces")() == n
+            out = C.conv_fwd(geom, xd, wp, tile_cfg=17)
+            grad = torch.zeros(Co, geom.Kp, device="cuda")
+            C.conv_wgrad(geom, dyd, xd, grad, False)
+            errs[n] = ((out.double().cpu() - yref).abs().max().item() / yref.abs().max().item(),
+                       (grad.double().cpu() - gref).abs().max().item() / gref.abs().max().item())
+    finally:
+        C.set_x3_pieces(None)
+        C.set_wgrad_x3(None)
+    assert errs[3][0] < 2e-6 and errs[3][1] < 2e-6, errs
+    assert 2e-6 < errs[2][0] < 6e-5 and 2e-6 < errs[2][1] < 6e-5, errs
+
+
 def test_split_operand_weight_gradient_follows_the_exact_fp32_switch():
     """set_gemm_x3(False) -- the exact-fp32 mode of the parity tools -- keeps the weight gradient on the fp32 pipe as well; launches
     with a prologue or a bias column stay on the fp32 kernel"""
